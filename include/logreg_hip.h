@@ -1,0 +1,143 @@
+/*
+ * logreg_hip.h -- C ABI of liblogreg_hip.so: many-chain MCMC for Bayesian logistic regression
+ * on AMD MI355X (gfx950).  Plain C, no exceptions, no torch types: pointers and sizes only.
+ *
+ * The reference (darrenjw/logreg) has no FFI for this path: its whole "interface" is the set of
+ * Python closures in Python/fit-numpy.py, Python/fit-np-mala.py, Python/fit-np-hmc.py and
+ * Python/fit-np-ul.py.  Each entry point below names the reference closure(s) it replaces
+ * (file:line under the reference root); logreg_amd/ binds them with ctypes and re-exposes the
+ * reference's Python names and signatures (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative lr_status on failure;
+ *     lr_last_error() returns a thread-local message for the last failure on this thread.
+ *   - a model handle is bound to one device; calls on one handle must be serialised by the
+ *     caller; different handles may be used from different threads/processes.
+ *   - "dtype" is the arithmetic type the device path computes in and the element type of every
+ *     `void*` array below: LR_F32 (float) or LR_F64 (double).  Model inputs and kernel tuning
+ *     vectors are always host doubles (they are tiny and converted once).
+ *   - arrays are row-major; C = number of chains, p = number of parameters.
+ *   - opts->on_device = 0: array pointers are HOST memory; the call copies in, runs, copies out
+ *     and returns when the results are in host memory.
+ *     opts->on_device = 1: array pointers are DEVICE memory on the model's device; work is
+ *     enqueued on opts->stream (a hipStream_t, NULL = default stream) and the call returns
+ *     without synchronising.
+ *   - randomness: Philox4x32-10, key = seed, counter = (chain_offset + c, iter_offset + t,
+ *     block).  Results depend only on (seed, global chain id, global iteration index): any
+ *     split of a run into launches (iter_offset) or shards (chain_offset) reproduces the
+ *     monolithic run bit for bit.
+ */
+#ifndef LOGREG_HIP_H
+#define LOGREG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LR_API __attribute__((visibility("default")))
+
+typedef enum lr_status {
+    LR_OK = 0,
+    LR_ERR_INVALID = -1,     /* bad argument */
+    LR_ERR_HIP = -2,         /* HIP runtime error (no device, launch failure, ...) */
+    LR_ERR_UNSUPPORTED = -3, /* no compiled kernel variant for this (dtype, p, n, group, mode) */
+    LR_ERR_NOMEM = -4
+} lr_status;
+
+enum { LR_F32 = 0, LR_F64 = 1 };
+enum { LR_MODE_AUTO = -1, LR_MODE_REG = 0, LR_MODE_LDS = 1, LR_MODE_GLOBAL = 2 };
+
+typedef struct lr_model lr_model;
+
+typedef struct lr_run_opts {
+    int64_t n_chains;     /* C: chains in this call */
+    int64_t chain_offset; /* global id of chain 0 of this call (sharding) */
+    int64_t thin;         /* iterations per kept sample      (mcmc(thin=...)) */
+    int64_t iters;        /* kept samples in this call       (mcmc(iters=...)) */
+    int64_t iter_offset;  /* global index of this call's first iteration (chunked runs) */
+    uint64_t seed;
+    int32_t group;        /* lanes per chain: 1,2,4,...,64; 0 = choose automatically */
+    int32_t mode;         /* LR_MODE_*: where the data rows live during the launch */
+    int32_t on_device;    /* see conventions */
+    void* stream;         /* hipStream_t when on_device = 1 */
+} lr_run_opts;
+
+LR_API const char* lr_last_error(void);
+LR_API int lr_device_count(void);
+/* number of compute units of `device` (<0 on error) */
+LR_API int lr_device_cus(int device);
+
+/*
+ * Model = data block + model closures.
+ * Replaces the data block Python/fit-np-hmc.py:12-19 (X with intercept column, y in {0,1}) and
+ * the closure state of ll/lprior/lpost/glp (fit-np-hmc.py:23-47; `pscale` fit-np-hmc.py:31).
+ * X [n,p] and y [n] and prior_sd [p] are host doubles, copied; caller keeps ownership.
+ */
+LR_API int lr_model_create(const double* X, const double* y, int64_t n, int32_t p, const double* prior_sd,
+                           int32_t dtype, int32_t device, lr_model** out);
+LR_API void lr_model_destroy(lr_model* m);
+LR_API int lr_model_info(const lr_model* m, int64_t* n, int32_t* p, int32_t* dtype, int32_t* device,
+                         int32_t* padded_p);
+
+/*
+ * ll(beta), lprior(beta), lpost(beta), glp(beta) for C parameter vectors at once.
+ * Replaces fit-np-hmc.py:23-24 (ll), :33-34 (lprior), :36-37 (lpost), :44-47 (glp).
+ * beta [C,p]; ll/lprior/lpost [C]; grad [C,p]; any output may be NULL.
+ * Only n_chains, group, mode, on_device, stream of `opts` are read.
+ */
+LR_API int lr_eval(lr_model* m, const void* beta, void* ll, void* lprior, void* lpost, void* grad,
+                   const lr_run_opts* opts);
+
+/*
+ * mcmc(init, kernel, thin, iters) with the kernel fused in: every call advances all chains by
+ * iters*thin iterations on the device and writes the thinned states.
+ * Replaces mcmc() fit-numpy.py:64-79 / fit-np-mala.py:80-95 / fit-np-hmc.py:89-103 /
+ * fit-np-ul.py:70-84 together with the kernel named per function.
+ *   state    [C,p]  in/out  current states
+ *   lp_state [C]    in/out  (double, always) the log-density threaded through mhKernel for
+ *                           RWMH/MALA; -inf is allowed and means "accept the first proposal"
+ *                           (fit-np-mala.py:82)
+ *   out      [iters,C,p] or NULL   row i = states after (i+1)*thin iterations
+ *   accepts  [C] or NULL           incremented by the number of accepted proposals
+ */
+/* mhKernel(lpost, rprop) with rprop(beta) = beta + prop_sd*N(0,I): fit-numpy.py:53-62, :81-84 */
+LR_API int lr_run_rwmh(lr_model* m, void* state, double* lp_state, const double* prop_sd,
+                       const lr_run_opts* opts, void* out, uint32_t* accepts);
+/* malaKernel(lpi, glpi, dt, pre) inside mhKernel: fit-np-mala.py:61-78 */
+LR_API int lr_run_mala(lr_model* m, void* state, double* lp_state, double dt, const double* pre,
+                       const lr_run_opts* opts, void* out, uint32_t* accepts);
+/* ulKernel(glpi, dt, pre): fit-np-ul.py:61-68 (no accept step; accepts counts iterations) */
+LR_API int lr_run_ul(lr_model* m, void* state, double dt, const double* pre, const lr_run_opts* opts,
+                     void* out, uint32_t* accepts);
+/* hmcKernel(lpi, glpi, eps, l, dmm) with its own mhKernel: fit-np-hmc.py:56-87 */
+LR_API int lr_run_hmc(lr_model* m, void* state, double eps, int32_t l, const double* dmm,
+                      const lr_run_opts* opts, void* out, uint32_t* accepts);
+
+/*
+ * Which kernel variant the library would launch for (model, n_chains, group, mode):
+ * mode_out in LR_MODE_*, group_out lanes per chain, rows_out rows per lane (REG mode, else 0).
+ */
+LR_API int lr_plan(const lr_model* m, int64_t n_chains, int32_t group, int32_t mode, int32_t* mode_out,
+                   int32_t* group_out, int32_t* rows_out);
+
+/* device memory + stream + event helpers so a host language needs no other GPU runtime */
+LR_API int lr_malloc(int device, uint64_t bytes, void** dptr);
+LR_API int lr_free(int device, void* dptr);
+LR_API int lr_memcpy_h2d(int device, void* dst, const void* src, uint64_t bytes, void* stream);
+LR_API int lr_memcpy_d2h(int device, void* dst, const void* src, uint64_t bytes, void* stream);
+LR_API int lr_memset(int device, void* dst, int value, uint64_t bytes, void* stream);
+LR_API int lr_stream_create(int device, void** stream);
+LR_API int lr_stream_destroy(int device, void* stream);
+LR_API int lr_stream_sync(int device, void* stream);
+LR_API int lr_event_create(int device, void** event);
+LR_API int lr_event_destroy(int device, void* event);
+LR_API int lr_event_record(int device, void* event, void* stream);
+/* synchronises on `stop`, then returns the time between the two events in milliseconds */
+LR_API int lr_event_elapsed_ms(int device, void* start, void* stop, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LOGREG_HIP_H */

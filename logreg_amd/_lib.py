@@ -1,0 +1,103 @@
+"""ctypes binding of liblogreg_hip.so (the C ABI in include/logreg_hip.h).
+
+There is no CPU fallback: if the library cannot be loaded, or no MI355X is visible, every entry
+point raises.  Nothing in this package imports the test oracle under oracle/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "liblogreg_hip.so")
+
+LR_F32, LR_F64 = 0, 1
+MODE_AUTO, MODE_REG, MODE_LDS, MODE_GLOBAL = -1, 0, 1, 2
+MODE_NAMES = {MODE_REG: "reg", MODE_LDS: "lds", MODE_GLOBAL: "global"}
+MODE_BY_NAME = {"auto": MODE_AUTO, "reg": MODE_REG, "lds": MODE_LDS, "global": MODE_GLOBAL}
+
+
+class LogregHipError(RuntimeError):
+    pass
+
+
+class RunOpts(C.Structure):
+    _fields_ = [("n_chains", C.c_int64), ("chain_offset", C.c_int64), ("thin", C.c_int64), ("iters", C.c_int64),
+                ("iter_offset", C.c_int64), ("seed", C.c_uint64), ("group", C.c_int32), ("mode", C.c_int32),
+                ("on_device", C.c_int32), ("stream", C.c_void_p)]
+
+
+# name -> (restype, argtypes); every symbol include/logreg_hip.h declares
+_vp, _dp, _i32, _i64, _u64 = C.c_void_p, C.POINTER(C.c_double), C.c_int32, C.c_int64, C.c_uint64
+_op = C.POINTER(RunOpts)
+SYMBOLS = {
+    "lr_last_error": (C.c_char_p, []),
+    "lr_device_count": (C.c_int, []),
+    "lr_device_cus": (C.c_int, [C.c_int]),
+    "lr_model_create": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _i32, _i32, C.POINTER(_vp)]),
+    "lr_model_destroy": (None, [_vp]),
+    "lr_model_info": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
+    "lr_eval": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _op]),
+    "lr_run_rwmh": (C.c_int, [_vp, _vp, _vp, _vp, _op, _vp, _vp]),
+    "lr_run_mala": (C.c_int, [_vp, _vp, _vp, C.c_double, _vp, _op, _vp, _vp]),
+    "lr_run_ul": (C.c_int, [_vp, _vp, C.c_double, _vp, _op, _vp, _vp]),
+    "lr_run_hmc": (C.c_int, [_vp, _vp, C.c_double, _i32, _vp, _op, _vp, _vp]),
+    "lr_plan": (C.c_int, [_vp, _i64, _i32, _i32, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
+    "lr_malloc": (C.c_int, [C.c_int, _u64, C.POINTER(_vp)]),
+    "lr_free": (C.c_int, [C.c_int, _vp]),
+    "lr_memcpy_h2d": (C.c_int, [C.c_int, _vp, _vp, _u64, _vp]),
+    "lr_memcpy_d2h": (C.c_int, [C.c_int, _vp, _vp, _u64, _vp]),
+    "lr_memset": (C.c_int, [C.c_int, _vp, C.c_int, _u64, _vp]),
+    "lr_stream_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "lr_stream_destroy": (C.c_int, [C.c_int, _vp]),
+    "lr_stream_sync": (C.c_int, [C.c_int, _vp]),
+    "lr_event_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "lr_event_destroy": (C.c_int, [C.c_int, _vp]),
+    "lr_event_record": (C.c_int, [C.c_int, _vp, _vp]),
+    "lr_event_elapsed_ms": (C.c_int, [C.c_int, _vp, _vp, C.POINTER(C.c_float)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the HIP library (building it first if the sources are newer and hipcc is present)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        from . import build as _build
+        try:
+            _build.build(verbose=False)
+        except Exception as e:  # no hipcc / compile error: loud, no fallback
+            raise LogregHipError(
+                f"liblogreg_hip.so is missing ({LIB_PATH}) and could not be built: {e}. "
+                "Run `python -m logreg_amd.build`. There is no CPU fallback.") from e
+    try:
+        L = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise LogregHipError(f"cannot load {LIB_PATH}: {e}. There is no CPU fallback.") from e
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(L, name)  # AttributeError if the ABI and the binding drift apart
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def check(rc: int):
+    if rc != 0:
+        msg = load().lr_last_error()
+        raise LogregHipError(f"liblogreg_hip error {rc}: {msg.decode() if msg else '?'}")
+
+
+def device_count() -> int:
+    return int(load().lr_device_count())
+
+
+def require_gpu():
+    n = device_count()
+    if n <= 0:
+        raise LogregHipError("no AMD GPU visible to HIP: logreg_amd has no CPU fallback "
+                             "(the CPU restatement under oracle/ is test infrastructure only)")
+    return n

@@ -1,0 +1,92 @@
+"""Build liblogreg_hip.so (hand-written HIP kernels + C ABI) for gfx950 with hipcc.
+
+    python -m logreg_amd.build [--force] [-j N]
+
+The kernels are instantiated once per (dtype, padded p) in separate translation units compiled
+in parallel, then linked with the C-ABI unit into logreg_amd/lib/liblogreg_hip.so (in-tree: the
+built library travels to the GPU box with the repo snapshot; it is git-ignored).
+hipcc cross-compiles for gfx950 without a GPU present.
+"""
+from __future__ import annotations
+
+import argparse
+import concurrent.futures as cf
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+OBJDIR = os.path.join(LIBDIR, "obj")
+LIB = os.path.join(LIBDIR, "liblogreg_hip.so")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+
+ARCH = "gfx950"
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall",
+          "-Wno-unused-function", "-I", CSRC, "-I", INCLUDE]
+
+INSTANCES = [(dt, dtype_id, ctype, p) for dt, dtype_id, ctype in (("f32", 0, "float"), ("f64", 1, "double"))
+             for p in (4, 8, 16, 32)]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return "hipcc"
+
+
+def _sources():
+    return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))] + [os.path.join(INCLUDE, "logreg_hip.h")]
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(s) > t for s in _sources())
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("command failed: %s\n%s\n%s" % (" ".join(cmd), r.stdout, r.stderr))
+    return r.stderr
+
+
+def build(force: bool = False, jobs: int | None = None, verbose: bool = True) -> str:
+    if not force and not needs_build():
+        return LIB
+    os.makedirs(OBJDIR, exist_ok=True)
+    hipcc = _hipcc()
+    jobs_list = []
+    objs = []
+    for dt, dtype_id, ctype, p in INSTANCES:
+        sfx = f"{dt}_p{p}"
+        obj = os.path.join(OBJDIR, f"lr_inst_{sfx}.o")
+        objs.append(obj)
+        jobs_list.append([hipcc, *COMMON, f"-DLR_T={ctype}", f"-DLR_P={p}", f"-DLR_SFX={sfx}",
+                          f"-DLR_DTYPE={dtype_id}", "-c", os.path.join(CSRC, "lr_inst.hip"), "-o", obj])
+    api_obj = os.path.join(OBJDIR, "lr_api.o")
+    objs.append(api_obj)
+    jobs_list.append([hipcc, *COMMON, "-c", os.path.join(CSRC, "lr_api.hip"), "-o", api_obj])
+    jobs = jobs or min(len(jobs_list), max(1, (os.cpu_count() or 2)))
+    if verbose:
+        print(f"[logreg_amd.build] compiling {len(jobs_list)} units for {ARCH} with {jobs} jobs", flush=True)
+    with cf.ThreadPoolExecutor(jobs) as ex:
+        for warn in ex.map(_run, jobs_list):
+            if warn.strip() and verbose:
+                print(warn, file=sys.stderr)
+    _run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB, *objs])
+    if verbose:
+        print(f"[logreg_amd.build] wrote {LIB}", flush=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("-j", type=int, default=None)
+    a = ap.parse_args()
+    build(force=a.force, jobs=a.j)

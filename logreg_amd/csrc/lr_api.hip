@@ -1,0 +1,534 @@
+// lr_api.hip -- implementation of the C ABI declared in include/logreg_hip.h.
+// Host-side only: argument checking, device buffers, variant planning, and packing the
+// by-value kernel argument structs.  All arithmetic of the path runs in lr_kernels.h.
+#include "../../include/logreg_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "lr_inst.h"
+#include "lr_kernels.h"
+
+LR_DECLARE_INST(f32_p4)
+LR_DECLARE_INST(f32_p8)
+LR_DECLARE_INST(f32_p16)
+LR_DECLARE_INST(f32_p32)
+LR_DECLARE_INST(f64_p4)
+LR_DECLARE_INST(f64_p8)
+LR_DECLARE_INST(f64_p16)
+LR_DECLARE_INST(f64_p32)
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define LR_HIP(call)                                                                                    \
+    do {                                                                                                \
+        hipError_t e_ = (call);                                                                         \
+        if (e_ != hipSuccess) return fail(LR_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));   \
+    } while (0)
+
+const lr::InstTable* find_table(int dtype, int P) {
+    const lr::InstTable* all[] = {lr_inst_table_f32_p4(),  lr_inst_table_f32_p8(), lr_inst_table_f32_p16(),
+                                  lr_inst_table_f32_p32(), lr_inst_table_f64_p4(), lr_inst_table_f64_p8(),
+                                  lr_inst_table_f64_p16(), lr_inst_table_f64_p32()};
+    for (const lr::InstTable* t : all)
+        if (t->dtype == dtype && t->P == P) return t;
+    return nullptr;
+}
+
+constexpr int kMaxP = 32;
+constexpr size_t kLdsBudget = 160 * 1024;
+
+}  // namespace
+
+struct lr_model {
+    int device = 0;
+    int dtype = LR_F32;
+    int64_t n = 0;
+    int p = 0;   // real parameter count
+    int P = 0;   // padded width (4, 8, 16, 32)
+    int cus = 256;
+    void* d_rows = nullptr;  // [n][P] signed rows, dtype
+    double inv_var[kMaxP];
+    double lprior_const = 0;
+    const lr::InstTable* table = nullptr;
+    size_t esize() const { return dtype == LR_F32 ? 4 : 8; }
+};
+
+namespace {
+
+struct Plan { int mode, G, R; size_t lds_bytes; };
+
+// Choose the kernel variant.  REG (rows in VGPRs) whenever the data fit (G*R >= n), then LDS,
+// then GLOBAL.  Group size: the smallest available G that still gives every SIMD a wavefront
+// (C*G/64 >= 4*CUs), else the largest; an explicit `group` request is honoured exactly.
+int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out) {
+    const lr::InstTable* t = m->table;
+    const int64_t want_waves = 4LL * m->cus;
+    int best = -1;
+    long best_score = -1;
+    for (int i = 0; i < t->nvariants; ++i) {
+        const lr::Variant& v = t->variants[i];
+        if (mode != LR_MODE_AUTO && v.mode != mode) continue;
+        if (group != 0 && v.G != group) continue;
+        if (v.mode == lr::MODE_REG && (int64_t)v.G * v.R < m->n) continue;
+        if (v.mode == lr::MODE_LDS && (size_t)m->n * m->P * m->esize() > kLdsBudget) continue;
+        // score: residency tier first (REG > LDS > GLOBAL), then group fitness, then fewer padded rows
+        const int64_t waves = (C * v.G + 63) / 64;
+        long score = (2 - v.mode) * 1000000L;
+        if (waves >= want_waves) score += 100000L - 1000L * v.G;  // filled: prefer small groups
+        else score += 10L * v.G;                                   // not filled: prefer large groups
+        if (v.mode == lr::MODE_REG) score -= v.R;                  // exact-fit R before padded R
+        if (score > best_score) { best_score = score; best = i; }
+    }
+    if (best < 0)
+        return fail(LR_ERR_UNSUPPORTED, "no kernel variant for dtype=%d p=%d (padded %d) n=%lld group=%d mode=%d",
+                    m->dtype, m->p, m->P, (long long)m->n, group, mode);
+    const lr::Variant& v = t->variants[best];
+    out->mode = v.mode;
+    out->G = v.G;
+    out->R = v.R;
+    out->lds_bytes = v.mode == lr::MODE_LDS ? (size_t)m->n * m->P * m->esize() : 0;
+    return LR_OK;
+}
+
+template <typename T, int P> lr::ModelArgs<T, P> model_args(const lr_model* m) {
+    lr::ModelArgs<T, P> a;
+    a.rows = static_cast<const T*>(m->d_rows);
+    a.n = m->n;
+    for (int j = 0; j < P; ++j) a.prior.inv_var[j] = (T)m->inv_var[j];
+    a.prior.lprior_const = m->lprior_const;
+    return a;
+}
+
+struct RunSpec {
+    int kind;
+    double step;
+    int l;
+    double a[kMaxP], b[kMaxP], c[kMaxP];
+};
+
+template <typename T, int P>
+int do_eval_t(lr_model* m, const Plan& pl, hipStream_t st, int64_t C, const void* beta, void* ll, void* lprior,
+              void* lpost, void* grad) {
+    auto ma = model_args<T, P>(m);
+    lr::EvalArgs<T> ea;
+    ea.beta = static_cast<const T*>(beta);
+    ea.C = C;
+    ea.p = m->p;
+    ea.ll = static_cast<T*>(ll);
+    ea.lprior = static_cast<T*>(lprior);
+    ea.lpost = static_cast<T*>(lpost);
+    ea.grad = static_cast<T*>(grad);
+    lr::LaunchCfg cfg{pl.mode, pl.G, pl.R, 0, st, pl.lds_bytes};
+    const int rc = m->table->launch_eval(&cfg, C, &ma, &ea);
+    if (rc != 0) return fail(rc == -3 ? LR_ERR_UNSUPPORTED : LR_ERR_HIP, "eval launch failed (%d): %s", rc,
+                             hipGetErrorString(hipGetLastError()));
+    return LR_OK;
+}
+
+template <typename T, int P>
+int do_chain_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs, const lr_run_opts* o, void* state,
+               double* lp_state, void* out, uint32_t* accepts) {
+    auto ma = model_args<T, P>(m);
+    lr::ChainArgs<T, P> ca;
+    ca.state = static_cast<T*>(state);
+    ca.lp_state = lp_state;
+    ca.out = static_cast<T*>(out);
+    ca.accepts = accepts;
+    ca.C = o->n_chains;
+    ca.chain_offset = o->chain_offset;
+    ca.iters = o->iters;
+    ca.thin = o->thin;
+    ca.iter_offset = o->iter_offset;
+    ca.seed = o->seed;
+    ca.p = m->p;
+    ca.l = rs.l;
+    ca.step = (T)rs.step;
+    for (int j = 0; j < P; ++j) {
+        ca.a[j] = (T)rs.a[j];
+        ca.b[j] = (T)rs.b[j];
+        ca.c[j] = (T)rs.c[j];
+    }
+    lr::LaunchCfg cfg{pl.mode, pl.G, pl.R, rs.kind, st, pl.lds_bytes};
+    const int rc = m->table->launch_chain(&cfg, o->n_chains, &ma, &ca);
+    if (rc != 0) return fail(rc == -3 ? LR_ERR_UNSUPPORTED : LR_ERR_HIP, "chain launch failed (%d): %s", rc,
+                             hipGetErrorString(hipGetLastError()));
+    return LR_OK;
+}
+
+#define LR_DISPATCH_TP(m, FN, ...)                                                       \
+    do {                                                                                 \
+        if ((m)->dtype == LR_F32) {                                                      \
+            switch ((m)->P) {                                                            \
+            case 4: return FN<float, 4>(__VA_ARGS__);                                    \
+            case 8: return FN<float, 8>(__VA_ARGS__);                                    \
+            case 16: return FN<float, 16>(__VA_ARGS__);                                  \
+            case 32: return FN<float, 32>(__VA_ARGS__);                                  \
+            }                                                                            \
+        } else {                                                                         \
+            switch ((m)->P) {                                                            \
+            case 4: return FN<double, 4>(__VA_ARGS__);                                   \
+            case 8: return FN<double, 8>(__VA_ARGS__);                                   \
+            case 16: return FN<double, 16>(__VA_ARGS__);                                 \
+            case 32: return FN<double, 32>(__VA_ARGS__);                                 \
+            }                                                                            \
+        }                                                                                \
+        return fail(LR_ERR_UNSUPPORTED, "unsupported padded width %d", (m)->P);          \
+    } while (0)
+
+int do_eval(lr_model* m, const Plan& pl, hipStream_t st, int64_t C, const void* beta, void* ll, void* lprior,
+            void* lpost, void* grad) {
+    LR_DISPATCH_TP(m, do_eval_t, m, pl, st, C, beta, ll, lprior, lpost, grad);
+}
+
+int do_chain(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs, const lr_run_opts* o, void* state,
+             double* lp_state, void* out, uint32_t* accepts) {
+    LR_DISPATCH_TP(m, do_chain_t, m, pl, st, rs, o, state, lp_state, out, accepts);
+}
+
+int check_opts(const lr_model* m, const lr_run_opts* o, bool run) {
+    if (!m) return fail(LR_ERR_INVALID, "model is NULL");
+    if (!o) return fail(LR_ERR_INVALID, "opts is NULL");
+    if (o->n_chains <= 0) return fail(LR_ERR_INVALID, "n_chains must be positive (got %lld)", (long long)o->n_chains);
+    if (o->group < 0 || o->group > 64 || (o->group & (o->group - 1)))
+        return fail(LR_ERR_INVALID, "group must be 0 or a power of two <= 64 (got %d)", o->group);
+    if (run) {
+        if (o->thin <= 0 || o->iters < 0) return fail(LR_ERR_INVALID, "thin must be > 0 and iters >= 0");
+        if (o->chain_offset < 0 || o->iter_offset < 0) return fail(LR_ERR_INVALID, "offsets must be >= 0");
+        if ((uint64_t)(o->chain_offset + o->n_chains) > 0xFFFFFFFFull)
+            return fail(LR_ERR_INVALID, "global chain ids must fit 32 bits");
+    }
+    return LR_OK;
+}
+
+// Host-pointer convenience path: stage through device buffers, run synchronously, copy back.
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) {
+        if (bytes == 0) bytes = 1;
+        return hipMalloc(&p, bytes) == hipSuccess ? 0 : -1;
+    }
+};
+
+int run_common(lr_model* m, const RunSpec& rs, const lr_run_opts* o, void* state, double* lp_state, void* out,
+               uint32_t* accepts) {
+    int rc = check_opts(m, o, true);
+    if (rc) return rc;
+    if (!state) return fail(LR_ERR_INVALID, "state is NULL");
+    const bool threaded = rs.kind == lr::KIND_RWMH || rs.kind == lr::KIND_MALA;
+    if (threaded && !lp_state) return fail(LR_ERR_INVALID, "lp_state is required for RWMH/MALA");
+    LR_HIP(hipSetDevice(m->device));
+    Plan pl;
+    rc = make_plan(m, o->n_chains, o->group, o->mode, &pl);
+    if (rc) return rc;
+    if (o->iters == 0) return LR_OK;
+    if (o->on_device) return do_chain(m, pl, (hipStream_t)o->stream, rs, o, state, threaded ? lp_state : nullptr, out, accepts);
+
+    const size_t es = m->esize();
+    const size_t sbytes = (size_t)o->n_chains * m->p * es;
+    const size_t obytes = out ? (size_t)o->iters * o->n_chains * m->p * es : 0;
+    DevBuf ds, dl, dout, dacc;
+    if (ds.alloc(sbytes) || dl.alloc(o->n_chains * sizeof(double)) || dout.alloc(obytes) ||
+        dacc.alloc(o->n_chains * sizeof(uint32_t)))
+        return fail(LR_ERR_NOMEM, "device allocation failed (%zu bytes of samples)", obytes);
+    LR_HIP(hipMemcpy(ds.p, state, sbytes, hipMemcpyHostToDevice));
+    if (threaded) LR_HIP(hipMemcpy(dl.p, lp_state, o->n_chains * sizeof(double), hipMemcpyHostToDevice));
+    if (accepts) LR_HIP(hipMemcpy(dacc.p, accepts, o->n_chains * sizeof(uint32_t), hipMemcpyHostToDevice));
+    rc = do_chain(m, pl, nullptr, rs, o, ds.p, threaded ? (double*)dl.p : nullptr, out ? dout.p : nullptr,
+                  accepts ? (uint32_t*)dacc.p : nullptr);
+    if (rc) return rc;
+    LR_HIP(hipDeviceSynchronize());
+    LR_HIP(hipMemcpy(state, ds.p, sbytes, hipMemcpyDeviceToHost));
+    if (threaded) LR_HIP(hipMemcpy(lp_state, dl.p, o->n_chains * sizeof(double), hipMemcpyDeviceToHost));
+    if (out) LR_HIP(hipMemcpy(out, dout.p, obytes, hipMemcpyDeviceToHost));
+    if (accepts) LR_HIP(hipMemcpy(accepts, dacc.p, o->n_chains * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return LR_OK;
+}
+
+int positive_vec(const char* name, const double* v, int p) {
+    if (!v) return fail(LR_ERR_INVALID, "%s is NULL", name);
+    for (int j = 0; j < p; ++j)
+        if (!(v[j] > 0) || !std::isfinite(v[j])) return fail(LR_ERR_INVALID, "%s[%d] must be finite and > 0", name, j);
+    return LR_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* lr_last_error(void) { return g_err; }
+
+int lr_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int lr_device_cus(int device) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return fail(LR_ERR_HIP, "hipGetDeviceProperties failed");
+    return prop.multiProcessorCount;
+}
+
+int lr_model_create(const double* X, const double* y, int64_t n, int32_t p, const double* prior_sd, int32_t dtype,
+                    int32_t device, lr_model** out) {
+    if (!X || !y || !prior_sd || !out) return fail(LR_ERR_INVALID, "NULL argument");
+    if (n <= 0 || p <= 0) return fail(LR_ERR_INVALID, "n and p must be positive");
+    if (p > kMaxP) return fail(LR_ERR_UNSUPPORTED, "p=%d > %d: the wide-p (MFMA) path is not built yet", p, kMaxP);
+    if (dtype != LR_F32 && dtype != LR_F64) return fail(LR_ERR_INVALID, "dtype must be LR_F32 or LR_F64");
+    int rc = positive_vec("prior_sd", prior_sd, p);
+    if (rc) return rc;
+    for (int64_t i = 0; i < n; ++i)
+        if (y[i] != 0.0 && y[i] != 1.0) return fail(LR_ERR_INVALID, "y[%lld]=%g is not 0/1", (long long)i, y[i]);
+    int ndev = 0;
+    LR_HIP(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(LR_ERR_HIP, "device %d not available (%d visible)", device, ndev);
+    LR_HIP(hipSetDevice(device));
+
+    lr_model* m = new lr_model();
+    m->device = device;
+    m->dtype = dtype;
+    m->n = n;
+    m->p = p;
+    m->P = p <= 4 ? 4 : p <= 8 ? 8 : p <= 16 ? 16 : 32;
+    m->table = find_table(dtype, m->P);
+    if (!m->table) { delete m; return fail(LR_ERR_UNSUPPORTED, "no kernels for dtype=%d padded p=%d", dtype, m->P); }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) m->cus = prop.multiProcessorCount;
+    m->lprior_const = 0;
+    for (int j = 0; j < kMaxP; ++j) m->inv_var[j] = 0;
+    for (int j = 0; j < p; ++j) {
+        m->inv_var[j] = 1.0 / (prior_sd[j] * prior_sd[j]);
+        m->lprior_const += -std::log(prior_sd[j]) - 0.91893853320467274178;
+    }
+    // signed rows  xs_i = (2 y_i - 1) x_i, zero-padded to P columns, in the compute dtype
+    const size_t elems = (size_t)n * m->P;
+    std::vector<unsigned char> host(elems * m->esize());
+    for (int64_t i = 0; i < n; ++i) {
+        const double s = 2.0 * y[i] - 1.0;
+        for (int j = 0; j < m->P; ++j) {
+            const double v = j < p ? s * X[i * p + j] : 0.0;
+            if (!std::isfinite(v)) { delete m; return fail(LR_ERR_INVALID, "X[%lld,%d] is not finite", (long long)i, j); }
+            if (dtype == LR_F32) reinterpret_cast<float*>(host.data())[i * m->P + j] = (float)v;
+            else reinterpret_cast<double*>(host.data())[i * m->P + j] = v;
+        }
+    }
+    if (hipMalloc(&m->d_rows, host.size()) != hipSuccess) { delete m; return fail(LR_ERR_NOMEM, "hipMalloc rows failed"); }
+    if (hipMemcpy(m->d_rows, host.data(), host.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(m->d_rows);
+        delete m;
+        return fail(LR_ERR_HIP, "hipMemcpy rows failed");
+    }
+    *out = m;
+    return LR_OK;
+}
+
+void lr_model_destroy(lr_model* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    if (m->d_rows) (void)hipFree(m->d_rows);
+    delete m;
+}
+
+int lr_model_info(const lr_model* m, int64_t* n, int32_t* p, int32_t* dtype, int32_t* device, int32_t* padded_p) {
+    if (!m) return fail(LR_ERR_INVALID, "model is NULL");
+    if (n) *n = m->n;
+    if (p) *p = m->p;
+    if (dtype) *dtype = m->dtype;
+    if (device) *device = m->device;
+    if (padded_p) *padded_p = m->P;
+    return LR_OK;
+}
+
+int lr_plan(const lr_model* m, int64_t n_chains, int32_t group, int32_t mode, int32_t* mode_out, int32_t* group_out,
+            int32_t* rows_out) {
+    if (!m) return fail(LR_ERR_INVALID, "model is NULL");
+    Plan pl;
+    const int rc = make_plan(m, n_chains, group, mode, &pl);
+    if (rc) return rc;
+    if (mode_out) *mode_out = pl.mode;
+    if (group_out) *group_out = pl.G;
+    if (rows_out) *rows_out = pl.R;
+    return LR_OK;
+}
+
+int lr_eval(lr_model* m, const void* beta, void* ll, void* lprior, void* lpost, void* grad, const lr_run_opts* o) {
+    int rc = check_opts(m, o, false);
+    if (rc) return rc;
+    if (!beta) return fail(LR_ERR_INVALID, "beta is NULL");
+    LR_HIP(hipSetDevice(m->device));
+    Plan pl;
+    rc = make_plan(m, o->n_chains, o->group, o->mode, &pl);
+    if (rc) return rc;
+    const int64_t C = o->n_chains;
+    if (o->on_device) return do_eval(m, pl, (hipStream_t)o->stream, C, beta, ll, lprior, lpost, grad);
+    const size_t es = m->esize();
+    DevBuf db, dll, dlpr, dlpo, dg;
+    if (db.alloc(C * m->p * es) || dll.alloc(C * es) || dlpr.alloc(C * es) || dlpo.alloc(C * es) || dg.alloc(C * m->p * es))
+        return fail(LR_ERR_NOMEM, "device allocation failed");
+    LR_HIP(hipMemcpy(db.p, beta, C * m->p * es, hipMemcpyHostToDevice));
+    rc = do_eval(m, pl, nullptr, C, db.p, ll ? dll.p : nullptr, lprior ? dlpr.p : nullptr, lpost ? dlpo.p : nullptr,
+                 grad ? dg.p : nullptr);
+    if (rc) return rc;
+    LR_HIP(hipDeviceSynchronize());
+    if (ll) LR_HIP(hipMemcpy(ll, dll.p, C * es, hipMemcpyDeviceToHost));
+    if (lprior) LR_HIP(hipMemcpy(lprior, dlpr.p, C * es, hipMemcpyDeviceToHost));
+    if (lpost) LR_HIP(hipMemcpy(lpost, dlpo.p, C * es, hipMemcpyDeviceToHost));
+    if (grad) LR_HIP(hipMemcpy(grad, dg.p, C * m->p * es, hipMemcpyDeviceToHost));
+    return LR_OK;
+}
+
+int lr_run_rwmh(lr_model* m, void* state, double* lp_state, const double* prop_sd, const lr_run_opts* o, void* out,
+                uint32_t* accepts) {
+    if (!m) return fail(LR_ERR_INVALID, "model is NULL");
+    if (!prop_sd) return fail(LR_ERR_INVALID, "prop_sd is NULL");
+    RunSpec rs{};
+    rs.kind = lr::KIND_RWMH;
+    for (int j = 0; j < m->p; ++j) {
+        if (!(prop_sd[j] >= 0) || !std::isfinite(prop_sd[j])) return fail(LR_ERR_INVALID, "prop_sd[%d] must be finite and >= 0", j);
+        rs.a[j] = prop_sd[j];
+    }
+    return run_common(m, rs, o, state, lp_state, out, accepts);
+}
+
+static int langevin_spec(lr_model* m, int kind, double dt, const double* pre, RunSpec* rs) {
+    if (!m) return fail(LR_ERR_INVALID, "model is NULL");
+    if (!(dt > 0) || !std::isfinite(dt)) return fail(LR_ERR_INVALID, "dt must be finite and > 0");
+    const int rc = positive_vec("pre", pre, m->p);
+    if (rc) return rc;
+    rs->kind = kind;
+    rs->step = dt;
+    for (int j = 0; j < m->p; ++j) {
+        rs->a[j] = 0.5 * pre[j] * dt;
+        rs->b[j] = std::sqrt(pre[j]) * std::sqrt(dt);
+        rs->c[j] = 1.0 / (rs->b[j] * rs->b[j]);
+    }
+    return LR_OK;
+}
+
+int lr_run_mala(lr_model* m, void* state, double* lp_state, double dt, const double* pre, const lr_run_opts* o, void* out,
+                uint32_t* accepts) {
+    RunSpec rs{};
+    const int rc = langevin_spec(m, lr::KIND_MALA, dt, pre, &rs);
+    if (rc) return rc;
+    return run_common(m, rs, o, state, lp_state, out, accepts);
+}
+
+int lr_run_ul(lr_model* m, void* state, double dt, const double* pre, const lr_run_opts* o, void* out, uint32_t* accepts) {
+    RunSpec rs{};
+    const int rc = langevin_spec(m, lr::KIND_UL, dt, pre, &rs);
+    if (rc) return rc;
+    return run_common(m, rs, o, state, nullptr, out, accepts);
+}
+
+int lr_run_hmc(lr_model* m, void* state, double eps, int32_t l, const double* dmm, const lr_run_opts* o, void* out,
+               uint32_t* accepts) {
+    if (!m) return fail(LR_ERR_INVALID, "model is NULL");
+    if (!(eps > 0) || !std::isfinite(eps)) return fail(LR_ERR_INVALID, "eps must be finite and > 0");
+    if (l < 1) return fail(LR_ERR_INVALID, "l must be >= 1");
+    const int rc = positive_vec("dmm", dmm, m->p);
+    if (rc) return rc;
+    RunSpec rs{};
+    rs.kind = lr::KIND_HMC;
+    rs.step = eps;
+    rs.l = l;
+    for (int j = 0; j < m->p; ++j) {
+        rs.a[j] = std::sqrt(dmm[j]);
+        rs.b[j] = eps / dmm[j];
+        rs.c[j] = 1.0 / dmm[j];
+    }
+    return run_common(m, rs, o, state, nullptr, out, accepts);
+}
+
+// ---- device memory / stream / event helpers -------------------------------------------------------
+int lr_malloc(int device, uint64_t bytes, void** dptr) {
+    if (!dptr) return fail(LR_ERR_INVALID, "dptr is NULL");
+    LR_HIP(hipSetDevice(device));
+    if (hipMalloc(dptr, bytes ? bytes : 1) != hipSuccess) return fail(LR_ERR_NOMEM, "hipMalloc(%llu) failed", (unsigned long long)bytes);
+    return LR_OK;
+}
+int lr_free(int device, void* dptr) {
+    LR_HIP(hipSetDevice(device));
+    LR_HIP(hipFree(dptr));
+    return LR_OK;
+}
+int lr_memcpy_h2d(int device, void* dst, const void* src, uint64_t bytes, void* stream) {
+    LR_HIP(hipSetDevice(device));
+    LR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    LR_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return LR_OK;
+}
+int lr_memcpy_d2h(int device, void* dst, const void* src, uint64_t bytes, void* stream) {
+    LR_HIP(hipSetDevice(device));
+    LR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    LR_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return LR_OK;
+}
+int lr_memset(int device, void* dst, int value, uint64_t bytes, void* stream) {
+    LR_HIP(hipSetDevice(device));
+    LR_HIP(hipMemsetAsync(dst, value, bytes, (hipStream_t)stream));
+    return LR_OK;
+}
+int lr_stream_create(int device, void** stream) {
+    if (!stream) return fail(LR_ERR_INVALID, "stream is NULL");
+    LR_HIP(hipSetDevice(device));
+    hipStream_t s;
+    LR_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = s;
+    return LR_OK;
+}
+int lr_stream_destroy(int device, void* stream) {
+    LR_HIP(hipSetDevice(device));
+    LR_HIP(hipStreamDestroy((hipStream_t)stream));
+    return LR_OK;
+}
+int lr_stream_sync(int device, void* stream) {
+    LR_HIP(hipSetDevice(device));
+    LR_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return LR_OK;
+}
+int lr_event_create(int device, void** event) {
+    if (!event) return fail(LR_ERR_INVALID, "event is NULL");
+    LR_HIP(hipSetDevice(device));
+    hipEvent_t e;
+    LR_HIP(hipEventCreate(&e));
+    *event = e;
+    return LR_OK;
+}
+int lr_event_destroy(int device, void* event) {
+    LR_HIP(hipSetDevice(device));
+    LR_HIP(hipEventDestroy((hipEvent_t)event));
+    return LR_OK;
+}
+int lr_event_record(int device, void* event, void* stream) {
+    LR_HIP(hipSetDevice(device));
+    LR_HIP(hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
+    return LR_OK;
+}
+int lr_event_elapsed_ms(int device, void* start, void* stop, float* ms) {
+    if (!ms) return fail(LR_ERR_INVALID, "ms is NULL");
+    LR_HIP(hipSetDevice(device));
+    LR_HIP(hipEventSynchronize((hipEvent_t)stop));
+    LR_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return LR_OK;
+}
+
+}  // extern "C"

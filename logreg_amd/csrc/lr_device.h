@@ -1,0 +1,254 @@
+// lr_device.h -- device-side building blocks of the fused many-chain MCMC kernels (gfx950 only).
+//
+// Mapping ("group per chain"): a chain is owned by G consecutive lanes of one wavefront
+// (G in {1,2,4,8,16,32,64}); the n data rows are dealt round-robin to the G lanes; every lane of
+// the group carries an identical copy of the chain state (q, p, gradient, log-density) in
+// registers.  One log-posterior evaluation is: each lane accumulates value/gradient partials
+// over its rows, then a butterfly ALL-reduce inside the group (DPP row_mirror / row_half_mirror
+// / quad_perm inside a 16-lane row, v_permlane16_swap / v_permlane32_swap across rows) leaves
+// bit-identical sums in every lane, so accept/reject decisions never diverge inside a group.
+// G = 64 is "one wavefront per chain"; G = 1 is "one lane per chain".
+//
+// Rows are the SIGNED design rows  xs_i = (2 y_i - 1) * x_i : with t_i = xs_i . beta,
+//     ll(beta)      = sum_i log sigma(t_i)              (== reference fit-np-hmc.py:23-24)
+//     grad ll(beta) = sum_i sigma(-t_i) * xs_i          (== X^T (y - sigma(X beta)), fit-np-hmc.py:46)
+// so y never has to be read in the hot loop and one pass over a row yields value and gradient.
+//
+// Row residency policies (template parameter `Rows`):
+//     RegRows    -- the lane's rows live in VGPRs for the whole launch (Pima-scale n)
+//     LdsRows    -- all rows staged once in LDS, lanes stride over them
+//     GlobalRows -- rows streamed from global memory / L2 (tall data)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lr {
+
+// ------------------------------------------------------------------------------------------
+// Philox4x32-10 counter-based generator (Salmon et al. SC'11).  Stream layout:
+// key = (seed_lo, seed_hi); counter = (chain, iter_lo, iter_hi, block | tag).
+// Normal j of an iteration comes from block j/4: Box-Muller pairs (w0,w1)->(z0,z1),
+// (w2,w3)->(z2,z3).  The accept uniform is word 0 of block tag 0x80000000.
+// 24-bit uniforms u = ((w >> 8) + 0.5) * 2^-24 are exact in fp32 and fp64.
+// ------------------------------------------------------------------------------------------
+struct U4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                            uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return U4{c0, c1, c2, c3};
+}
+
+constexpr uint32_t TAG_UNIFORM = 0x80000000u;
+
+template <typename T> __device__ __forceinline__ T u01(uint32_t w) {
+    return (T(w >> 8) + T(0.5)) * T(1.0 / 16777216.0);
+}
+
+__device__ __forceinline__ void box_muller(uint32_t wa, uint32_t wb, float& z0, float& z1) {
+    const float r = sqrtf(-2.0f * logf(u01<float>(wa)));
+    float s, c;
+    sincospif(2.0f * u01<float>(wb), &s, &c);
+    z0 = r * c;
+    z1 = r * s;
+}
+__device__ __forceinline__ void box_muller(uint32_t wa, uint32_t wb, double& z0, double& z1) {
+    const double r = sqrt(-2.0 * log(u01<double>(wa)));
+    double s, c;
+    sincospi(2.0 * u01<double>(wb), &s, &c);
+    z0 = r * c;
+    z1 = r * s;
+}
+
+// z[0..P) standard normals for (seed, chain, iter).  P is the padded width; padded entries are
+// generated but always multiplied by a zero scale by the callers.
+template <typename T, int P>
+__device__ __forceinline__ void draw_normals(uint64_t seed, uint64_t chain, uint64_t iter, T (&z)[P]) {
+#pragma unroll
+    for (int b = 0; 4 * b < P; ++b) {
+        const U4 w = philox4x32_10((uint32_t)chain, (uint32_t)iter, (uint32_t)(iter >> 32), (uint32_t)b,
+                                   (uint32_t)seed, (uint32_t)(seed >> 32));
+        T a0, a1, a2, a3;
+        box_muller(w.x, w.y, a0, a1);
+        box_muller(w.z, w.w, a2, a3);
+        if (4 * b + 0 < P) z[4 * b + 0] = a0;
+        if (4 * b + 1 < P) z[4 * b + 1] = a1;
+        if (4 * b + 2 < P) z[4 * b + 2] = a2;
+        if (4 * b + 3 < P) z[4 * b + 3] = a3;
+    }
+}
+
+// log(u) of the accept uniform for (seed, chain, iter)
+template <typename T>
+__device__ __forceinline__ T draw_log_uniform(uint64_t seed, uint64_t chain, uint64_t iter) {
+    const U4 w = philox4x32_10((uint32_t)chain, (uint32_t)iter, (uint32_t)(iter >> 32), TAG_UNIFORM,
+                               (uint32_t)seed, (uint32_t)(seed >> 32));
+    if constexpr (sizeof(T) == 4) return logf(u01<float>(w.x));
+    else return log(u01<double>(w.x));
+}
+
+// ------------------------------------------------------------------------------------------
+// group all-reduce (sum) over G consecutive lanes; result bit-identical in all G lanes.
+// ------------------------------------------------------------------------------------------
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL> __device__ __forceinline__ double dpp_mov(double v) {
+    const uint64_t b = __builtin_bit_cast(uint64_t, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), CTRL, 0xF, 0xF, true);
+    return __builtin_bit_cast(double, ((uint64_t)(uint32_t)hi << 32) | (uint64_t)(uint32_t)lo);
+}
+
+// x-row exchange via v_permlane{16,32}_swap (gfx950).  ROCm 7.2's clang builtin for these
+// returns element 0 twice, so they are issued as inline asm; the s_nop covers the
+// VALU-write -> permlane-read hazard hipcc does not pad inside an asm statement.
+__device__ __forceinline__ float swap16_sum(float v) {
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 0" : "+v"(a), "+v"(b));
+    return a + b;
+}
+__device__ __forceinline__ float swap32_sum(float v) {
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 0" : "+v"(a), "+v"(b));
+    return a + b;
+}
+__device__ __forceinline__ double swap16_sum(double v) {
+    const uint64_t bits = __builtin_bit_cast(uint64_t, v);
+    uint32_t al = (uint32_t)bits, bl = al, ah = (uint32_t)(bits >> 32), bh = ah;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 0"
+                 : "+v"(al), "+v"(bl), "+v"(ah), "+v"(bh));
+    return __builtin_bit_cast(double, ((uint64_t)ah << 32) | al) + __builtin_bit_cast(double, ((uint64_t)bh << 32) | bl);
+}
+__device__ __forceinline__ double swap32_sum(double v) {
+    const uint64_t bits = __builtin_bit_cast(uint64_t, v);
+    uint32_t al = (uint32_t)bits, bl = al, ah = (uint32_t)(bits >> 32), bh = ah;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\ts_nop 0"
+                 : "+v"(al), "+v"(bl), "+v"(ah), "+v"(bh));
+    return __builtin_bit_cast(double, ((uint64_t)ah << 32) | al) + __builtin_bit_cast(double, ((uint64_t)bh << 32) | bl);
+}
+
+template <int G, typename T> __device__ __forceinline__ T group_sum(T v) {
+    static_assert(G == 1 || G == 2 || G == 4 || G == 8 || G == 16 || G == 32 || G == 64, "bad group");
+    if constexpr (G >= 16) v += dpp_mov<0x140>(v);  // row_mirror       : lane i <-> 15-i
+    if constexpr (G >= 8) v += dpp_mov<0x141>(v);   // row_half_mirror  : lane i <-> 7-i (within 8)
+    if constexpr (G >= 4) v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+    if constexpr (G >= 2) v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+    if constexpr (G >= 32) v = swap16_sum(v);       // rows 0<->1, 2<->3
+    if constexpr (G >= 64) v = swap32_sum(v);       // halves
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// fast scalar math for the hot loop
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+__device__ __forceinline__ double fast_exp(double x) { return exp(x); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ double fast_rcp(double x) { return 1.0 / x; }
+// log(1 + e) for e in [0, 1]
+__device__ __forceinline__ float log1p_unit(float e) { return __builtin_amdgcn_logf(1.0f + e) * 0.693147180559945309f; }
+__device__ __forceinline__ double log1p_unit(double e) { return log1p(e); }
+
+// one signed row: accumulate sigma(-t) * xs into g[], and (VALUE) log sigma(t) into v
+template <typename T, int P, bool VALUE, bool GRAD>
+__device__ __forceinline__ void row_term(const T (&xs)[P], const T (&beta)[P], T (&g)[P], T& v) {
+    T t = xs[0] * beta[0];
+#pragma unroll
+    for (int j = 1; j < P; ++j) t = fma_t(xs[j], beta[j], t);
+    if constexpr (GRAD) {
+        const T w = fast_rcp(T(1) + fast_exp(t));  // sigma(-t); exp overflow -> rcp(inf) = 0
+#pragma unroll
+        for (int j = 0; j < P; ++j) g[j] = fma_t(w, xs[j], g[j]);
+    }
+    if constexpr (VALUE) {
+        // log sigma(t) = min(t,0) - log1p(exp(-|t|))  (stable for both signs)
+        const T at = t < T(0) ? -t : t;
+        v += (t < T(0) ? t : T(0)) - log1p_unit(fast_exp(-at));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// row residency policies.  for_each(f) calls f(xs[P]) for every row owned by this lane.
+// ------------------------------------------------------------------------------------------
+template <typename T, int P, int R, int G> struct RegRows {
+    T x[R][P];
+    int pad_rows;  // zero rows held by this lane (each contributes log sigma(0) = -log 2 to the value)
+    __device__ __forceinline__ void load(const T* __restrict__ rows, int64_t n, int gl) {
+        pad_rows = 0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int64_t i = gl + (int64_t)k * G;
+            if (i < n) {
+#pragma unroll
+                for (int j = 0; j < P; ++j) x[k][j] = rows[i * P + j];
+            } else {
+                ++pad_rows;
+#pragma unroll
+                for (int j = 0; j < P; ++j) x[k][j] = T(0);
+            }
+        }
+    }
+    template <class F> __device__ __forceinline__ void for_each(F&& f) const {
+#pragma unroll
+        for (int k = 0; k < R; ++k) f(x[k]);
+    }
+    __device__ __forceinline__ T value_fixup() const { return T(pad_rows) * T(0.693147180559945309); }
+};
+
+template <typename T, int P, int G> struct StridedRows {  // LDS or global: same access code
+    const T* base;  // row-major [n][P]
+    int64_t n;
+    int gl;
+    template <class F> __device__ __forceinline__ void for_each(F&& f) const {
+        for (int64_t i = gl; i < n; i += G) {
+            T xs[P];
+#pragma unroll
+            for (int j = 0; j < P; ++j) xs[j] = base[i * P + j];
+            f(xs);
+        }
+    }
+    __device__ __forceinline__ T value_fixup() const { return T(0); }
+};
+
+// ------------------------------------------------------------------------------------------
+// log-posterior value / gradient of one chain, cooperatively over the G lanes of its group.
+//   value = ll + lprior (double), grad = d/dbeta (T), both replicated in all lanes of the group.
+// ------------------------------------------------------------------------------------------
+template <typename T, int P> struct Prior {
+    T inv_var[P];         // 1/sd^2 ; 0 for padded coordinates
+    double lprior_const;  // sum_j ( -log sd_j - 0.5 log 2 pi ) over the real coordinates
+};
+
+template <typename T, int P, int G, bool VALUE, bool GRAD, class Rows>
+__device__ __forceinline__ void eval_lpost(const Rows& rows, const Prior<T, P>& pr, const T (&beta)[P], T (&grad)[P],
+                                           double& ll, double& lprior) {
+    T g[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) g[j] = T(0);
+    T v = T(0);
+    rows.for_each([&](const T(&xs)[P]) { row_term<T, P, VALUE, GRAD>(xs, beta, g, v); });
+    if constexpr (GRAD) {
+#pragma unroll
+        for (int j = 0; j < P; ++j) grad[j] = group_sum<G>(g[j]) - beta[j] * pr.inv_var[j];
+    }
+    if constexpr (VALUE) {
+        ll = group_sum<G>((double)(v + rows.value_fixup()));
+        T quad = T(0);
+#pragma unroll
+        for (int j = 0; j < P; ++j) quad = fma_t(beta[j] * beta[j], pr.inv_var[j], quad);
+        lprior = pr.lprior_const - 0.5 * (double)quad;
+    }
+}
+
+}  // namespace lr

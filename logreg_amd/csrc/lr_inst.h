@@ -1,0 +1,28 @@
+// lr_inst.h -- type-erased launch interface between the C-ABI translation unit (lr_api.hip) and
+// the per-(dtype, padded p) kernel instantiation units (lr_inst.hip compiled once per pair).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lr {
+
+struct LaunchCfg {
+    int mode, G, R, kind;
+    hipStream_t stream;
+    size_t lds_bytes;
+};
+
+struct Variant { int mode, G, R; };
+
+struct InstTable {
+    int dtype;  // LR_F32 / LR_F64
+    int P;      // padded parameter width
+    int nvariants;
+    const Variant* variants;
+    int (*launch_eval)(const LaunchCfg*, int64_t C, const void* model_args, const void* eval_args);
+    int (*launch_chain)(const LaunchCfg*, int64_t C, const void* model_args, const void* chain_args);
+};
+
+}  // namespace lr
+
+#define LR_DECLARE_INST(sfx) extern "C" const lr::InstTable* lr_inst_table_##sfx();

@@ -1,0 +1,98 @@
+// lr_inst.hip -- instantiates the kernels for ONE (dtype, padded p) pair.
+// Compiled several times:  hipcc -DLR_T=float -DLR_P=8 -DLR_SFX=f32_p8 -DLR_DTYPE=0 ...
+#include "lr_inst.h"
+#include "lr_kernels.h"
+
+#ifndef LR_T
+#error "compile with -DLR_T=<float|double> -DLR_P=<4|8|16|32> -DLR_SFX=<suffix> -DLR_DTYPE=<0|1>"
+#endif
+
+namespace lr {
+namespace {
+
+using T = LR_T;
+constexpr int P = LR_P;
+
+// Variant table: X(mode, lanes-per-chain G, rows-per-lane R).  REG variants keep R*P <= 128
+// VGPRs of data per lane; exact R for Pima's n = 200 (G*R >= 200: 64x4, 32x7, 16x13) plus
+// power-of-two fallbacks.
+#if LR_DTYPE == 0 && LR_P == 8
+#define LR_VARIANTS(X)                                                                                \
+    X(MODE_REG, 64, 4) X(MODE_REG, 32, 7) X(MODE_REG, 32, 8) X(MODE_REG, 16, 13) X(MODE_REG, 16, 16) \
+    X(MODE_LDS, 1, 0) X(MODE_LDS, 8, 0) X(MODE_LDS, 64, 0) X(MODE_GLOBAL, 64, 0)
+#elif LR_DTYPE == 0 && LR_P == 4
+#define LR_VARIANTS(X) \
+    X(MODE_REG, 64, 8) X(MODE_REG, 16, 16) X(MODE_LDS, 1, 0) X(MODE_LDS, 8, 0) X(MODE_LDS, 64, 0) X(MODE_GLOBAL, 64, 0)
+#elif LR_DTYPE == 0 && LR_P == 16
+#define LR_VARIANTS(X) X(MODE_REG, 64, 8) X(MODE_LDS, 1, 0) X(MODE_LDS, 8, 0) X(MODE_LDS, 64, 0) X(MODE_GLOBAL, 64, 0)
+#elif LR_DTYPE == 0 && LR_P == 32
+#define LR_VARIANTS(X) X(MODE_REG, 64, 4) X(MODE_LDS, 8, 0) X(MODE_LDS, 64, 0) X(MODE_GLOBAL, 64, 0)
+#else  // float64: validation-grade path, no register-resident variants
+#define LR_VARIANTS(X) X(MODE_LDS, 1, 0) X(MODE_LDS, 8, 0) X(MODE_LDS, 64, 0) X(MODE_GLOBAL, 64, 0)
+#endif
+
+#define LR_VARIANT_ROW(M_, G_, R_) {M_, G_, R_},
+const Variant kVariants[] = {LR_VARIANTS(LR_VARIANT_ROW)};
+
+inline int check(hipError_t e) { return e == hipSuccess ? 0 : -2; }
+
+inline dim3 grid_for(int64_t C, int G) {
+    const int64_t lanes = C * G;
+    return dim3((unsigned)((lanes + 255) / 256));
+}
+
+template <int G, int MODE, int R>
+int launch_eval_v(const LaunchCfg* cfg, int64_t C, const ModelArgs<T, P>& m, const EvalArgs<T>& a) {
+    hipLaunchKernelGGL((k_eval<T, P, G, MODE, R>), grid_for(C, G), dim3(256), cfg->lds_bytes, cfg->stream, m, a);
+    return check(hipGetLastError());
+}
+
+template <int G, int MODE, int R>
+int launch_chain_v(const LaunchCfg* cfg, int64_t C, const ModelArgs<T, P>& m, const ChainArgs<T, P>& a) {
+    const dim3 grid = grid_for(C, G), block(256);
+    switch (cfg->kind) {
+    case KIND_RWMH:
+        hipLaunchKernelGGL((k_chain<T, P, G, MODE, R, KIND_RWMH>), grid, block, cfg->lds_bytes, cfg->stream, m, a);
+        break;
+    case KIND_MALA:
+        hipLaunchKernelGGL((k_chain<T, P, G, MODE, R, KIND_MALA>), grid, block, cfg->lds_bytes, cfg->stream, m, a);
+        break;
+    case KIND_HMC:
+        hipLaunchKernelGGL((k_chain<T, P, G, MODE, R, KIND_HMC>), grid, block, cfg->lds_bytes, cfg->stream, m, a);
+        break;
+    case KIND_UL:
+        hipLaunchKernelGGL((k_chain<T, P, G, MODE, R, KIND_UL>), grid, block, cfg->lds_bytes, cfg->stream, m, a);
+        break;
+    default:
+        return -1;
+    }
+    return check(hipGetLastError());
+}
+
+int launch_eval(const LaunchCfg* cfg, int64_t C, const void* model_args, const void* eval_args) {
+    const auto& m = *static_cast<const ModelArgs<T, P>*>(model_args);
+    const auto& a = *static_cast<const EvalArgs<T>*>(eval_args);
+#define LR_DISPATCH_EVAL(M_, G_, R_) \
+    if (cfg->mode == M_ && cfg->G == G_ && cfg->R == R_) return launch_eval_v<G_, M_, R_>(cfg, C, m, a);
+    LR_VARIANTS(LR_DISPATCH_EVAL)
+    return -3;
+}
+
+int launch_chain(const LaunchCfg* cfg, int64_t C, const void* model_args, const void* chain_args) {
+    const auto& m = *static_cast<const ModelArgs<T, P>*>(model_args);
+    const auto& a = *static_cast<const ChainArgs<T, P>*>(chain_args);
+#define LR_DISPATCH_CHAIN(M_, G_, R_) \
+    if (cfg->mode == M_ && cfg->G == G_ && cfg->R == R_) return launch_chain_v<G_, M_, R_>(cfg, C, m, a);
+    LR_VARIANTS(LR_DISPATCH_CHAIN)
+    return -3;
+}
+
+const InstTable kTable = {LR_DTYPE, P, (int)(sizeof(kVariants) / sizeof(kVariants[0])), kVariants, &launch_eval,
+                          &launch_chain};
+
+}  // namespace
+}  // namespace lr
+
+#define LR_CAT2(a, b) a##b
+#define LR_CAT(a, b) LR_CAT2(a, b)
+extern "C" const lr::InstTable* LR_CAT(lr_inst_table_, LR_SFX)() { return &lr::kTable; }

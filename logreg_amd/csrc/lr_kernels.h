@@ -1,0 +1,245 @@
+// lr_kernels.h -- the fused many-chain kernels: one launch runs `iters x thin` MCMC iterations
+// for every chain and writes only the thinned states (the whole of the reference's mcmc() double
+// loop, Python/fit-np-hmc.py:89-103, lives inside the kernel).
+#pragma once
+#include "lr_device.h"
+
+namespace lr {
+
+enum Kind { KIND_RWMH = 0, KIND_MALA = 1, KIND_HMC = 2, KIND_UL = 3 };
+enum Mode { MODE_REG = 0, MODE_LDS = 1, MODE_GLOBAL = 2 };
+
+template <typename T, int P> struct ModelArgs {
+    const T* rows;  // [n][P] signed rows (2y-1)*x, zero-padded to P columns (device)
+    int64_t n;
+    Prior<T, P> prior;
+};
+
+template <typename T> struct EvalArgs {
+    const T* beta;  // [C][p]
+    int64_t C;
+    int p;  // real parameter count (<= P)
+    T* ll;  // [C] each, any may be null
+    T* lprior;
+    T* lpost;
+    T* grad;  // [C][p]
+};
+
+// kind-specific vectors, precomputed on the host in double (zero in padded coordinates):
+//   RWMH : a = proposal sd                                   (0.02*pre, fit-numpy.py:83-84)
+//   MALA : a = 0.5*pre*dt, b = sqrt(pre*dt), c = 1/(pre*dt)  (fit-np-mala.py:72-78)
+//   UL   : a = 0.5*pre*dt, b = sqrt(pre*dt)                  (fit-np-ul.py:61-68)
+//   HMC  : a = sqrt(dmm),  b = eps/dmm,      c = 1/dmm       (fit-np-hmc.py:65-87)
+template <typename T, int P> struct ChainArgs {
+    T* state;           // [C][p] in/out
+    double* lp_state;   // [C] threaded log-density of RWMH/MALA (in/out, -inf allowed); null for HMC/UL
+    T* out;             // [iters][C][p] or null
+    uint32_t* accepts;  // [C], incremented; or null
+    int64_t C;
+    int64_t chain_offset;  // global id of local chain 0 (Philox counter)
+    int64_t iters, thin;
+    int64_t iter_offset;  // global index of this launch's first iteration (Philox counter)
+    uint64_t seed;
+    int p;
+    int l;   // HMC leapfrog steps
+    T step;  // HMC eps
+    T a[P], b[P], c[P];
+};
+
+// --------------------------------------------------------------------------------------------
+template <typename T, int P, int G, int MODE, int R> struct RowsOf {
+    using type = StridedRows<T, P, G>;
+};
+template <typename T, int P, int G, int R> struct RowsOf<T, P, G, MODE_REG, R> {
+    using type = RegRows<T, P, R, G>;
+};
+
+template <typename T, int P, int G, int MODE, int R>
+__device__ __forceinline__ typename RowsOf<T, P, G, MODE, R>::type make_rows(const ModelArgs<T, P>& m, int gl,
+                                                                             T* smem) {
+    typename RowsOf<T, P, G, MODE, R>::type rows;
+    if constexpr (MODE == MODE_REG) {
+        rows.load(m.rows, m.n, gl);
+    } else if constexpr (MODE == MODE_LDS) {
+        // stage all rows once; coalesced copy by the whole workgroup
+        const int64_t tot = m.n * P;
+        for (int64_t i = threadIdx.x; i < tot; i += blockDim.x) smem[i] = m.rows[i];
+        __syncthreads();
+        rows.base = smem;
+        rows.n = m.n;
+        rows.gl = gl;
+    } else {
+        rows.base = m.rows;
+        rows.n = m.n;
+        rows.gl = gl;
+    }
+    return rows;
+}
+
+// --------------------------------------------------------------------------------------------
+// batched ll / lprior / lpost / glp   (reference fit-np-hmc.py:23-47)
+template <typename T, int P, int G, int MODE, int R>
+__global__ void __launch_bounds__(256) k_eval(ModelArgs<T, P> m, EvalArgs<T> a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int gl = threadIdx.x % G;
+    int64_t chain = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const bool live = chain < a.C;
+    if (!live) chain = a.C - 1;
+    const auto rows = make_rows<T, P, G, MODE, R>(m, gl, reinterpret_cast<T*>(smem_raw));
+    T beta[P], grad[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) beta[j] = j < a.p ? a.beta[chain * a.p + j] : T(0);
+    double ll, lpr;
+    eval_lpost<T, P, G, true, true>(rows, m.prior, beta, grad, ll, lpr);
+    if (live && gl == 0) {
+        if (a.ll) a.ll[chain] = (T)ll;
+        if (a.lprior) a.lprior[chain] = (T)lpr;
+        if (a.lpost) a.lpost[chain] = (T)(ll + lpr);
+        if (a.grad) {
+#pragma unroll
+            for (int j = 0; j < P; ++j)
+                if (j < a.p) a.grad[chain * a.p + j] = grad[j];
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// the chain kernel
+template <typename T, int P, int G, int MODE, int R, int KIND>
+__global__ void __launch_bounds__(256) k_chain(ModelArgs<T, P> m, ChainArgs<T, P> a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int gl = threadIdx.x % G;
+    int64_t chain = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const bool live = chain < a.C;
+    if (!live) chain = a.C - 1;  // whole waves stay converged for the DPP reductions; stores are masked
+    const bool writer = live && gl == 0;
+    const auto rows = make_rows<T, P, G, MODE, R>(m, gl, reinterpret_cast<T*>(smem_raw));
+    const uint64_t gchain = (uint64_t)(a.chain_offset + chain);
+
+    T x[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) x[j] = j < a.p ? a.state[chain * a.p + j] : T(0);
+
+    T g[P];        // gradient at x (MALA / HMC / UL)
+    double lp;     // log-density attached to x: threaded value (RWMH/MALA) or lpost(x) (HMC)
+    uint32_t nacc = 0;
+    {
+        double ll0 = 0, lpr0 = 0;
+        if constexpr (KIND == KIND_HMC) {
+            eval_lpost<T, P, G, true, true>(rows, m.prior, x, g, ll0, lpr0);
+            lp = ll0 + lpr0;
+        } else if constexpr (KIND == KIND_MALA) {
+            eval_lpost<T, P, G, false, true>(rows, m.prior, x, g, ll0, lpr0);
+            lp = a.lp_state[chain];
+        } else if constexpr (KIND == KIND_UL) {
+            eval_lpost<T, P, G, false, true>(rows, m.prior, x, g, ll0, lpr0);
+            lp = 0;
+        } else {
+            lp = a.lp_state[chain];
+        }
+    }
+
+    for (int64_t it = 0; it < a.iters; ++it) {
+        for (int64_t jt = 0; jt < a.thin; ++jt) {
+            const uint64_t iter = (uint64_t)(a.iter_offset + it * a.thin + jt);
+            T z[P];
+            draw_normals<T, P>(a.seed, gchain, iter, z);
+
+            if constexpr (KIND == KIND_UL) {
+                // x <- x + 0.5*pre*dt*glp(x) + sqrt(pre*dt)*z            fit-np-ul.py:65-67
+#pragma unroll
+                for (int j = 0; j < P; ++j) x[j] = fma_t(a.b[j], z[j], fma_t(a.a[j], g[j], x[j]));
+                double d0, d1;
+                eval_lpost<T, P, G, false, true>(rows, m.prior, x, g, d0, d1);
+                ++nacc;
+            } else {
+                const double logu = (double)draw_log_uniform<T>(a.seed, gchain, iter);
+                T xp[P], gp[P];
+                double llp = 0, lprp = 0, logr;
+                if constexpr (KIND == KIND_RWMH) {
+                    // prop = x + sd*z; a = lpost(prop) - ll                  fit-numpy.py:53-62,83-84
+#pragma unroll
+                    for (int j = 0; j < P; ++j) xp[j] = fma_t(a.a[j], z[j], x[j]);
+                    eval_lpost<T, P, G, true, false>(rows, m.prior, xp, gp, llp, lprp);
+                    logr = (llp + lprp) - lp;
+                } else if constexpr (KIND == KIND_MALA) {
+                    // prop = advance(x) + sqrt(pre*dt) z ; advance(x) = x + 0.5*pre*dt*glp(x)
+                    // a = lp' - ll + dprop(x,prop) - dprop(prop,x)           fit-np-mala.py:61-78
+                    T advx[P];
+#pragma unroll
+                    for (int j = 0; j < P; ++j) {
+                        advx[j] = fma_t(a.a[j], g[j], x[j]);
+                        xp[j] = fma_t(a.b[j], z[j], advx[j]);
+                    }
+                    eval_lpost<T, P, G, true, true>(rows, m.prior, xp, gp, llp, lprp);
+                    T dq = T(0);
+#pragma unroll
+                    for (int j = 0; j < P; ++j) {
+                        const T advp = fma_t(a.a[j], gp[j], xp[j]);
+                        const T d1 = x[j] - advp;       // dprop(x, prop): new = x, old = prop
+                        const T d2 = xp[j] - advx[j];   // dprop(prop, x)
+                        dq = fma_t(a.c[j], d1 * d1 - d2 * d2, dq);
+                    }
+                    logr = (llp + lprp) - lp - 0.5 * (double)dq;
+                } else {  // HMC
+                    // p ~ N(0, dmm); leapfrog l steps; a = alpi(prop) - alpi(x)     fit-np-hmc.py:65-87
+                    T pm[P];
+                    T k0 = T(0);
+#pragma unroll
+                    for (int j = 0; j < P; ++j) {
+                        pm[j] = z[j] * a.a[j];
+                        k0 = fma_t(pm[j] * pm[j], a.c[j], k0);
+                        xp[j] = x[j];
+                        gp[j] = g[j];
+                    }
+                    const T heps = T(0.5) * a.step;
+#pragma unroll
+                    for (int j = 0; j < P; ++j) pm[j] = fma_t(heps, gp[j], pm[j]);
+                    for (int i = 0; i < a.l - 1; ++i) {
+#pragma unroll
+                        for (int j = 0; j < P; ++j) xp[j] = fma_t(a.b[j], pm[j], xp[j]);
+                        double d0, d1;
+                        eval_lpost<T, P, G, false, true>(rows, m.prior, xp, gp, d0, d1);
+#pragma unroll
+                        for (int j = 0; j < P; ++j) pm[j] = fma_t(a.step, gp[j], pm[j]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < P; ++j) xp[j] = fma_t(a.b[j], pm[j], xp[j]);
+                    eval_lpost<T, P, G, true, true>(rows, m.prior, xp, gp, llp, lprp);
+                    T k1 = T(0);
+#pragma unroll
+                    for (int j = 0; j < P; ++j) {
+                        pm[j] = fma_t(heps, gp[j], pm[j]);
+                        k1 = fma_t(pm[j] * pm[j], a.c[j], k1);
+                    }
+                    logr = ((llp + lprp) - lp) - 0.5 * ((double)k1 - (double)k0);
+                }
+                const bool acc = logu < logr;  // NaN -> reject, as `np.log(np.random.rand()) < a`
+                if (acc) {
+                    ++nacc;
+                    lp = llp + lprp;
+                }
+#pragma unroll
+                for (int j = 0; j < P; ++j) {
+                    x[j] = acc ? xp[j] : x[j];
+                    if constexpr (KIND != KIND_RWMH) g[j] = acc ? gp[j] : g[j];
+                }
+            }
+        }
+        if (a.out && writer) {
+            T* o = a.out + (it * a.C + chain) * a.p;
+#pragma unroll
+            for (int j = 0; j < P; ++j)
+                if (j < a.p) o[j] = x[j];
+        }
+    }
+    if (writer) {
+#pragma unroll
+        for (int j = 0; j < P; ++j)
+            if (j < a.p) a.state[chain * a.p + j] = x[j];
+        if (a.accepts) a.accepts[chain] += nacc;
+        if constexpr (KIND == KIND_RWMH || KIND == KIND_MALA) a.lp_state[chain] = lp;
+    }
+}
+
+}  // namespace lr

@@ -1,0 +1,344 @@
+"""The reference's kernel constructors and chain driver, with the same names and signatures:
+
+    mhKernel(lpost, rprop, dprop=...)            fit-numpy.py:53-62 / fit-np-mala.py:61-70 / fit-np-hmc.py:56-63
+    malaKernel(lpi, glpi, dt=1e-4, pre=1)        fit-np-mala.py:72-78
+    hmcKernel(lpi, glpi, eps=1e-4, l=10, dmm=1)  fit-np-hmc.py:65-87
+    ulKernel(glpi, dt=1e-4, pre=1)               fit-np-ul.py:61-68
+    mcmc(init, kernel, thin=10, iters=10000, verb=True)   fit-np-hmc.py:89-103
+
+When the callables passed in are the closures of a `LogReg` model (and, for RWMH, a
+`rwProposal`), the constructors return a `FusedKernel`: still callable one step at a time with
+the reference's per-step signature, but `mcmc()` recognises it and runs the whole
+`iters x thin` loop for all chains inside one HIP kernel launch per chunk.
+
+Any other callables get the reference's generic composition semantics (the kernel simply calls
+what it was given, drawing from NumPy's global RNG exactly where the reference does); that path
+contains no model arithmetic of its own.
+
+Extensions (additive): `init` may be `[C, p]` (then `mcmc` returns `[iters, C, p]`);
+`mcmc(..., seed=, chunk=, group=, mode=, chain_offset=, return_info=)`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import sys
+
+import numpy as np
+
+from . import _lib
+from ._lib import RunOpts, check
+from .model import DeviceArray, LogReg, ModelFn
+
+
+# ------------------------------------------------------------------------------------------------
+def _default_dprop(new, old):  # fit-numpy.py:53 `dprop = lambda new, old: 1.`
+    return 1.0
+
+
+class RandomWalkProposal:
+    """rprop(beta) = beta + sd * N(0, I)   (fit-numpy.py:81-84 with sd = 0.02*pre)."""
+
+    def __init__(self, sd):
+        self.sd = np.asarray(sd, dtype=np.float64)
+
+    def __call__(self, beta):
+        beta = np.asarray(beta, dtype=np.float64)
+        return beta + self.sd * np.random.randn(*beta.shape)
+
+
+def rwProposal(sd) -> RandomWalkProposal:
+    return RandomWalkProposal(sd)
+
+
+def _model_of(fn, kind):
+    return fn.model if isinstance(fn, ModelFn) and fn.kind == kind else None
+
+
+# ------------------------------------------------------------------------------------------------
+class FusedKernel:
+    """A transition kernel whose whole step runs inside the HIP chain kernel.
+
+    kind in {"rwmh", "mala", "hmc", "ul"}.  Calling it performs ONE iteration on the device with
+    the reference's per-step signature: `kernel(x, ll) -> (x, ll)` for rwmh/mala (the threaded
+    log-density, fit-np-mala.py:61-70), `kernel(x) -> x` for hmc/ul.  Successive calls use
+    successive iteration indices of the kernel's own Philox stream.
+    """
+
+    def __init__(self, kind: str, model: LogReg, **params):
+        self.kind = kind
+        self.model = model
+        self.params = params
+        self.threaded = kind in ("rwmh", "mala")
+        self._seed = None
+        self._calls = 0
+
+    def __repr__(self):
+        return f"FusedKernel({self.kind}, {self.params}, {self.model!r})"
+
+    def _vec(self, name):
+        return np.ascontiguousarray(np.broadcast_to(np.asarray(self.params[name], dtype=np.float64), (self.model.p,)))
+
+    def launch(self, opts: RunOpts, state_ptr, lp_ptr, out_ptr, acc_ptr):
+        L = _lib.load()
+        h = self.model.handle
+        if self.kind == "rwmh":
+            v = self._vec("prop_sd")
+            check(L.lr_run_rwmh(h, state_ptr, lp_ptr, v.ctypes.data, C.byref(opts), out_ptr, acc_ptr))
+        elif self.kind == "mala":
+            v = self._vec("pre")
+            check(L.lr_run_mala(h, state_ptr, lp_ptr, float(self.params["dt"]), v.ctypes.data, C.byref(opts), out_ptr,
+                                acc_ptr))
+        elif self.kind == "ul":
+            v = self._vec("pre")
+            check(L.lr_run_ul(h, state_ptr, float(self.params["dt"]), v.ctypes.data, C.byref(opts), out_ptr, acc_ptr))
+        elif self.kind == "hmc":
+            v = self._vec("dmm")
+            check(L.lr_run_hmc(h, state_ptr, float(self.params["eps"]), int(self.params["l"]), v.ctypes.data,
+                               C.byref(opts), out_ptr, acc_ptr))
+        else:
+            raise ValueError(self.kind)
+
+    # one step, reference signature
+    def __call__(self, x, ll=None):
+        if self._seed is None:
+            self._seed = int(np.random.randint(0, 2**31 - 1))
+        x = np.asarray(x, dtype=np.float64)
+        single = x.ndim == 1
+        st = np.ascontiguousarray(np.atleast_2d(x), dtype=self.model.np_dtype)
+        Cn = st.shape[0]
+        lp = np.ascontiguousarray(np.broadcast_to(np.asarray(-np.inf if ll is None else ll, dtype=np.float64), (Cn,))).copy()
+        opts = RunOpts(n_chains=Cn, chain_offset=0, thin=1, iters=1, iter_offset=self._calls, seed=self._seed,
+                       group=0, mode=_lib.MODE_AUTO, on_device=0)
+        self.launch(opts, st.ctypes.data, lp.ctypes.data, None, None)
+        self._calls += 1
+        xo = st.astype(np.float64)
+        if single:
+            xo = xo[0]
+        if self.threaded:
+            return xo, (float(lp[0]) if single else lp)
+        return xo
+
+
+# ------------------------------------------------------------------------------------------------
+def mhKernel(lpost, rprop, dprop=_default_dprop):
+    """Metropolis-Hastings kernel constructor.
+
+    Fused when `lpost` is a LogReg's lpost and `rprop` a `rwProposal(sd)` (random-walk MH,
+    fit-numpy.py:53-62,81-84).  Otherwise the reference's generic composition: the returned
+    `kernel(x, ll)` threads the current log-density (fit-numpy.py:54-61); called as `kernel(x)`
+    it re-evaluates both ends like the HMC script's variant (fit-np-hmc.py:56-63)."""
+    model = _model_of(lpost, "lpost")
+    if model is not None and isinstance(rprop, RandomWalkProposal) and dprop is _default_dprop:
+        return FusedKernel("rwmh", model, prop_sd=rprop.sd)
+
+    def kernel(x, ll=None):
+        prop = rprop(x)
+        lp = lpost(prop)
+        if ll is None:  # fit-np-hmc.py:59
+            a = lp - lpost(x)
+        else:  # fit-numpy.py:57
+            a = lp - ll + dprop(x, prop) - dprop(prop, x)
+        if np.log(np.random.rand()) < a:
+            x = prop
+            ll = lp if ll is not None else None
+        return x if ll is None else (x, ll)
+    return kernel
+
+
+def malaKernel(lpi, glpi, dt=1e-4, pre=1):
+    """MALA with diagonal pre-conditioner (fit-np-mala.py:72-78)."""
+    model = _model_of(lpi, "lpost")
+    if model is not None and _model_of(glpi, "glp") is model:
+        return FusedKernel("mala", model, dt=float(dt), pre=pre)
+    sdt = np.sqrt(dt)
+    spre = np.sqrt(pre)
+
+    def advance(x):
+        return x + 0.5 * pre * glpi(x) * dt
+
+    def lognorm(x, loc, scale):
+        z = (x - loc) / scale
+        return np.sum(-0.5 * z * z - 0.5 * np.log(2 * np.pi) - np.log(scale))
+    return mhKernel(lpi, lambda x: advance(x) + np.random.randn(*np.shape(x)) * spre * sdt,
+                    lambda new, old: lognorm(new, advance(old), spre * sdt * np.ones(np.shape(new))))
+
+
+def ulKernel(glpi, dt=1e-4, pre=1):
+    """Unadjusted Langevin (fit-np-ul.py:61-68)."""
+    model = _model_of(glpi, "glp")
+    if model is not None:
+        return FusedKernel("ul", model, dt=float(dt), pre=pre)
+    sdt = np.sqrt(dt)
+    spre = np.sqrt(pre)
+
+    def kernel(x):
+        return x + 0.5 * pre * glpi(x) * dt + np.random.randn(*np.shape(x)) * spre * sdt
+    return kernel
+
+
+def hmcKernel(lpi, glpi, eps=1e-4, l=10, dmm=1):
+    """HMC with diagonal mass matrix (fit-np-hmc.py:65-87)."""
+    model = _model_of(lpi, "lpost")
+    if model is not None and _model_of(glpi, "glp") is model:
+        return FusedKernel("hmc", model, eps=float(eps), l=int(l), dmm=dmm)
+    sdmm = np.sqrt(dmm)
+
+    def leapf(q, p):
+        p = p + 0.5 * eps * glpi(q)
+        for i in range(l):
+            q = q + eps * p / dmm
+            p = p + (eps if i < l - 1 else 0.5 * eps) * glpi(q)
+        return (q, -p)
+
+    def alpi(x):
+        q, p = x
+        return lpi(q) - 0.5 * np.sum((p ** 2) / dmm)
+    mhk = mhKernel(alpi, lambda x: leapf(*x))
+
+    def kern(q):
+        p = np.random.randn(len(q)) * sdmm
+        return mhk((q, p))[0]
+    return kern
+
+
+# ------------------------------------------------------------------------------------------------
+class ChainSet:
+    """C chains of one FusedKernel, resident on the device between launches.
+
+    `advance(iters, thin)` enqueues one fused launch (iters*thin iterations per chain) and
+    returns the thinned samples as a DeviceArray [iters, C, p] (or None with keep=False).
+    Iteration counters advance automatically, so any chunking of a run gives identical output.
+    """
+
+    def __init__(self, kernel: FusedKernel, init, seed: int, chain_offset: int = 0, ll=None, group: int = 0,
+                 mode: str = "auto", stream=None):
+        self.kernel = kernel
+        self.model = kernel.model
+        m = self.model
+        st = np.ascontiguousarray(np.atleast_2d(np.asarray(init, dtype=np.float64)), dtype=m.np_dtype)
+        if st.ndim != 2 or st.shape[1] != m.p:
+            raise ValueError(f"init must be [p] or [C,p] with p={m.p}; got {np.shape(init)}")
+        self.C = st.shape[0]
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.chain_offset = int(chain_offset)
+        self.iter_offset = 0
+        self.group = int(group)
+        self.mode = _lib.MODE_BY_NAME[mode]
+        self.stream = stream
+        self.state = DeviceArray.from_host(m.device, st)
+        lp0 = np.full(self.C, -np.inf) if ll is None else np.broadcast_to(np.asarray(ll, dtype=np.float64), (self.C,))
+        self.lp = DeviceArray.from_host(m.device, lp0, dtype=np.float64)
+        self.acc = DeviceArray(m.device, (self.C,), np.uint32)
+        self.acc.zero_()
+        check(_lib.load().lr_stream_sync(m.device, None))
+
+    def plan(self):
+        return self.model.plan(self.C, self.group, _lib.MODE_NAMES.get(self.mode, "auto"))
+
+    def advance(self, iters: int, thin: int, keep: bool = True, out: DeviceArray | None = None):
+        m = self.model
+        if keep and out is None:
+            out = DeviceArray(m.device, (iters, self.C, m.p), m.np_dtype)
+        opts = RunOpts(n_chains=self.C, chain_offset=self.chain_offset, thin=int(thin), iters=int(iters),
+                       iter_offset=self.iter_offset, seed=self.seed, group=self.group, mode=self.mode, on_device=1,
+                       stream=self.stream)
+        self.kernel.launch(opts, self.state.ptr, self.lp.ptr, out.ptr if keep else None, self.acc.ptr)
+        self.iter_offset += int(iters) * int(thin)
+        return out if keep else None
+
+    def sync(self):
+        check(_lib.load().lr_stream_sync(self.model.device, self.stream))
+
+    def get_state(self):
+        self.sync()
+        return self.state.to_host().astype(np.float64)
+
+    def get_ll(self):
+        self.sync()
+        return self.lp.to_host()
+
+    def get_accepts(self):
+        self.sync()
+        return self.acc.to_host()
+
+
+def _auto_chunk(kernel: FusedKernel, C: int, thin: int, iters: int) -> int:
+    """Kept samples per launch.  A launch is bounded to ~2e9 data-element visits per chain (a few
+    hundred ms at Pima scale): short enough to report progress and to stay far from any watchdog,
+    long enough that launch overhead is invisible.  Chunking never changes the samples."""
+    evals = {"hmc": kernel.params.get("l", 1), "mala": 1, "ul": 1, "rwmh": 1}[kernel.kind]
+    work_per_kept = max(1, thin * evals * kernel.model.n * kernel.model.p)
+    return int(max(1, min(iters, 2_000_000_000 // work_per_kept)))
+
+
+def mcmc(init, kernel, thin=10, iters=10000, verb=True, *, seed=None, chunk=None, chain_offset=0, ll=None,
+         group=0, mode="auto", return_info=False):
+    """Run a chain (or C chains): `mat[i]` = state after (i+1)*thin iterations (fit-np-hmc.py:89-103).
+
+    Fused kernels run on the device; `init` of shape [p] returns a float64 `[iters, p]` matrix
+    like the reference, `[C, p]` returns `[iters, C, p]` in the model's dtype.  RWMH/MALA start
+    with the threaded log-density at -inf as the reference does (fit-np-mala.py:82) unless
+    `ll=` is given.  `seed=None` draws the Philox key from NumPy's global RNG, so
+    `np.random.seed(s)` before the call makes a run reproducible, like the reference.
+    """
+    if not isinstance(kernel, FusedKernel):
+        return _mcmc_generic(init, kernel, thin, iters, verb)
+    init = np.asarray(init, dtype=np.float64)
+    single = init.ndim == 1
+    if seed is None:
+        seed = int(np.random.randint(0, 2**31 - 1))
+    cs = ChainSet(kernel, init, seed, chain_offset=chain_offset, ll=ll, group=group, mode=mode)
+    m = kernel.model
+    if chunk is None:
+        chunk = _auto_chunk(kernel, cs.C, thin, iters)
+    mat = np.empty((iters, cs.C, m.p), dtype=m.np_dtype)
+    if verb:
+        print(str(iters) + " iterations")
+    done = 0
+    while done < iters:
+        k = min(chunk, iters - done)
+        out = cs.advance(k, thin, keep=True)
+        cs.sync()
+        mat[done:done + k] = out.to_host()
+        out.free()
+        done += k
+        if verb:
+            print(str(done), end=" ", flush=True)
+    if verb:
+        print("\nDone.", flush=True)
+    res = mat[:, 0, :].astype(np.float64) if single else mat
+    if return_info:
+        info = {"accepts": cs.get_accepts(), "state": cs.get_state(), "ll": cs.get_ll(), "seed": seed,
+                "plan": cs.plan(), "iterations": iters * thin}
+        return res, info
+    return res
+
+
+def _mcmc_generic(init, kernel, thin, iters, verb):
+    """The reference's driver for arbitrary Python kernels.  Kernels built by the generic
+    `mhKernel` / `malaKernel` thread `ll` (fit-np-mala.py:80-95); `hmcKernel` / `ulKernel`
+    kernels take and return the state only (fit-np-hmc.py:89-103)."""
+    import inspect
+    p = len(init)
+    mat = np.zeros((iters, p))
+    x = init
+    try:
+        nparams = len(inspect.signature(kernel).parameters)
+    except (TypeError, ValueError):
+        nparams = 1
+    threaded = nparams >= 2
+    ll = -np.inf
+    if verb:
+        print(str(iters) + " iterations")
+    for i in range(iters):
+        if verb:
+            print(str(i), end=" ", flush=True)
+        for j in range(thin):
+            if threaded:
+                x, ll = kernel(x, ll)
+            else:
+                x = kernel(x)
+        mat[i, :] = x
+    if verb:
+        print("\nDone.", flush=True)
+    return mat

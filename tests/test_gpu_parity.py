@@ -1,0 +1,337 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle and the golden fixtures.
+Needs a real MI355X:  python -m pytest tests -m gpu
+
+Tolerances.  The reference computes in float64; the product path computes in float32
+(north_star: posterior parity within 3 Monte-Carlo SEs).  Deterministic pieces are compared at
+  float64 device path : rtol 1e-10 (value) / 1e-9 (states)  -- same arithmetic class as the oracle
+  float32 device path : lpost rel 2e-5; glp abs 3e-6 * sum_i|x_ij| (+1e-5); one-step states
+                        1e-3 posterior-sd; accept decisions identical wherever the oracle's
+                        |a - log u| margin exceeds 1e-3.
+Sampler-level parity is statistical (3 MCSE) plus bit-exact reruns / chunk / shard invariance.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+PSCALE = np.array([10.0, 1, 1, 1, 1, 1, 1, 1])
+PRE = np.array([100.0, 1, 1, 1, 1, 1, 25, 1])
+POST_SD = np.array([1.71, 0.0655, 0.0068, 0.0184, 0.0226, 0.0429, 0.547, 0.0225])
+KW = {
+    "hmc": dict(step=1e-3, l=50, scale=1 / PRE),
+    "mala": dict(step=1e-5, scale=PRE),
+    "ul": dict(step=1e-6, scale=PRE),
+    "rwmh": dict(scale=0.02 * np.array([10.0, 1, 1, 1, 1, 1, 5, 1])),
+}
+
+
+@pytest.fixture(scope="module")
+def la():
+    import logreg_amd
+    return logreg_amd
+
+
+@pytest.fixture(scope="module")
+def models(la, pima):
+    X, y = pima
+    return {"float32": la.LogReg(X, y, PSCALE, dtype="float32"), "float64": la.LogReg(X, y, PSCALE, dtype="float64")}
+
+
+def make_kernel(la, model, kind):
+    if kind == "hmc":
+        return la.hmcKernel(model.lpost, model.glp, eps=1e-3, l=50, dmm=1 / PRE)
+    if kind == "mala":
+        return la.malaKernel(model.lpost, model.glp, dt=1e-5, pre=PRE)
+    if kind == "ul":
+        return la.ulKernel(model.glp, dt=1e-6, pre=PRE)
+    return la.mhKernel(model.lpost, la.rwProposal(KW["rwmh"]["scale"]))
+
+
+VARIANTS = [("reg", 64), ("reg", 32), ("reg", 16), ("lds", 1), ("lds", 8), ("lds", 64), ("global", 64)]
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_model_closures_match_golden(models, pima, dtype):  # F1 through the C ABI
+    g = load_golden("model_eval.json")
+    beta = np.array(g["beta"])
+    m = models[dtype]
+    X, _ = pima
+    r = m.eval(beta)
+    colsum = np.abs(X).sum(axis=0)
+    for nm in ("ll", "lprior", "lpost"):
+        ref = np.array(g[nm])
+        np.testing.assert_allclose(r[nm], ref, rtol=2e-5 if dtype == "float32" else 1e-10)
+    ref = np.array(g["glp"])
+    if dtype == "float32":
+        assert np.all(np.abs(r["glp"] - ref) <= 3e-6 * colsum + 1e-5 + 2e-6 * np.abs(ref))
+    else:
+        np.testing.assert_allclose(r["glp"], ref, rtol=1e-9, atol=1e-8)
+    # reference call shapes: beta [p] -> float / ndarray[p]
+    b = beta[2]
+    assert isinstance(m.lpost(b), float) and m.glp(b).shape == (8,)
+    assert m.ll(b) == pytest.approx(-93.29888360251877, rel=2e-5)
+    assert m.lprior(b) == pytest.approx(-11.193243358631427, rel=2e-5)
+
+
+@pytest.mark.parametrize("mode,group", VARIANTS)
+def test_every_kernel_variant_evaluates_the_same_model(models, oracle_model, mode, group):
+    rng = np.random.default_rng(3)
+    beta = np.array(load_golden("map.json")["map"]) + 2 * POST_SD * rng.standard_normal((300, 8))
+    ref_lp, ref_g = oracle_model.lpost(beta), oracle_model.glp(beta)
+    for dtype in ("float32", "float64"):
+        if dtype == "float64" and mode == "reg":
+            continue  # float64 has no register-resident variants
+        m = models[dtype]
+        assert m.plan(300, group, mode) ["group"] == group
+        r = m.eval(beta, group=group, mode=mode)
+        np.testing.assert_allclose(r["lpost"], ref_lp, rtol=2e-5 if dtype == "float32" else 1e-11)
+        tol = 5e-2 if dtype == "float32" else 1e-7
+        assert np.max(np.abs(r["glp"] - ref_g)) < tol
+
+
+# ------------------------------------------------------------------------------------------------
+def one_step(la, model, kind, q0, seed, iter_offset=0, ll=None, group=0, mode="auto"):
+    cs = la.ChainSet(make_kernel(la, model, kind), q0, seed=seed, ll=ll, group=group, mode=mode)
+    cs.iter_offset = iter_offset
+    out = cs.advance(1, 1).to_host()[0].astype(np.float64)
+    return out, cs.get_accepts(), cs.get_ll()
+
+
+@pytest.mark.parametrize("kind", ["hmc", "mala", "rwmh", "ul"])
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_single_iteration_matches_oracle(la, models, oracle_model, map_beta, kind, dtype):
+    """Teacher-forced parity: one iteration from identical states on the identical Philox stream."""
+    C = 512
+    rng = np.random.default_rng(11)
+    q0 = (map_beta + 0.7 * POST_SD * rng.standard_normal((C, 8))).astype(np.float32).astype(np.float64)
+    ll0 = oracle_model.lpost(q0) if kind in ("mala", "rwmh") else None
+    for it in (0, 7, 2**33 + 5):  # also exercises the high word of the iteration counter
+        ref = oracle_model.run(kind, q0, thin=1, iters=1, seed=77, iter_offset=it, ll_state=ll0, threads=0, **KW[kind])
+        out, acc, llo = one_step(la, models[dtype], kind, q0, 77, it, ll=ll0)
+        clear = ref["margin"] > (1e-3 if dtype == "float32" else 1e-9)
+        assert clear.mean() > 0.95
+        assert np.array_equal(acc[clear], ref["accepts"][clear].astype(np.uint32))
+        err = np.abs(out - ref["out"][0]) / POST_SD
+        assert np.max(err[clear]) < (1e-3 if dtype == "float32" else 1e-9)
+        if kind in ("mala", "rwmh"):
+            np.testing.assert_allclose(llo[clear], ref["ll"][clear], rtol=2e-5 if dtype == "float32" else 1e-11)
+        if kind != "ul":
+            assert 0 < acc.sum() <= C
+
+
+@pytest.mark.parametrize("mode,group", VARIANTS)
+def test_single_hmc_iteration_every_variant(la, models, oracle_model, map_beta, mode, group):
+    C = 130  # not a multiple of any group count per wave: exercises the masked tail
+    rng = np.random.default_rng(5)
+    q0 = (map_beta + 0.7 * POST_SD * rng.standard_normal((C, 8))).astype(np.float32).astype(np.float64)
+    ref = oracle_model.run("hmc", q0, thin=1, iters=1, seed=3, threads=0, **KW["hmc"])
+    out, acc, _ = one_step(la, models["float32"], "hmc", q0, 3, group=group, mode=mode)
+    clear = ref["margin"] > 1e-3
+    assert np.array_equal(acc[clear], ref["accepts"][clear].astype(np.uint32))
+    assert np.max((np.abs(out - ref["out"][0]) / POST_SD)[clear]) < 1e-3
+
+
+def test_first_proposal_accepted_when_ll_is_minus_inf(la, models, map_beta):
+    """mcmc() starts RWMH/MALA with ll = -inf (fit-np-mala.py:82): first proposal always accepted."""
+    q0 = np.tile(map_beta, (256, 1))
+    for kind in ("rwmh", "mala"):
+        _, acc, llo = one_step(la, models["float32"], kind, q0, 5)
+        assert np.all(acc == 1) and np.all(np.isfinite(llo))
+
+
+def test_float64_free_running_matches_oracle(la, models, oracle_model, map_beta):
+    """Whole mcmc() loops in float64 on the device vs the oracle: identical decisions, states 1e-8.
+    (MALA is compared over a short run only: its drift map at dt=1e-5 amplifies last-bit
+    differences ~7x per accepted step on raw-scale Pima, see tests/test_oracle.py.)"""
+    C = 64
+    q0 = np.tile(map_beta, (C, 1))
+    for kind, iters, thin in (("hmc", 10, 2), ("rwmh", 100, 3), ("ul", 20, 2), ("mala", 6, 1)):
+        ref = oracle_model.run(kind, q0, thin=thin, iters=iters, seed=9, threads=0, **KW[kind])
+        out, info = la.mcmc(q0, make_kernel(la, models["float64"], kind), thin=thin, iters=iters, verb=False, seed=9,
+                            return_info=True)
+        ok = ref["margin"] > 1e-7
+        assert ok.mean() > 0.9
+        np.testing.assert_allclose(out[:, ok, :], ref["out"][:, ok, :], rtol=1e-6 if kind == "mala" else 1e-8, atol=1e-10)
+        assert np.array_equal(info["accepts"][ok], ref["accepts"][ok].astype(np.uint32))
+
+
+def test_float32_short_run_tracks_oracle(la, models, oracle_model, map_beta):
+    """float32 HMC for 20 iterations: the large majority of chains never hit a near-tie and must
+    stay within 1e-3 posterior-sd of the float64 oracle with identical accept counts."""
+    C = 1024
+    q0 = np.tile(map_beta, (C, 1))
+    ref = oracle_model.run("hmc", q0, thin=4, iters=5, seed=21, threads=0, **KW["hmc"])
+    out, info = la.mcmc(q0, make_kernel(la, models["float32"], "hmc"), thin=4, iters=5, verb=False, seed=21,
+                        return_info=True)
+    ok = ref["margin"] > 2e-3
+    assert ok.mean() > 0.9
+    assert np.array_equal(info["accepts"][ok], ref["accepts"][ok].astype(np.uint32))
+    assert np.max(np.abs(out[:, ok, :] - ref["out"][:, ok, :]) / POST_SD) < 2e-3
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind", ["hmc", "mala", "rwmh", "ul"])
+def test_bit_exact_rerun_chunk_and_shard_invariance(la, models, map_beta, kind):
+    """Counter-based RNG: results depend only on (seed, global chain id, global iteration)."""
+    C = 200
+    rng = np.random.default_rng(1)
+    q0 = map_beta + 0.3 * POST_SD * rng.standard_normal((C, 8))
+    k = make_kernel(la, models["float32"], kind)
+    full, info = la.mcmc(q0, k, thin=3, iters=8, verb=False, seed=1234, return_info=True)
+    again = la.mcmc(q0, k, thin=3, iters=8, verb=False, seed=1234)
+    assert np.array_equal(full, again)
+    chunked = la.mcmc(q0, k, thin=3, iters=8, verb=False, seed=1234, chunk=3)
+    assert np.array_equal(full, chunked)
+    a = la.mcmc(q0[:77], k, thin=3, iters=8, verb=False, seed=1234)
+    b = la.mcmc(q0[77:], k, thin=3, iters=8, verb=False, seed=1234, chain_offset=77)
+    assert np.array_equal(full, np.concatenate([a, b], axis=1))
+    other = la.mcmc(q0, k, thin=3, iters=8, verb=False, seed=1235)
+    assert not np.array_equal(full, other)
+
+
+def test_groups_agree_statistically_not_bitwise(la, models, map_beta):
+    """Different lanes-per-chain change the summation order only."""
+    q0 = np.tile(map_beta, (256, 1))
+    k = make_kernel(la, models["float32"], "hmc")
+    outs = [la.mcmc(q0, k, thin=1, iters=1, verb=False, seed=5, group=g) for g in (16, 32, 64)]
+    for o in outs[1:]:
+        same = np.max(np.abs(o - outs[0]) / POST_SD, axis=(0, 2)) < 1e-3
+        assert same.mean() > 0.97
+
+
+# ------------------------------------------------------------------------------------------------
+def z_scores(summ, ref):
+    zm = (summ["mean"] - np.array(ref["mean"])) / np.sqrt(summ["mcse"] ** 2 + np.array(ref["mcse"]) ** 2)
+    se_sd = summ["sd"] / np.sqrt(2 * summ["ess"])
+    zs = (summ["sd"] - np.array(ref["sd"])) / np.sqrt(se_sd ** 2 + np.array(ref["se_sd"]) ** 2)
+    return zm, zs
+
+
+def test_hmc_posterior_matches_reference_within_3_mcse(la, models, map_beta):  # F7: the north_star criterion
+    ref = load_golden("posterior_hmc.json")["pooled"]
+    C = 4096
+    q0 = np.tile(map_beta, (C, 1))
+    k = make_kernel(la, models["float32"], "hmc")
+    cs = la.ChainSet(k, q0, seed=2024)
+    cs.advance(1, 1000, keep=False)  # burn-in away from the common start
+    samples = cs.advance(60, 20).to_host()
+    acc = cs.get_accepts().sum() / (C * (1000 + 60 * 20))
+    assert abs(acc - load_golden("accept_rates.json")["hmc"]["rate"]) < 0.015
+    summ = la.summarise(samples, max_chains=128)
+    zm, zs = z_scores(summ, ref)
+    print("HMC z(mean)", np.round(zm, 2), "z(sd)", np.round(zs, 2), "accept", acc)
+    assert np.max(np.abs(zm)) < 3.0 and np.max(np.abs(zs)) < 3.0
+
+
+@pytest.mark.parametrize("kind,thin,burn,keep", [("mala", 1000, 30, 40), ("rwmh", 1000, 30, 40)])
+def test_mala_rwmh_posteriors_match_reference(la, models, map_beta, kind, thin, burn, keep):  # F8 + F8b
+    import os
+    from conftest import GOLDEN
+    name = f"posterior_{kind}.json"
+    if not os.path.exists(os.path.join(GOLDEN, name)):
+        pytest.skip(name + " not generated yet")
+    ref = load_golden(name)["pooled"]
+    C = 2048
+    q0 = np.tile(map_beta, (C, 1))
+    k = make_kernel(la, models["float32"], kind)
+    cs = la.ChainSet(k, q0, seed=99)
+    cs.advance(1, burn * thin, keep=False)
+    samples = cs.advance(keep, thin).to_host()
+    acc = cs.get_accepts().sum() / (C * (burn + keep) * thin)
+    assert abs(acc - load_golden("accept_rates.json")[kind]["rate"]) < (0.03 if kind == "mala" else 0.01)
+    summ = la.summarise(samples, max_chains=128)
+    zm, zs = z_scores(summ, ref)
+    print(kind, "z(mean)", np.round(zm, 2), "z(sd)", np.round(zs, 2), "accept", acc)
+    assert np.max(np.abs(zm)) < 3.0 and np.max(np.abs(zs)) < 3.0
+
+
+# ------------------------------------------------------------------------------------------------
+def test_mcmc_signature_and_shapes_like_the_reference(la, models, map_beta, capsys):
+    m = models["float32"]
+    kern = la.hmcKernel(m.lpost, m.glp, eps=1e-3, l=50, dmm=1 / PRE)
+    np.random.seed(42)
+    out = la.mcmc(map_beta, kern, thin=2, iters=30)  # verb=True default, prints like the reference
+    txt = capsys.readouterr().out
+    assert txt.startswith("30 iterations") and "Done." in txt
+    assert out.shape == (30, 8) and out.dtype == np.float64
+    np.random.seed(42)
+    assert np.array_equal(out, la.mcmc(map_beta, kern, thin=2, iters=30, verb=False))  # np.random.seed reproducibility
+    # per-step call signatures
+    q = kern(map_beta)
+    assert q.shape == (8,)
+    mk = la.malaKernel(m.lpost, m.glp, dt=1e-5, pre=PRE)
+    x, ll = mk(map_beta, -np.inf)
+    assert x.shape == (8,) and np.isfinite(ll) and ll == pytest.approx(m.lpost(x), rel=1e-5)
+    rk = la.mhKernel(m.lpost, la.rwProposal(0.02 * PRE))
+    x, ll = rk(map_beta, -np.inf)
+    assert np.isfinite(ll)
+    u = la.ulKernel(m.glp, dt=1e-6, pre=PRE)(map_beta)
+    assert u.shape == (8,)
+
+
+def test_generic_composition_with_device_closures_replays_reference_draws(la, models):
+    """Drop-in check: the reference's own higher-order-function semantics with OUR closures.
+    Seeding NumPy as the fixture generator did reproduces the reference's recorded HMC states
+    (fixture F6), because the generic kernels draw randn/rand in the reference's order."""
+    g = load_golden("accept_replay.json")
+    m = models["float64"]
+    lpost, glp = (lambda b: m.lpost(b)), (lambda b: m.glp(b))  # plain callables: forces the generic path
+    kern = la.hmcKernel(lpost, glp, eps=1e-3, l=50, dmm=1 / PRE)
+    np.random.seed(1000 + len("hmc"))
+    out = la.mcmc(np.array(g["hmc"]["init"]), kern, thin=1, iters=12, verb=False)
+    np.testing.assert_allclose(out, np.array(g["hmc"]["states"])[:12], rtol=1e-7, atol=1e-9)
+
+
+def test_errors_are_loud(la, models, map_beta):
+    m = models["float32"]
+    with pytest.raises(la.LogregHipError):
+        la.mcmc(map_beta, la.hmcKernel(m.lpost, m.glp, eps=-1.0, l=5, dmm=1), iters=1, verb=False)
+    with pytest.raises(la.LogregHipError):
+        la.mcmc(map_beta, la.hmcKernel(m.lpost, m.glp, eps=1e-3, l=0, dmm=1), iters=1, verb=False)
+    with pytest.raises(la.LogregHipError):
+        la.LogReg(np.ones((4, 2)), np.array([0, 1, 2, 0.0]), 1.0)
+    with pytest.raises(ValueError):
+        m.lpost(np.zeros(5))
+
+
+def test_other_parameter_counts_use_padded_kernels(la, oracle_model):
+    """p = 3, 11, 20: padded to 4 / 16 / 32 columns; padded coordinates are frozen at 0."""
+    from oracle.oracle import OracleModel
+    rng = np.random.default_rng(8)
+    for p, n in ((3, 50), (11, 300), (20, 1000)):
+        X, y, _ = la.synthetic_logreg(n, p, seed=p)
+        ps = np.full(p, 2.0)
+        orc = OracleModel(X, y, ps)
+        for dtype in ("float32", "float64"):
+            m = la.LogReg(X, y, ps, dtype=dtype)
+            b = 0.3 * rng.standard_normal((40, p))
+            r = m.eval(b)
+            np.testing.assert_allclose(r["lpost"], orc.lpost(b), rtol=3e-5 if dtype == "float32" else 1e-11)
+            assert np.max(np.abs(r["glp"] - orc.glp(b))) < (2e-2 if dtype == "float32" else 1e-8)
+            q0 = 0.1 * rng.standard_normal((64, p))
+            ref = orc.run("hmc", q0, step=0.02, l=7, scale=np.ones(p), thin=1, iters=1, seed=4, threads=0)
+            out, info = la.mcmc(q0, la.hmcKernel(m.lpost, m.glp, eps=0.02, l=7, dmm=np.ones(p)), thin=1, iters=1,
+                                verb=False, seed=4, return_info=True)
+            ok = ref["margin"] > 1e-3
+            assert np.array_equal(info["accepts"][ok], ref["accepts"][ok].astype(np.uint32))
+            assert np.max(np.abs(out[0, ok] - ref["out"][0, ok])) < (2e-3 if dtype == "float32" else 1e-9)
+
+
+# ------------------------------------------------------------------------------------------------
+def test_full_size_properties_4096_chains(la, models, map_beta):
+    """BASELINE size (4096 chains, L=50): size-independent properties."""
+    C = 4096
+    q0 = np.tile(map_beta, (C, 1))
+    k = make_kernel(la, models["float32"], "hmc")
+    a, ia = la.mcmc(q0, k, thin=20, iters=10, verb=False, seed=7, return_info=True)
+    b = la.mcmc(q0, k, thin=20, iters=10, verb=False, seed=7, chunk=4)
+    assert np.array_equal(a, b)  # bit-exact rerun under a different chunking
+    assert np.all(np.isfinite(a))
+    rate = ia["accepts"].sum() / (C * 200)
+    assert 0.93 < rate < 0.98
+    # chains are exchangeable and independent: per-chain means scatter like posterior_sd/sqrt(ESS)
+    last = a[-1]
+    assert np.all(np.abs(last.mean(axis=0) - np.array([-9.6, 0.1, 0.033, -0.007, 0.001, 0.084, 1.31, 0.042])) < 6 * POST_SD / np.sqrt(C) + 0.05 * POST_SD)
