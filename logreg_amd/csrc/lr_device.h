@@ -147,6 +147,53 @@ template <int G, typename T> __device__ __forceinline__ T group_sum(T v) {
     return v;
 }
 
+// N independent float values at once: level-major order keeps >= N-1 instructions between a
+// value's write and its next DPP read, and each level is ONE fused v_add_f32_dpp per value
+// (hipcc otherwise emits v_mov_dpp + v_pk_add).  hipcc pads no hazards inside asm statements:
+// the s_nop opening each level covers "VALU write -> DPP read" for the level's first value.
+#define LR_DPP_ADD(ctrl) "v_add_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1"
+template <int G, int N> __device__ __forceinline__ void group_sum_vec(float (&v)[N]) {
+    static_assert(G == 1 || G == 2 || G == 4 || G == 8 || G == 16 || G == 32 || G == 64, "bad group");
+    if constexpr (N < 4) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) v[j] = group_sum<G>(v[j]);
+    } else {
+        if constexpr (G >= 16) {
+            asm volatile("s_nop 1\n\t" LR_DPP_ADD("row_mirror") : "+v"(v[0]));
+#pragma unroll
+            for (int j = 1; j < N; ++j) asm volatile(LR_DPP_ADD("row_mirror") : "+v"(v[j]));
+        }
+        if constexpr (G >= 8) {
+            asm volatile("s_nop 1\n\t" LR_DPP_ADD("row_half_mirror") : "+v"(v[0]));
+#pragma unroll
+            for (int j = 1; j < N; ++j) asm volatile(LR_DPP_ADD("row_half_mirror") : "+v"(v[j]));
+        }
+        if constexpr (G >= 4) {
+            asm volatile("s_nop 1\n\t" LR_DPP_ADD("quad_perm:[2,3,0,1]") : "+v"(v[0]));
+#pragma unroll
+            for (int j = 1; j < N; ++j) asm volatile(LR_DPP_ADD("quad_perm:[2,3,0,1]") : "+v"(v[j]));
+        }
+        if constexpr (G >= 2) {
+            asm volatile("s_nop 1\n\t" LR_DPP_ADD("quad_perm:[1,0,3,2]") : "+v"(v[0]));
+#pragma unroll
+            for (int j = 1; j < N; ++j) asm volatile(LR_DPP_ADD("quad_perm:[1,0,3,2]") : "+v"(v[j]));
+            asm volatile("s_nop 0" ::: );  // last DPP result -> first compiler-scheduled consumer
+        }
+        if constexpr (G >= 32) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) v[j] = swap16_sum(v[j]);
+        }
+        if constexpr (G >= 64) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) v[j] = swap32_sum(v[j]);
+        }
+    }
+}
+template <int G, int N> __device__ __forceinline__ void group_sum_vec(double (&v)[N]) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] = group_sum<G>(v[j]);
+}
+
 // ------------------------------------------------------------------------------------------
 // fast scalar math for the hot loop
 // ------------------------------------------------------------------------------------------
@@ -160,21 +207,34 @@ __device__ __forceinline__ double fast_rcp(double x) { return 1.0 / x; }
 __device__ __forceinline__ float log1p_unit(float e) { return __builtin_amdgcn_logf(1.0f + e) * 0.693147180559945309f; }
 __device__ __forceinline__ double log1p_unit(double e) { return log1p(e); }
 
-// one signed row: accumulate sigma(-t) * xs into g[], and (VALUE) log sigma(t) into v
+// exp(t) given ts = t * kScale<T> (float: the log2(e) factor is folded into beta once per
+// evaluation instead of once per row; double: kScale = 1)
+template <typename T> struct ExpScale;
+template <> struct ExpScale<float> {
+    static constexpr float k = 1.44269504088896341f, inv = 0.693147180559945309f;
+    static __device__ __forceinline__ float exp_scaled(float ts) { return __builtin_amdgcn_exp2f(ts); }
+};
+template <> struct ExpScale<double> {
+    static constexpr double k = 1.0, inv = 1.0;
+    static __device__ __forceinline__ double exp_scaled(double ts) { return exp(ts); }
+};
+
+// one signed row: accumulate sigma(-t) * xs into g[], and (VALUE) log sigma(t) into v.
+// `bs` is beta * ExpScale<T>::k.
 template <typename T, int P, bool VALUE, bool GRAD>
-__device__ __forceinline__ void row_term(const T (&xs)[P], const T (&beta)[P], T (&g)[P], T& v) {
-    T t = xs[0] * beta[0];
+__device__ __forceinline__ void row_term(const T (&xs)[P], const T (&bs)[P], T (&g)[P], T& v) {
+    T ts = xs[0] * bs[0];
 #pragma unroll
-    for (int j = 1; j < P; ++j) t = fma_t(xs[j], beta[j], t);
+    for (int j = 1; j < P; ++j) ts = fma_t(xs[j], bs[j], ts);
     if constexpr (GRAD) {
-        const T w = fast_rcp(T(1) + fast_exp(t));  // sigma(-t); exp overflow -> rcp(inf) = 0
+        const T w = fast_rcp(T(1) + ExpScale<T>::exp_scaled(ts));  // sigma(-t); exp overflow -> rcp(inf) = 0
 #pragma unroll
         for (int j = 0; j < P; ++j) g[j] = fma_t(w, xs[j], g[j]);
     }
     if constexpr (VALUE) {
         // log sigma(t) = min(t,0) - log1p(exp(-|t|))  (stable for both signs)
-        const T at = t < T(0) ? -t : t;
-        v += (t < T(0) ? t : T(0)) - log1p_unit(fast_exp(-at));
+        const T ats = ts < T(0) ? -ts : ts;
+        v += (ts < T(0) ? ts * ExpScale<T>::inv : T(0)) - log1p_unit(ExpScale<T>::exp_scaled(-ats));
     }
 }
 
@@ -237,10 +297,14 @@ __device__ __forceinline__ void eval_lpost(const Rows& rows, const Prior<T, P>& 
 #pragma unroll
     for (int j = 0; j < P; ++j) g[j] = T(0);
     T v = T(0);
-    rows.for_each([&](const T(&xs)[P]) { row_term<T, P, VALUE, GRAD>(xs, beta, g, v); });
-    if constexpr (GRAD) {
+    T bs[P];
 #pragma unroll
-        for (int j = 0; j < P; ++j) grad[j] = group_sum<G>(g[j]) - beta[j] * pr.inv_var[j];
+    for (int j = 0; j < P; ++j) bs[j] = beta[j] * ExpScale<T>::k;
+    rows.for_each([&](const T(&xs)[P]) { row_term<T, P, VALUE, GRAD>(xs, bs, g, v); });
+    if constexpr (GRAD) {
+        group_sum_vec<G, P>(g);
+#pragma unroll
+        for (int j = 0; j < P; ++j) grad[j] = g[j] - beta[j] * pr.inv_var[j];
     }
     if constexpr (VALUE) {
         ll = group_sum<G>((double)(v + rows.value_fixup()));
