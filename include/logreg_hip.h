@@ -47,7 +47,10 @@ typedef enum lr_status {
 } lr_status;
 
 enum { LR_F32 = 0, LR_F64 = 1 };
-enum { LR_MODE_AUTO = -1, LR_MODE_REG = 0, LR_MODE_LDS = 1, LR_MODE_GLOBAL = 2 };
+/* where the data rows live / which pipe does the matvecs: REG/LDS/GLOBAL use the vector ALU with rows in
+ * VGPRs / LDS / memory; MFMA uses the fp32 matrix cores with rows in VGPRs (p = 8, small n; there `group`
+ * selects the row-split ways S in {1,4} instead of lanes per chain) */
+enum { LR_MODE_AUTO = -1, LR_MODE_REG = 0, LR_MODE_LDS = 1, LR_MODE_GLOBAL = 2, LR_MODE_MFMA = 3 };
 
 typedef struct lr_model lr_model;
 

@@ -77,13 +77,32 @@ struct Plan { int mode, G, R; size_t lds_bytes; };
 // Choose the kernel variant.  REG (rows in VGPRs) whenever the data fit (G*R >= n), then LDS,
 // then GLOBAL.  Group size: the smallest available G that still gives every SIMD a wavefront
 // (C*G/64 >= 4*CUs), else the largest; an explicit `group` request is honoured exactly.
-int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out) {
+int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool for_eval = false) {
     const lr::InstTable* t = m->table;
     const int64_t want_waves = 4LL * m->cus;
     int best = -1;
     long best_score = -1;
+    if (for_eval && mode == LR_MODE_MFMA) { mode = LR_MODE_AUTO; group = 0; }
     for (int i = 0; i < t->nvariants; ++i) {
         const lr::Variant& v = t->variants[i];
+        if (v.mode == lr::MODE_MFMA) {
+            // matrix-core variants; G = row-split ways S, R = tiles per wave.  Measured on MI355X
+            // (profiles/): with >= 16 chains for every SIMD the S=1 variant beats the best vector-ALU
+            // variant by 11-25 %; below that the vector-ALU group-per-chain variants win, so AUTO
+            // only picks MFMA S=1 when the chip is filled; mode = LR_MODE_MFMA forces it.
+            if (for_eval) continue;
+            if ((int64_t)16 * v.G * v.R < m->n) continue;
+            const bool filled = C >= 16LL * want_waves;
+            if (mode == LR_MODE_MFMA) {
+                if (group != 0 && v.G != group) continue;
+                const long score = (filled ? (v.G == 1) : (v.G == 4)) ? 2 : 1;
+                if (score > best_score) { best_score = score; best = i; }
+            } else if (mode == LR_MODE_AUTO && group == 0 && filled && v.G == 1) {
+                const long score = 3000000L;
+                if (score > best_score) { best_score = score; best = i; }
+            }
+            continue;
+        }
         if (mode != LR_MODE_AUTO && v.mode != mode) continue;
         if (group != 0 && v.G != group) continue;
         if (v.mode == lr::MODE_REG && (int64_t)v.G * v.R < m->n) continue;
@@ -376,7 +395,7 @@ int lr_eval(lr_model* m, const void* beta, void* ll, void* lprior, void* lpost, 
     if (!beta) return fail(LR_ERR_INVALID, "beta is NULL");
     LR_HIP(hipSetDevice(m->device));
     Plan pl;
-    rc = make_plan(m, o->n_chains, o->group, o->mode, &pl);
+    rc = make_plan(m, o->n_chains, o->group, o->mode, &pl, true);
     if (rc) return rc;
     const int64_t C = o->n_chains;
     if (o->on_device) return do_eval(m, pl, (hipStream_t)o->stream, C, beta, ll, lprior, lpost, grad);

@@ -2,6 +2,9 @@
 // Compiled several times:  hipcc -DLR_T=float -DLR_P=8 -DLR_SFX=f32_p8 -DLR_DTYPE=0 ...
 #include "lr_inst.h"
 #include "lr_kernels.h"
+#if LR_DTYPE == 0 && LR_P == 8
+#include "lr_mfma.h"
+#endif
 
 #ifndef LR_T
 #error "compile with -DLR_T=<float|double> -DLR_P=<4|8|16|32> -DLR_SFX=<suffix> -DLR_DTYPE=<0|1>"
@@ -31,8 +34,16 @@ constexpr int P = LR_P;
 #define LR_VARIANTS(X) X(MODE_LDS, 1, 0) X(MODE_LDS, 8, 0) X(MODE_LDS, 64, 0) X(MODE_GLOBAL, 64, 0)
 #endif
 
+// matrix-core variants (fp32, p = 8): X(row-split ways S, tiles per wave NTW); n <= 16*S*NTW
+#if LR_DTYPE == 0 && LR_P == 8
+#define LR_MFMA_VARIANTS(X) X(1, 13) X(4, 4)
+#else
+#define LR_MFMA_VARIANTS(X)
+#endif
+
 #define LR_VARIANT_ROW(M_, G_, R_) {M_, G_, R_},
-const Variant kVariants[] = {LR_VARIANTS(LR_VARIANT_ROW)};
+#define LR_MFMA_ROW(S_, N_) {MODE_MFMA, S_, N_},
+const Variant kVariants[] = {LR_VARIANTS(LR_VARIANT_ROW) LR_MFMA_VARIANTS(LR_MFMA_ROW)};
 
 inline int check(hipError_t e) { return e == hipSuccess ? 0 : -2; }
 
@@ -69,6 +80,22 @@ int launch_chain_v(const LaunchCfg* cfg, int64_t C, const ModelArgs<T, P>& m, co
     return check(hipGetLastError());
 }
 
+#if LR_DTYPE == 0 && LR_P == 8
+template <int S, int NTW>
+int launch_mfma_v(const LaunchCfg* cfg, int64_t C, const ModelArgs<T, P>& m, const ChainArgs<T, P>& a) {
+    const int64_t per_block = S == 1 ? 64 : 16;
+    const dim3 grid((unsigned)((C + per_block - 1) / per_block)), block(256);
+    switch (cfg->kind) {
+    case KIND_RWMH: hipLaunchKernelGGL((k_chain_mfma<NTW, S, KIND_RWMH>), grid, block, 0, cfg->stream, m, a); break;
+    case KIND_MALA: hipLaunchKernelGGL((k_chain_mfma<NTW, S, KIND_MALA>), grid, block, 0, cfg->stream, m, a); break;
+    case KIND_HMC: hipLaunchKernelGGL((k_chain_mfma<NTW, S, KIND_HMC>), grid, block, 0, cfg->stream, m, a); break;
+    case KIND_UL: hipLaunchKernelGGL((k_chain_mfma<NTW, S, KIND_UL>), grid, block, 0, cfg->stream, m, a); break;
+    default: return -1;
+    }
+    return check(hipGetLastError());
+}
+#endif
+
 int launch_eval(const LaunchCfg* cfg, int64_t C, const void* model_args, const void* eval_args) {
     const auto& m = *static_cast<const ModelArgs<T, P>*>(model_args);
     const auto& a = *static_cast<const EvalArgs<T>*>(eval_args);
@@ -84,6 +111,9 @@ int launch_chain(const LaunchCfg* cfg, int64_t C, const void* model_args, const 
 #define LR_DISPATCH_CHAIN(M_, G_, R_) \
     if (cfg->mode == M_ && cfg->G == G_ && cfg->R == R_) return launch_chain_v<G_, M_, R_>(cfg, C, m, a);
     LR_VARIANTS(LR_DISPATCH_CHAIN)
+#define LR_DISPATCH_MFMA(S_, N_) \
+    if (cfg->mode == MODE_MFMA && cfg->G == S_ && cfg->R == N_) return launch_mfma_v<S_, N_>(cfg, C, m, a);
+    LR_MFMA_VARIANTS(LR_DISPATCH_MFMA)
     return -3;
 }
 

@@ -7,7 +7,7 @@
 namespace lr {
 
 enum Kind { KIND_RWMH = 0, KIND_MALA = 1, KIND_HMC = 2, KIND_UL = 3 };
-enum Mode { MODE_REG = 0, MODE_LDS = 1, MODE_GLOBAL = 2 };
+enum Mode { MODE_REG = 0, MODE_LDS = 1, MODE_GLOBAL = 2, MODE_MFMA = 3 };
 
 template <typename T, int P> struct ModelArgs {
     const T* rows;  // [n][P] signed rows (2y-1)*x, zero-padded to P columns (device)

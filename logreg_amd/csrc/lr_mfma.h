@@ -1,0 +1,289 @@
+// lr_mfma.h -- matrix-core formulation of the fused chain kernel (fp32 in, fp32 accumulate;
+// p = 8; gfx950 v_mfma_f32_16x16x4_f32, which is bit-for-bit a k-ordered fmaf chain).
+//
+// One wavefront owns 16 chains.  Lane l = (c, k): c = l & 15 is the chain, k = l >> 4 the
+// parameter group; the lane OWNS parameters k and k+4 of chain c (position, momentum, gradient
+// for those two coordinates live only in this lane).  Data rows are processed in tiles of 16:
+//
+//   eta tile  E[16 rows x 16 chains] = Xs[16 x 8] . B^T[8 x 16]       2 MFMAs (K = 4 each)
+//       A operand (lane l): Xs[16T + (l&15)][(l>>4) + 4h]       h = 0,1     (registers xa[t][h])
+//       B operand (lane l): beta[chain l&15][(l>>4) + 4h]  = the lane's own two coordinates
+//       D (lane l, reg r) : eta[row 16T + 4(l>>4) + r][chain l&15]
+//   w = sigma(-eta) elementwise on the 4 D registers                    (VALU: exp2, add, rcp)
+//   grad tile G^T[16 slots x 16 chains] += XsT[16 slots x 4 rows] . W[4 rows x 16 chains]   4 MFMAs
+//       B operand for K-slice s (lane l): w[row 16T + 4(l>>4) + s][chain l&15] = D register s of
+//                                         the eta MFMA -- NO data movement between the two GEMMs
+//       A operand (lane l): Xs[16T + 4(l>>4) + s][mu(l&15)], slot m = 4k'+r' -> parameter
+//                           mu(m) = k' + 4r' for r' < 2, empty (0) otherwise  (registers xg[t][s])
+//       D (lane l, reg r) : gradient of parameter k + 4r of chain c for r = 0,1 = the lane's own
+//                           two coordinates -- the leapfrog update is lane-local, no transposes.
+//
+// Only per-iteration scalars (energies, prior) cross lanes (2 permlane swaps over k).
+// S = 4 ("row split"): the 4 waves of a workgroup share the same 16 chains and each takes every
+// 4th tile; per leapfrog step the partial gradients are combined through LDS in a fixed order
+// (bit-identical in all 4 waves).  S = 1: every wave has its own 16 chains.
+#pragma once
+#include <type_traits>
+
+#include "lr_kernels.h"
+
+namespace lr {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int NTW, int S> struct MfmaRows {
+    float xa[NTW][2];
+    float xg[NTW][4];
+    int pad_rows;  // rows >= n among this lane's eta rows (each adds log sigma(0) = -log 2)
+
+    __device__ __forceinline__ void load(const float* __restrict__ rows, int64_t n, int wave, int lane) {
+        const int c = lane & 15, k = lane >> 4;
+        const int rp = c & 3, kp = c >> 2;           // slot m = c = 4*kp + rp
+        const int gpar = rp < 2 ? kp + 4 * rp : -1;  // parameter of the gradient A operand
+        pad_rows = 0;
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const int64_t base = 16 * ((int64_t)t * S + wave);
+            const int64_t ra = base + c;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) xa[t][h] = ra < n ? rows[ra * 8 + k + 4 * h] : 0.0f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int64_t rg = base + 4 * k + s;
+                xg[t][s] = (rg < n && gpar >= 0) ? rows[rg * 8 + gpar] : 0.0f;
+                if (rg >= n) ++pad_rows;
+            }
+        }
+    }
+
+    // likelihood part for the lane's two coordinates over THIS wave's tiles:
+    //   gl[h] = sum_rows sigma(-t) * xs[row][k+4h],  vsum = sum over the lane's eta rows of log sigma(t)
+    template <bool VALUE>
+    __device__ __forceinline__ void eval(const float (&q2)[2], float (&gl)[2], float& vsum) const {
+        const float bs0 = q2[0] * ExpScale<float>::k, bs1 = q2[1] * ExpScale<float>::k;
+        f32x4 ga = {0, 0, 0, 0}, gb = {0, 0, 0, 0};
+        float v = 0.0f;
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            f32x4 e = {0, 0, 0, 0};
+            e = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[t][0], bs0, e, 0, 0, 0);
+            e = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[t][1], bs1, e, 0, 0, 0);
+            float w[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                w[r] = fast_rcp(1.0f + __builtin_amdgcn_exp2f(e[r]));
+                if constexpr (VALUE) {
+                    const float ats = e[r] < 0.0f ? -e[r] : e[r];
+                    v += (e[r] < 0.0f ? e[r] * ExpScale<float>::inv : 0.0f) - log1p_unit(__builtin_amdgcn_exp2f(-ats));
+                }
+            }
+            ga = __builtin_amdgcn_mfma_f32_16x16x4f32(xg[t][0], w[0], ga, 0, 0, 0);
+            gb = __builtin_amdgcn_mfma_f32_16x16x4f32(xg[t][1], w[1], gb, 0, 0, 0);
+            ga = __builtin_amdgcn_mfma_f32_16x16x4f32(xg[t][2], w[2], ga, 0, 0, 0);
+            gb = __builtin_amdgcn_mfma_f32_16x16x4f32(xg[t][3], w[3], gb, 0, 0, 0);
+        }
+        gl[0] = ga[0] + gb[0];
+        gl[1] = ga[1] + gb[1];
+        if constexpr (VALUE) vsum = v + (float)pad_rows * 0.693147180559945309f;
+    }
+};
+
+// sum over the 4 parameter groups k (lanes c, c+16, c+32, c+48); identical in all 4 lanes
+template <typename T> __device__ __forceinline__ T ksum(T v) { return swap32_sum(swap16_sum(v)); }
+
+template <int NTW, int S, int KIND>
+__global__ void __launch_bounds__(256) k_chain_mfma(ModelArgs<float, 8> m, ChainArgs<float, 8> a) {
+    __shared__ float red[2][4][64][2];   // S = 4: per-step partial gradients, double-buffered
+    __shared__ double redv[4][64];       // S = 4: partial log-likelihood values
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, k = lane >> 4;
+    const int64_t tile0 = S == 1 ? ((int64_t)blockIdx.x * 4 + wave) * 16 : (int64_t)blockIdx.x * 16;
+    int64_t chain = tile0 + c;
+    const bool live = chain < a.C;
+    if (!live) chain = a.C - 1;
+    const bool writer = live && (S == 1 || wave == 0);
+    const uint64_t gchain = (uint64_t)(a.chain_offset + chain);
+
+    MfmaRows<NTW, S> rows;
+    rows.load(m.rows, m.n, S == 1 ? 0 : wave, lane);
+
+    // the lane's two coordinates: j_h = k + 4h
+    auto pick = [&](const float (&v)[8], int h) {
+        const float lo = k == 0 ? v[4 * h] : v[4 * h + 1], hi = k == 2 ? v[4 * h + 2] : v[4 * h + 3];
+        return k < 2 ? lo : hi;
+    };
+    float inv_var[2], ka[2], kb[2], kc[2], x[2], g[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        inv_var[h] = pick(m.prior.inv_var, h);
+        ka[h] = pick(a.a, h);
+        kb[h] = pick(a.b, h);
+        kc[h] = pick(a.c, h);
+        const int j = k + 4 * h;
+        x[h] = j < a.p ? a.state[chain * a.p + j] : 0.0f;
+    }
+
+    int step_parity = 0;
+    // full gradient (likelihood over all tiles + prior) for own coordinates; VALUE: ll (double, replicated)
+    auto evaluate = [&](auto want_value, const float (&q2)[2], float (&grad)[2], double& ll) {
+        constexpr bool VALUE = decltype(want_value)::value;
+        float gl[2], vs = 0.0f;
+        rows.template eval<VALUE>(q2, gl, vs);
+        if constexpr (S > 1) {
+            red[step_parity][wave][lane][0] = gl[0];
+            red[step_parity][wave][lane][1] = gl[1];
+            if constexpr (VALUE) redv[wave][lane] = (double)vs;
+            __syncthreads();
+            gl[0] = (red[step_parity][0][lane][0] + red[step_parity][1][lane][0]) +
+                    (red[step_parity][2][lane][0] + red[step_parity][3][lane][0]);
+            gl[1] = (red[step_parity][0][lane][1] + red[step_parity][1][lane][1]) +
+                    (red[step_parity][2][lane][1] + red[step_parity][3][lane][1]);
+            double dv = 0;
+            if constexpr (VALUE) {
+                dv = (redv[0][lane] + redv[1][lane]) + (redv[2][lane] + redv[3][lane]);
+                __syncthreads();  // redv is single-buffered; value passes are rare
+            }
+            step_parity ^= 1;
+            if constexpr (VALUE) ll = ksum(dv);
+        } else {
+            if constexpr (VALUE) ll = ksum((double)vs);
+        }
+        grad[0] = gl[0] - q2[0] * inv_var[0];
+        grad[1] = gl[1] - q2[1] * inv_var[1];
+    };
+    using True = std::integral_constant<bool, true>;
+    using False = std::integral_constant<bool, false>;
+    auto lprior_of = [&](const float (&q2)[2]) {
+        const float quad = ksum(fma_t(q2[0] * q2[0], inv_var[0], q2[1] * q2[1] * inv_var[1]));
+        return m.prior.lprior_const - 0.5 * (double)quad;
+    };
+
+    double lp;
+    uint32_t nacc = 0;
+    {
+        double ll0 = 0;
+        if constexpr (KIND == KIND_HMC) {
+            evaluate(True{}, x, g, ll0);
+            lp = ll0 + lprior_of(x);
+        } else if constexpr (KIND == KIND_MALA) {
+            evaluate(False{}, x, g, ll0);
+            lp = a.lp_state[chain];
+        } else if constexpr (KIND == KIND_UL) {
+            evaluate(False{}, x, g, ll0);
+            lp = 0;
+        } else {
+            lp = a.lp_state[chain];
+        }
+    }
+
+    for (int64_t it = 0; it < a.iters; ++it) {
+        for (int64_t jt = 0; jt < a.thin; ++jt) {
+            const uint64_t iter = (uint64_t)(a.iter_offset + it * a.thin + jt);
+            // normals for coordinates k (block 0) and k+4 (block 1): word pair k>>1, element k&1
+            float z[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const U4 w4 = philox4x32_10((uint32_t)gchain, (uint32_t)iter, (uint32_t)(iter >> 32), (uint32_t)h,
+                                            (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+                const uint32_t wa = k < 2 ? w4.x : w4.z, wb = k < 2 ? w4.y : w4.w;
+                float z0, z1;
+                box_muller(wa, wb, z0, z1);
+                z[h] = (k & 1) ? z1 : z0;
+            }
+            if constexpr (KIND == KIND_UL) {
+                x[0] = fma_t(kb[0], z[0], fma_t(ka[0], g[0], x[0]));
+                x[1] = fma_t(kb[1], z[1], fma_t(ka[1], g[1], x[1]));
+                double d0;
+                evaluate(False{}, x, g, d0);
+                ++nacc;
+            } else {
+                const double logu = (double)draw_log_uniform<float>(a.seed, gchain, iter);
+                float xp[2], gp[2];
+                double llp = 0, lprp = 0, logr;
+                if constexpr (KIND == KIND_RWMH) {
+                    xp[0] = fma_t(ka[0], z[0], x[0]);
+                    xp[1] = fma_t(ka[1], z[1], x[1]);
+                    evaluate(True{}, xp, gp, llp);
+                    lprp = lprior_of(xp);
+                    logr = (llp + lprp) - lp;
+                } else if constexpr (KIND == KIND_MALA) {
+                    float advx[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        advx[h] = fma_t(ka[h], g[h], x[h]);
+                        xp[h] = fma_t(kb[h], z[h], advx[h]);
+                    }
+                    evaluate(True{}, xp, gp, llp);
+                    lprp = lprior_of(xp);
+                    float dq = 0.0f;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const float advp = fma_t(ka[h], gp[h], xp[h]);
+                        const float d1 = x[h] - advp, d2 = xp[h] - advx[h];
+                        dq = fma_t(kc[h], d1 * d1 - d2 * d2, dq);
+                    }
+                    logr = (llp + lprp) - lp - 0.5 * (double)ksum(dq);
+                } else {  // HMC
+                    float pm[2];
+                    float k0 = 0.0f;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        pm[h] = z[h] * ka[h];
+                        k0 = fma_t(pm[h] * pm[h], kc[h], k0);
+                        xp[h] = x[h];
+                        gp[h] = g[h];
+                    }
+                    const float heps = 0.5f * a.step;
+                    pm[0] = fma_t(heps, gp[0], pm[0]);
+                    pm[1] = fma_t(heps, gp[1], pm[1]);
+                    for (int i = 0; i < a.l - 1; ++i) {
+                        xp[0] = fma_t(kb[0], pm[0], xp[0]);
+                        xp[1] = fma_t(kb[1], pm[1], xp[1]);
+                        double d0;
+                        evaluate(False{}, xp, gp, d0);
+                        pm[0] = fma_t(a.step, gp[0], pm[0]);
+                        pm[1] = fma_t(a.step, gp[1], pm[1]);
+                    }
+                    xp[0] = fma_t(kb[0], pm[0], xp[0]);
+                    xp[1] = fma_t(kb[1], pm[1], xp[1]);
+                    evaluate(True{}, xp, gp, llp);
+                    lprp = lprior_of(xp);
+                    float k1 = 0.0f;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        pm[h] = fma_t(heps, gp[h], pm[h]);
+                        k1 = fma_t(pm[h] * pm[h], kc[h], k1);
+                    }
+                    logr = ((llp + lprp) - lp) - 0.5 * (double)ksum(k1 - k0);
+                }
+                const bool acc = logu < logr;
+                if (acc) {
+                    ++nacc;
+                    lp = llp + lprp;
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    x[h] = acc ? xp[h] : x[h];
+                    if constexpr (KIND != KIND_RWMH) g[h] = acc ? gp[h] : g[h];
+                }
+            }
+        }
+        if (a.out && writer) {
+            float* o = a.out + (it * a.C + chain) * a.p;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                if (k + 4 * h < a.p) o[k + 4 * h] = x[h];
+        }
+    }
+    if (writer) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            if (k + 4 * h < a.p) a.state[chain * a.p + k + 4 * h] = x[h];
+        if (k == 0) {
+            if (a.accepts) a.accepts[chain] += nacc;
+            if constexpr (KIND == KIND_RWMH || KIND == KIND_MALA) a.lp_state[chain] = lp;
+        }
+    }
+}
+
+}  // namespace lr

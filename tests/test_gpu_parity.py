@@ -134,6 +134,46 @@ def test_single_hmc_iteration_every_variant(la, models, oracle_model, map_beta, 
     assert np.max((np.abs(out - ref["out"][0]) / POST_SD)[clear]) < 1e-3
 
 
+@pytest.mark.parametrize("ways", [1, 4])
+@pytest.mark.parametrize("kind", ["hmc", "mala", "rwmh", "ul"])
+def test_matrix_core_variant_single_iteration(la, models, oracle_model, map_beta, kind, ways):
+    """mode="mfma": eta = Xs.B^T and grad = Xs^T.W on v_mfma_f32_16x16x4_f32 (16 chains per wave,
+    `group` = row-split ways).  Same Philox stream, same oracle, same tolerances."""
+    C = 77  # not a multiple of 16: masked tail tile
+    rng = np.random.default_rng(17)
+    q0 = (map_beta + 0.7 * POST_SD * rng.standard_normal((C, 8))).astype(np.float32).astype(np.float64)
+    ll0 = oracle_model.lpost(q0) if kind in ("mala", "rwmh") else None
+    assert models["float32"].plan(C, ways, "mfma") == {"mode": "mfma", "group": ways, "rows_per_lane": 13 if ways == 1 else 4}
+    for it in (0, 3):
+        ref = oracle_model.run(kind, q0, thin=1, iters=1, seed=5, iter_offset=it, ll_state=ll0, threads=0, **KW[kind])
+        out, acc, llo = one_step(la, models["float32"], kind, q0, 5, it, ll=ll0, group=ways, mode="mfma")
+        clear = ref["margin"] > 1e-3
+        assert clear.mean() > 0.9
+        assert np.array_equal(acc[clear], ref["accepts"][clear].astype(np.uint32))
+        assert np.max((np.abs(out - ref["out"][0]) / POST_SD)[clear]) < 1e-3
+        if kind in ("mala", "rwmh"):
+            np.testing.assert_allclose(llo[clear], ref["ll"][clear], rtol=2e-5)
+
+
+@pytest.mark.parametrize("ways", [1, 4])
+def test_matrix_core_variant_invariances_and_short_run(la, models, oracle_model, map_beta, ways):
+    C = 200
+    rng = np.random.default_rng(2)
+    q0 = map_beta + 0.3 * POST_SD * rng.standard_normal((C, 8))
+    k = make_kernel(la, models["float32"], "hmc")
+    kw = dict(thin=3, iters=6, verb=False, seed=99, group=ways, mode="mfma")
+    full = la.mcmc(q0, k, **kw)
+    assert np.array_equal(full, la.mcmc(q0, k, **kw))
+    assert np.array_equal(full, la.mcmc(q0, k, chunk=4, **kw))
+    a = la.mcmc(q0[:50], k, **kw)
+    b = la.mcmc(q0[50:], k, chain_offset=50, **kw)
+    assert np.array_equal(full, np.concatenate([a, b], axis=1))
+    ref = oracle_model.run("hmc", q0, thin=3, iters=6, seed=99, threads=0, **KW["hmc"])
+    ok = ref["margin"] > 2e-3
+    assert ok.mean() > 0.9
+    assert np.max(np.abs(full[:, ok, :] - ref["out"][:, ok, :]) / POST_SD) < 2e-3
+
+
 def test_first_proposal_accepted_when_ll_is_minus_inf(la, models, map_beta):
     """mcmc() starts RWMH/MALA with ll = -inf (fit-np-mala.py:82): first proposal always accepted."""
     q0 = np.tile(map_beta, (256, 1))
