@@ -49,8 +49,10 @@ typedef enum lr_status {
 enum { LR_F32 = 0, LR_F64 = 1 };
 /* where the data rows live / which pipe does the matvecs: REG/LDS/GLOBAL use the vector ALU with rows in
  * VGPRs / LDS / memory; MFMA uses the fp32 matrix cores with rows in VGPRs (p = 8, small n; there `group`
- * selects the row-split ways S in {1,4} instead of lanes per chain) */
-enum { LR_MODE_AUTO = -1, LR_MODE_REG = 0, LR_MODE_LDS = 1, LR_MODE_GLOBAL = 2, LR_MODE_MFMA = 3 };
+ * selects the row-split ways S in {1,4} instead of lanes per chain); STEPWISE is the tall-data engine: two
+ * small kernels per log-posterior evaluation, the rows split into slices across the whole chip (`group` is
+ * ignored; lr_plan reports the slice count as group_out and the slice length as rows_out) */
+enum { LR_MODE_AUTO = -1, LR_MODE_REG = 0, LR_MODE_LDS = 1, LR_MODE_GLOBAL = 2, LR_MODE_MFMA = 3, LR_MODE_STEPWISE = 4 };
 
 typedef struct lr_model lr_model;
 

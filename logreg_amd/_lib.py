@@ -12,9 +12,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "liblogreg_hip.so")
 
 LR_F32, LR_F64 = 0, 1
-MODE_AUTO, MODE_REG, MODE_LDS, MODE_GLOBAL, MODE_MFMA = -1, 0, 1, 2, 3
-MODE_NAMES = {MODE_REG: "reg", MODE_LDS: "lds", MODE_GLOBAL: "global", MODE_MFMA: "mfma"}
-MODE_BY_NAME = {"auto": MODE_AUTO, "reg": MODE_REG, "lds": MODE_LDS, "global": MODE_GLOBAL, "mfma": MODE_MFMA}
+MODE_AUTO, MODE_REG, MODE_LDS, MODE_GLOBAL, MODE_MFMA, MODE_STEPWISE = -1, 0, 1, 2, 3, 4
+MODE_NAMES = {MODE_REG: "reg", MODE_LDS: "lds", MODE_GLOBAL: "global", MODE_MFMA: "mfma", MODE_STEPWISE: "stepwise"}
+MODE_BY_NAME = {"auto": MODE_AUTO, "reg": MODE_REG, "lds": MODE_LDS, "global": MODE_GLOBAL, "mfma": MODE_MFMA, "stepwise": MODE_STEPWISE}
 
 
 class LogregHipError(RuntimeError):

@@ -14,6 +14,7 @@
 
 #include "lr_inst.h"
 #include "lr_kernels.h"
+#include "lr_tall.h"
 
 LR_DECLARE_INST(f32_p4)
 LR_DECLARE_INST(f32_p8)
@@ -67,6 +68,8 @@ struct lr_model {
     double inv_var[kMaxP];
     double lprior_const = 0;
     const lr::InstTable* table = nullptr;
+    void* ws = nullptr;  // stepwise-engine workspace (grow-only, owned by the handle)
+    size_t ws_bytes = 0;
     size_t esize() const { return dtype == LR_F32 ? 4 : 8; }
 };
 
@@ -82,7 +85,25 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
     const int64_t want_waves = 4LL * m->cus;
     int best = -1;
     long best_score = -1;
-    if (for_eval && mode == LR_MODE_MFMA) { mode = LR_MODE_AUTO; group = 0; }
+    if (for_eval && (mode == LR_MODE_MFMA || mode == LR_MODE_STEPWISE)) { mode = LR_MODE_AUTO; group = 0; }
+    // tall data: neither VGPRs nor LDS can hold the rows -> stepwise engine (lr_tall.h): split the rows into
+    // RS slices so that every evaluation occupies the whole chip with ~4 waves per SIMD
+    const bool fits_lds = (size_t)m->n * m->P * m->esize() <= kLdsBudget;
+    if (!for_eval && (mode == LR_MODE_STEPWISE || (mode == LR_MODE_AUTO && group == 0 && !fits_lds && m->n >= 8192))) {
+        // a workgroup = NW waves x 64 chains working on one slice (NW as lr::TallGeom: LDS-limited)
+        const int raw = 2048 / (m->P * (int)m->esize());
+        const int64_t NW = raw >= 16 ? 16 : (raw >= 8 ? 8 : 4);
+        const int64_t waves_per_slice = NW * ((C + 63) / 64);
+        int64_t RS = (4 * want_waves + waves_per_slice - 1) / waves_per_slice;
+        int64_t slice_len = (m->n + RS - 1) / RS;
+        if (slice_len < 16 * NW) slice_len = 16 * NW;  // at least 16 rows per wave
+        RS = (m->n + slice_len - 1) / slice_len;
+        out->mode = lr::MODE_STEPWISE;
+        out->G = (int)RS;
+        out->R = (int)slice_len;
+        out->lds_bytes = 0;
+        return LR_OK;
+    }
     for (int i = 0; i < t->nvariants; ++i) {
         const lr::Variant& v = t->variants[i];
         if (v.mode == lr::MODE_MFMA) {
@@ -113,6 +134,12 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
         if (waves >= want_waves) score += 100000L - 1000L * v.G;  // filled: prefer small groups
         else score += 10L * v.G;                                   // not filled: prefer large groups
         if (v.mode == lr::MODE_REG) score -= v.R;                  // exact-fit R before padded R
+        // lane-per-chain with rows broadcast from the scalar unit has no replicated work and no
+        // reductions: measured fastest (2.0e8 it/s, 47 % of fp32 peak) once there are >= 4 waves per
+        // SIMD to hide the SMEM latency, provided the rows fit the 16 KB scalar cache
+        if (mode == LR_MODE_AUTO && group == 0 && v.mode == lr::MODE_GLOBAL && v.G == 1 && waves >= 4 * want_waves &&
+            (size_t)m->n * m->P * m->esize() <= 16 * 1024)
+            score = 4000000L;
         if (score > best_score) { best_score = score; best = i; }
     }
     if (best < 0)
@@ -191,6 +218,91 @@ int do_chain_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs, c
     return LR_OK;
 }
 
+template <typename T, int P>
+int do_stepwise_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs, const lr_run_opts* o, void* state,
+                  double* lp_state, void* out, uint32_t* accepts) {
+    const int64_t C = o->n_chains;
+    const int RS = pl.G;
+    auto align = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t vec = align((size_t)C * P * sizeof(T)), dbl = align((size_t)C * sizeof(double));
+    const size_t need = 4 * vec + 2 * dbl + align((size_t)C * 4) + align((size_t)RS * C * P * sizeof(T)) +
+                        align((size_t)RS * C * sizeof(double));
+    if (need > m->ws_bytes) {
+        if (m->ws) (void)hipFree(m->ws);
+        m->ws = nullptr;
+        m->ws_bytes = 0;
+        if (hipMalloc(&m->ws, need) != hipSuccess) return fail(LR_ERR_NOMEM, "stepwise workspace of %zu bytes", need);
+        m->ws_bytes = need;
+    }
+    unsigned char* w = static_cast<unsigned char*>(m->ws);
+    auto carve = [&](size_t b) { unsigned char* r = w; w += b; return r; };
+    lr::TallArgs<T, P> a;
+    a.rows = static_cast<const T*>(m->d_rows);
+    a.n = m->n;
+    a.slice_len = pl.R;
+    a.RS = RS;
+    for (int j = 0; j < P; ++j) a.prior.inv_var[j] = (T)m->inv_var[j];
+    a.prior.lprior_const = m->lprior_const;
+    a.x = (T*)carve(vec);
+    a.g = (T*)carve(vec);
+    a.q1 = (T*)carve(vec);
+    a.pm = (T*)carve(vec);
+    a.lp = (double*)carve(dbl);
+    a.aux = (double*)carve(dbl);
+    a.nacc = (uint32_t*)carve(align((size_t)C * 4));
+    a.part_g = (T*)carve(align((size_t)RS * C * P * sizeof(T)));
+    a.part_v = (double*)carve(align((size_t)RS * C * sizeof(double)));
+    a.state = static_cast<T*>(state);
+    a.lp_state = lp_state;
+    a.out = static_cast<T*>(out);
+    a.accepts = accepts;
+    a.C = C;
+    a.chain_offset = o->chain_offset;
+    a.seed = o->seed;
+    a.p = m->p;
+    a.l = rs.l;
+    a.step = (T)rs.step;
+    for (int j = 0; j < P; ++j) {
+        a.a[j] = (T)rs.a[j];
+        a.b[j] = (T)rs.b[j];
+        a.c[j] = (T)rs.c[j];
+    }
+    const lr::InstTable* t = m->table;
+    int rc = 0;
+    auto U = [&](int phase, int64_t iter, int64_t out_row, int bn) {
+        if (!rc) rc = t->launch_tall_update(st, rs.kind, phase, iter, out_row, bn, &a);
+    };
+    auto K = [&](int v, int g) {
+        if (!rc) rc = t->launch_tall_partial(st, v, g, &a);
+    };
+    const int kind = rs.kind;
+    U(lr::PH_LOAD, 0, -1, 0);
+    if (kind == lr::KIND_HMC) K(1, 1);
+    else if (kind != lr::KIND_RWMH) K(0, 1);
+    U(lr::PH_INIT, o->iter_offset, -1, 0);
+    const int64_t total = o->iters * o->thin;
+    for (int64_t tt = 0; tt < total && !rc; ++tt) {
+        if (kind == lr::KIND_HMC) {
+            for (int i = 0; i < rs.l - 1; ++i) {
+                K(0, 1);
+                U(lr::PH_MID, 0, -1, 0);
+            }
+            K(1, 1);
+        } else if (kind == lr::KIND_MALA) {
+            K(1, 1);
+        } else if (kind == lr::KIND_RWMH) {
+            K(1, 0);
+        } else {
+            K(0, 1);
+        }
+        const int64_t out_row = ((tt + 1) % o->thin == 0) ? (tt + 1) / o->thin - 1 : -1;
+        U(lr::PH_END, o->iter_offset + tt, out_row, tt + 1 < total);
+    }
+    U(lr::PH_STORE, 0, -1, 0);
+    if (rc) return fail(LR_ERR_HIP, "stepwise launch failed (%d): %s", rc, hipGetErrorString(hipGetLastError()));
+    return LR_OK;
+}
+
 #define LR_DISPATCH_TP(m, FN, ...)                                                       \
     do {                                                                                 \
         if ((m)->dtype == LR_F32) {                                                      \
@@ -216,8 +328,14 @@ int do_eval(lr_model* m, const Plan& pl, hipStream_t st, int64_t C, const void* 
     LR_DISPATCH_TP(m, do_eval_t, m, pl, st, C, beta, ll, lprior, lpost, grad);
 }
 
+int do_stepwise(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs, const lr_run_opts* o, void* state,
+                double* lp_state, void* out, uint32_t* accepts) {
+    LR_DISPATCH_TP(m, do_stepwise_t, m, pl, st, rs, o, state, lp_state, out, accepts);
+}
+
 int do_chain(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs, const lr_run_opts* o, void* state,
              double* lp_state, void* out, uint32_t* accepts) {
+    if (pl.mode == lr::MODE_STEPWISE) return do_stepwise(m, pl, st, rs, o, state, lp_state, out, accepts);
     LR_DISPATCH_TP(m, do_chain_t, m, pl, st, rs, o, state, lp_state, out, accepts);
 }
 
@@ -364,6 +482,7 @@ void lr_model_destroy(lr_model* m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
     if (m->d_rows) (void)hipFree(m->d_rows);
+    if (m->ws) (void)hipFree(m->ws);
     delete m;
 }
 

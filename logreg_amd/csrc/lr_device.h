@@ -281,6 +281,42 @@ template <typename T, int P, int G> struct StridedRows {  // LDS or global: same
     __device__ __forceinline__ T value_fixup() const { return T(0); }
 };
 
+// Lane-per-chain (G = 1) with rows broadcast from the SCALAR unit: every lane of the wave needs
+// the same row, so the row is fetched with s_load (constant address space -> SMEM through the
+// scalar cache) into SGPRs and used as the scalar operand of v_fmac: no LDS, no VGPRs for data,
+// no cross-lane reduction, nothing replicated.  [i0, i1) is the row slice this wave works on.
+template <typename T, int P, int PF = 1> struct ScalarRows {
+    typedef const __attribute__((address_space(4))) T* cptr;
+    const T* base;
+    int64_t i0, i1;
+    // PF rows are fetched per wait (PF s_loads in flight): SMEM latency (~500 cycles from L2) is
+    // paid once per PF rows.  The fused chain kernels use PF = 1 -- their uniform arguments already
+    // fill the 102-SGPR budget and deeper prefetch spills to VGPR lanes (measured 2.5x slower);
+    // the stepwise partial kernel has SGPRs to spare and uses PF = 4.
+    template <class F> __device__ __forceinline__ void for_each(F&& f) const {
+        cptr cb = (cptr)base;
+        int64_t i = i0;
+        if constexpr (PF > 1) {
+            for (; i + PF <= i1; i += PF) {
+                T xs[PF][P];
+#pragma unroll
+                for (int k = 0; k < PF; ++k)
+#pragma unroll
+                    for (int j = 0; j < P; ++j) xs[k][j] = cb[(i + k) * P + j];
+#pragma unroll
+                for (int k = 0; k < PF; ++k) f(xs[k]);
+            }
+        }
+        for (; i < i1; ++i) {
+            T xs[P];
+#pragma unroll
+            for (int j = 0; j < P; ++j) xs[j] = cb[i * P + j];
+            f(xs);
+        }
+    }
+    __device__ __forceinline__ T value_fixup() const { return T(0); }
+};
+
 // ------------------------------------------------------------------------------------------
 // log-posterior value / gradient of one chain, cooperatively over the G lanes of its group.
 //   value = ll + lprior (double), grad = d/dbeta (T), both replicated in all lanes of the group.

@@ -21,6 +21,10 @@ struct InstTable {
     const Variant* variants;
     int (*launch_eval)(const LaunchCfg*, int64_t C, const void* model_args, const void* eval_args);
     int (*launch_chain)(const LaunchCfg*, int64_t C, const void* model_args, const void* chain_args);
+    // stepwise (tall-data) engine, lr_tall.h; `tall_args` is a TallArgs<T,P>
+    int (*launch_tall_partial)(hipStream_t, int want_value, int want_grad, const void* tall_args);
+    int (*launch_tall_update)(hipStream_t, int kind, int phase, int64_t iter, int64_t out_row, int begin_next,
+                              const void* tall_args);
 };
 
 }  // namespace lr

@@ -2,6 +2,7 @@
 // Compiled several times:  hipcc -DLR_T=float -DLR_P=8 -DLR_SFX=f32_p8 -DLR_DTYPE=0 ...
 #include "lr_inst.h"
 #include "lr_kernels.h"
+#include "lr_tall.h"
 #if LR_DTYPE == 0 && LR_P == 8
 #include "lr_mfma.h"
 #endif
@@ -22,16 +23,18 @@ constexpr int P = LR_P;
 #if LR_DTYPE == 0 && LR_P == 8
 #define LR_VARIANTS(X)                                                                                \
     X(MODE_REG, 64, 4) X(MODE_REG, 32, 7) X(MODE_REG, 32, 8) X(MODE_REG, 16, 13) X(MODE_REG, 16, 16) \
-    X(MODE_LDS, 1, 0) X(MODE_LDS, 8, 0) X(MODE_LDS, 64, 0) X(MODE_GLOBAL, 64, 0)
+    X(MODE_LDS, 1, 0) X(MODE_LDS, 8, 0) X(MODE_LDS, 64, 0) X(MODE_GLOBAL, 64, 0) X(MODE_GLOBAL, 1, 0)
 #elif LR_DTYPE == 0 && LR_P == 4
 #define LR_VARIANTS(X) \
-    X(MODE_REG, 64, 8) X(MODE_REG, 16, 16) X(MODE_LDS, 1, 0) X(MODE_LDS, 8, 0) X(MODE_LDS, 64, 0) X(MODE_GLOBAL, 64, 0)
+    X(MODE_REG, 64, 8) X(MODE_REG, 16, 16) X(MODE_LDS, 1, 0) X(MODE_LDS, 8, 0) X(MODE_LDS, 64, 0) X(MODE_GLOBAL, 64, 0) \
+    X(MODE_GLOBAL, 1, 0)
 #elif LR_DTYPE == 0 && LR_P == 16
-#define LR_VARIANTS(X) X(MODE_REG, 64, 8) X(MODE_LDS, 1, 0) X(MODE_LDS, 8, 0) X(MODE_LDS, 64, 0) X(MODE_GLOBAL, 64, 0)
+#define LR_VARIANTS(X) \
+    X(MODE_REG, 64, 8) X(MODE_LDS, 1, 0) X(MODE_LDS, 8, 0) X(MODE_LDS, 64, 0) X(MODE_GLOBAL, 64, 0) X(MODE_GLOBAL, 1, 0)
 #elif LR_DTYPE == 0 && LR_P == 32
-#define LR_VARIANTS(X) X(MODE_REG, 64, 4) X(MODE_LDS, 8, 0) X(MODE_LDS, 64, 0) X(MODE_GLOBAL, 64, 0)
+#define LR_VARIANTS(X) X(MODE_REG, 64, 4) X(MODE_LDS, 8, 0) X(MODE_LDS, 64, 0) X(MODE_GLOBAL, 64, 0) X(MODE_GLOBAL, 1, 0)
 #else  // float64: validation-grade path, no register-resident variants
-#define LR_VARIANTS(X) X(MODE_LDS, 1, 0) X(MODE_LDS, 8, 0) X(MODE_LDS, 64, 0) X(MODE_GLOBAL, 64, 0)
+#define LR_VARIANTS(X) X(MODE_LDS, 1, 0) X(MODE_LDS, 8, 0) X(MODE_LDS, 64, 0) X(MODE_GLOBAL, 64, 0) X(MODE_GLOBAL, 1, 0)
 #endif
 
 // matrix-core variants (fp32, p = 8): X(row-split ways S, tiles per wave NTW); n <= 16*S*NTW
@@ -117,8 +120,31 @@ int launch_chain(const LaunchCfg* cfg, int64_t C, const void* model_args, const 
     return -3;
 }
 
+int launch_tall_partial(hipStream_t st, int want_value, int want_grad, const void* tall_args) {
+    const auto& a = *static_cast<const TallArgs<T, P>*>(tall_args);
+    const dim3 grid((unsigned)((a.C + 63) / 64), (unsigned)a.RS), block(64 * TallGeom<T, P>::NW);
+    if (want_value && want_grad) hipLaunchKernelGGL((k_tall_partial<T, P, true, true>), grid, block, 0, st, a);
+    else if (want_grad) hipLaunchKernelGGL((k_tall_partial<T, P, false, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((k_tall_partial<T, P, true, false>), grid, block, 0, st, a);
+    return check(hipGetLastError());
+}
+
+int launch_tall_update(hipStream_t st, int kind, int phase, int64_t iter, int64_t out_row, int begin_next,
+                       const void* tall_args) {
+    const auto& a = *static_cast<const TallArgs<T, P>*>(tall_args);
+    const dim3 grid((unsigned)((a.C * P + 255) / 256)), block(256);
+    switch (kind) {
+    case KIND_RWMH: hipLaunchKernelGGL((k_tall_update<T, P, KIND_RWMH>), grid, block, 0, st, a, phase, iter, out_row, begin_next); break;
+    case KIND_MALA: hipLaunchKernelGGL((k_tall_update<T, P, KIND_MALA>), grid, block, 0, st, a, phase, iter, out_row, begin_next); break;
+    case KIND_HMC: hipLaunchKernelGGL((k_tall_update<T, P, KIND_HMC>), grid, block, 0, st, a, phase, iter, out_row, begin_next); break;
+    case KIND_UL: hipLaunchKernelGGL((k_tall_update<T, P, KIND_UL>), grid, block, 0, st, a, phase, iter, out_row, begin_next); break;
+    default: return -1;
+    }
+    return check(hipGetLastError());
+}
+
 const InstTable kTable = {LR_DTYPE, P, (int)(sizeof(kVariants) / sizeof(kVariants[0])), kVariants, &launch_eval,
-                          &launch_chain};
+                          &launch_chain, &launch_tall_partial, &launch_tall_update};
 
 }  // namespace
 }  // namespace lr

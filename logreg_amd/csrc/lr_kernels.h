@@ -7,7 +7,7 @@
 namespace lr {
 
 enum Kind { KIND_RWMH = 0, KIND_MALA = 1, KIND_HMC = 2, KIND_UL = 3 };
-enum Mode { MODE_REG = 0, MODE_LDS = 1, MODE_GLOBAL = 2, MODE_MFMA = 3 };
+enum Mode { MODE_REG = 0, MODE_LDS = 1, MODE_GLOBAL = 2, MODE_MFMA = 3, MODE_STEPWISE = 4 };
 
 template <typename T, int P> struct ModelArgs {
     const T* rows;  // [n][P] signed rows (2y-1)*x, zero-padded to P columns (device)
@@ -53,6 +53,9 @@ template <typename T, int P, int G, int MODE, int R> struct RowsOf {
 template <typename T, int P, int G, int R> struct RowsOf<T, P, G, MODE_REG, R> {
     using type = RegRows<T, P, R, G>;
 };
+template <typename T, int P, int R> struct RowsOf<T, P, 1, MODE_GLOBAL, R> {
+    using type = ScalarRows<T, P>;  // lane-per-chain: rows broadcast through the scalar unit
+};
 
 template <typename T, int P, int G, int MODE, int R>
 __device__ __forceinline__ typename RowsOf<T, P, G, MODE, R>::type make_rows(const ModelArgs<T, P>& m, int gl,
@@ -68,6 +71,10 @@ __device__ __forceinline__ typename RowsOf<T, P, G, MODE, R>::type make_rows(con
         rows.base = smem;
         rows.n = m.n;
         rows.gl = gl;
+    } else if constexpr (G == 1) {
+        rows.base = m.rows;
+        rows.i0 = 0;
+        rows.i1 = m.n;
     } else {
         rows.base = m.rows;
         rows.n = m.n;

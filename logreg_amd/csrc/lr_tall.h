@@ -1,0 +1,283 @@
+// lr_tall.h -- "stepwise" engine for data that do not fit on chip (tall n): the leapfrog /
+// proposal loop is driven from the host as a sequence of two small kernels per log-posterior
+// evaluation, so that the rows can be split across the WHOLE chip for every evaluation:
+//
+//   k_tall_partial  grid (chains/256, RS row slices): lane per chain, the slice's rows broadcast
+//                   from the scalar unit (s_load -> SGPR operands of v_fmac); writes the partial
+//                   gradient / value of its slice:  part_g[RS][C][P], part_v[RS][C].
+//                   X is read C/256 times per evaluation in total (not once per chain).
+//   k_tall_update   P lanes per chain (lane = coordinate): sums the RS partials in a fixed order
+//                   (deterministic, no atomics), adds the prior, and advances the chain state
+//                   machine by one phase (leapfrog kick/drift, proposal, accept/reject, sample).
+//
+// Launch boundaries provide the device-wide synchronisation between "all slices reduced" and
+// "next position known"; at tall n one evaluation is tens of microseconds, so the two
+// boundaries per evaluation (~1.5 us each) cost a few percent.  Same Philox stream, same
+// arithmetic per row, same accept rule as the fused kernels (lr_kernels.h).
+#pragma once
+#include "lr_kernels.h"
+
+namespace lr {
+
+enum TallPhase { PH_LOAD = 0, PH_INIT = 1, PH_MID = 2, PH_END = 3, PH_STORE = 4 };
+
+template <typename T, int P> struct TallArgs {
+    const T* rows;  // [n][P] signed rows
+    int64_t n, slice_len;
+    int RS;
+    Prior<T, P> prior;
+    // workspace (device), padded layout [C][P]
+    T* x;        // current state
+    T* g;        // gradient at x
+    double* lp;  // log-density attached to x
+    T* q1;       // point being evaluated (trajectory position / proposal)
+    T* pm;       // HMC momentum | MALA advance(x)
+    double* aux; // HMC: initial kinetic energy
+    uint32_t* nacc;
+    T* part_g;       // [RS][C][P]
+    double* part_v;  // [RS][C]
+    // caller's arrays (device)
+    T* state;
+    double* lp_state;
+    T* out;
+    uint32_t* accepts;
+    int64_t C, chain_offset;
+    uint64_t seed;
+    int p, l;
+    T step;
+    T a[P], b[P], c[P];
+};
+
+// ---------------------------------------------------------------------------------------------
+// Workgroup = NW waves x 64 chains: wave w of the group takes the w-th sub-slice of the group's
+// row slice; the NW partial results are combined through LDS in wave order, so only RS partials
+// per (chain, coordinate) reach memory.
+template <typename T, int P> struct TallGeom {
+    static constexpr int kRaw = 2048 / (P * (int)sizeof(T));
+    static constexpr int NW = kRaw >= 16 ? 16 : (kRaw >= 8 ? 8 : 4);  // LDS = NW*64*P*sizeof(T) <= 128 KB
+};
+
+template <typename T, int P, bool VALUE, bool GRAD>
+__global__ void __launch_bounds__((64 * TallGeom<T, P>::NW)) k_tall_partial(TallArgs<T, P> a) {
+    constexpr int NW = TallGeom<T, P>::NW;
+    __shared__ T red_g[GRAD ? NW : 1][64][P];
+    __shared__ double red_v[VALUE ? NW : 1][64];
+    const int lane = threadIdx.x & 63;
+    // wave-uniform by construction; readfirstlane makes it PROVABLY uniform so the row addresses
+    // stay scalar and the rows are fetched with s_load (not 64-fold redundant vector loads)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int64_t chain = (int64_t)blockIdx.x * 64 + lane;
+    const bool live = chain < a.C;
+    if (!live) chain = a.C - 1;
+    const int rs = blockIdx.y;
+    const int64_t sub = (a.slice_len + NW - 1) / NW;
+    const int64_t s0 = (int64_t)rs * a.slice_len, s1 = s0 + a.slice_len < a.n ? s0 + a.slice_len : a.n;
+    ScalarRows<T, P, (P * sizeof(T) <= 64 ? 4 : 2)> rows;
+    rows.base = a.rows;
+    rows.i0 = s0 + wave * sub;
+    rows.i1 = rows.i0 + sub < s1 ? rows.i0 + sub : s1;
+    T bs[P], g[P];
+    double gd[P];  // blocked summation: fp32 over 16 rows, then fp64 -- a sub-slice can be thousands of
+                   // rows of strongly cancelling terms; a plain fp32 running sum loses ~sqrt(rows) ulps
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+        bs[j] = a.q1[chain * P + j] * ExpScale<T>::k;
+        g[j] = T(0);
+        gd[j] = 0.0;
+    }
+    double v = 0.0;
+    int cnt = 0;
+    rows.for_each([&](const T(&xs)[P]) {
+        T vt = T(0);
+        row_term<T, P, VALUE, GRAD>(xs, bs, g, vt);
+        if constexpr (VALUE) v += (double)vt;
+        if constexpr (GRAD && sizeof(T) == 4) {
+            if (++cnt == 16) {
+                cnt = 0;
+#pragma unroll
+                for (int j = 0; j < P; ++j) {
+                    gd[j] += (double)g[j];
+                    g[j] = T(0);
+                }
+            }
+        }
+    });
+    if constexpr (GRAD) {
+#pragma unroll
+        for (int j = 0; j < P; ++j) red_g[wave][lane][j] = (T)(gd[j] + (double)g[j]);
+    }
+    if constexpr (VALUE) red_v[wave][lane] = v;
+    __syncthreads();
+    if constexpr (GRAD) {
+        for (int e = threadIdx.x; e < 64 * P; e += 64 * NW) {  // element e = (chain c, coordinate j)
+            const int c = e / P, j = e % P;
+            double s = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) s += (double)red_g[w][c][j];
+            const int64_t ch = (int64_t)blockIdx.x * 64 + c;
+            if (ch < a.C) a.part_g[((int64_t)rs * a.C + ch) * P + j] = (T)s;
+        }
+    }
+    if constexpr (VALUE) {
+        if (wave == 0 && live) {
+            double s = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) s += red_v[w][lane];
+            a.part_v[(int64_t)rs * a.C + chain] = s;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// one coordinate per lane; chain = (global thread) / P
+template <typename T, int P, int KIND>
+__global__ void __launch_bounds__(256) k_tall_update(TallArgs<T, P> a, int phase, int64_t iter, int64_t out_row,
+                                                     int begin_next) {
+    const int64_t gt = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t chain = gt / P;
+    const int j = (int)(gt % P);
+    const bool live = chain < a.C;
+    if (!live) chain = a.C - 1;
+    const int64_t ix = chain * P + j;
+    const uint64_t gchain = (uint64_t)(a.chain_offset + chain);
+    const T aj = a.a[j], bj = a.b[j], cj = a.c[j], ivj = a.prior.inv_var[j];
+
+    auto reduced_grad = [&]() {  // likelihood partials in slice order + prior
+        double s = 0.0;
+        for (int r = 0; r < a.RS; ++r) s += (double)a.part_g[((int64_t)r * a.C + chain) * P + j];
+        return (T)s - a.q1[ix] * ivj;
+    };
+    auto reduced_value = [&]() {  // lpost(q1) = sum of slice values + lprior(q1)
+        double s = 0.0;
+        for (int r = 0; r < a.RS; ++r) s += a.part_v[(int64_t)r * a.C + chain];
+        const T q = a.q1[ix];
+        const T quad = group_sum<P>(q * q * ivj);
+        return s + a.prior.lprior_const - 0.5 * (double)quad;
+    };
+    auto normal_j = [&](uint64_t it) {  // coordinate j: Philox block j/4, word pair (j%4)/2, element j&1
+        const U4 w = philox4x32_10((uint32_t)gchain, (uint32_t)it, (uint32_t)(it >> 32), (uint32_t)(j >> 2),
+                                   (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+        const uint32_t wa = (j & 2) ? w.z : w.x, wb = (j & 2) ? w.w : w.y;
+        T z0, z1;
+        box_muller(wa, wb, z0, z1);
+        return (j & 1) ? z1 : z0;
+    };
+    // start iteration `it` from (x, g, lp): draw, set q1 (+pm, aux)
+    auto begin = [&](uint64_t it, T x, T g) {
+        const T z = normal_j(it);
+        if constexpr (KIND == KIND_HMC) {
+            T p = z * aj;
+            const T k0 = group_sum<P>(p * p * cj);
+            p = fma_t(T(0.5) * a.step, g, p);
+            if (live) {
+                a.pm[ix] = p;
+                a.q1[ix] = fma_t(bj, p, x);
+                if (j == 0) a.aux[chain] = (double)k0;
+            }
+        } else if constexpr (KIND == KIND_MALA) {
+            const T advx = fma_t(aj, g, x);
+            if (live) {
+                a.pm[ix] = advx;
+                a.q1[ix] = fma_t(bj, z, advx);
+            }
+        } else if constexpr (KIND == KIND_UL) {
+            const T xn = fma_t(bj, z, fma_t(aj, g, x));
+            if (live) {
+                a.x[ix] = xn;
+                a.q1[ix] = xn;
+            }
+        } else {
+            if (live) a.q1[ix] = fma_t(aj, z, x);
+        }
+    };
+
+    if (phase == PH_LOAD) {
+        const T x = j < a.p ? a.state[chain * a.p + j] : T(0);
+        if (live) {
+            a.x[ix] = x;
+            a.q1[ix] = x;
+            if (j == 0) a.nacc[chain] = 0;
+        }
+        return;
+    }
+    if (phase == PH_INIT) {  // after the evaluation at x
+        T g = T(0);
+        if constexpr (KIND != KIND_RWMH) g = reduced_grad();
+        double lp;
+        if constexpr (KIND == KIND_HMC) lp = reduced_value();
+        else if constexpr (KIND == KIND_UL) lp = 0.0;
+        else lp = a.lp_state[chain];
+        if (live) {
+            a.g[ix] = g;
+            if (j == 0) a.lp[chain] = lp;
+        }
+        begin((uint64_t)iter, a.x[ix], g);
+        return;
+    }
+    if (phase == PH_MID) {  // HMC interior step: kick with the new gradient, drift
+        const T g1 = reduced_grad();
+        const T p = fma_t(a.step, g1, a.pm[ix]);
+        if (live) {
+            a.pm[ix] = p;
+            a.q1[ix] = fma_t(bj, p, a.q1[ix]);
+        }
+        return;
+    }
+    if (phase == PH_END) {
+        T x = a.x[ix], g = a.g[ix];
+        if constexpr (KIND == KIND_UL) {
+            g = reduced_grad();
+            if (live) {
+                a.g[ix] = g;
+                if (j == 0) a.nacc[chain] += 1;
+            }
+        } else {
+            const T q1 = a.q1[ix];
+            T g1 = T(0);
+            if constexpr (KIND != KIND_RWMH) g1 = reduced_grad();
+            const double lp1 = reduced_value();
+            const double lp = a.lp[chain];
+            double logr;
+            if constexpr (KIND == KIND_HMC) {
+                const T p = fma_t(T(0.5) * a.step, g1, a.pm[ix]);
+                const T k1 = group_sum<P>(p * p * cj);
+                logr = (lp1 - lp) - 0.5 * ((double)k1 - a.aux[chain]);
+            } else if constexpr (KIND == KIND_MALA) {
+                const T advp = fma_t(aj, g1, q1);
+                const T d1 = x - advp, d2 = q1 - a.pm[ix];
+                const T dq = group_sum<P>(cj * (d1 * d1 - d2 * d2));
+                logr = (lp1 - lp) - 0.5 * (double)dq;
+            } else {
+                logr = lp1 - lp;
+            }
+            const double logu = (double)draw_log_uniform<T>(a.seed, gchain, (uint64_t)iter);
+            const bool acc = logu < logr;
+            if (acc) {
+                x = q1;
+                g = g1;
+            }
+            if (live && acc) {
+                a.x[ix] = x;
+                if constexpr (KIND != KIND_RWMH) a.g[ix] = g;
+                if (j == 0) {
+                    a.lp[chain] = lp1;
+                    a.nacc[chain] += 1;
+                }
+            }
+        }
+        if (out_row >= 0 && live && j < a.p && a.out) a.out[(out_row * a.C + chain) * a.p + j] = x;
+        if (begin_next) begin((uint64_t)iter + 1, x, g);
+        return;
+    }
+    if (phase == PH_STORE) {
+        if (live) {
+            if (j < a.p) a.state[chain * a.p + j] = a.x[ix];
+            if (j == 0) {
+                if (a.accepts) a.accepts[chain] += a.nacc[chain];
+                if constexpr (KIND == KIND_RWMH || KIND == KIND_MALA) a.lp_state[chain] = a.lp[chain];
+            }
+        }
+    }
+}
+
+}  // namespace lr

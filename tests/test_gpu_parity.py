@@ -174,6 +174,66 @@ def test_matrix_core_variant_invariances_and_short_run(la, models, oracle_model,
     assert np.max(np.abs(full[:, ok, :] - ref["out"][:, ok, :]) / POST_SD) < 2e-3
 
 
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+@pytest.mark.parametrize("kind", ["hmc", "mala", "rwmh", "ul"])
+def test_stepwise_engine_matches_oracle(la, models, oracle_model, map_beta, kind, dtype):
+    """mode="stepwise" (tall-data engine: row slices across the chip, two kernels per evaluation)
+    forced on Pima: same stream, same oracle; float64 is compared over a free-running run."""
+    C = 300
+    rng = np.random.default_rng(23)
+    q0 = (map_beta + 0.7 * POST_SD * rng.standard_normal((C, 8))).astype(np.float32).astype(np.float64)
+    ll0 = oracle_model.lpost(q0) if kind in ("mala", "rwmh") else None
+    k = make_kernel(la, models[dtype], kind)
+    assert models[dtype].plan(C, 0, "stepwise")["mode"] == "stepwise"
+    # float32: one iteration at the one-step tolerance of the fused kernels (fp32 trajectories drift
+    # ~1e-3 sd per iteration from spread-out starts); float64: a free-running multi-iteration run
+    iters, thin = (1, 1) if dtype == "float32" else ((3, 2) if kind != "mala" else (2, 1))
+    ref = oracle_model.run(kind, q0, thin=thin, iters=iters, seed=8, ll_state=ll0, threads=0, **KW[kind])
+    out, info = la.mcmc(q0, k, thin=thin, iters=iters, verb=False, seed=8, ll=ll0, mode="stepwise", return_info=True)
+    clear = ref["margin"] > (1e-3 if dtype == "float32" else 1e-7)
+    assert clear.mean() > 0.9
+    assert np.array_equal(info["accepts"][clear], ref["accepts"][clear].astype(np.uint32))
+    err = np.abs(out - ref["out"]) / POST_SD
+    assert np.max(err[:, clear, :]) < (1e-3 if dtype == "float32" else 1e-7)
+    if dtype == "float32":  # and a longer run must agree with the fused float32 kernels to fp32 noise
+        iters, thin = 3, 2
+        fused = la.mcmc(q0, k, thin=thin, iters=iters, verb=False, seed=8, ll=ll0)
+        out = la.mcmc(q0, k, thin=thin, iters=iters, verb=False, seed=8, ll=ll0, mode="stepwise")
+        same = np.max(np.abs(out - fused) / POST_SD, axis=(0, 2)) < 2e-2
+        assert same.mean() > (0.97 if kind != "mala" else 0.8)
+    # chunking and sharding stay bit-exact in this engine too
+    again = la.mcmc(q0, k, thin=thin, iters=iters, verb=False, seed=8, ll=ll0, mode="stepwise", chunk=1)
+    assert np.array_equal(out, again)
+    a = la.mcmc(q0[:100], k, thin=thin, iters=iters, verb=False, seed=8, ll=None if ll0 is None else ll0[:100], mode="stepwise")
+    b = la.mcmc(q0[100:], k, thin=thin, iters=iters, verb=False, seed=8, ll=None if ll0 is None else ll0[100:], mode="stepwise",
+                chain_offset=100)
+    assert np.array_equal(out, np.concatenate([a, b], axis=1))
+
+
+def test_tall_data_uses_stepwise_engine_and_matches_oracle(la):
+    """n = 20000 rows (640 KB of rows: beyond VGPRs and LDS): AUTO selects the stepwise engine."""
+    from oracle.oracle import OracleModel
+    n, p, C = 20000, 8, 96
+    X, y, _ = la.synthetic_logreg(n, p, seed=20240004)
+    ps = np.array([10.0] + [1.0] * 7)
+    orc = OracleModel(X, y, ps)
+    rng = np.random.default_rng(4)
+    q0 = 0.05 * rng.standard_normal((C, p))
+    dmm = np.full(p, n / 200.0)
+    ref = orc.run("hmc", q0, step=2e-4, l=6, scale=dmm, thin=1, iters=2, seed=12, threads=0)
+    for dtype, tol in (("float32", 2e-4), ("float64", 1e-9)):
+        m = la.LogReg(X, y, ps, dtype=dtype)
+        assert m.plan(C)["mode"] == "stepwise"
+        r = m.eval(q0[:16])
+        np.testing.assert_allclose(r["lpost"], orc.lpost(q0[:16]), rtol=5e-6 if dtype == "float32" else 1e-12)
+        out, info = la.mcmc(q0, la.hmcKernel(m.lpost, m.glp, eps=2e-4, l=6, dmm=dmm), thin=1, iters=2, verb=False,
+                            seed=12, return_info=True)
+        ok = ref["margin"] > (5e-3 if dtype == "float32" else 1e-7)
+        assert ok.mean() > 0.9
+        assert np.array_equal(info["accepts"][ok], ref["accepts"][ok].astype(np.uint32))
+        assert np.max(np.abs(out[:, ok] - ref["out"][:, ok])) < tol
+
+
 def test_first_proposal_accepted_when_ll_is_minus_inf(la, models, map_beta):
     """mcmc() starts RWMH/MALA with ll = -inf (fit-np-mala.py:82): first proposal always accepted."""
     q0 = np.tile(map_beta, (256, 1))
