@@ -68,6 +68,12 @@ def build(force: bool = False, jobs: int | None = None, verbose: bool = True) ->
         objs.append(obj)
         jobs_list.append([hipcc, *COMMON, f"-DLR_T={ctype}", f"-DLR_P={p}", f"-DLR_SFX={sfx}",
                           f"-DLR_DTYPE={dtype_id}", "-c", os.path.join(CSRC, "lr_inst.hip"), "-o", obj])
+    for p in (64, 128):  # wide models: MFMA stepwise engine, float32 only
+        sfx = f"f32_p{p}"
+        obj = os.path.join(OBJDIR, f"lr_inst_{sfx}.o")
+        objs.append(obj)
+        jobs_list.append([hipcc, *COMMON, f"-DLR_P={p}", f"-DLR_SFX={sfx}", "-c",
+                          os.path.join(CSRC, "lr_inst_wide.hip"), "-o", obj])
     api_obj = os.path.join(OBJDIR, "lr_api.o")
     objs.append(api_obj)
     jobs_list.append([hipcc, *COMMON, "-c", os.path.join(CSRC, "lr_api.hip"), "-o", api_obj])

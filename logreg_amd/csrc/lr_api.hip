@@ -24,6 +24,8 @@ LR_DECLARE_INST(f64_p4)
 LR_DECLARE_INST(f64_p8)
 LR_DECLARE_INST(f64_p16)
 LR_DECLARE_INST(f64_p32)
+LR_DECLARE_INST(f32_p64)   // wide models: stepwise engine with the MFMA partial kernel only
+LR_DECLARE_INST(f32_p128)
 
 namespace {
 
@@ -46,13 +48,14 @@ int fail(int code, const char* fmt, ...) {
 const lr::InstTable* find_table(int dtype, int P) {
     const lr::InstTable* all[] = {lr_inst_table_f32_p4(),  lr_inst_table_f32_p8(), lr_inst_table_f32_p16(),
                                   lr_inst_table_f32_p32(), lr_inst_table_f64_p4(), lr_inst_table_f64_p8(),
-                                  lr_inst_table_f64_p16(), lr_inst_table_f64_p32()};
+                                  lr_inst_table_f64_p16(), lr_inst_table_f64_p32(), lr_inst_table_f32_p64(),
+                                  lr_inst_table_f32_p128()};
     for (const lr::InstTable* t : all)
         if (t->dtype == dtype && t->P == P) return t;
     return nullptr;
 }
 
-constexpr int kMaxP = 32;
+constexpr int kMaxP = 128;
 constexpr size_t kLdsBudget = 160 * 1024;
 
 }  // namespace
@@ -85,6 +88,27 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
     const int64_t want_waves = 4LL * m->cus;
     int best = -1;
     long best_score = -1;
+    if (m->P > 32) {
+        // wide models (32 < p <= 128): only the stepwise engine exists; its partial kernel is an MFMA
+        // GEMM over blocks of 64 chains x row slices (lr_wide.h).  ~2 workgroups per CU.
+        if (mode != LR_MODE_AUTO && mode != LR_MODE_STEPWISE)
+            return fail(LR_ERR_UNSUPPORTED, "p=%d > 32 runs on the stepwise engine only (mode=%d requested)", m->p, mode);
+        const int64_t blocks = (C + 63) / 64;
+        // measured (tools/wide_sweep.py): 2 workgroups per CU pay off only when each still gets >= 32
+        // row tiles (8192 chains: 96 vs 77 TFLOP/s); with less work 1 per CU wins (1024 chains: 51 vs 44)
+        const char* env = std::getenv("LOGREG_WIDE_WG_PER_CU");  // tuning override
+        const int64_t tiles_at_2 = (m->n / 16) * blocks / (2LL * m->cus);
+        const int64_t per_cu = env && std::atoi(env) > 0 ? std::atoi(env) : (tiles_at_2 >= 32 ? 2 : 1);
+        int64_t RS = (per_cu * m->cus + blocks - 1) / blocks;
+        int64_t slice_len = (m->n + RS - 1) / RS;
+        slice_len = (slice_len + 15) / 16 * 16;
+        RS = (m->n + slice_len - 1) / slice_len;
+        out->mode = lr::MODE_STEPWISE;
+        out->G = (int)RS;
+        out->R = (int)slice_len;
+        out->lds_bytes = 0;
+        return LR_OK;
+    }
     if (for_eval && (mode == LR_MODE_MFMA || mode == LR_MODE_STEPWISE)) { mode = LR_MODE_AUTO; group = 0; }
     // tall data: neither VGPRs nor LDS can hold the rows -> stepwise engine (lr_tall.h): split the rows into
     // RS slices so that every evaluation occupies the whole chip with ~4 waves per SIMD
@@ -219,9 +243,8 @@ int do_chain_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs, c
 }
 
 template <typename T, int P>
-int do_stepwise_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs, const lr_run_opts* o, void* state,
-                  double* lp_state, void* out, uint32_t* accepts) {
-    const int64_t C = o->n_chains;
+int setup_tall(lr_model* m, const Plan& pl, int64_t C, lr::TallArgs<T, P>* pa) {
+    lr::TallArgs<T, P>& a = *pa;
     const int RS = pl.G;
     auto align = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t vec = align((size_t)C * P * sizeof(T)), dbl = align((size_t)C * sizeof(double));
@@ -236,7 +259,7 @@ int do_stepwise_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs
     }
     unsigned char* w = static_cast<unsigned char*>(m->ws);
     auto carve = [&](size_t b) { unsigned char* r = w; w += b; return r; };
-    lr::TallArgs<T, P> a;
+    std::memset(&a, 0, sizeof(a));
     a.rows = static_cast<const T*>(m->d_rows);
     a.n = m->n;
     a.slice_len = pl.R;
@@ -252,6 +275,38 @@ int do_stepwise_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs
     a.nacc = (uint32_t*)carve(align((size_t)C * 4));
     a.part_g = (T*)carve(align((size_t)RS * C * P * sizeof(T)));
     a.part_v = (double*)carve(align((size_t)RS * C * sizeof(double)));
+    a.C = C;
+    a.p = m->p;
+    return LR_OK;
+}
+
+// lr_eval through the stepwise engine (tall or wide models): load -> partial(value, grad) -> finish
+template <typename T, int P>
+int do_eval_stepwise_t(lr_model* m, const Plan& pl, hipStream_t st, int64_t C, const void* beta, void* ll, void* lprior,
+                       void* lpost, void* grad) {
+    lr::TallArgs<T, P> a;
+    int rc = setup_tall<T, P>(m, pl, C, &a);
+    if (rc) return rc;
+    a.state = static_cast<T*>(const_cast<void*>(beta));
+    a.ev_ll = static_cast<T*>(ll);
+    a.ev_lprior = static_cast<T*>(lprior);
+    a.ev_lpost = static_cast<T*>(lpost);
+    a.ev_grad = static_cast<T*>(grad);
+    const lr::InstTable* t = m->table;
+    rc = t->launch_tall_update(st, lr::KIND_HMC, lr::PH_LOAD, 0, -1, 0, &a);
+    if (!rc) rc = t->launch_tall_partial(st, 1, 1, &a);
+    if (!rc) rc = t->launch_tall_update(st, lr::KIND_HMC, lr::PH_EVAL, 0, -1, 0, &a);
+    if (rc) return fail(LR_ERR_HIP, "stepwise eval launch failed (%d): %s", rc, hipGetErrorString(hipGetLastError()));
+    return LR_OK;
+}
+
+template <typename T, int P>
+int do_stepwise_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs, const lr_run_opts* o, void* state,
+                  double* lp_state, void* out, uint32_t* accepts) {
+    const int64_t C = o->n_chains;
+    lr::TallArgs<T, P> a;
+    int rc = setup_tall<T, P>(m, pl, C, &a);
+    if (rc) return rc;
     a.state = static_cast<T*>(state);
     a.lp_state = lp_state;
     a.out = static_cast<T*>(out);
@@ -268,7 +323,6 @@ int do_stepwise_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs
         a.c[j] = (T)rs.c[j];
     }
     const lr::InstTable* t = m->table;
-    int rc = 0;
     auto U = [&](int phase, int64_t iter, int64_t out_row, int bn) {
         if (!rc) rc = t->launch_tall_update(st, rs.kind, phase, iter, out_row, bn, &a);
     };
@@ -323,14 +377,30 @@ int do_stepwise_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs
         return fail(LR_ERR_UNSUPPORTED, "unsupported padded width %d", (m)->P);          \
     } while (0)
 
+int do_eval_stepwise(lr_model* m, const Plan& pl, hipStream_t st, int64_t C, const void* beta, void* ll, void* lprior,
+                     void* lpost, void* grad);
+
 int do_eval(lr_model* m, const Plan& pl, hipStream_t st, int64_t C, const void* beta, void* ll, void* lprior,
             void* lpost, void* grad) {
+    if (pl.mode == lr::MODE_STEPWISE) return do_eval_stepwise(m, pl, st, C, beta, ll, lprior, lpost, grad);
     LR_DISPATCH_TP(m, do_eval_t, m, pl, st, C, beta, ll, lprior, lpost, grad);
 }
 
+#define LR_DISPATCH_STEP(m, FN, ...)                                                     \
+    do {                                                                                 \
+        if ((m)->dtype == LR_F32 && (m)->P == 64) return FN<float, 64>(__VA_ARGS__);     \
+        if ((m)->dtype == LR_F32 && (m)->P == 128) return FN<float, 128>(__VA_ARGS__);   \
+        LR_DISPATCH_TP(m, FN, __VA_ARGS__);                                              \
+    } while (0)
+
 int do_stepwise(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs, const lr_run_opts* o, void* state,
                 double* lp_state, void* out, uint32_t* accepts) {
-    LR_DISPATCH_TP(m, do_stepwise_t, m, pl, st, rs, o, state, lp_state, out, accepts);
+    LR_DISPATCH_STEP(m, do_stepwise_t, m, pl, st, rs, o, state, lp_state, out, accepts);
+}
+
+int do_eval_stepwise(lr_model* m, const Plan& pl, hipStream_t st, int64_t C, const void* beta, void* ll, void* lprior,
+                     void* lpost, void* grad) {
+    LR_DISPATCH_STEP(m, do_eval_stepwise_t, m, pl, st, C, beta, ll, lprior, lpost, grad);
 }
 
 int do_chain(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs, const lr_run_opts* o, void* state,
@@ -429,7 +499,8 @@ int lr_model_create(const double* X, const double* y, int64_t n, int32_t p, cons
                     int32_t device, lr_model** out) {
     if (!X || !y || !prior_sd || !out) return fail(LR_ERR_INVALID, "NULL argument");
     if (n <= 0 || p <= 0) return fail(LR_ERR_INVALID, "n and p must be positive");
-    if (p > kMaxP) return fail(LR_ERR_UNSUPPORTED, "p=%d > %d: the wide-p (MFMA) path is not built yet", p, kMaxP);
+    if (p > kMaxP) return fail(LR_ERR_UNSUPPORTED, "p=%d > %d is not supported", p, kMaxP);
+    if (p > 32 && dtype != LR_F32) return fail(LR_ERR_UNSUPPORTED, "p=%d > 32 is float32 only (MFMA stepwise engine)", p);
     if (dtype != LR_F32 && dtype != LR_F64) return fail(LR_ERR_INVALID, "dtype must be LR_F32 or LR_F64");
     int rc = positive_vec("prior_sd", prior_sd, p);
     if (rc) return rc;
@@ -445,7 +516,7 @@ int lr_model_create(const double* X, const double* y, int64_t n, int32_t p, cons
     m->dtype = dtype;
     m->n = n;
     m->p = p;
-    m->P = p <= 4 ? 4 : p <= 8 ? 8 : p <= 16 ? 16 : 32;
+    m->P = p <= 4 ? 4 : p <= 8 ? 8 : p <= 16 ? 16 : p <= 32 ? 32 : p <= 64 ? 64 : 128;
     m->table = find_table(dtype, m->P);
     if (!m->table) { delete m; return fail(LR_ERR_UNSUPPORTED, "no kernels for dtype=%d padded p=%d", dtype, m->P); }
     hipDeviceProp_t prop;

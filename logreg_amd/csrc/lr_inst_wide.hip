@@ -1,0 +1,42 @@
+// lr_inst_wide.hip -- kernels for WIDE models (padded p = 64 or 128, float32): only the stepwise
+// engine exists at these widths; its partial kernel is the MFMA GEMM of lr_wide.h.
+// Compiled twice:  hipcc -DLR_P=64 -DLR_SFX=f32_p64 ... / -DLR_P=128 -DLR_SFX=f32_p128 ...
+#include "lr_inst.h"
+#include "lr_wide.h"
+
+namespace lr {
+namespace {
+
+constexpr int P = LR_P;
+inline int check(hipError_t e) { return e == hipSuccess ? 0 : -2; }
+
+int launch_tall_partial(hipStream_t st, int want_value, int /*want_grad*/, const void* tall_args) {
+    const auto& a = *static_cast<const TallArgs<float, P>*>(tall_args);
+    const dim3 grid((unsigned)((a.C + 63) / 64), (unsigned)a.RS), block(256);
+    if (want_value) hipLaunchKernelGGL((k_wide_partial<P, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((k_wide_partial<P, false>), grid, block, 0, st, a);
+    return check(hipGetLastError());
+}
+
+int launch_tall_update(hipStream_t st, int kind, int phase, int64_t iter, int64_t out_row, int begin_next,
+                       const void* tall_args) {
+    const auto& a = *static_cast<const TallArgs<float, P>*>(tall_args);
+    const dim3 grid((unsigned)((a.C * P + 255) / 256)), block(256);
+    switch (kind) {
+    case KIND_RWMH: hipLaunchKernelGGL((k_tall_update<float, P, KIND_RWMH>), grid, block, 0, st, a, phase, iter, out_row, begin_next); break;
+    case KIND_MALA: hipLaunchKernelGGL((k_tall_update<float, P, KIND_MALA>), grid, block, 0, st, a, phase, iter, out_row, begin_next); break;
+    case KIND_HMC: hipLaunchKernelGGL((k_tall_update<float, P, KIND_HMC>), grid, block, 0, st, a, phase, iter, out_row, begin_next); break;
+    case KIND_UL: hipLaunchKernelGGL((k_tall_update<float, P, KIND_UL>), grid, block, 0, st, a, phase, iter, out_row, begin_next); break;
+    default: return -1;
+    }
+    return check(hipGetLastError());
+}
+
+const InstTable kTable = {0, P, 0, nullptr, nullptr, nullptr, &launch_tall_partial, &launch_tall_update};
+
+}  // namespace
+}  // namespace lr
+
+#define LR_CAT2(a, b) a##b
+#define LR_CAT(a, b) LR_CAT2(a, b)
+extern "C" const lr::InstTable* LR_CAT(lr_inst_table_, LR_SFX)() { return &lr::kTable; }

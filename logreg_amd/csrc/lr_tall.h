@@ -19,7 +19,30 @@
 
 namespace lr {
 
-enum TallPhase { PH_LOAD = 0, PH_INIT = 1, PH_MID = 2, PH_END = 3, PH_STORE = 4 };
+enum TallPhase { PH_LOAD = 0, PH_INIT = 1, PH_MID = 2, PH_END = 3, PH_STORE = 4, PH_EVAL = 5 };
+
+// sum over the P coordinate-lanes of one chain (lane = coordinate, 256-thread blocks).
+// P <= 64: the chain sits inside one wave (DPP butterfly).  P > 64: the chain spans P/64 waves
+// of the block; wave sums are combined through LDS in wave order (identical in every lane).
+// Must be called by all threads of the block (it synchronises).
+template <int P, typename T> __device__ __forceinline__ T chain_sum(T v) {
+    if constexpr (P <= 64) {
+        return group_sum<P>(v);
+    } else {
+        __shared__ double part[4];
+        constexpr int WPC = P / 64;  // waves per chain
+        const int wave = threadIdx.x >> 6;
+        const double ws = (double)group_sum<64>(v);
+        __syncthreads();  // previous use of `part` is over
+        if ((threadIdx.x & 63) == 0) part[wave] = ws;
+        __syncthreads();
+        const int w0 = (wave / WPC) * WPC;
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < WPC; ++i) s += part[w0 + i];
+        return (T)s;
+    }
+}
 
 template <typename T, int P> struct TallArgs {
     const T* rows;  // [n][P] signed rows
@@ -41,6 +64,11 @@ template <typename T, int P> struct TallArgs {
     double* lp_state;
     T* out;
     uint32_t* accepts;
+    // lr_eval outputs (PH_EVAL), unpadded; any may be null
+    T* ev_ll;
+    T* ev_lprior;
+    T* ev_lpost;
+    T* ev_grad;
     int64_t C, chain_offset;
     uint64_t seed;
     int p, l;
@@ -151,7 +179,7 @@ __global__ void __launch_bounds__(256) k_tall_update(TallArgs<T, P> a, int phase
         double s = 0.0;
         for (int r = 0; r < a.RS; ++r) s += a.part_v[(int64_t)r * a.C + chain];
         const T q = a.q1[ix];
-        const T quad = group_sum<P>(q * q * ivj);
+        const T quad = chain_sum<P>(q * q * ivj);
         return s + a.prior.lprior_const - 0.5 * (double)quad;
     };
     auto normal_j = [&](uint64_t it) {  // coordinate j: Philox block j/4, word pair (j%4)/2, element j&1
@@ -167,7 +195,7 @@ __global__ void __launch_bounds__(256) k_tall_update(TallArgs<T, P> a, int phase
         const T z = normal_j(it);
         if constexpr (KIND == KIND_HMC) {
             T p = z * aj;
-            const T k0 = group_sum<P>(p * p * cj);
+            const T k0 = chain_sum<P>(p * p * cj);
             p = fma_t(T(0.5) * a.step, g, p);
             if (live) {
                 a.pm[ix] = p;
@@ -240,12 +268,12 @@ __global__ void __launch_bounds__(256) k_tall_update(TallArgs<T, P> a, int phase
             double logr;
             if constexpr (KIND == KIND_HMC) {
                 const T p = fma_t(T(0.5) * a.step, g1, a.pm[ix]);
-                const T k1 = group_sum<P>(p * p * cj);
+                const T k1 = chain_sum<P>(p * p * cj);
                 logr = (lp1 - lp) - 0.5 * ((double)k1 - a.aux[chain]);
             } else if constexpr (KIND == KIND_MALA) {
                 const T advp = fma_t(aj, g1, q1);
                 const T d1 = x - advp, d2 = q1 - a.pm[ix];
-                const T dq = group_sum<P>(cj * (d1 * d1 - d2 * d2));
+                const T dq = chain_sum<P>(cj * (d1 * d1 - d2 * d2));
                 logr = (lp1 - lp) - 0.5 * (double)dq;
             } else {
                 logr = lp1 - lp;
@@ -267,6 +295,22 @@ __global__ void __launch_bounds__(256) k_tall_update(TallArgs<T, P> a, int phase
         }
         if (out_row >= 0 && live && j < a.p && a.out) a.out[(out_row * a.C + chain) * a.p + j] = x;
         if (begin_next) begin((uint64_t)iter + 1, x, g);
+        return;
+    }
+    if (phase == PH_EVAL) {  // ll / lprior / lpost / glp at q1 (lr_eval through the stepwise engine)
+        const T gq = reduced_grad();
+        double s = 0.0;
+        for (int r = 0; r < a.RS; ++r) s += a.part_v[(int64_t)r * a.C + chain];
+        const T q = a.q1[ix];
+        const double lpr = a.prior.lprior_const - 0.5 * (double)chain_sum<P>(q * q * ivj);
+        if (live) {
+            if (a.ev_grad && j < a.p) a.ev_grad[chain * a.p + j] = gq;
+            if (j == 0) {
+                if (a.ev_ll) a.ev_ll[chain] = (T)s;
+                if (a.ev_lprior) a.ev_lprior[chain] = (T)lpr;
+                if (a.ev_lpost) a.ev_lpost[chain] = (T)(s + lpr);
+            }
+        }
         return;
     }
     if (phase == PH_STORE) {

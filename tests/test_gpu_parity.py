@@ -234,6 +234,43 @@ def test_tall_data_uses_stepwise_engine_and_matches_oracle(la):
         assert np.max(np.abs(out[:, ok] - ref["out"][:, ok])) < tol
 
 
+@pytest.mark.parametrize("p,n,C", [(128, 1000, 70), (100, 513, 64), (40, 300, 130)])
+def test_wide_models_run_on_the_matrix_cores(la, p, n, C):
+    """32 < p <= 128: X.beta over a chain block is a dense GEMM -> fp32 MFMA partial kernel of the
+    stepwise engine (lr_wide.h).  fp32-in/fp32-accumulate MFMA is an exact fmaf chain, so the
+    tolerances are the fp32 ones."""
+    from oracle.oracle import OracleModel
+    X, y, _ = la.synthetic_logreg(n, p, seed=20240005 + p, beta_sd=0.1)
+    ps = np.full(p, 1.5)
+    orc = OracleModel(X, y, ps)
+    m = la.LogReg(X, y, ps)
+    assert m.plan(C)["mode"] == "stepwise"
+    rng = np.random.default_rng(p)
+    b = 0.1 * rng.standard_normal((C, p))
+    r = m.eval(b)
+    np.testing.assert_allclose(r["ll"], orc.ll(b), rtol=3e-6)
+    np.testing.assert_allclose(r["lprior"], orc.lprior(b), rtol=3e-6)
+    np.testing.assert_allclose(r["lpost"], orc.lpost(b), rtol=3e-6)
+    assert np.max(np.abs(r["glp"] - orc.glp(b))) < 2e-4 * np.sqrt(n)
+    assert isinstance(m.lpost(b[0]), float) and m.glp(b[0]).shape == (p,)
+    eps, L = 0.02, 6
+    for kind, kw in (("hmc", dict(step=eps, l=L, scale=np.ones(p))), ("mala", dict(step=1e-3, scale=np.ones(p))),
+                     ("rwmh", dict(scale=np.full(p, 0.02))), ("ul", dict(step=1e-3, scale=np.ones(p)))):
+        k = {"hmc": lambda: la.hmcKernel(m.lpost, m.glp, eps=eps, l=L, dmm=np.ones(p)),
+             "mala": lambda: la.malaKernel(m.lpost, m.glp, dt=1e-3, pre=np.ones(p)),
+             "rwmh": lambda: la.mhKernel(m.lpost, la.rwProposal(np.full(p, 0.02))),
+             "ul": lambda: la.ulKernel(m.glp, dt=1e-3, pre=np.ones(p))}[kind]()
+        ll0 = orc.lpost(b) if kind in ("mala", "rwmh") else None
+        ref = orc.run(kind, b, thin=1, iters=2, seed=6, ll_state=ll0, threads=0, **kw)
+        out, info = la.mcmc(b, k, thin=1, iters=2, verb=False, seed=6, ll=ll0, return_info=True)
+        ok = ref["margin"] > 2e-3
+        assert ok.mean() > 0.85, kind
+        assert np.array_equal(info["accepts"][ok], ref["accepts"][ok].astype(np.uint32)), kind
+        assert np.max(np.abs(out[:, ok] - ref["out"][:, ok])) < 5e-4, kind
+        again = la.mcmc(b, k, thin=1, iters=2, verb=False, seed=6, ll=ll0, chunk=1)
+        assert np.array_equal(out, again)
+
+
 def test_first_proposal_accepted_when_ll_is_minus_inf(la, models, map_beta):
     """mcmc() starts RWMH/MALA with ll = -inf (fit-np-mala.py:82): first proposal always accepted."""
     q0 = np.tile(map_beta, (256, 1))

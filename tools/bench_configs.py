@@ -74,7 +74,20 @@ def config4(chains=1024, n=100000):
             "accept": float(cs.get_accepts().sum() / (chains * 3))}
 
 
+def config5(chains=1024, n=4096, p=128):
+    X, y, _ = la.synthetic_logreg(n, p, seed=20240005, beta_sd=0.1)
+    m = la.LogReg(X, y, np.ones(p))
+    k = la.hmcKernel(m.lpost, m.glp, eps=5e-3, l=50, dmm=np.ones(p))
+    cs = la.ChainSet(k, np.zeros((chains, p)), seed=5)
+    dt, _ = timed(cs, 4, 1, warm=1)
+    its = chains * 4
+    fg = 4 * n * p + 5 * n + 2 * p
+    return {"config": 5, "what": f"HMC L=50, n={n}, p={p}, {chains} chains (one GPU's shard of 8192)", "plan": cs.plan(),
+            "it_per_s": its / dt, "grad_evals_per_s": its * 50 / dt, "tflops_algorithmic": its * 50 * fg / dt / 1e12,
+            "accept": float(cs.get_accepts().sum() / (chains * 5))}
+
+
 if __name__ == "__main__":
-    which = [int(a) for a in sys.argv[1:]] or [1, 3, 4]
+    which = [int(a) for a in sys.argv[1:]] or [1, 3, 4, 5]
     for c in which:
-        print(json.dumps({1: config1, 3: config3, 4: config4}[c]()), flush=True)
+        print(json.dumps({1: config1, 3: config3, 4: config4, 5: config5}[c]()), flush=True)
