@@ -80,7 +80,7 @@ def main():
         if rank == 0:
             print(f"warning: WORLD_SIZE={world} != --gpus {a.gpus}; using WORLD_SIZE", file=sys.stderr)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("LOGREG_BENCH_FORCE_DIST") == "1":  # the env var exercises the RCCL path at N=1
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import torch
         import torch.distributed as dist
@@ -100,7 +100,7 @@ def main():
     rng = np.random.Generator(np.random.Philox(SEED + 1000 * rank))
     q0 = init + 0.1 * 0.17 * rng.standard_normal((C, N_PAR))
 
-    dev = local_rank if world > 1 else 0
+    dev = local_rank if dist is not None else 0
     model = la.LogReg(X, y, pscale, dtype="float32", device=dev)
     kern = la.hmcKernel(model.lpost, model.glp, eps=EPS, l=LEAP, dmm=np.ones(N_PAR))
     L = _lib.load()
@@ -188,6 +188,15 @@ def main():
                                  "ALU + transcendental unit (peak = 157.3 TF fp32 vector = fp32-MFMA peak), not by "
                                  "HBM (8 TB/s) nor by the bf16 matrix cores; see DESIGN.md"},
         }
+        # HBM traffic of the same launch from the committed rocprofv3 PMC passes (profiles/), if they
+        # were taken for this kernel variant and shape
+        try:
+            tr = json.load(open(os.path.join(REPO, "profiles", "r1_traffic.json")))
+            if tr["kernel_variant"] == plan and tr["chains"] == C and tr["thin"] == THIN:
+                line["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+                line["roofline"]["traffic_source"] = "profiles/r1_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)"
+        except (OSError, KeyError, ValueError):
+            pass
         if not a.no_ess:
             samples = out.to_host()  # rank 0's chains, [steps, C, p]
             ess = la.ess_pooled(samples, max_chains=64)
