@@ -261,6 +261,31 @@ class ChainSet:
         self.sync()
         return self.acc.to_host()
 
+    # -- checkpoint / resume (the reference has none: a run is all-or-nothing).  Because the random
+    # stream is counter-based, (state, threaded ll, iteration counter, seed, chain offset) IS the
+    # complete sampler state: a resumed run continues bit-for-bit.
+    def checkpoint(self) -> dict:
+        self.sync()
+        return {"state": self.state.to_host(), "ll": self.lp.to_host(), "accepts": self.acc.to_host(),
+                "iter_offset": np.int64(self.iter_offset), "seed": np.uint64(self.seed),
+                "chain_offset": np.int64(self.chain_offset), "kind": self.kernel.kind}
+
+    def save(self, path: str):
+        np.savez(path, **self.checkpoint())
+        return path
+
+    @classmethod
+    def resume(cls, kernel: "FusedKernel", ckpt, group: int = 0, mode: str = "auto", stream=None) -> "ChainSet":
+        if isinstance(ckpt, str):
+            ckpt = dict(np.load(ckpt, allow_pickle=False))
+        if str(ckpt["kind"]) != kernel.kind:
+            raise ValueError(f"checkpoint is for a {ckpt['kind']} kernel, got {kernel.kind}")
+        cs = cls(kernel, ckpt["state"], int(ckpt["seed"]), chain_offset=int(ckpt["chain_offset"]), ll=ckpt["ll"],
+                 group=group, mode=mode, stream=stream)
+        cs.iter_offset = int(ckpt["iter_offset"])
+        cs.acc.copy_from(np.asarray(ckpt["accepts"], dtype=np.uint32))
+        return cs
+
 
 def _auto_chunk(kernel: FusedKernel, C: int, thin: int, iters: int) -> int:
     """Kept samples per launch.  A launch is bounded to ~2e9 data-element visits per chain (a few

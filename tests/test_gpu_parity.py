@@ -422,6 +422,34 @@ def test_generic_composition_with_device_closures_replays_reference_draws(la, mo
     np.testing.assert_allclose(out, np.array(g["hmc"]["states"])[:12], rtol=1e-7, atol=1e-9)
 
 
+def test_device_map_finder_matches_bfgs_fixture(la, models, map_beta):  # F2, section 8(f) item 1
+    g = load_golden("map.json")
+    beta, info = la.find_map(models["float64"], np.zeros(8))
+    assert info["converged"] and info["lpost"] == pytest.approx(g["lpost_map"], abs=1e-7)
+    np.testing.assert_allclose(beta, map_beta, atol=2e-4)
+    beta32, info32 = la.find_map(models["float32"], np.zeros(8))
+    assert info32["lpost"] == pytest.approx(g["lpost_map"], abs=2e-3)
+    assert np.max(np.abs(beta32 - map_beta) / POST_SD) < 0.05
+
+
+@pytest.mark.parametrize("kind", ["hmc", "mala", "rwmh"])
+def test_checkpoint_resume_is_bit_exact(la, models, map_beta, tmp_path, kind):  # section 8(f) item 3
+    q0 = np.tile(map_beta, (96, 1))
+    k = make_kernel(la, models["float32"], kind)
+    full = la.ChainSet(k, q0, seed=77)
+    ref = full.advance(10, 3).to_host()
+    cs = la.ChainSet(k, q0, seed=77)
+    first = cs.advance(4, 3).to_host()
+    path = cs.save(str(tmp_path / "ckpt.npz"))
+    del cs
+    cs2 = la.ChainSet.resume(k, path)
+    rest = cs2.advance(6, 3).to_host()
+    assert np.array_equal(np.concatenate([first, rest]), ref)
+    assert np.array_equal(cs2.get_accepts(), full.get_accepts())
+    with pytest.raises(ValueError):
+        la.ChainSet.resume(make_kernel(la, models["float32"], "ul"), path)
+
+
 def test_errors_are_loud(la, models, map_beta):
     m = models["float32"]
     with pytest.raises(la.LogregHipError):

@@ -120,3 +120,36 @@ def test_synthetic_design_is_deterministic():
     X2, y2, b2 = la.synthetic_logreg(200, 8)
     assert np.array_equal(X1, X2) and np.array_equal(y1, y2) and np.all(X1[:, 0] == 1)
     assert set(np.unique(y1)) <= {0.0, 1.0}
+
+
+def test_output_writer_roundtrip(tmp_path):
+    pd = pytest.importorskip("pandas")
+    pytest.importorskip("pyarrow")
+    rng = np.random.default_rng(0)
+    one = rng.standard_normal((50, 8))
+    path = la.write_parquet(one, str(tmp_path / "fit.parquet"))
+    df = pd.read_parquet(path)
+    assert list(df.columns) == ["b0", "b1", "b2", "b3", "b4", "b5", "b6", "b7"]  # fit-np-hmc.py:111
+    np.testing.assert_array_equal(la.read_parquet(path), one)
+    many = rng.standard_normal((20, 3, 8)).astype(np.float32)
+    path = la.write_parquet(many, str(tmp_path / "many.parquet"))
+    np.testing.assert_array_equal(la.read_parquet(path), many)
+    d = la.print_summary(one)
+    assert d["nobs"] == 50
+
+
+def test_find_map_on_oracle_closures(oracle_model, map_beta):
+    """The Newton warm start only needs an object with .p, .np_dtype and a batched .eval()."""
+    class Shim:
+        p, np_dtype = 8, np.float64
+
+        def eval(self, beta, want=("lpost", "glp")):
+            b = np.atleast_2d(np.asarray(beta, dtype=np.float64))
+            single = np.ndim(beta) == 1
+            r = {"lpost": oracle_model.lpost(b), "glp": oracle_model.glp(b)}
+            return {k: (v[0] if single else v) for k, v in r.items() if k in want}
+    from logreg_amd.optimize import find_map
+    beta, info = find_map(Shim(), np.zeros(8))
+    assert info["converged"]
+    assert oracle_model.lpost(beta) == pytest.approx(-100.44943693563212, abs=1e-7)
+    np.testing.assert_allclose(beta, map_beta, atol=2e-4)
