@@ -147,6 +147,62 @@ template <int G, typename T> __device__ __forceinline__ T group_sum(T v) {
     return v;
 }
 
+// All draws of one iteration for a chain owned by G lanes: z[0..P) and log(u).
+// With G >= P/4 + 1 lanes the work is SPLIT: lane gl computes ONE Philox block (normal blocks
+// 0..NB-1, or the uniform block NB) and its two Box-Muller pairs, and the values are then
+// broadcast inside the group with ds_swizzle (bit-mask mode: lane' = (lane & and) | or within 32
+// lanes; v_readlane when the group is the whole wave).  Per lane: 1 Philox + 2 Box-Muller + 1 log
+// instead of NB+1 Philox + 2 NB Box-Muller + 1 log -- the RNG is 60 % of a MALA/RWMH iteration.
+// The VALUES are those of draw_normals/draw_log_uniform bit for bit.
+template <int G, int SRC> __device__ __forceinline__ float group_bcast(float v) {
+    static_assert(SRC < G, "source lane outside the group");
+    if constexpr (G == 64) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), SRC));
+    } else {
+        constexpr int and_mask = 0x1F & ~(G - 1), pattern = and_mask | (SRC << 5);
+        return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), pattern));
+    }
+}
+template <int G, int SRC> __device__ __forceinline__ double group_bcast(double v) {
+    const uint64_t b = __builtin_bit_cast(uint64_t, v);
+    const float lo = group_bcast<G, SRC>(__builtin_bit_cast(float, (uint32_t)b));
+    const float hi = group_bcast<G, SRC>(__builtin_bit_cast(float, (uint32_t)(b >> 32)));
+    return __builtin_bit_cast(double, ((uint64_t)__builtin_bit_cast(uint32_t, hi) << 32) | __builtin_bit_cast(uint32_t, lo));
+}
+
+template <typename T, int P, int G, int B = 0>
+__device__ __forceinline__ void bcast_blocks(const T (&mine)[4], T (&z)[P]) {
+    if constexpr (4 * B < P) {
+        if constexpr (4 * B + 0 < P) z[4 * B + 0] = group_bcast<G, B>(mine[0]);
+        if constexpr (4 * B + 1 < P) z[4 * B + 1] = group_bcast<G, B>(mine[1]);
+        if constexpr (4 * B + 2 < P) z[4 * B + 2] = group_bcast<G, B>(mine[2]);
+        if constexpr (4 * B + 3 < P) z[4 * B + 3] = group_bcast<G, B>(mine[3]);
+        bcast_blocks<T, P, G, B + 1>(mine, z);
+    }
+}
+
+template <typename T, int P, int G>
+__device__ __forceinline__ void draw_group(uint64_t seed, uint64_t chain, uint64_t iter, int gl, T (&z)[P], T& logu) {
+    constexpr int NB = (P + 3) / 4;
+    if constexpr (G < NB + 1) {
+        draw_normals<T, P>(seed, chain, iter, z);
+        logu = draw_log_uniform<T>(seed, chain, iter);
+    } else {
+        const bool is_u = gl == NB;  // lanes beyond NB recompute block NB's neighbours; their values are never read
+        const uint32_t blk = is_u ? TAG_UNIFORM : (uint32_t)(gl > NB ? 0 : gl);
+        const U4 w = philox4x32_10((uint32_t)chain, (uint32_t)iter, (uint32_t)(iter >> 32), blk, (uint32_t)seed,
+                                   (uint32_t)(seed >> 32));
+        T mine[4];
+        box_muller(w.x, w.y, mine[0], mine[1]);
+        box_muller(w.z, w.w, mine[2], mine[3]);
+        T lu;
+        if constexpr (sizeof(T) == 4) lu = logf(u01<float>(w.x));
+        else lu = log(u01<double>(w.x));
+        bcast_blocks<T, P, G>(mine, z);
+        logu = group_bcast<G, NB>(lu);
+    }
+}
+
 // N independent float values at once: level-major order keeps >= N-1 instructions between a
 // value's write and its next DPP read, and each level is ONE fused v_add_f32_dpp per value
 // (hipcc otherwise emits v_mov_dpp + v_pk_add).  hipcc pads no hazards inside asm statements:

@@ -150,7 +150,8 @@ __global__ void __launch_bounds__(256) k_chain(ModelArgs<T, P> m, ChainArgs<T, P
         for (int64_t jt = 0; jt < a.thin; ++jt) {
             const uint64_t iter = (uint64_t)(a.iter_offset + it * a.thin + jt);
             T z[P];
-            draw_normals<T, P>(a.seed, gchain, iter, z);
+            T logu_t;
+            draw_group<T, P, G>(a.seed, gchain, iter, gl, z, logu_t);
 
             if constexpr (KIND == KIND_UL) {
                 // x <- x + 0.5*pre*dt*glp(x) + sqrt(pre*dt)*z            fit-np-ul.py:65-67
@@ -160,7 +161,7 @@ __global__ void __launch_bounds__(256) k_chain(ModelArgs<T, P> m, ChainArgs<T, P
                 eval_lpost<T, P, G, false, true>(rows, m.prior, x, g, d0, d1);
                 ++nacc;
             } else {
-                const double logu = (double)draw_log_uniform<T>(a.seed, gchain, iter);
+                const double logu = (double)logu_t;
                 T xp[P], gp[P];
                 double llp = 0, lprp = 0, logr;
                 if constexpr (KIND == KIND_RWMH) {
