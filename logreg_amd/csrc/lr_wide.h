@@ -22,7 +22,13 @@ namespace lr {
 template <int P> struct WideGeom {
     static constexpr int H = P / 4;    // coordinates per lane = eta MFMAs per tile
     static constexpr int MB = P / 16;  // gradient M-blocks
-    static constexpr int LD = P + 4;   // padded LDS row (floats): keeps 16-B alignment, staggers banks
+    // LDS layouts chosen so that every ds_read_b128 of a 16-lane service group touches 16 distinct
+    // 4-bank slots (the first version, row-major with a +4 pad, had 2-way conflicts on every read):
+    //   LA row = 4 k-blocks of 64 floats (H used) + 4 pad  -> bank(c, k, i) = 4c + 4i      (LDA = 260)
+    //   LG row = MB/4 chunks x [16 cidx][4 mb]             -> bank(cidx, i) = 4 cidx        (LDG = 16 MB)
+    static constexpr int LDA = 4 * 64 + 4;
+    static constexpr int LDG = 16 * MB;
+    static constexpr int SMEM = 2 * 16 * LDA + 2 * 16 * LDG;  // floats
 };
 
 template <int P, bool VALUE>
@@ -30,9 +36,9 @@ __global__ void __launch_bounds__(256) k_wide_partial(TallArgs<float, P> a) {
     using G = WideGeom<P>;
     // one LDS block: [LA buffers | LG buffers] during the row loop, then reused as the 64 x P
     // output tile so that the partial gradient leaves the CU as one contiguous 64*P*4-byte copy
-    __shared__ __attribute__((aligned(16))) float smem[4 * 16 * G::LD];
-    float (*LA)[16][G::LD] = reinterpret_cast<float (*)[16][G::LD]>(smem);
-    float (*LG)[16][G::LD] = reinterpret_cast<float (*)[16][G::LD]>(smem + 2 * 16 * G::LD);
+    __shared__ __attribute__((aligned(16))) float smem[G::SMEM];
+    float (*LA)[16][G::LDA] = reinterpret_cast<float (*)[16][G::LDA]>(smem);
+    float (*LG)[16][G::LDG] = reinterpret_cast<float (*)[16][G::LDG]>(smem + 2 * 16 * G::LDA);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, k = lane >> 4;
     int64_t chain = (int64_t)blockIdx.x * 64 + 16 * wave + c;
@@ -67,8 +73,9 @@ __global__ void __launch_bounds__(256) k_wide_partial(TallArgs<float, P> a) {
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
             const int col = scol + i;
-            LA[buf][srow][(col & 3) * G::H + (col >> 2)] = stage[i];
-            LG[buf][srow][(col & 15) * G::MB + (col >> 4)] = stage[i];
+            LA[buf][srow][(col & 3) * 64 + (col >> 2)] = stage[i];
+            const int mb = col >> 4;
+            LG[buf][srow][(mb >> 2) * 64 + (col & 15) * 4 + (mb & 3)] = stage[i];
         }
     };
     if (ntiles > 0) {
@@ -84,14 +91,14 @@ __global__ void __launch_bounds__(256) k_wide_partial(TallArgs<float, P> a) {
         //      group of 8 MFMAs would wait a full LDS round trip
         f32x4 av[G::H / 4], gv[4][G::MB / 4];
         {
-            const f32x4* la4 = reinterpret_cast<const f32x4*>(&LA[buf][c][k * G::H]);
+            const f32x4* la4 = reinterpret_cast<const f32x4*>(&LA[buf][c][k * 64]);
 #pragma unroll
             for (int i = 0; i < G::H / 4; ++i) av[i] = la4[i];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const f32x4* lg4 = reinterpret_cast<const f32x4*>(&LG[buf][4 * k + s][cidx * G::MB]);
+                const f32x4* lg4 = reinterpret_cast<const f32x4*>(&LG[buf][4 * k + s][cidx * 4]);
 #pragma unroll
-                for (int i = 0; i < G::MB / 4; ++i) gv[s][i] = lg4[i];
+                for (int i = 0; i < G::MB / 4; ++i) gv[s][i] = lg4[i * 16];  // chunk i is 64 floats further
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -126,7 +133,7 @@ __global__ void __launch_bounds__(256) k_wide_partial(TallArgs<float, P> a) {
     }
     // epilogue: registers -> LDS tile [64 chains][P] -> coalesced 16-byte stores.  (Direct stores
     // from the MFMA layout are 16-byte fragments 512 B apart: measured ~20 us per launch for 16 MB.)
-    static_assert(64 * P <= 4 * 16 * G::LD, "output tile must fit the staging block");
+    static_assert(64 * P <= G::SMEM, "output tile must fit the staging block");
     float* otile = smem;
 #pragma unroll
     for (int mb = 0; mb < G::MB; ++mb)
