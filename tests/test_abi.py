@@ -55,3 +55,16 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(root, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
                 assert "lr_oracle" not in src and "liblr_oracle" not in src, f
+
+
+def test_plain_c_client_compiles_against_the_header(tmp_path):
+    """examples/fit_bayes.c (the reference's C/fit-bayes.c as a client of the C ABI) builds with gcc."""
+    import subprocess
+    from logreg_amd import _lib, build
+    build.build(verbose=False)
+    lib_dir = os.path.dirname(_lib.LIB_PATH)
+    exe = tmp_path / "fit_bayes"
+    subprocess.run(["gcc", "-O2", "-Wall", "-Werror", "-I", os.path.join(REPO, "include"),
+                    os.path.join(REPO, "examples", "fit_bayes.c"), "-L", lib_dir, "-llogreg_hip",
+                    "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)], check=True)
+    assert exe.exists()

@@ -500,3 +500,24 @@ def test_full_size_properties_4096_chains(la, models, map_beta):
     # chains are exchangeable and independent: per-chain means scatter like posterior_sd/sqrt(ESS)
     last = a[-1]
     assert np.all(np.abs(last.mean(axis=0) - np.array([-9.6, 0.1, 0.033, -0.007, 0.001, 0.084, 1.31, 0.042])) < 6 * POST_SD / np.sqrt(C) + 0.05 * POST_SD)
+
+
+def test_plain_c_client_runs_the_reference_c_program(tmp_path):
+    """examples/fit_bayes.c == C/fit-bayes.c (RWMH, start (-10,0..), proposal sd 0.2/0.02) through the C ABI."""
+    import os
+    import subprocess
+    from conftest import REPO
+    from logreg_amd import _lib
+    lib_dir = os.path.dirname(_lib.LIB_PATH)
+    exe = tmp_path / "fit_bayes"
+    subprocess.run(["gcc", "-O2", "-I", os.path.join(REPO, "include"), os.path.join(REPO, "examples", "fit_bayes.c"),
+                    "-L", lib_dir, "-llogreg_hip", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)], check=True)
+    r = subprocess.run([str(exe), os.path.join(REPO, "logreg_amd", "data", "Pima.tr.txt"), "600", "500"],
+                       capture_output=True, text=True, check=True)
+    lines = r.stdout.strip().split("\n")
+    assert lines[0].split() == [f"beta{j}" for j in range(8)]  # C/fit-bayes.c:104-107
+    a = np.array([[float(v) for v in ln.split()] for ln in lines[1:]])
+    assert a.shape == (600, 8)
+    ref = load_golden("posterior_rwmh.json")["pooled"]
+    z = (a[200:].mean(axis=0) - np.array(ref["mean"])) / (POST_SD / np.sqrt(20))  # ~20 effective draws at worst
+    assert np.max(np.abs(z)) < 4.0
