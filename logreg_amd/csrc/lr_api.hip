@@ -143,7 +143,7 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
                 const long score = (filled ? (v.G == 1) : (v.G == 4)) ? 2 : 1;
                 if (score > best_score) { best_score = score; best = i; }
             } else if (mode == LR_MODE_AUTO && group == 0 && filled && v.G == 1) {
-                const long score = 5000000L;  // above the scalar-row rule below (1.86e8 vs 1.78e8 it/s at 2^18 chains)
+                const long score = 3000000L;  // below the scalar-row rule (2^18 chains: scalar 1.99e8, mfma 1.90e8, reg16 1.82e8)
                 if (score > best_score) { best_score = score; best = i; }
             }
             continue;

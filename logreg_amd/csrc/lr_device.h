@@ -279,9 +279,21 @@ template <> struct ExpScale<double> {
 // `bs` is beta * ExpScale<T>::k.
 template <typename T, int P, bool VALUE, bool GRAD>
 __device__ __forceinline__ void row_term(const T (&xs)[P], const T (&bs)[P], T (&g)[P], T& v) {
-    T ts = xs[0] * bs[0];
+    T ts;
+    if constexpr (sizeof(T) == 4 && P % 2 == 0 && P >= 4) {
+        // two interleaved partial dot products on v_pk_fma_f32: P/2 packed ops + 1 add instead of P
+        // serial v_fmac.  A single wave per SIMD is issue-limited (one VALU op per ~4-6 cycles whatever
+        // its width), so at 4096 chains packed ops are nearly free extra work per issue slot.
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        f2 acc = f2{xs[0], xs[1]} * f2{bs[0], bs[1]};
 #pragma unroll
-    for (int j = 1; j < P; ++j) ts = fma_t(xs[j], bs[j], ts);
+        for (int j = 2; j < P; j += 2) acc = __builtin_elementwise_fma(f2{xs[j], xs[j + 1]}, f2{bs[j], bs[j + 1]}, acc);
+        ts = acc.x + acc.y;
+    } else {
+        ts = xs[0] * bs[0];
+#pragma unroll
+        for (int j = 1; j < P; ++j) ts = fma_t(xs[j], bs[j], ts);
+    }
     if constexpr (GRAD) {
         const T w = fast_rcp(T(1) + ExpScale<T>::exp_scaled(ts));  // sigma(-t); exp overflow -> rcp(inf) = 0
 #pragma unroll
