@@ -195,6 +195,8 @@ def main():
             if tr["kernel_variant"] == plan and tr["chains"] == C and tr["thin"] == THIN:
                 line["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
                 line["roofline"]["traffic_source"] = "profiles/r1_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)"
+                line["roofline"]["hbm_GBps_measured"] = tr["hbm_bytes_per_launch"] / kern_s / 1e9
+                line["roofline"]["hbm_frac"] = tr["hbm_bytes_per_launch"] / kern_s / (HBM_PEAK_GBS * 1e9)
         except (OSError, KeyError, ValueError):
             pass
         if not a.no_ess:

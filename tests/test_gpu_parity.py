@@ -347,15 +347,20 @@ def z_scores(summ, ref):
     return zm, zs
 
 
-def test_hmc_posterior_matches_reference_within_3_mcse(la, models, map_beta):  # F7: the north_star criterion
+@pytest.mark.parametrize("mode,group,C,burn,keep", [("auto", 0, 4096, 1000, 60), ("mfma", 1, 4096, 1000, 60),
+                                                    ("mfma", 4, 2048, 1000, 60), ("global", 1, 4096, 1000, 60),
+                                                    ("lds", 8, 2048, 1000, 60), ("stepwise", 0, 1024, 400, 40)])
+def test_hmc_posterior_matches_reference_within_3_mcse(la, models, map_beta, mode, group, C, burn, keep):
+    """F7, the north_star criterion, for every engine: pooled posterior mean and sd of the 8-vector
+    within 3 Monte-Carlo SEs of the seeded full reference runs, acceptance rate as the reference's."""
     ref = load_golden("posterior_hmc.json")["pooled"]
-    C = 4096
     q0 = np.tile(map_beta, (C, 1))
     k = make_kernel(la, models["float32"], "hmc")
-    cs = la.ChainSet(k, q0, seed=2024)
-    cs.advance(1, 1000, keep=False)  # burn-in away from the common start
-    samples = cs.advance(60, 20).to_host()
-    acc = cs.get_accepts().sum() / (C * (1000 + 60 * 20))
+    cs = la.ChainSet(k, q0, seed=2024, mode=mode, group=group)
+    assert mode == "auto" or cs.plan()["mode"] == mode
+    cs.advance(1, burn, keep=False)  # burn-in away from the common start
+    samples = cs.advance(keep, 20).to_host()
+    acc = cs.get_accepts().sum() / (C * (burn + keep * 20))
     assert abs(acc - load_golden("accept_rates.json")["hmc"]["rate"]) < 0.015
     summ = la.summarise(samples, max_chains=128)
     zm, zs = z_scores(summ, ref)
