@@ -126,6 +126,7 @@ def main():
         import torch
         tout = torch.as_tensor(out, device=f"cuda:{dev}")
         gathered = [torch.empty_like(tout) for _ in range(world)] if rank == 0 else None
+        dist.gather(tout, gathered, dst=0)  # untimed warm-up: RCCL sets up its p2p channels on first use
         dist.barrier()
         torch.cuda.synchronize()
     acc0 = cs.get_accepts().astype(np.int64).sum()
