@@ -15,6 +15,7 @@
 #include "lr_inst.h"
 #include "lr_kernels.h"
 #include "lr_tall.h"
+#include "lr_wide_bf16.h"
 
 LR_DECLARE_INST(f32_p4)
 LR_DECLARE_INST(f32_p8)
@@ -71,6 +72,7 @@ struct lr_model {
     double inv_var[kMaxP];
     double lprior_const = 0;
     const lr::InstTable* table = nullptr;
+    void* d_xblk = nullptr;  // wide models: per-32-row-block bf16-piece images of the rows (lr_wide_bf16.h)
     void* ws = nullptr;  // stepwise-engine workspace (grow-only, owned by the handle)
     size_t ws_bytes = 0;
     size_t esize() const { return dtype == LR_F32 ? 4 : 8; }
@@ -101,7 +103,7 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
         const int64_t per_cu = env && std::atoi(env) > 0 ? std::atoi(env) : (tiles_at_2 >= 32 ? 2 : 1);
         int64_t RS = (per_cu * m->cus + blocks - 1) / blocks;
         int64_t slice_len = (m->n + RS - 1) / RS;
-        slice_len = (slice_len + 15) / 16 * 16;
+        slice_len = (slice_len + 31) / 32 * 32;  // whole 32-row blocks (the bf16 kernel's K = 32)
         RS = (m->n + slice_len - 1) / slice_len;
         out->mode = lr::MODE_STEPWISE;
         out->G = (int)RS;
@@ -277,6 +279,13 @@ int setup_tall(lr_model* m, const Plan& pl, int64_t C, lr::TallArgs<T, P>* pa) {
     a.part_v = (double*)carve(align((size_t)RS * C * sizeof(double)));
     a.C = C;
     a.p = m->p;
+    {
+        // wide models: the exact-split bf16 matrix-core kernel (lr_wide_bf16.h) is the default -- same fp32
+        // tolerances, 1.5x the fp32-MFMA kernel; LOGREG_WIDE_BF16=0 selects the fp32-MFMA kernel (lr_wide.h)
+        const char* env = std::getenv("LOGREG_WIDE_BF16");
+        a.wide_bf16 = (m->P > 32 && m->d_xblk) ? (env ? std::atoi(env) : 1) : 0;
+        a.xblk = static_cast<const uint16_t*>(m->d_xblk);
+    }
     return LR_OK;
 }
 
@@ -545,6 +554,19 @@ int lr_model_create(const double* X, const double* y, int64_t n, int32_t p, cons
         delete m;
         return fail(LR_ERR_HIP, "hipMemcpy rows failed");
     }
+    if (m->P > 32) {  // wide models: bf16-piece block images for the exact-split matrix-core kernel
+        const float* hrows = reinterpret_cast<const float*>(host.data());
+        const int64_t nblk = (n + 31) / 32;
+        const size_t elems_blk = m->P == 64 ? (size_t)lr::WideBf16Geom<64>::BUF : (size_t)lr::WideBf16Geom<128>::BUF;
+        std::vector<uint16_t> img((size_t)nblk * elems_blk);
+        if (m->P == 64) lr::wide_bf16_prepare<64>(hrows, n, img.data());
+        else lr::wide_bf16_prepare<128>(hrows, n, img.data());
+        if (hipMalloc(&m->d_xblk, img.size() * 2) != hipSuccess ||
+            hipMemcpy(m->d_xblk, img.data(), img.size() * 2, hipMemcpyHostToDevice) != hipSuccess) {
+            lr_model_destroy(m);
+            return fail(LR_ERR_NOMEM, "allocating the bf16 block images (%zu bytes) failed", img.size() * 2);
+        }
+    }
     *out = m;
     return LR_OK;
 }
@@ -554,6 +576,7 @@ void lr_model_destroy(lr_model* m) {
     (void)hipSetDevice(m->device);
     if (m->d_rows) (void)hipFree(m->d_rows);
     if (m->ws) (void)hipFree(m->ws);
+    if (m->d_xblk) (void)hipFree(m->d_xblk);
     delete m;
 }
 

@@ -3,6 +3,7 @@
 // Compiled twice:  hipcc -DLR_P=64 -DLR_SFX=f32_p64 ... / -DLR_P=128 -DLR_SFX=f32_p128 ...
 #include "lr_inst.h"
 #include "lr_wide.h"
+#include "lr_wide_bf16.h"
 
 namespace lr {
 namespace {
@@ -13,8 +14,13 @@ inline int check(hipError_t e) { return e == hipSuccess ? 0 : -2; }
 int launch_tall_partial(hipStream_t st, int want_value, int /*want_grad*/, const void* tall_args) {
     const auto& a = *static_cast<const TallArgs<float, P>*>(tall_args);
     const dim3 grid((unsigned)((a.C + 63) / 64), (unsigned)a.RS), block(256);
-    if (want_value) hipLaunchKernelGGL((k_wide_partial<P, true>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((k_wide_partial<P, false>), grid, block, 0, st, a);
+    if (a.wide_bf16) {
+        if (want_value) hipLaunchKernelGGL((k_wide_partial_bf16<P, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((k_wide_partial_bf16<P, false>), grid, block, 0, st, a);
+    } else {
+        if (want_value) hipLaunchKernelGGL((k_wide_partial<P, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((k_wide_partial<P, false>), grid, block, 0, st, a);
+    }
     return check(hipGetLastError());
 }
 

@@ -71,6 +71,8 @@ template <typename T, int P> struct TallArgs {
     T* ev_grad;
     int64_t C, chain_offset;
     uint64_t seed;
+    int wide_bf16;  // wide models: 0 = fp32 MFMA partial kernel, 1 = exact-split bf16 MFMA partial kernel
+    const uint16_t* xblk;  // wide bf16: per-32-row-block LDS images of the split rows (lr_wide_bf16.h)
     int p, l;
     T step;
     T a[P], b[P], c[P];

@@ -1,0 +1,239 @@
+// lr_wide_bf16.h -- wide-model partial kernel on the bf16 matrix pipe with fp32-EXACT inputs.
+//
+// v_mfma_f32_16x16x32_bf16 runs at 16x the fp32-MFMA rate on a pipe of its own.  To keep fp32
+// numerics every fp32 operand is split by truncation into three bf16 pieces, x = h + m + l (8 + 8 + 8
+// significand bits: the split is EXACT), and a product a.b is formed from the six piece products of
+// weight >= 2^-24 (hh, hm, mh, hl, mm, lh; each exact in fp32, accumulated in fp32 by the MFMA):
+// the result differs from the fp32 product by the three dropped terms (relative <= 2^-23), i.e. it
+// is in the fp32 rounding class.  Per 32 rows x 16 chains: 96 bf16 MFMAs (17 cycles) instead of
+// 128 fp32 MFMAs (32-44 cycles).
+//
+// Workgroup = 4 waves x 16 chains, row slice walked in blocks of 32 rows (two 16-row eta tiles
+// T0, T1).  Lane l = (c, kg): chain c = l & 15, kg = l >> 4; the lane OWNS coordinates
+// {32 m + 8 kg + i : m < P/32, i < 8}.
+//   eta tile (16 rows x 16 chains), K = 32 per MFMA = coordinates 32 m + 8 kg + i:
+//       A (lane (row, kg)) = 8 consecutive coordinates of an X piece      LA[q][m][kg][row][8]
+//       B (lane (c,   kg)) = the same 8 coordinates of a beta piece (registers)
+//       D (lane (c, kg), reg r) = eta[row 4 kg + r][chain c]
+//   w = sigma(-eta) on the 8 accumulator values of T0, T1; split into 3 pieces; K = 32 rows per
+//   gradient MFMA with K-slot 8 kg + i <-> (i < 4: T0 row 4 kg + i; i >= 4: T1 row 4 kg + i - 4),
+//   so the B operand is built from the lane's OWN eta outputs (no data movement):
+//       B (lane (c, kg))  = 8 w pieces                       (registers)
+//       A (lane (m', kg)) = the 8 rows of slot group kg, coordinate mu(mb', m')   LG[q][mb'][kg][m'][8]
+//       M-block mb' = (m, h): slot m' = 4 kg' + r' <-> coordinate 32 m + 8 kg' + 4 h + r'
+//       D (lane (c, kg), reg r) = gradient of coordinate 32 m + 8 kg + 4 h + r = one the lane owns.
+// Both LDS layouts put the 16 lanes of every ds_read_b128 service group on 16 distinct 4-bank slots.
+// The split + transposition of the rows is done ONCE at model creation (wide_bf16_prepare): HBM holds,
+// per 32-row block, exactly the 48 KB LDS image (P = 128), so staging is a contiguous copy.  (A first
+// version split the fp32 rows while staging them: 48 ds_write_b16 + ~300 VALU ops per thread per
+// block cost as much as the MFMAs saved.)
+#pragma once
+#include <cstring>
+
+#include "lr_wide.h"
+
+namespace lr {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// truncation split x = h + m + l; returns the pieces as fp32 values whose low 16 bits are zero
+__device__ __forceinline__ void split3(float x, float& h, float& m, float& l) {
+    h = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, x) & 0xFFFF0000u);
+    const float r1 = x - h;  // exact
+    m = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, r1) & 0xFFFF0000u);
+    l = r1 - m;              // exact, <= 8 significant bits
+}
+// pack the bf16 (high) halves of two fp32 values: low half <- a, high half <- b
+__device__ __forceinline__ uint32_t pack_hi(float a, float b) {
+    return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, b), __builtin_bit_cast(uint32_t, a), 0x07060302u);
+}
+__device__ __forceinline__ bf16x8 as_bf16x8(const u32x4& v) { return __builtin_bit_cast(bf16x8, v); }
+
+template <int P> struct WideBf16Geom {
+    static constexpr int M32 = P / 32;    // coordinate chunks of 32 = eta MFMA K-chunks
+    static constexpr int MBP = P / 16;    // gradient M-blocks (m, h)
+    static constexpr int LA_Q = M32 * 4 * 16 * 8;  // bf16 elements per piece of LA (32-row block: x2 tiles)
+    static constexpr int LG_Q = MBP * 4 * 16 * 8;  // bf16 elements per piece of LG
+    static constexpr int BUF = 3 * (2 * LA_Q + LG_Q);  // bf16 elements per 32-row buffer
+};
+
+template <int P, bool VALUE>
+__global__ void __launch_bounds__(256) k_wide_partial_bf16(TallArgs<float, P> a) {
+    using G = WideBf16Geom<P>;
+    // [buffer][ LA: piece q, tile T, chunk m, kg, row, 8 | LG: piece q, mb', kg, m', 8 ]  (bf16)
+    __shared__ __attribute__((aligned(16))) uint16_t smem[2 * G::BUF];
+    static_assert(2 * G::BUF * 2 >= 64 * P * 4, "output tile must fit");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, kg = lane >> 4;
+    int64_t chain = (int64_t)blockIdx.x * 64 + 16 * wave + c;
+    const bool live = chain < a.C;
+    if (!live) chain = a.C - 1;
+    const int rs = blockIdx.y;
+    const int64_t s0 = (int64_t)rs * a.slice_len, s1 = s0 + a.slice_len < a.n ? s0 + a.slice_len : a.n;
+    const int64_t nblk = s1 > s0 ? (s1 - s0 + 31) / 32 : 0;
+
+    // beta pieces of the lane's coordinates 32 m + 8 kg + i, pre-scaled by log2(e): B operands
+    u32x4 bq[G::M32][3];
+#pragma unroll
+    for (int m = 0; m < G::M32; ++m) {
+        float h[8], md[8], lo[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) split3(a.q1[chain * P + 32 * m + 8 * kg + i] * ExpScale<float>::k, h[i], md[i], lo[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bq[m][0][i] = pack_hi(h[2 * i], h[2 * i + 1]);
+            bq[m][1][i] = pack_hi(md[2 * i], md[2 * i + 1]);
+            bq[m][2][i] = pack_hi(lo[2 * i], lo[2 * i + 1]);
+        }
+    }
+    f32x4 gacc[G::MBP];
+#pragma unroll
+    for (int mb = 0; mb < G::MBP; ++mb) gacc[mb] = f32x4{0, 0, 0, 0};
+    double vsum = 0.0;
+
+    // staging: the block image is contiguous in HBM: 256 threads x 16-byte chunks
+    constexpr int CHUNKS = G::BUF * 2 / 16 / 256;  // 16-byte chunks per thread per block
+    static_assert(G::BUF * 2 % (16 * 256) == 0, "block image must split evenly");
+    u32x4 stage[CHUNKS];
+    const int64_t blk0 = s0 / 32;  // slices are multiples of 32 rows
+    auto fetch = [&](int64_t b) {
+        const u32x4* src = reinterpret_cast<const u32x4*>(a.xblk + (blk0 + b) * (int64_t)G::BUF);
+#pragma unroll
+        for (int i = 0; i < CHUNKS; ++i) stage[i] = src[tid + 256 * i];
+    };
+    auto deposit = [&](int buf) {
+        u32x4* dst = reinterpret_cast<u32x4*>(smem + buf * G::BUF);
+#pragma unroll
+        for (int i = 0; i < CHUNKS; ++i) dst[tid + 256 * i] = stage[i];
+    };
+    // the six piece products of weight >= 2^-24: (x piece, other piece)
+    constexpr int QX[6] = {0, 0, 1, 0, 1, 2}, QO[6] = {0, 1, 0, 2, 1, 0};
+
+    if (nblk > 0) {
+        fetch(0);
+        deposit(0);
+    }
+    __syncthreads();
+    for (int64_t b = 0; b < nblk; ++b) {
+        const int buf = (int)(b & 1);
+        const uint16_t* base = smem + buf * G::BUF;
+        if (b + 1 < nblk) fetch(b + 1);
+        // ---- eta for the two tiles
+        float w8[8];
+#pragma unroll
+        for (int T = 0; T < 2; ++T) {
+            f32x4 e0 = {0, 0, 0, 0}, e1 = {0, 0, 0, 0};
+#pragma unroll
+            for (int m = 0; m < G::M32; ++m) {
+                u32x4 xa[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    xa[q] = *reinterpret_cast<const u32x4*>(base + q * 2 * G::LA_Q + ((T * G::M32 + m) * 4 + kg) * 16 * 8 + c * 8);
+#pragma unroll
+                for (int t = 0; t < 6; t += 2) {
+                    e0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(xa[QX[t]]), as_bf16x8(bq[m][QO[t]]), e0, 0, 0, 0);
+                    e1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(xa[QX[t + 1]]), as_bf16x8(bq[m][QO[t + 1]]), e1, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float ts = e0[r] + e1[r];
+                w8[4 * T + r] = fast_rcp(1.0f + __builtin_amdgcn_exp2f(ts));
+                if constexpr (VALUE) {
+                    const int64_t row = s0 + 32 * b + 16 * T + 4 * kg + r;
+                    const float ats = ts < 0.0f ? -ts : ts;
+                    const float lv = (ts < 0.0f ? ts * ExpScale<float>::inv : 0.0f) - log1p_unit(__builtin_amdgcn_exp2f(-ats));
+                    if (row < s1) vsum += (double)lv;
+                }
+            }
+        }
+        // ---- w pieces: the B operand of the gradient MFMAs (K-slot 8 kg + i <-> w8[i])
+        u32x4 wq[3];
+        {
+            float h[8], md[8], lo[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) split3(w8[i], h[i], md[i], lo[i]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                wq[0][i] = pack_hi(h[2 * i], h[2 * i + 1]);
+                wq[1][i] = pack_hi(md[2 * i], md[2 * i + 1]);
+                wq[2][i] = pack_hi(lo[2 * i], lo[2 * i + 1]);
+            }
+        }
+        // ---- grad += Xs^T . W
+        const uint16_t* g0 = base + 3 * 2 * G::LA_Q;
+#pragma unroll
+        for (int mb = 0; mb < G::MBP; ++mb) {
+            u32x4 xg[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                xg[q] = *reinterpret_cast<const u32x4*>(g0 + q * G::LG_Q + ((mb * 4 + kg) * 16 + c) * 8);
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+                gacc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(xg[QX[t]]), as_bf16x8(wq[QO[t]]), gacc[mb], 0, 0, 0);
+        }
+        if (b + 1 < nblk) deposit(buf ^ 1);
+        __syncthreads();
+    }
+    // epilogue: gradient register (mb' = 2m + h, r) of lane (c, kg) is coordinate 32m + 8kg + 4h + r
+    float* otile = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int mb = 0; mb < G::MBP; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            otile[(16 * wave + c) * P + 32 * (mb >> 1) + 8 * kg + 4 * (mb & 1) + r] = gacc[mb][r];
+    __syncthreads();
+    {
+        const int64_t chain0 = (int64_t)blockIdx.x * 64;
+        const int64_t nlive = a.C - chain0 < 64 ? a.C - chain0 : 64;
+        f32x4* dst = reinterpret_cast<f32x4*>(a.part_g + ((int64_t)rs * a.C + chain0) * P);
+        const f32x4* src = reinterpret_cast<const f32x4*>(otile);
+        for (int i = tid; i < (int)(nlive * P / 4); i += 256) dst[i] = src[i];
+    }
+    if constexpr (VALUE) {
+        const double tot = ksum(vsum);
+        if (live && kg == 0) a.part_v[(int64_t)rs * a.C + chain] = tot;
+    }
+}
+
+// Host side: build the per-32-row-block LDS images (bf16 pieces, both layouts) from the signed rows.
+// rows: [n][P] fp32 (host).  out: [ceil(n/32)][BUF] bf16 bit patterns.
+template <int P> inline void wide_bf16_prepare(const float* rows, int64_t n, uint16_t* out) {
+    using G = WideBf16Geom<P>;
+    const int64_t nblk = (n + 31) / 32;
+    for (int64_t b = 0; b < nblk; ++b) {
+        uint16_t* base = out + b * (int64_t)G::BUF;
+        for (int e = 0; e < G::BUF; ++e) base[e] = 0;
+        for (int srow = 0; srow < 32; ++srow) {
+            const int64_t r = 32 * b + srow;
+            if (r >= n) continue;
+            const int T = srow >> 4, rr = srow & 15, gkg = rr >> 2, gi = (rr & 3) + 4 * T;
+            for (int cc = 0; cc < P; ++cc) {
+                const float x = rows[r * P + cc];
+                uint32_t xb, hb, mb_, lb;
+                memcpy(&xb, &x, 4);
+                hb = xb & 0xFFFF0000u;
+                float h, r1, md, lo;
+                memcpy(&h, &hb, 4);
+                r1 = x - h;
+                memcpy(&mb_, &r1, 4);
+                mb_ &= 0xFFFF0000u;
+                memcpy(&md, &mb_, 4);
+                lo = r1 - md;
+                memcpy(&lb, &lo, 4);
+                const uint16_t pc[3] = {(uint16_t)(hb >> 16), (uint16_t)(mb_ >> 16), (uint16_t)(lb >> 16)};
+                const int m = cc >> 5, w5 = cc & 31, akg = w5 >> 3, ai = w5 & 7;
+                const int la = ((T * G::M32 + m) * 4 + akg) * 16 * 8 + rr * 8 + ai;
+                const int hh = (w5 & 7) >> 2, rp = w5 & 3;
+                const int lg = (((2 * m + hh) * 4 + gkg) * 16 + (4 * akg + rp)) * 8 + gi;
+                for (int q = 0; q < 3; ++q) {
+                    base[q * 2 * G::LA_Q + la] = pc[q];
+                    base[3 * 2 * G::LA_Q + q * G::LG_Q + lg] = pc[q];
+                }
+            }
+        }
+    }
+}
+
+}  // namespace lr

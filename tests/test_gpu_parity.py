@@ -234,12 +234,16 @@ def test_tall_data_uses_stepwise_engine_and_matches_oracle(la):
         assert np.max(np.abs(out[:, ok] - ref["out"][:, ok])) < tol
 
 
+@pytest.mark.parametrize("engine", ["bf16x3", "fp32"])
 @pytest.mark.parametrize("p,n,C", [(128, 1000, 70), (100, 513, 64), (40, 300, 130)])
-def test_wide_models_run_on_the_matrix_cores(la, p, n, C):
+def test_wide_models_run_on_the_matrix_cores(la, p, n, C, engine, monkeypatch):
     """32 < p <= 128: X.beta over a chain block is a dense GEMM -> fp32 MFMA partial kernel of the
     stepwise engine (lr_wide.h).  fp32-in/fp32-accumulate MFMA is an exact fmaf chain, so the
     tolerances are the fp32 ones."""
     from oracle.oracle import OracleModel
+    # default engine: bf16 matrix pipe with every fp32 operand split exactly into three bf16 pieces
+    # (lr_wide_bf16.h); LOGREG_WIDE_BF16=0: fp32-input MFMA (lr_wide.h).  Same tolerances for both.
+    monkeypatch.setenv("LOGREG_WIDE_BF16", "1" if engine == "bf16x3" else "0")
     X, y, _ = la.synthetic_logreg(n, p, seed=20240005 + p, beta_sd=0.1)
     ps = np.full(p, 1.5)
     orc = OracleModel(X, y, ps)
@@ -526,3 +530,22 @@ def test_plain_c_client_runs_the_reference_c_program(tmp_path):
     ref = load_golden("posterior_rwmh.json")["pooled"]
     z = (a[200:].mean(axis=0) - np.array(ref["mean"])) / (POST_SD / np.sqrt(20))  # ~20 effective draws at worst
     assert np.max(np.abs(z)) < 4.0
+
+
+def test_wide_bf16_split_stays_in_the_fp32_error_class(la, monkeypatch):
+    """|bf16x3 - oracle| is of the size of |fp32 MFMA - oracle| (the split drops only 2^-24 terms)."""
+    from oracle.oracle import OracleModel
+    n, p, C = 2000, 128, 64
+    X, y, _ = la.synthetic_logreg(n, p, seed=99, beta_sd=0.1)
+    orc = OracleModel(X, y, np.ones(p))
+    m = la.LogReg(X, y, np.ones(p))
+    b = 0.1 * np.random.default_rng(1).standard_normal((C, p))
+    ref_lp, ref_g = orc.lpost(b), orc.glp(b)
+    err = {}
+    for eng in ("1", "0"):
+        monkeypatch.setenv("LOGREG_WIDE_BF16", eng)
+        r = m.eval(b)
+        err[eng] = (np.max(np.abs(r["lpost"] - ref_lp) / np.abs(ref_lp)), np.max(np.abs(r["glp"] - ref_g)))
+    print("rel lpost err / abs grad err: bf16x3", err["1"], "fp32-mfma", err["0"])
+    assert err["1"][0] < 3e-6 and err["0"][0] < 3e-6
+    assert err["1"][1] < 3.0 * err["0"][1] + 1e-4
