@@ -82,6 +82,15 @@ namespace {
 
 struct Plan { int mode, G, R; size_t lds_bytes; };
 
+// wide models: 0 = fp32-MFMA kernel (LOGREG_WIDE_BF16=0), 1 = bf16x3 with 4 waves (64 chains) per workgroup,
+// 2 = bf16x3 with 8 waves (128 chains) per workgroup -- chosen by chain count (measured, lr_wide_bf16.h)
+int wide_engine(int64_t C) {
+    const char* env = std::getenv("LOGREG_WIDE_BF16");
+    if (env) return std::atoi(env);
+    return C >= 4096 ? 2 : 1;
+}
+int64_t wide_chains_per_block(int64_t C) { return wide_engine(C) == 2 ? 128 : 64; }
+
 // Choose the kernel variant.  REG (rows in VGPRs) whenever the data fit (G*R >= n), then LDS,
 // then GLOBAL.  Group size: the smallest available G that still gives every SIMD a wavefront
 // (C*G/64 >= 4*CUs), else the largest; an explicit `group` request is honoured exactly.
@@ -95,12 +104,15 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
         // GEMM over blocks of 64 chains x row slices (lr_wide.h).  ~2 workgroups per CU.
         if (mode != LR_MODE_AUTO && mode != LR_MODE_STEPWISE)
             return fail(LR_ERR_UNSUPPORTED, "p=%d > 32 runs on the stepwise engine only (mode=%d requested)", m->p, mode);
-        const int64_t blocks = (C + 63) / 64;
+        const int64_t cpb = wide_chains_per_block(C);
+        const int64_t blocks = (C + cpb - 1) / cpb;
         // measured (tools/wide_sweep.py): 2 workgroups per CU pay off only when each still gets >= 32
         // row tiles (8192 chains: 96 vs 77 TFLOP/s); with less work 1 per CU wins (1024 chains: 51 vs 44)
         const char* env = std::getenv("LOGREG_WIDE_WG_PER_CU");  // tuning override
         const int64_t tiles_at_2 = (m->n / 16) * blocks / (2LL * m->cus);
-        const int64_t per_cu = env && std::atoi(env) > 0 ? std::atoi(env) : (tiles_at_2 >= 32 ? 2 : 1);
+        // the bf16 kernels hold 96 KB of LDS: one workgroup per CU is all that fits
+        const int64_t per_cu = env && std::atoi(env) > 0 ? std::atoi(env)
+                               : (wide_engine(C) != 0 ? 1 : (tiles_at_2 >= 32 ? 2 : 1));
         int64_t RS = (per_cu * m->cus + blocks - 1) / blocks;
         int64_t slice_len = (m->n + RS - 1) / RS;
         slice_len = (slice_len + 31) / 32 * 32;  // whole 32-row blocks (the bf16 kernel's K = 32)
@@ -282,8 +294,7 @@ int setup_tall(lr_model* m, const Plan& pl, int64_t C, lr::TallArgs<T, P>* pa) {
     {
         // wide models: the exact-split bf16 matrix-core kernel (lr_wide_bf16.h) is the default -- same fp32
         // tolerances, 1.5x the fp32-MFMA kernel; LOGREG_WIDE_BF16=0 selects the fp32-MFMA kernel (lr_wide.h)
-        const char* env = std::getenv("LOGREG_WIDE_BF16");
-        a.wide_bf16 = (m->P > 32 && m->d_xblk) ? (env ? std::atoi(env) : 1) : 0;
+        a.wide_bf16 = (m->P > 32 && m->d_xblk) ? wide_engine(C) : 0;
         a.xblk = static_cast<const uint16_t*>(m->d_xblk);
     }
     return LR_OK;

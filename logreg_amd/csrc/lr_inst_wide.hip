@@ -14,9 +14,13 @@ inline int check(hipError_t e) { return e == hipSuccess ? 0 : -2; }
 int launch_tall_partial(hipStream_t st, int want_value, int /*want_grad*/, const void* tall_args) {
     const auto& a = *static_cast<const TallArgs<float, P>*>(tall_args);
     const dim3 grid((unsigned)((a.C + 63) / 64), (unsigned)a.RS), block(256);
-    if (a.wide_bf16) {
-        if (want_value) hipLaunchKernelGGL((k_wide_partial_bf16<P, true>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((k_wide_partial_bf16<P, false>), grid, block, 0, st, a);
+    if (a.wide_bf16 == 2) {  // 8 waves x 16 chains per workgroup
+        const dim3 gridb((unsigned)((a.C + 127) / 128), (unsigned)a.RS), blockb(512);
+        if (want_value) hipLaunchKernelGGL((k_wide_partial_bf16<P, true, 8>), gridb, blockb, 0, st, a);
+        else hipLaunchKernelGGL((k_wide_partial_bf16<P, false, 8>), gridb, blockb, 0, st, a);
+    } else if (a.wide_bf16 == 1) {  // 4 waves x 16 chains
+        if (want_value) hipLaunchKernelGGL((k_wide_partial_bf16<P, true, 4>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((k_wide_partial_bf16<P, false, 4>), grid, block, 0, st, a);
     } else {
         if (want_value) hipLaunchKernelGGL((k_wide_partial<P, true>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((k_wide_partial<P, false>), grid, block, 0, st, a);

@@ -58,15 +58,19 @@ template <int P> struct WideBf16Geom {
     static constexpr int BUF = 3 * (2 * LA_Q + LG_Q);  // bf16 elements per 32-row buffer
 };
 
-template <int P, bool VALUE>
-__global__ void __launch_bounds__(256) k_wide_partial_bf16(TallArgs<float, P> a) {
+// NW waves per workgroup (4 or 8): every wave owns 16 chains, all share the staged 32-row block.
+// 8 waves halve the staging traffic per chain (191 vs 140 TF at 8192 chains); 4 waves give more
+// workgroups when there are few chains (80 vs 73 TF at 1024 chains).
+template <int P, bool VALUE, int NW>
+__global__ void __launch_bounds__((64 * NW)) k_wide_partial_bf16(TallArgs<float, P> a) {
     using G = WideBf16Geom<P>;
+    constexpr int NT = 64 * NW, CPB = 16 * NW;  // threads, chains per block
     // [buffer][ LA: piece q, tile T, chunk m, kg, row, 8 | LG: piece q, mb', kg, m', 8 ]  (bf16)
     __shared__ __attribute__((aligned(16))) uint16_t smem[2 * G::BUF];
-    static_assert(2 * G::BUF * 2 >= 64 * P * 4, "output tile must fit");
+    static_assert(2 * G::BUF * 2 >= CPB * P * 4, "output tile must fit");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, kg = lane >> 4;
-    int64_t chain = (int64_t)blockIdx.x * 64 + 16 * wave + c;
+    int64_t chain = (int64_t)blockIdx.x * CPB + 16 * wave + c;
     const bool live = chain < a.C;
     if (!live) chain = a.C - 1;
     const int rs = blockIdx.y;
@@ -93,19 +97,19 @@ __global__ void __launch_bounds__(256) k_wide_partial_bf16(TallArgs<float, P> a)
     double vsum = 0.0;
 
     // staging: the block image is contiguous in HBM: 256 threads x 16-byte chunks
-    constexpr int CHUNKS = G::BUF * 2 / 16 / 256;  // 16-byte chunks per thread per block
-    static_assert(G::BUF * 2 % (16 * 256) == 0, "block image must split evenly");
+    constexpr int CHUNKS = G::BUF * 2 / 16 / NT;  // 16-byte chunks per thread per block
+    static_assert(G::BUF * 2 % (16 * NT) == 0, "block image must split evenly");
     u32x4 stage[CHUNKS];
     const int64_t blk0 = s0 / 32;  // slices are multiples of 32 rows
     auto fetch = [&](int64_t b) {
         const u32x4* src = reinterpret_cast<const u32x4*>(a.xblk + (blk0 + b) * (int64_t)G::BUF);
 #pragma unroll
-        for (int i = 0; i < CHUNKS; ++i) stage[i] = src[tid + 256 * i];
+        for (int i = 0; i < CHUNKS; ++i) stage[i] = src[tid + NT * i];
     };
     auto deposit = [&](int buf) {
         u32x4* dst = reinterpret_cast<u32x4*>(smem + buf * G::BUF);
 #pragma unroll
-        for (int i = 0; i < CHUNKS; ++i) dst[tid + 256 * i] = stage[i];
+        for (int i = 0; i < CHUNKS; ++i) dst[tid + NT * i] = stage[i];
     };
     // the six piece products of weight >= 2^-24: (x piece, other piece)
     constexpr int QX[6] = {0, 0, 1, 0, 1, 2}, QO[6] = {0, 1, 0, 2, 1, 0};
@@ -185,11 +189,11 @@ __global__ void __launch_bounds__(256) k_wide_partial_bf16(TallArgs<float, P> a)
             otile[(16 * wave + c) * P + 32 * (mb >> 1) + 8 * kg + 4 * (mb & 1) + r] = gacc[mb][r];
     __syncthreads();
     {
-        const int64_t chain0 = (int64_t)blockIdx.x * 64;
-        const int64_t nlive = a.C - chain0 < 64 ? a.C - chain0 : 64;
+        const int64_t chain0 = (int64_t)blockIdx.x * CPB;
+        const int64_t nlive = a.C - chain0 < CPB ? a.C - chain0 : CPB;
         f32x4* dst = reinterpret_cast<f32x4*>(a.part_g + ((int64_t)rs * a.C + chain0) * P);
         const f32x4* src = reinterpret_cast<const f32x4*>(otile);
-        for (int i = tid; i < (int)(nlive * P / 4); i += 256) dst[i] = src[i];
+        for (int i = tid; i < (int)(nlive * P / 4); i += NT) dst[i] = src[i];
     }
     if constexpr (VALUE) {
         const double tot = ksum(vsum);
