@@ -145,19 +145,17 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
     for (int i = 0; i < t->nvariants; ++i) {
         const lr::Variant& v = t->variants[i];
         if (v.mode == lr::MODE_MFMA) {
-            // matrix-core variants; G = row-split ways S, R = tiles per wave.  Measured on MI355X
-            // (profiles/): with >= 16 chains for every SIMD the S=1 variant beats the best vector-ALU
-            // variant by 11-25 %; below that the vector-ALU group-per-chain variants win, so AUTO
-            // only picks MFMA S=1 when the chip is filled; mode = LR_MODE_MFMA forces it.
+            // fp32 matrix-core variants; G = row-split ways S, R = tiles per wave.  Opt-in only
+            // (mode = LR_MODE_MFMA): fp32 MFMA shares the fp32 multipliers with the vector ALU, and
+            // since the vector kernels went fully packed (v_pk_fma_f32 + fused v_add_f32_dpp) reg 16x13
+            // is faster at every chain count measured (profiles/: 1.93e8 vs 1.65e8 it/s at 16 384
+            // chains, 2.00e8 vs 1.86e8 at 65 536).
             if (for_eval) continue;
             if ((int64_t)16 * v.G * v.R < m->n) continue;
             const bool filled = C >= 16LL * want_waves;
             if (mode == LR_MODE_MFMA) {
                 if (group != 0 && v.G != group) continue;
                 const long score = (filled ? (v.G == 1) : (v.G == 4)) ? 2 : 1;
-                if (score > best_score) { best_score = score; best = i; }
-            } else if (mode == LR_MODE_AUTO && group == 0 && filled && v.G == 1) {
-                const long score = 3000000L;  // below the scalar-row rule (2^18 chains: scalar 1.99e8, mfma 1.90e8, reg16 1.82e8)
                 if (score > best_score) { best_score = score; best = i; }
             }
             continue;

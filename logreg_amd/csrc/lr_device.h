@@ -263,6 +263,70 @@ __device__ __forceinline__ double fast_rcp(double x) { return 1.0 / x; }
 __device__ __forceinline__ float log1p_unit(float e) { return __builtin_amdgcn_logf(1.0f + e) * 0.693147180559945309f; }
 __device__ __forceinline__ double log1p_unit(double e) { return log1p(e); }
 
+// elementwise helpers written on explicit 2-vectors (v_pk_fma_f32 / v_pk_mul_f32) for float: the
+// library is built with -fno-slp-vectorize so that the DPP reduction adds stay fused
+// (v_add_f32_dpp instead of v_mov_b32_dpp + v_pk_add_f32), hence packing is spelled out here.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// y[j] = a[j] * x[j] + y[j]
+template <typename T, int P> __device__ __forceinline__ void vfma_v(const T (&a)[P], const T (&x)[P], T (&y)[P]) {
+    if constexpr (sizeof(T) == 4 && P % 2 == 0) {
+#pragma unroll
+        for (int j = 0; j < P; j += 2) {
+            const f32x2 r = __builtin_elementwise_fma(f32x2{a[j], a[j + 1]}, f32x2{x[j], x[j + 1]}, f32x2{y[j], y[j + 1]});
+            y[j] = r.x;
+            y[j + 1] = r.y;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < P; ++j) y[j] = fma_t(a[j], x[j], y[j]);
+    }
+}
+// y[j] = s * x[j] + y[j]
+template <typename T, int P> __device__ __forceinline__ void vfma_s(T s, const T (&x)[P], T (&y)[P]) {
+    if constexpr (sizeof(T) == 4 && P % 2 == 0) {
+        const f32x2 s2 = {s, s};
+#pragma unroll
+        for (int j = 0; j < P; j += 2) {
+            const f32x2 r = __builtin_elementwise_fma(s2, f32x2{x[j], x[j + 1]}, f32x2{y[j], y[j + 1]});
+            y[j] = r.x;
+            y[j + 1] = r.y;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < P; ++j) y[j] = fma_t(s, x[j], y[j]);
+    }
+}
+// out[j] = c[j] - a[j] * b[j]
+template <typename T, int P>
+__device__ __forceinline__ void vnmsub(const T (&a)[P], const T (&b)[P], const T (&c)[P], T (&out)[P]) {
+    if constexpr (sizeof(T) == 4 && P % 2 == 0) {
+#pragma unroll
+        for (int j = 0; j < P; j += 2) {
+            const f32x2 r = __builtin_elementwise_fma(-f32x2{a[j], a[j + 1]}, f32x2{b[j], b[j + 1]}, f32x2{c[j], c[j + 1]});
+            out[j] = r.x;
+            out[j + 1] = r.y;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < P; ++j) out[j] = c[j] - a[j] * b[j];
+    }
+}
+// out[j] = s * x[j]
+template <typename T, int P> __device__ __forceinline__ void vscale(T s, const T (&x)[P], T (&out)[P]) {
+    if constexpr (sizeof(T) == 4 && P % 2 == 0) {
+        const f32x2 s2 = {s, s};
+#pragma unroll
+        for (int j = 0; j < P; j += 2) {
+            const f32x2 r = s2 * f32x2{x[j], x[j + 1]};
+            out[j] = r.x;
+            out[j + 1] = r.y;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < P; ++j) out[j] = s * x[j];
+    }
+}
+
 // exp(t) given ts = t * kScale<T> (float: the log2(e) factor is folded into beta once per
 // evaluation instead of once per row; double: kScale = 1)
 template <typename T> struct ExpScale;
@@ -296,8 +360,19 @@ __device__ __forceinline__ void row_term(const T (&xs)[P], const T (&bs)[P], T (
     }
     if constexpr (GRAD) {
         const T w = fast_rcp(T(1) + ExpScale<T>::exp_scaled(ts));  // sigma(-t); exp overflow -> rcp(inf) = 0
+        if constexpr (sizeof(T) == 4 && P % 2 == 0) {
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            const f2 w2 = {w, w};
 #pragma unroll
-        for (int j = 0; j < P; ++j) g[j] = fma_t(w, xs[j], g[j]);
+            for (int j = 0; j < P; j += 2) {
+                const f2 r = __builtin_elementwise_fma(w2, f2{xs[j], xs[j + 1]}, f2{g[j], g[j + 1]});
+                g[j] = r.x;
+                g[j + 1] = r.y;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < P; ++j) g[j] = fma_t(w, xs[j], g[j]);
+        }
     }
     if constexpr (VALUE) {
         // log sigma(t) = min(t,0) - log1p(exp(-|t|))  (stable for both signs)
@@ -402,8 +477,7 @@ __device__ __forceinline__ void eval_lpost(const Rows& rows, const Prior<T, P>& 
     for (int j = 0; j < P; ++j) g[j] = T(0);
     T v = T(0);
     T bs[P];
-#pragma unroll
-    for (int j = 0; j < P; ++j) bs[j] = beta[j] * ExpScale<T>::k;
+    vscale<T, P>(ExpScale<T>::k, beta, bs);
     rows.for_each([&](const T(&xs)[P]) { row_term<T, P, VALUE, GRAD>(xs, bs, g, v); });
     if constexpr (GRAD) {
 #ifdef LR_FUSED_DPP_REDUCE
@@ -412,8 +486,7 @@ __device__ __forceinline__ void eval_lpost(const Rows& rows, const Prior<T, P>& 
 #pragma unroll
         for (int j = 0; j < P; ++j) g[j] = group_sum<G>(g[j]);  // compiler-scheduled (v_mov_dpp + v_pk_add)
 #endif
-#pragma unroll
-        for (int j = 0; j < P; ++j) grad[j] = g[j] - beta[j] * pr.inv_var[j];
+        vnmsub<T, P>(beta, pr.inv_var, g, grad);
     }
     if constexpr (VALUE) {
         ll = group_sum<G>((double)(v + rows.value_fixup()));

@@ -201,18 +201,14 @@ __global__ void __launch_bounds__(256) k_chain(ModelArgs<T, P> m, ChainArgs<T, P
                         gp[j] = g[j];
                     }
                     const T heps = T(0.5) * a.step;
-#pragma unroll
-                    for (int j = 0; j < P; ++j) pm[j] = fma_t(heps, gp[j], pm[j]);
+                    vfma_s<T, P>(heps, gp, pm);
                     for (int i = 0; i < a.l - 1; ++i) {
-#pragma unroll
-                        for (int j = 0; j < P; ++j) xp[j] = fma_t(a.b[j], pm[j], xp[j]);
+                        vfma_v<T, P>(a.b, pm, xp);  // drift
                         double d0, d1;
                         eval_lpost<T, P, G, false, true>(rows, m.prior, xp, gp, d0, d1);
-#pragma unroll
-                        for (int j = 0; j < P; ++j) pm[j] = fma_t(a.step, gp[j], pm[j]);
+                        vfma_s<T, P>(a.step, gp, pm);  // kick
                     }
-#pragma unroll
-                    for (int j = 0; j < P; ++j) xp[j] = fma_t(a.b[j], pm[j], xp[j]);
+                    vfma_v<T, P>(a.b, pm, xp);
                     eval_lpost<T, P, G, true, true>(rows, m.prior, xp, gp, llp, lprp);
                     T k1 = T(0);
 #pragma unroll
