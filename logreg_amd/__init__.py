@@ -14,14 +14,14 @@ kernels through the C ABI in include/logreg_hip.h.  There is no CPU fallback.
 """
 from ._lib import LogregHipError, device_count  # noqa: F401
 from .data import load_pima, load_pima_parquet, synthetic_logreg  # noqa: F401
-from .diagnostics import describe, ess_geyer, ess_per_param, ess_pooled, summarise  # noqa: F401
+from .diagnostics import describe, ess_geyer, ess_per_param, ess_pooled, split_rhat, summarise  # noqa: F401
 from .kernels import (ChainSet, FusedKernel, hmcKernel, malaKernel, mcmc, mhKernel, rwProposal,  # noqa: F401
                       ulKernel)
 from .model import DeviceArray, LogReg  # noqa: F401
-from .optimize import find_map  # noqa: F401
+from .optimize import find_map, overdispersed_init  # noqa: F401
 from .output import print_summary, read_parquet, to_frame, write_parquet  # noqa: F401
 
 __all__ = ["LogReg", "DeviceArray", "ChainSet", "FusedKernel", "mhKernel", "malaKernel", "hmcKernel", "ulKernel",
            "rwProposal", "mcmc", "load_pima", "load_pima_parquet", "synthetic_logreg", "summarise", "describe",
-           "ess_geyer", "ess_per_param", "ess_pooled", "device_count", "LogregHipError", "find_map", "write_parquet",
+           "ess_geyer", "ess_per_param", "ess_pooled", "split_rhat", "device_count", "LogregHipError", "find_map", "overdispersed_init", "write_parquet",
            "read_parquet", "to_frame", "print_summary"]

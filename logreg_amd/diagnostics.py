@@ -91,6 +91,20 @@ def summarise(samples: np.ndarray, max_chains: int | None = 256) -> dict:
     return {"mean": mean, "sd": sd, "ess": ess, "mcse": sd / np.sqrt(ess)}
 
 
+def split_rhat(samples: np.ndarray) -> np.ndarray:
+    """Split-R-hat (Gelman et al., BDA3) per parameter for `[iters, C, p]` samples: every chain is
+    split in two halves; values near 1 indicate the chains agree."""
+    s = np.asarray(samples, dtype=np.float64)
+    iters, C, p = s.shape
+    h = iters // 2
+    halves = np.concatenate([s[:h], s[h:2 * h]], axis=1)  # [h, 2C, p]
+    m = halves.mean(axis=0)
+    W = halves.var(axis=0, ddof=1).mean(axis=0)
+    B = h * m.var(axis=0, ddof=1)
+    var_plus = (h - 1) / h * W + B / h
+    return np.sqrt(var_plus / W)
+
+
 def describe(out: np.ndarray) -> dict:
     """Same numbers `scipy.stats.describe(out)` reports in the reference
     (`Python/fit-np-hmc.py:113-117`): nobs, minmax, mean, variance (ddof=1)."""

@@ -48,4 +48,17 @@ def find_map(model, init=None, max_iter=50, gtol=None, verbose=False):
             break
     r = model.eval(beta, ("lpost", "glp"))
     info.update(lpost=float(r["lpost"]), grad=r["glp"])
+    # Laplace scale at the mode: sd_j = sqrt(diag((-H)^-1)) from the last difference Hessian
+    try:
+        info["sd"] = np.sqrt(np.maximum(np.diag(np.linalg.inv(-H)), 0.0))
+    except (np.linalg.LinAlgError, UnboundLocalError):
+        info["sd"] = None
     return beta, info
+
+
+def overdispersed_init(beta_map, sd, chains, scale=2.0, seed=0):
+    """Chain starting points MAP + scale * sd * N(0, I) for many-chain runs (the reference starts its
+    single chain at the MAP, fit-np-hmc.py:107; over-dispersed starts make split-R-hat meaningful)."""
+    rng = np.random.Generator(np.random.Philox(seed))
+    beta_map = np.asarray(beta_map, dtype=np.float64)
+    return beta_map[None, :] + scale * np.asarray(sd)[None, :] * rng.standard_normal((int(chains), beta_map.shape[0]))

@@ -153,3 +153,15 @@ def test_find_map_on_oracle_closures(oracle_model, map_beta):
     assert info["converged"]
     assert oracle_model.lpost(beta) == pytest.approx(-100.44943693563212, abs=1e-7)
     np.testing.assert_allclose(beta, map_beta, atol=2e-4)
+
+
+def test_split_rhat_and_overdispersed_init():
+    rng = np.random.default_rng(3)
+    good = rng.standard_normal((400, 8, 3))
+    assert np.all(np.abs(la.split_rhat(good) - 1.0) < 0.02)
+    bad = good + np.arange(8)[None, :, None]  # chains stuck at different levels
+    assert np.all(la.split_rhat(bad) > 1.5)
+    init = la.overdispersed_init(np.zeros(3), np.array([1.0, 2.0, 3.0]), 5000, scale=2.0, seed=1)
+    assert init.shape == (5000, 3)
+    np.testing.assert_allclose(init.std(axis=0), [2.0, 4.0, 6.0], rtol=0.05)
+    np.testing.assert_array_equal(init, la.overdispersed_init(np.zeros(3), np.array([1.0, 2.0, 3.0]), 5000, 2.0, 1))
