@@ -40,18 +40,37 @@ def flops_per_grad_eval(n, p):  # F_g = 4np + 5n + 2p
     return 4 * n * p + 5 * n + 2 * p
 
 
+def usable_cores() -> int:
+    """CPU cores this process may actually use: the affinity mask, capped by the cgroup CPU quota
+    (a container can see 256 logical CPUs and be allowed a handful)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(X, y, pscale, init, target_s=12.0):
     """Time the CPU oracle (float64 C restatement, OpenMP over chains) on a bounded sample of the
     same workload.  The oracle is the checker, used here only as the reported CPU baseline."""
     from oracle.oracle import OracleModel, max_threads
     m = OracleModel(X, y, pscale)
-    threads = max_threads()
+    threads = min(max_threads(), usable_cores())
     chains = 8 * threads
     st = np.tile(init, (chains, 1))
     t0 = time.perf_counter()
     m.run("hmc", st, step=EPS, l=LEAP, scale=np.ones(N_PAR), thin=1, iters=4, seed=SEED, keep=False, threads=threads)
     probe = (time.perf_counter() - t0) / 4
-    iters = int(max(4, min(4000, target_s / max(probe, 1e-6))))
+    iters = int(max(4, min(200000, target_s / max(probe, 1e-6))))
     t0 = time.perf_counter()
     m.run("hmc", st, step=EPS, l=LEAP, scale=np.ones(N_PAR), thin=1, iters=iters, seed=SEED, keep=False, threads=threads)
     dt = time.perf_counter() - t0
