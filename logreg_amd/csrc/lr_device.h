@@ -181,14 +181,38 @@ __device__ __forceinline__ void bcast_blocks(const T (&mine)[4], T (&z)[P]) {
     }
 }
 
+// pair-level split: lane 2b+h of the group owns Box-Muller pair h of block b
+template <typename T, int P, int G, int J = 0>
+__device__ __forceinline__ void bcast_pairs(const T (&mine)[2], T (&z)[P]) {
+    if constexpr (2 * J < P) {
+        z[2 * J] = group_bcast<G, J>(mine[0]);
+        if constexpr (2 * J + 1 < P) z[2 * J + 1] = group_bcast<G, J>(mine[1]);
+        bcast_pairs<T, P, G, J + 1>(mine, z);
+    }
+}
+
 template <typename T, int P, int G>
 __device__ __forceinline__ void draw_group(uint64_t seed, uint64_t chain, uint64_t iter, int gl, T (&z)[P], T& logu) {
-    constexpr int NB = (P + 3) / 4;
-    if constexpr (G < NB + 1) {
-        draw_normals<T, P>(seed, chain, iter, z);
-        logu = draw_log_uniform<T>(seed, chain, iter);
-    } else {
-        const bool is_u = gl == NB;  // lanes beyond NB recompute block NB's neighbours; their values are never read
+    constexpr int NB = (P + 3) / 4;   // normal blocks
+    constexpr int NP = (P + 1) / 2;   // Box-Muller pairs
+    if constexpr (G >= NP + 1) {
+        // lane j < NP: pair j (block j/2, words 2(j&1), 2(j&1)+1); lane NP: the accept uniform.
+        // Per lane: 1 Philox + 1 Box-Muller + 1 log.  Lanes beyond NP recompute lane 0's work (never read).
+        const int j = gl > NP ? 0 : gl;
+        const bool is_u = j == NP;
+        const uint32_t blk = is_u ? TAG_UNIFORM : (uint32_t)(j >> 1);
+        const U4 w = philox4x32_10((uint32_t)chain, (uint32_t)iter, (uint32_t)(iter >> 32), blk, (uint32_t)seed,
+                                   (uint32_t)(seed >> 32));
+        const uint32_t wa = (j & 1) ? w.z : w.x, wb = (j & 1) ? w.w : w.y;
+        T mine[2];
+        box_muller(wa, wb, mine[0], mine[1]);
+        T lu;
+        if constexpr (sizeof(T) == 4) lu = logf(u01<float>(w.x));
+        else lu = log(u01<double>(w.x));
+        bcast_pairs<T, P, G>(mine, z);
+        logu = group_bcast<G, NP>(lu);
+    } else if constexpr (G >= NB + 1) {
+        const bool is_u = gl == NB;  // lanes beyond NB recompute block 0; their values are never read
         const uint32_t blk = is_u ? TAG_UNIFORM : (uint32_t)(gl > NB ? 0 : gl);
         const U4 w = philox4x32_10((uint32_t)chain, (uint32_t)iter, (uint32_t)(iter >> 32), blk, (uint32_t)seed,
                                    (uint32_t)(seed >> 32));
@@ -200,6 +224,9 @@ __device__ __forceinline__ void draw_group(uint64_t seed, uint64_t chain, uint64
         else lu = log(u01<double>(w.x));
         bcast_blocks<T, P, G>(mine, z);
         logu = group_bcast<G, NB>(lu);
+    } else {
+        draw_normals<T, P>(seed, chain, iter, z);
+        logu = draw_log_uniform<T>(seed, chain, iter);
     }
 }
 
