@@ -110,7 +110,8 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
         // row tiles (8192 chains: 96 vs 77 TFLOP/s); with less work 1 per CU wins (1024 chains: 51 vs 44)
         const char* env = std::getenv("LOGREG_WIDE_WG_PER_CU");  // tuning override
         const int64_t tiles_at_2 = (m->n / 16) * blocks / (2LL * m->cus);
-        // the bf16 kernels hold 96 KB of LDS: one workgroup per CU is all that fits
+        // bf16 kernels (48-64 KB of LDS: 2-3 workgroups per CU would fit): one per CU -- the fewest row
+        // slices -- measured fastest (8192 chains: 188 / 170 / 155 TFLOP/s at 1 / 2 / 3 per CU)
         const int64_t per_cu = env && std::atoi(env) > 0 ? std::atoi(env)
                                : (wide_engine(C) != 0 ? 1 : (tiles_at_2 >= 32 ? 2 : 1));
         int64_t RS = (per_cu * m->cus + blocks - 1) / blocks;

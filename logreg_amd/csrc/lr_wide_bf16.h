@@ -12,21 +12,30 @@
 // T0, T1).  Lane l = (c, kg): chain c = l & 15, kg = l >> 4; the lane OWNS coordinates
 // {32 m + 8 kg + i : m < P/32, i < 8}.
 //   eta tile (16 rows x 16 chains), K = 32 per MFMA = coordinates 32 m + 8 kg + i:
-//       A (lane (row, kg)) = 8 consecutive coordinates of an X piece      LA[q][m][kg][row][8]
+//       A (lane (row, kg)) = 8 consecutive coordinates of an X piece      LA[q][T][m][kg][row][8]
 //       B (lane (c,   kg)) = the same 8 coordinates of a beta piece (registers)
 //       D (lane (c, kg), reg r) = eta[row 4 kg + r][chain c]
 //   w = sigma(-eta) on the 8 accumulator values of T0, T1; split into 3 pieces; K = 32 rows per
 //   gradient MFMA with K-slot 8 kg + i <-> (i < 4: T0 row 4 kg + i; i >= 4: T1 row 4 kg + i - 4),
 //   so the B operand is built from the lane's OWN eta outputs (no data movement):
 //       B (lane (c, kg))  = 8 w pieces                       (registers)
-//       A (lane (m', kg)) = the 8 rows of slot group kg, coordinate mu(mb', m')   LG[q][mb'][kg][m'][8]
+//       A (lane (m', kg)) = the 8 rows of slot group kg, coordinate mu(mb', m')
 //       M-block mb' = (m, h): slot m' = 4 kg' + r' <-> coordinate 32 m + 8 kg' + 4 h + r'
 //       D (lane (c, kg), reg r) = gradient of coordinate 32 m + 8 kg + 4 h + r = one the lane owns.
-// Both LDS layouts put the 16 lanes of every ds_read_b128 service group on 16 distinct 4-bank slots.
-// The split + transposition of the rows is done ONCE at model creation (wide_bf16_prepare): HBM holds,
-// per 32-row block, exactly the 48 KB LDS image (P = 128), so staging is a contiguous copy.  (A first
-// version split the fp32 rows while staging them: 48 ds_write_b16 + ~300 VALU ops per thread per
-// block cost as much as the MFMAs saved.)
+//   The gradient A operand is the TRANSPOSE of what the eta operand holds (4 rows of one coordinate
+//   instead of 4 coordinates of one row); gfx950's ds_read_b64_tr_b16 does exactly that transposition
+//   inside a 16-lane group (source lane (ri, ci) supplies the 8-byte chunk [row ri][4 coordinates of
+//   kg' = ci]; result lane m' = 4 ci + r' receives [rows 0..3][coordinate r' of the chunk]), so ONE
+//   LDS image serves both products.  A (kg', row, half) swizzle keeps the 16 lanes of every
+//   ds_read_b128 service group on distinct 4-bank slots AND the 32 lanes of every transposing b64 read
+//   on distinct 2-bank slots:  row -> (row + 8 (kg' >> 1)) & 15, half -> half ^ (kg' & 1)
+//   (odd-kg lanes see their two 4-coordinate halves swapped in the eta read; their beta operands are
+//   built with the same swap, once).
+// The split of the rows is done ONCE at model creation (wide_bf16_prepare): HBM holds, per 32-row
+// block, exactly the 24 KB LDS image (P = 128), so staging is a contiguous copy.  (A first version
+// split the fp32 rows while staging them: 48 ds_write_b16 + ~300 VALU ops per thread per block cost
+// as much as the MFMAs saved; a second kept a separate transposed image for the gradient: twice the
+// staging traffic and LDS.)
 #pragma once
 #include <cstring>
 
@@ -36,6 +45,13 @@ namespace lr {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+// ds_read_b64_tr_b16: see the header comment
+__device__ __forceinline__ u32x2 lds_read_tr16(const uint16_t* p) {
+    return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p)));
+}
 
 // truncation split x = h + m + l; returns the pieces as fp32 values whose low 16 bits are zero
 __device__ __forceinline__ void split3(float x, float& h, float& m, float& l) {
@@ -53,9 +69,13 @@ __device__ __forceinline__ bf16x8 as_bf16x8(const u32x4& v) { return __builtin_b
 template <int P> struct WideBf16Geom {
     static constexpr int M32 = P / 32;    // coordinate chunks of 32 = eta MFMA K-chunks
     static constexpr int MBP = P / 16;    // gradient M-blocks (m, h)
-    static constexpr int LA_Q = M32 * 4 * 16 * 8;  // bf16 elements per piece of LA (32-row block: x2 tiles)
-    static constexpr int LG_Q = MBP * 4 * 16 * 8;  // bf16 elements per piece of LG
-    static constexpr int BUF = 3 * (2 * LA_Q + LG_Q);  // bf16 elements per 32-row buffer
+    static constexpr int TILE = 4 * 16 * 8;         // bf16 elements of one (piece, tile, chunk): [kg'][row][8]
+    static constexpr int BUF = 3 * 2 * M32 * TILE;  // bf16 elements per 32-row block image
+    // element offset of (kg', row, i) inside a tile (the swizzle of the header comment)
+    static constexpr int elem(int kgp, int row, int i) {
+        return kgp * 128 + ((row + 8 * (kgp >> 1)) & 15) * 8 + 4 * ((i >> 2) ^ (kgp & 1)) + (i & 3);
+    }
+    static constexpr int tile(int q, int T, int m) { return ((q * 2 + T) * M32 + m) * TILE; }
 };
 
 // NW waves per workgroup (4 or 8): every wave owns 16 chains, all share the staged 32-row block.
@@ -65,9 +85,9 @@ template <int P, bool VALUE, int NW>
 __global__ void __launch_bounds__((64 * NW)) k_wide_partial_bf16(TallArgs<float, P> a) {
     using G = WideBf16Geom<P>;
     constexpr int NT = 64 * NW, CPB = 16 * NW;  // threads, chains per block
-    // [buffer][ LA: piece q, tile T, chunk m, kg, row, 8 | LG: piece q, mb', kg, m', 8 ]  (bf16)
-    __shared__ __attribute__((aligned(16))) uint16_t smem[2 * G::BUF];
-    static_assert(2 * G::BUF * 2 >= CPB * P * 4, "output tile must fit");
+    // [buffer][piece q][tile T][chunk m][kg'][row][8]  (bf16), reused as the fp32 output tile
+    constexpr int SMEM = 2 * G::BUF > CPB * P * 2 ? 2 * G::BUF : CPB * P * 2;
+    __shared__ __attribute__((aligned(16))) uint16_t smem[SMEM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, kg = lane >> 4;
     int64_t chain = (int64_t)blockIdx.x * CPB + 16 * wave + c;
@@ -86,30 +106,37 @@ __global__ void __launch_bounds__((64 * NW)) k_wide_partial_bf16(TallArgs<float,
         for (int i = 0; i < 8; ++i) split3(a.q1[chain * P + 32 * m + 8 * kg + i] * ExpScale<float>::k, h[i], md[i], lo[i]);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            bq[m][0][i] = pack_hi(h[2 * i], h[2 * i + 1]);
-            bq[m][1][i] = pack_hi(md[2 * i], md[2 * i + 1]);
-            bq[m][2][i] = pack_hi(lo[2 * i], lo[2 * i + 1]);
+            const int j = (kg & 1) ? (i ^ 2) : i;  // odd kg: halves swapped, as the eta read delivers them
+            bq[m][0][i] = pack_hi(h[2 * j], h[2 * j + 1]);
+            bq[m][1][i] = pack_hi(md[2 * j], md[2 * j + 1]);
+            bq[m][2][i] = pack_hi(lo[2 * j], lo[2 * j + 1]);
         }
     }
+    // per-lane offsets: eta read (lane = (row c, kg)); transposing read (lane = (kg, ri, ci))
+    const int eta_off = G::elem(kg, c, 0) & ~7;
+    const int ri = (lane & 15) >> 2, ci = lane & 3;
+    const int tr_off[2] = {G::elem(ci, 4 * kg + ri, 0), G::elem(ci, 4 * kg + ri, 4)};
     f32x4 gacc[G::MBP];
 #pragma unroll
     for (int mb = 0; mb < G::MBP; ++mb) gacc[mb] = f32x4{0, 0, 0, 0};
     double vsum = 0.0;
 
     // staging: the block image is contiguous in HBM: 256 threads x 16-byte chunks
-    constexpr int CHUNKS = G::BUF * 2 / 16 / NT;  // 16-byte chunks per thread per block
-    static_assert(G::BUF * 2 % (16 * NT) == 0, "block image must split evenly");
+    constexpr int NCH = G::BUF * 2 / 16;           // 16-byte chunks per block image
+    constexpr int CHUNKS = (NCH + NT - 1) / NT;    // per thread
     u32x4 stage[CHUNKS];
     const int64_t blk0 = s0 / 32;  // slices are multiples of 32 rows
     auto fetch = [&](int64_t b) {
         const u32x4* src = reinterpret_cast<const u32x4*>(a.xblk + (blk0 + b) * (int64_t)G::BUF);
 #pragma unroll
-        for (int i = 0; i < CHUNKS; ++i) stage[i] = src[tid + NT * i];
+        for (int i = 0; i < CHUNKS; ++i)
+            if (NT * (i + 1) <= NCH || tid + NT * i < NCH) stage[i] = src[tid + NT * i];
     };
     auto deposit = [&](int buf) {
         u32x4* dst = reinterpret_cast<u32x4*>(smem + buf * G::BUF);
 #pragma unroll
-        for (int i = 0; i < CHUNKS; ++i) dst[tid + NT * i] = stage[i];
+        for (int i = 0; i < CHUNKS; ++i)
+            if (NT * (i + 1) <= NCH || tid + NT * i < NCH) dst[tid + NT * i] = stage[i];
     };
     // the six piece products of weight >= 2^-24: (x piece, other piece)
     constexpr int QX[6] = {0, 0, 1, 0, 1, 2}, QO[6] = {0, 1, 0, 2, 1, 0};
@@ -133,7 +160,7 @@ __global__ void __launch_bounds__((64 * NW)) k_wide_partial_bf16(TallArgs<float,
                 u32x4 xa[3];
 #pragma unroll
                 for (int q = 0; q < 3; ++q)
-                    xa[q] = *reinterpret_cast<const u32x4*>(base + q * 2 * G::LA_Q + ((T * G::M32 + m) * 4 + kg) * 16 * 8 + c * 8);
+                    xa[q] = *reinterpret_cast<const u32x4*>(base + G::tile(q, T, m) + eta_off);
 #pragma unroll
                 for (int t = 0; t < 6; t += 2) {
                     e0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(xa[QX[t]]), as_bf16x8(bq[m][QO[t]]), e0, 0, 0, 0);
@@ -166,13 +193,15 @@ __global__ void __launch_bounds__((64 * NW)) k_wide_partial_bf16(TallArgs<float,
             }
         }
         // ---- grad += Xs^T . W
-        const uint16_t* g0 = base + 3 * 2 * G::LA_Q;
 #pragma unroll
         for (int mb = 0; mb < G::MBP; ++mb) {
             u32x4 xg[3];
 #pragma unroll
-            for (int q = 0; q < 3; ++q)
-                xg[q] = *reinterpret_cast<const u32x4*>(g0 + q * G::LG_Q + ((mb * 4 + kg) * 16 + c) * 8);
+            for (int q = 0; q < 3; ++q) {
+                const u32x2 t0 = lds_read_tr16(base + G::tile(q, 0, mb >> 1) + tr_off[mb & 1]);
+                const u32x2 t1 = lds_read_tr16(base + G::tile(q, 1, mb >> 1) + tr_off[mb & 1]);
+                xg[q] = u32x4{t0[0], t0[1], t1[0], t1[1]};
+            }
 #pragma unroll
             for (int t = 0; t < 6; ++t)
                 gacc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(xg[QX[t]]), as_bf16x8(wq[QO[t]]), gacc[mb], 0, 0, 0);
@@ -201,7 +230,7 @@ __global__ void __launch_bounds__((64 * NW)) k_wide_partial_bf16(TallArgs<float,
     }
 }
 
-// Host side: build the per-32-row-block LDS images (bf16 pieces, both layouts) from the signed rows.
+// Host side: build the per-32-row-block LDS images (bf16 pieces, swizzled layout) from the signed rows.
 // rows: [n][P] fp32 (host).  out: [ceil(n/32)][BUF] bf16 bit patterns.
 template <int P> inline void wide_bf16_prepare(const float* rows, int64_t n, uint16_t* out) {
     using G = WideBf16Geom<P>;
@@ -212,7 +241,7 @@ template <int P> inline void wide_bf16_prepare(const float* rows, int64_t n, uin
         for (int srow = 0; srow < 32; ++srow) {
             const int64_t r = 32 * b + srow;
             if (r >= n) continue;
-            const int T = srow >> 4, rr = srow & 15, gkg = rr >> 2, gi = (rr & 3) + 4 * T;
+            const int T = srow >> 4, rr = srow & 15;
             for (int cc = 0; cc < P; ++cc) {
                 const float x = rows[r * P + cc];
                 uint32_t xb, hb, mb_, lb;
@@ -227,14 +256,8 @@ template <int P> inline void wide_bf16_prepare(const float* rows, int64_t n, uin
                 lo = r1 - md;
                 memcpy(&lb, &lo, 4);
                 const uint16_t pc[3] = {(uint16_t)(hb >> 16), (uint16_t)(mb_ >> 16), (uint16_t)(lb >> 16)};
-                const int m = cc >> 5, w5 = cc & 31, akg = w5 >> 3, ai = w5 & 7;
-                const int la = ((T * G::M32 + m) * 4 + akg) * 16 * 8 + rr * 8 + ai;
-                const int hh = (w5 & 7) >> 2, rp = w5 & 3;
-                const int lg = (((2 * m + hh) * 4 + gkg) * 16 + (4 * akg + rp)) * 8 + gi;
-                for (int q = 0; q < 3; ++q) {
-                    base[q * 2 * G::LA_Q + la] = pc[q];
-                    base[3 * 2 * G::LA_Q + q * G::LG_Q + lg] = pc[q];
-                }
+                const int m = cc >> 5, w5 = cc & 31;
+                for (int q = 0; q < 3; ++q) base[G::tile(q, T, m) + G::elem(w5 >> 3, rr, w5 & 7)] = pc[q];
             }
         }
     }
