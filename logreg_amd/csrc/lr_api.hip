@@ -247,6 +247,9 @@ int do_chain_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs, c
         ca.a[j] = (T)rs.a[j];
         ca.b[j] = (T)rs.b[j];
         ca.c[j] = (T)rs.c[j];
+        const double ks = sizeof(T) == 4 ? 1.4426950408889634 : 1.0;  // lr::ExpScale<T>::k
+        ca.d[j] = (T)(rs.b[j] * ks);
+        ca.e[j] = (T)(m->inv_var[j] / ks);
     }
     lr::LaunchCfg cfg{pl.mode, pl.G, pl.R, rs.kind, st, pl.lds_bytes};
     const int rc = m->table->launch_chain(&cfg, o->n_chains, &ma, &ca);

@@ -436,6 +436,105 @@ template <typename T, int P, int R, int G> struct RegRows {
     __device__ __forceinline__ T value_fixup() const { return T(pad_rows) * T(0.693147180559945309); }
 };
 
+// float rows in registers, stored as TWISTED ROW PAIRS.  For the row pair (A, B) = (2k, 2k+1) and the
+// coordinate pair (j, j+1), j even, two 64-bit register pairs hold
+//       q[k][j] = (A_j, B_{j+1})        q[k][j+1] = (A_{j+1}, B_j)
+// so that BOTH contractions run on v_pk_fma_f32 without any horizontal add per row:
+//   eta   (t_A, t_B) += q[k][j] * (b_j, b_{j+1})  +  q[k][j+1] * (b_{j+1}, b_j)      (op_sel swap of the beta pair)
+//   grad  G[j/2] += q[k][j]   * (w_A, w_B)  =  (A_j w_A,     B_{j+1} w_B)  -> (g_j, g_{j+1})
+//         H[j/2] += q[k][j+1] * (w_A, w_B)  =  (A_{j+1} w_A, B_j w_B)      -> (g_{j+1}, g_j)
+//   once per evaluation:  (g_j, g_{j+1}) = G[j/2] + swap(H[j/2])                      (one v_pk_add per pair)
+// and the two sigmoids of a pair share one v_pk_add: 10.5 VALU instructions per row instead of the 12
+// of the coordinate-pair form (row_term: a horizontal add per row and a scalar +1 per sigmoid).  An odd
+// R keeps its last row in coordinate-pair form (s[j/2] = (x_j, x_{j+1})); its gradient lands in G directly.
+template <int P, int R, int G> struct RegRowPairs {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    static_assert(P % 2 == 0, "coordinate pairs");
+    static constexpr int RP = R / 2;
+    static constexpr bool ODD = (R & 1) != 0;
+    f2 q[RP > 0 ? RP : 1][P];
+    f2 s[P / 2];  // the unpaired last row (ODD)
+    int pad_rows;
+    __device__ __forceinline__ void load(const float* __restrict__ rows, int64_t n, int gl) {
+        pad_rows = 0;
+        auto at = [&](int k, int j) {  // element j of the lane's k-th row (zero beyond n)
+            const int64_t i = gl + (int64_t)k * G;
+            return i < n ? rows[i * P + j] : 0.0f;
+        };
+#pragma unroll
+        for (int k = 0; k < R; ++k)
+            if (gl + (int64_t)k * G >= n) ++pad_rows;
+#pragma unroll
+        for (int k = 0; k < RP; ++k)
+#pragma unroll
+            for (int j = 0; j < P; j += 2) {
+                q[k][j] = f2{at(2 * k, j), at(2 * k + 1, j + 1)};
+                q[k][j + 1] = f2{at(2 * k, j + 1), at(2 * k + 1, j)};
+            }
+        if constexpr (ODD) {
+#pragma unroll
+            for (int j = 0; j < P; j += 2) s[j / 2] = f2{at(R - 1, j), at(R - 1, j + 1)};
+        }
+    }
+    __device__ __forceinline__ float value_fixup() const { return float(pad_rows) * 0.693147180559945309f; }
+};
+template <class Rows> struct is_row_pairs { static constexpr bool value = false; };
+template <int P, int R, int G> struct is_row_pairs<RegRowPairs<P, R, G>> { static constexpr bool value = true; };
+
+__device__ __forceinline__ float log_sigmoid_scaled(float t) {  // log sigma(t), t pre-scaled by ExpScale::k
+    const float at = t < 0.0f ? -t : t;
+    return (t < 0.0f ? t * ExpScale<float>::inv : 0.0f) - log1p_unit(ExpScale<float>::exp_scaled(-at));
+}
+
+// all rows of a RegRowPairs lane: gradient partial sums into gp[P/2] = (g_j, g_{j+1}) pairs, value into v.
+// bb[j/2] = (b_j, b_{j+1}) is beta * ExpScale::k.
+template <int P, int R, int G, bool VALUE, bool GRAD>
+__device__ __forceinline__ void row_pairs_eval(const RegRowPairs<P, R, G>& rows,
+                                               const float __attribute__((ext_vector_type(2))) (&bb)[P / 2],
+                                               float __attribute__((ext_vector_type(2))) (&gp)[P / 2], float& v) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 hp[P / 2];
+#pragma unroll
+    for (int j = 0; j < P / 2; ++j) gp[j] = hp[j] = f2{0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k < RegRowPairs<P, R, G>::RP; ++k) {
+        const f2(&q)[P] = rows.q[k];
+        f2 ts = q[0] * bb[0];
+        ts = __builtin_elementwise_fma(q[1], __builtin_shufflevector(bb[0], bb[0], 1, 0), ts);
+#pragma unroll
+        for (int j = 2; j < P; j += 2) {
+            ts = __builtin_elementwise_fma(q[j], bb[j / 2], ts);
+            ts = __builtin_elementwise_fma(q[j + 1], __builtin_shufflevector(bb[j / 2], bb[j / 2], 1, 0), ts);
+        }
+        if constexpr (GRAD) {
+            const f2 d = f2{ExpScale<float>::exp_scaled(ts.x), ExpScale<float>::exp_scaled(ts.y)} + f2{1.0f, 1.0f};
+            const f2 w = {fast_rcp(d.x), fast_rcp(d.y)};  // sigma(-t); exp overflow -> rcp(inf) = 0
+#pragma unroll
+            for (int j = 0; j < P; j += 2) {
+                gp[j / 2] = __builtin_elementwise_fma(q[j], w, gp[j / 2]);
+                hp[j / 2] = __builtin_elementwise_fma(q[j + 1], w, hp[j / 2]);
+            }
+        }
+        if constexpr (VALUE) v += log_sigmoid_scaled(ts.x) + log_sigmoid_scaled(ts.y);
+    }
+    if constexpr (RegRowPairs<P, R, G>::ODD) {
+        f2 acc = rows.s[0] * bb[0];
+#pragma unroll
+        for (int j = 1; j < P / 2; ++j) acc = __builtin_elementwise_fma(rows.s[j], bb[j], acc);
+        const float ts = acc.x + acc.y;
+        if constexpr (GRAD) {
+            const float w = fast_rcp(1.0f + ExpScale<float>::exp_scaled(ts));
+#pragma unroll
+            for (int j = 0; j < P / 2; ++j) gp[j] = __builtin_elementwise_fma(f2{w, w}, rows.s[j], gp[j]);
+        }
+        if constexpr (VALUE) v += log_sigmoid_scaled(ts);
+    }
+    if constexpr (GRAD) {
+#pragma unroll
+        for (int j = 0; j < P / 2; ++j) gp[j] += __builtin_shufflevector(hp[j], hp[j], 1, 0);
+    }
+}
+
 template <typename T, int P, int G> struct StridedRows {  // LDS or global: same access code
     const T* base;  // row-major [n][P]
     int64_t n;
@@ -496,16 +595,37 @@ template <typename T, int P> struct Prior {
     double lprior_const;  // sum_j ( -log sd_j - 0.5 log 2 pi ) over the real coordinates
 };
 
-template <typename T, int P, int G, bool VALUE, bool GRAD, class Rows>
+// PRESCALED (gradient only): `beta` is already multiplied by ExpScale<T>::k and pr.inv_var divided by it
+// (HMC carries the trajectory position in those units: no rescaling per evaluation); grad is d/dbeta.
+template <typename T, int P, int G, bool VALUE, bool GRAD, bool PRESCALED = false, class Rows = void>
 __device__ __forceinline__ void eval_lpost(const Rows& rows, const Prior<T, P>& pr, const T (&beta)[P], T (&grad)[P],
                                            double& ll, double& lprior) {
+    static_assert(!(PRESCALED && VALUE), "the value pass takes the plain position");
     T g[P];
 #pragma unroll
     for (int j = 0; j < P; ++j) g[j] = T(0);
     T v = T(0);
     T bs[P];
-    vscale<T, P>(ExpScale<T>::k, beta, bs);
-    rows.for_each([&](const T(&xs)[P]) { row_term<T, P, VALUE, GRAD>(xs, bs, g, v); });
+    if constexpr (PRESCALED) {
+#pragma unroll
+        for (int j = 0; j < P; ++j) bs[j] = beta[j];
+    } else {
+        vscale<T, P>(ExpScale<T>::k, beta, bs);
+    }
+    if constexpr (is_row_pairs<Rows>::value) {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        f2 bb[P / 2], gp[P / 2];
+#pragma unroll
+        for (int j = 0; j < P / 2; ++j) bb[j] = f2{bs[2 * j], bs[2 * j + 1]};
+        row_pairs_eval<P, Rows::RP * 2 + (Rows::ODD ? 1 : 0), G, VALUE, GRAD>(rows, bb, gp, v);
+#pragma unroll
+        for (int j = 0; j < P / 2; ++j) {
+            g[2 * j] = gp[j].x;
+            g[2 * j + 1] = gp[j].y;
+        }
+    } else {
+        rows.for_each([&](const T(&xs)[P]) { row_term<T, P, VALUE, GRAD>(xs, bs, g, v); });
+    }
     if constexpr (GRAD) {
 #ifdef LR_FUSED_DPP_REDUCE
         group_sum_vec<G, P>(g);  // hand-fused v_add_f32_dpp: +7 % at >= 4 waves/SIMD, -5 % at 1 wave/SIMD

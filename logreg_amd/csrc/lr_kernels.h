@@ -30,6 +30,8 @@ template <typename T> struct EvalArgs {
 //   MALA : a = 0.5*pre*dt, b = sqrt(pre*dt), c = 1/(pre*dt)  (fit-np-mala.py:72-78)
 //   UL   : a = 0.5*pre*dt, b = sqrt(pre*dt)                  (fit-np-ul.py:61-68)
 //   HMC  : a = sqrt(dmm),  b = eps/dmm,      c = 1/dmm       (fit-np-hmc.py:65-87)
+//          d = b*k, e = prior inv_var/k with k = ExpScale<T>::k: the leapfrog position is carried as k*q, which
+//          is what the row dot products want (exp2), so interior evaluations do no rescaling at all
 template <typename T, int P> struct ChainArgs {
     T* state;           // [C][p] in/out
     double* lp_state;   // [C] threaded log-density of RWMH/MALA (in/out, -inf allowed); null for HMC/UL
@@ -44,6 +46,7 @@ template <typename T, int P> struct ChainArgs {
     int l;   // HMC leapfrog steps
     T step;  // HMC eps
     T a[P], b[P], c[P];
+    T d[P], e[P];  // HMC: d = b * ExpScale<T>::k, e = prior inv_var / ExpScale<T>::k (trajectory in scaled units)
 };
 
 // --------------------------------------------------------------------------------------------
@@ -52,6 +55,9 @@ template <typename T, int P, int G, int MODE, int R> struct RowsOf {
 };
 template <typename T, int P, int G, int R> struct RowsOf<T, P, G, MODE_REG, R> {
     using type = RegRows<T, P, R, G>;
+};
+template <int P, int G, int R> struct RowsOf<float, P, G, MODE_REG, R> {
+    using type = RegRowPairs<P, R, G>;
 };
 template <typename T, int P, int R> struct RowsOf<T, P, 1, MODE_GLOBAL, R> {
     using type = ScalarRows<T, P>;  // lane-per-chain: rows broadcast through the scalar unit
@@ -126,6 +132,11 @@ __global__ void __launch_bounds__(256) k_chain(ModelArgs<T, P> m, ChainArgs<T, P
     T x[P];
 #pragma unroll
     for (int j = 0; j < P; ++j) x[j] = j < a.p ? a.state[chain * a.p + j] : T(0);
+
+    Prior<T, P> prior_k;  // HMC: inv_var / ExpScale<T>::k, for positions carried as k * q
+#pragma unroll
+    for (int j = 0; j < P; ++j) prior_k.inv_var[j] = a.e[j];
+    prior_k.lprior_const = 0.0;
 
     T g[P];        // gradient at x (MALA / HMC / UL)
     double lp;     // log-density attached to x: threaded value (RWMH/MALA) or lpost(x) (HMC)
@@ -202,13 +213,16 @@ __global__ void __launch_bounds__(256) k_chain(ModelArgs<T, P> m, ChainArgs<T, P
                     }
                     const T heps = T(0.5) * a.step;
                     vfma_s<T, P>(heps, gp, pm);
+                    T xk[P];  // k * position
+                    vscale<T, P>(ExpScale<T>::k, xp, xk);
                     for (int i = 0; i < a.l - 1; ++i) {
-                        vfma_v<T, P>(a.b, pm, xp);  // drift
+                        vfma_v<T, P>(a.d, pm, xk);  // drift
                         double d0, d1;
-                        eval_lpost<T, P, G, false, true>(rows, m.prior, xp, gp, d0, d1);
+                        eval_lpost<T, P, G, false, true, true>(rows, prior_k, xk, gp, d0, d1);
                         vfma_s<T, P>(a.step, gp, pm);  // kick
                     }
-                    vfma_v<T, P>(a.b, pm, xp);
+                    vfma_v<T, P>(a.d, pm, xk);
+                    vscale<T, P>(ExpScale<T>::inv, xk, xp);
                     eval_lpost<T, P, G, true, true>(rows, m.prior, xp, gp, llp, lprp);
                     T k1 = T(0);
 #pragma unroll

@@ -70,6 +70,36 @@ template <int KIND> __global__ void k(float* out, long long* cyc, float seed) {
 #define S(i) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[(i)&3]) : "v"(b[i]), "v"(s));
             REP16(S)
 #undef S
+        } else if constexpr (KIND == 15) {  // 12 v_pk_fma + 4 v_exp interleaved 3:1 (does the transcendental overlap?)
+#define F(i) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(*(double*)&a[(i)&~1]) : "v"(*(double*)&b[(i)&~1]), "v"(*(double*)&b[((i)+2)&14]));
+#define E(i) asm volatile("v_exp_f32 %0, %1" : "=v"(b[i]) : "v"(b[i]));
+            F(0) F(2) F(4) E(12) F(6) F(8) F(10) E(13) F(0) F(2) F(4) E(14) F(6) F(8) F(10) E(15)
+#undef F
+#undef E
+        } else if constexpr (KIND == 16) {  // v_pk_add_f32
+#define S(i) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(*(double*)&a[(i)&~1]) : "v"(*(double*)&b[(i)&~1]));
+            REP16(S)
+#undef S
+        } else if constexpr (KIND == 17) {  // v_add_f32
+#define S(i) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(s));
+            REP16(S)
+#undef S
+        } else if constexpr (KIND == 18) {  // 12 v_fmac + 4 v_exp interleaved
+#define F(i) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[i]) : "v"(b[i]), "v"(s));
+#define E(i) asm volatile("v_exp_f32 %0, %1" : "=v"(b[i]) : "v"(b[i]));
+            F(0) F(1) F(2) E(12) F(3) F(4) F(5) E(13) F(6) F(7) F(8) E(14) F(9) F(10) F(11) E(15)
+#undef F
+#undef E
+        } else if constexpr (KIND == 19) {  // v_pk_fma_f32 with an SGPR-pair operand
+            float ss = __builtin_amdgcn_readfirstlane(s);
+            double sd; { float t2[2] = {ss, ss}; sd = *(double*)t2; }
+#define S(i) asm volatile("v_pk_fma_f32 %0, %2, %1, %0" : "+v"(*(double*)&a[(i)&~1]) : "v"(*(double*)&b[(i)&~1]), "s"(sd));
+            REP16(S)
+#undef S
+        } else if constexpr (KIND == 20) {  // v_pk_fma_f32 with op_sel broadcast of one source
+#define S(i) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(*(double*)&a[(i)&~1]) : "v"(*(double*)&b[(i)&~1]), "v"(*(double*)&b[((i)+2)&14]));
+            REP16(S)
+#undef S
         } else if constexpr (KIND == 13) {  // f32 MFMA 16x16x4
             typedef float f4 __attribute__((ext_vector_type(4)));
             f4 acc0 = {a[0], a[1], a[2], a[3]}, acc1 = {a[4], a[5], a[6], a[7]}, acc2 = {a[8], a[9], a[10], a[11]}, acc3 = {a[12], a[13], a[14], a[15]};
@@ -144,6 +174,12 @@ int main() {
     run<6>("v_fmac dependent x1", 16);
     run<7>("v_fmac dependent x2", 16);
     run<12>("v_fmac dependent x4", 16);
+    run<16>("v_pk_add_f32 indep", 16);
+    run<17>("v_add_f32 indep", 16);
+    run<15>("12 v_pk_fma + 4 v_exp mixed", 16);
+    run<18>("12 v_fmac + 4 v_exp mixed", 16);
+    run<19>("v_pk_fma_f32 sgpr operand", 16);
+    run<20>("v_pk_fma_f32 op_sel bcast", 16);
     run<13>("mfma_f32_16x16x4f32", 16);
     run<14>("mfma + 16 fmac each (2+32..)", 2 * (2 + 32));
     return 0;
