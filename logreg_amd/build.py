@@ -26,7 +26,7 @@ ARCH = "gfx950"
 # -fno-slp-vectorize: packing is explicit in the sources (f32x2); SLP would re-pack the DPP reduction adds
 # into v_pk_add_f32 and lose the fused v_add_f32_dpp form (16 more instructions per evaluation)
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-fno-slp-vectorize", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall",
-          "-Wno-unused-function", "-I", CSRC, "-I", INCLUDE]
+          "-Wno-unused-function", "-I", CSRC, "-I", INCLUDE] + os.environ.get("LOGREG_HIPCC_FLAGS", "").split()
 
 INSTANCES = [(dt, dtype_id, ctype, p) for dt, dtype_id, ctype in (("f32", 0, "float"), ("f64", 1, "double"))
              for p in (4, 8, 16, 32)]
