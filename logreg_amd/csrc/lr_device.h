@@ -230,53 +230,6 @@ __device__ __forceinline__ void draw_group(uint64_t seed, uint64_t chain, uint64
     }
 }
 
-// N independent float values at once: level-major order keeps >= N-1 instructions between a
-// value's write and its next DPP read, and each level is ONE fused v_add_f32_dpp per value
-// (hipcc otherwise emits v_mov_dpp + v_pk_add).  hipcc pads no hazards inside asm statements:
-// the s_nop opening each level covers "VALU write -> DPP read" for the level's first value.
-#define LR_DPP_ADD(ctrl) "v_add_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1"
-template <int G, int N> __device__ __forceinline__ void group_sum_vec(float (&v)[N]) {
-    static_assert(G == 1 || G == 2 || G == 4 || G == 8 || G == 16 || G == 32 || G == 64, "bad group");
-    if constexpr (N < 4) {
-#pragma unroll
-        for (int j = 0; j < N; ++j) v[j] = group_sum<G>(v[j]);
-    } else {
-        if constexpr (G >= 16) {
-            asm volatile("s_nop 1\n\t" LR_DPP_ADD("row_mirror") : "+v"(v[0]));
-#pragma unroll
-            for (int j = 1; j < N; ++j) asm volatile(LR_DPP_ADD("row_mirror") : "+v"(v[j]));
-        }
-        if constexpr (G >= 8) {
-            asm volatile("s_nop 1\n\t" LR_DPP_ADD("row_half_mirror") : "+v"(v[0]));
-#pragma unroll
-            for (int j = 1; j < N; ++j) asm volatile(LR_DPP_ADD("row_half_mirror") : "+v"(v[j]));
-        }
-        if constexpr (G >= 4) {
-            asm volatile("s_nop 1\n\t" LR_DPP_ADD("quad_perm:[2,3,0,1]") : "+v"(v[0]));
-#pragma unroll
-            for (int j = 1; j < N; ++j) asm volatile(LR_DPP_ADD("quad_perm:[2,3,0,1]") : "+v"(v[j]));
-        }
-        if constexpr (G >= 2) {
-            asm volatile("s_nop 1\n\t" LR_DPP_ADD("quad_perm:[1,0,3,2]") : "+v"(v[0]));
-#pragma unroll
-            for (int j = 1; j < N; ++j) asm volatile(LR_DPP_ADD("quad_perm:[1,0,3,2]") : "+v"(v[j]));
-            asm volatile("s_nop 0" ::: );  // last DPP result -> first compiler-scheduled consumer
-        }
-        if constexpr (G >= 32) {
-#pragma unroll
-            for (int j = 0; j < N; ++j) v[j] = swap16_sum(v[j]);
-        }
-        if constexpr (G >= 64) {
-#pragma unroll
-            for (int j = 0; j < N; ++j) v[j] = swap32_sum(v[j]);
-        }
-    }
-}
-template <int G, int N> __device__ __forceinline__ void group_sum_vec(double (&v)[N]) {
-#pragma unroll
-    for (int j = 0; j < N; ++j) v[j] = group_sum<G>(v[j]);
-}
-
 // ------------------------------------------------------------------------------------------
 // fast scalar math for the hot loop
 // ------------------------------------------------------------------------------------------
@@ -627,12 +580,8 @@ __device__ __forceinline__ void eval_lpost(const Rows& rows, const Prior<T, P>& 
         rows.for_each([&](const T(&xs)[P]) { row_term<T, P, VALUE, GRAD>(xs, bs, g, v); });
     }
     if constexpr (GRAD) {
-#ifdef LR_FUSED_DPP_REDUCE
-        group_sum_vec<G, P>(g);  // hand-fused v_add_f32_dpp: +7 % at >= 4 waves/SIMD, -5 % at 1 wave/SIMD
-#else
 #pragma unroll
-        for (int j = 0; j < P; ++j) g[j] = group_sum<G>(g[j]);  // compiler-scheduled (v_mov_dpp + v_pk_add)
-#endif
+        for (int j = 0; j < P; ++j) g[j] = group_sum<G>(g[j]);  // fused v_add_f32_dpp per level (-fno-slp-vectorize)
         vnmsub<T, P>(beta, pr.inv_var, g, grad);
     }
     if constexpr (VALUE) {

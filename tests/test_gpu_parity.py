@@ -494,6 +494,43 @@ def test_other_parameter_counts_use_padded_kernels(la, oracle_model):
             assert np.max(np.abs(out[0, ok] - ref["out"][0, ok])) < (2e-3 if dtype == "float32" else 1e-9)
 
 
+@pytest.mark.parametrize("n", [1, 2, 17, 64, 208, 250, 256])
+def test_register_row_pair_layouts_for_every_row_count(la, n):
+    """Rows live in VGPRs as twisted row pairs (+ one unpaired row when the per-lane count is odd):
+    exercise even and odd rows-per-lane, ragged last rows and all-padding lanes for every register
+    variant that can hold n rows, all four kernels, against the oracle."""
+    from oracle.oracle import OracleModel
+    p, C = 8, 96
+    X, y, _ = la.synthetic_logreg(n, p, seed=1000 + n)
+    ps = np.full(p, 1.5)
+    orc = OracleModel(X, y, ps)
+    m = la.LogReg(X, y, ps)
+    rng = np.random.default_rng(n)
+    q0 = 0.2 * rng.standard_normal((C, p))
+    for group in (16, 32, 64):
+        try:
+            plan = m.plan(C, group, "reg")
+        except la.LogregHipError:
+            continue  # n does not fit this variant's registers
+        assert plan["mode"] == "reg" and plan["group"] == group and plan["group"] * plan["rows_per_lane"] >= n
+        r = m.eval(q0, group=group, mode="reg")
+        np.testing.assert_allclose(r["lpost"], orc.lpost(q0), rtol=3e-6)
+        assert np.max(np.abs(r["glp"] - orc.glp(q0))) < 3e-4
+        for kind, kw, kern in (
+                ("hmc", dict(step=0.05, l=5, scale=np.ones(p)), la.hmcKernel(m.lpost, m.glp, eps=0.05, l=5, dmm=np.ones(p))),
+                ("mala", dict(step=1e-2, scale=np.ones(p)), la.malaKernel(m.lpost, m.glp, dt=1e-2, pre=np.ones(p))),
+                ("rwmh", dict(scale=np.full(p, 0.1)), la.mhKernel(m.lpost, la.rwProposal(np.full(p, 0.1)))),
+                ("ul", dict(step=1e-2, scale=np.ones(p)), la.ulKernel(m.glp, dt=1e-2, pre=np.ones(p)))):
+            ll0 = orc.lpost(q0) if kind in ("mala", "rwmh") else None
+            ref = orc.run(kind, q0, thin=1, iters=2, seed=9, ll_state=ll0, threads=0, **kw)
+            out, info = la.mcmc(q0, kern, thin=1, iters=2, verb=False, seed=9, ll=ll0, group=group, mode="reg",
+                                return_info=True)
+            ok = ref["margin"] > 1e-3
+            assert ok.mean() > 0.9, (kind, group)
+            assert np.array_equal(info["accepts"][ok], ref["accepts"][ok].astype(np.uint32)), (kind, group)
+            assert np.max(np.abs(out[:, ok] - ref["out"][:, ok])) < 2e-4, (kind, group)
+
+
 # ------------------------------------------------------------------------------------------------
 def test_full_size_properties_4096_chains(la, models, map_beta):
     """BASELINE size (4096 chains, L=50): size-independent properties."""

@@ -100,6 +100,22 @@ template <int KIND> __global__ void k(float* out, long long* cyc, float seed) {
 #define S(i) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(*(double*)&a[(i)&~1]) : "v"(*(double*)&b[(i)&~1]), "v"(*(double*)&b[((i)+2)&14]));
             REP16(S)
 #undef S
+        } else if constexpr (KIND == 21) {  // v_permlane32_swap_b32 (8 swaps of register pairs)
+#define S(i) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a[i]), "+v"(b[i]));
+            REP16(S)
+#undef S
+        } else if constexpr (KIND == 22) {  // v_permlane16_swap_b32
+#define S(i) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(a[i]), "+v"(b[i]));
+            REP16(S)
+#undef S
+        } else if constexpr (KIND == 23) {  // v_mov_b64
+#define S(i) asm volatile("v_mov_b64 %0, %1" : "=v"(*(double*)&a[(i)&~1]) : "v"(*(double*)&b[(i)&~1]));
+            REP16(S)
+#undef S
+        } else if constexpr (KIND == 24) {  // swap + dependent add (the transposing reduction step)
+#define S(i) asm volatile("v_permlane32_swap_b32 %0, %1\n\ts_nop 0\n\tv_add_f32 %0, %0, %1" : "+v"(a[i]), "+v"(b[i]));
+            REP16(S)
+#undef S
         } else if constexpr (KIND == 13) {  // f32 MFMA 16x16x4
             typedef float f4 __attribute__((ext_vector_type(4)));
             f4 acc0 = {a[0], a[1], a[2], a[3]}, acc1 = {a[4], a[5], a[6], a[7]}, acc2 = {a[8], a[9], a[10], a[11]}, acc3 = {a[12], a[13], a[14], a[15]};
@@ -180,6 +196,10 @@ int main() {
     run<18>("12 v_fmac + 4 v_exp mixed", 16);
     run<19>("v_pk_fma_f32 sgpr operand", 16);
     run<20>("v_pk_fma_f32 op_sel bcast", 16);
+    run<21>("v_permlane32_swap indep", 16);
+    run<22>("v_permlane16_swap indep", 16);
+    run<23>("v_mov_b64 indep", 16);
+    run<24>("swap32 + nop + add (2 inst)", 32);
     run<13>("mfma_f32_16x16x4f32", 16);
     run<14>("mfma + 16 fmac each (2+32..)", 2 * (2 + 32));
     return 0;
