@@ -147,6 +147,28 @@ template <int G, typename T> __device__ __forceinline__ T group_sum(T v) {
     return v;
 }
 
+// N independent float values at once, LEVEL-major: between a value's write and its next DPP read there
+// are N-1 other instructions, so no hazard padding and no dependency stall.  The scheduling barriers pin
+// that order: left alone, the scheduler sometimes serialises the reduction value by value (32 dependent
+// v_add_f32_dpp separated by s_nop: measured 10 % of the whole HMC kernel), depending on register
+// pressure elsewhere in the kernel.
+template <int G, int N> __device__ __forceinline__ void group_sum_levels(float (&v)[N]) {
+    static_assert(G == 1 || G == 2 || G == 4 || G == 8 || G == 16 || G == 32 || G == 64, "bad group");
+#define LR_LEVEL(COND, EXPR)                       \
+    if constexpr (COND) {                          \
+        __builtin_amdgcn_sched_barrier(0);         \
+        _Pragma("unroll") for (int j = 0; j < N; ++j) v[j] = EXPR; \
+    }
+    LR_LEVEL(G >= 16, v[j] + dpp_mov<0x140>(v[j]))
+    LR_LEVEL(G >= 8, v[j] + dpp_mov<0x141>(v[j]))
+    LR_LEVEL(G >= 4, v[j] + dpp_mov<0x4E>(v[j]))
+    LR_LEVEL(G >= 2, v[j] + dpp_mov<0xB1>(v[j]))
+    LR_LEVEL(G >= 32, swap16_sum(v[j]))
+    LR_LEVEL(G >= 64, swap32_sum(v[j]))
+#undef LR_LEVEL
+    if constexpr (G >= 2) __builtin_amdgcn_sched_barrier(0);
+}
+
 // All draws of one iteration for a chain owned by G lanes: z[0..P) and log(u).
 // With G >= P/4 + 1 lanes the work is SPLIT: lane gl computes ONE Philox block (normal blocks
 // 0..NB-1, or the uniform block NB) and its two Box-Muller pairs, and the values are then
@@ -289,6 +311,61 @@ __device__ __forceinline__ void vnmsub(const T (&a)[P], const T (&b)[P], const T
     } else {
 #pragma unroll
         for (int j = 0; j < P; ++j) out[j] = c[j] - a[j] * b[j];
+    }
+}
+// out[j] = a[j] * x[j] + y[j]
+template <typename T, int P>
+__device__ __forceinline__ void vfma_o(const T (&a)[P], const T (&x)[P], const T (&y)[P], T (&out)[P]) {
+    if constexpr (sizeof(T) == 4 && P % 2 == 0) {
+#pragma unroll
+        for (int j = 0; j < P; j += 2) {
+            const f32x2 r = __builtin_elementwise_fma(f32x2{a[j], a[j + 1]}, f32x2{x[j], x[j + 1]}, f32x2{y[j], y[j + 1]});
+            out[j] = r.x;
+            out[j + 1] = r.y;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < P; ++j) out[j] = fma_t(a[j], x[j], y[j]);
+    }
+}
+// sum_j c[j] * ((u[j] - v[j])^2 - (w[j] - z[j])^2)     (MALA proposal-density difference)
+template <typename T, int P>
+__device__ __forceinline__ T vdiffsq(const T (&c)[P], const T (&u)[P], const T (&v)[P], const T (&w)[P], const T (&z)[P]) {
+    if constexpr (sizeof(T) == 4 && P % 2 == 0) {
+        f32x2 acc = {0.0f, 0.0f};
+#pragma unroll
+        for (int j = 0; j < P; j += 2) {
+            const f32x2 d1 = f32x2{u[j], u[j + 1]} - f32x2{v[j], v[j + 1]};
+            const f32x2 d2 = f32x2{w[j], w[j + 1]} - f32x2{z[j], z[j + 1]};
+            const f32x2 t = __builtin_elementwise_fma(-d2, d2, d1 * d1);
+            acc = __builtin_elementwise_fma(f32x2{c[j], c[j + 1]}, t, acc);
+        }
+        return acc.x + acc.y;
+    } else {
+        T acc = T(0);
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const T d1 = u[j] - v[j], d2 = w[j] - z[j];
+            acc = fma_t(c[j], d1 * d1 - d2 * d2, acc);
+        }
+        return acc;
+    }
+}
+// sum_j a[j] * x[j]^2
+template <typename T, int P> __device__ __forceinline__ T vquad(const T (&a)[P], const T (&x)[P]) {
+    if constexpr (sizeof(T) == 4 && P % 2 == 0) {
+        f32x2 acc = {0.0f, 0.0f};
+#pragma unroll
+        for (int j = 0; j < P; j += 2) {
+            const f32x2 xx = f32x2{x[j], x[j + 1]};
+            acc = __builtin_elementwise_fma(xx * xx, f32x2{a[j], a[j + 1]}, acc);
+        }
+        return acc.x + acc.y;
+    } else {
+        T acc = T(0);
+#pragma unroll
+        for (int j = 0; j < P; ++j) acc = fma_t(x[j] * x[j], a[j], acc);
+        return acc;
     }
 }
 // out[j] = s * x[j]
@@ -434,11 +511,6 @@ template <int P, int R, int G> struct RegRowPairs {
 template <class Rows> struct is_row_pairs { static constexpr bool value = false; };
 template <int P, int R, int G> struct is_row_pairs<RegRowPairs<P, R, G>> { static constexpr bool value = true; };
 
-__device__ __forceinline__ float log_sigmoid_scaled(float t) {  // log sigma(t), t pre-scaled by ExpScale::k
-    const float at = t < 0.0f ? -t : t;
-    return (t < 0.0f ? t * ExpScale<float>::inv : 0.0f) - log1p_unit(ExpScale<float>::exp_scaled(-at));
-}
-
 // all rows of a RegRowPairs lane: gradient partial sums into gp[P/2] = (g_j, g_{j+1}) pairs, value into v.
 // bb[j/2] = (b_j, b_{j+1}) is beta * ExpScale::k.
 template <int P, int R, int G, bool VALUE, bool GRAD>
@@ -449,6 +521,13 @@ __device__ __forceinline__ void row_pairs_eval(const RegRowPairs<P, R, G>& rows,
     f2 hp[P / 2];
 #pragma unroll
     for (int j = 0; j < P / 2; ++j) gp[j] = hp[j] = f2{0.0f, 0.0f};
+    // value: log sigma(t) = ln2 * (ts - log2(1 + 2^ts)) with ts = t log2(e): the SAME 1 + 2^ts the gradient
+    // needs, so the value costs one v_log per row on top (accumulated in log2 units, scaled once).  ts is
+    // clamped at 100 (sigma(-t) < 2^-100 there: nothing changes) so that 2^ts stays finite; for ts -> -inf the
+    // expression tends to ts exactly.  Cancellation at large ts costs an absolute ulp(ts) ~ 1e-6 per row,
+    // the size of the fp32 summation error of the value itself.
+    f2 vacc = {0.0f, 0.0f};
+    float vs = 0.0f;
 #pragma unroll
     for (int k = 0; k < RegRowPairs<P, R, G>::RP; ++k) {
         const f2(&q)[P] = rows.q[k];
@@ -459,8 +538,9 @@ __device__ __forceinline__ void row_pairs_eval(const RegRowPairs<P, R, G>& rows,
             ts = __builtin_elementwise_fma(q[j], bb[j / 2], ts);
             ts = __builtin_elementwise_fma(q[j + 1], __builtin_shufflevector(bb[j / 2], bb[j / 2], 1, 0), ts);
         }
+        if constexpr (VALUE) ts = f2{__builtin_fminf(ts.x, 100.0f), __builtin_fminf(ts.y, 100.0f)};
+        const f2 d = f2{ExpScale<float>::exp_scaled(ts.x), ExpScale<float>::exp_scaled(ts.y)} + f2{1.0f, 1.0f};
         if constexpr (GRAD) {
-            const f2 d = f2{ExpScale<float>::exp_scaled(ts.x), ExpScale<float>::exp_scaled(ts.y)} + f2{1.0f, 1.0f};
             const f2 w = {fast_rcp(d.x), fast_rcp(d.y)};  // sigma(-t); exp overflow -> rcp(inf) = 0
 #pragma unroll
             for (int j = 0; j < P; j += 2) {
@@ -468,20 +548,23 @@ __device__ __forceinline__ void row_pairs_eval(const RegRowPairs<P, R, G>& rows,
                 hp[j / 2] = __builtin_elementwise_fma(q[j + 1], w, hp[j / 2]);
             }
         }
-        if constexpr (VALUE) v += log_sigmoid_scaled(ts.x) + log_sigmoid_scaled(ts.y);
+        if constexpr (VALUE) vacc += ts - f2{__builtin_amdgcn_logf(d.x), __builtin_amdgcn_logf(d.y)};
     }
     if constexpr (RegRowPairs<P, R, G>::ODD) {
         f2 acc = rows.s[0] * bb[0];
 #pragma unroll
         for (int j = 1; j < P / 2; ++j) acc = __builtin_elementwise_fma(rows.s[j], bb[j], acc);
-        const float ts = acc.x + acc.y;
+        float ts = acc.x + acc.y;
+        if constexpr (VALUE) ts = __builtin_fminf(ts, 100.0f);
+        const float d = 1.0f + ExpScale<float>::exp_scaled(ts);
         if constexpr (GRAD) {
-            const float w = fast_rcp(1.0f + ExpScale<float>::exp_scaled(ts));
+            const float w = fast_rcp(d);
 #pragma unroll
             for (int j = 0; j < P / 2; ++j) gp[j] = __builtin_elementwise_fma(f2{w, w}, rows.s[j], gp[j]);
         }
-        if constexpr (VALUE) v += log_sigmoid_scaled(ts);
+        if constexpr (VALUE) vs = ts - __builtin_amdgcn_logf(d);
     }
+    if constexpr (VALUE) v += ((vacc.x + vacc.y) + vs) * ExpScale<float>::inv;
     if constexpr (GRAD) {
 #pragma unroll
         for (int j = 0; j < P / 2; ++j) gp[j] += __builtin_shufflevector(hp[j], hp[j], 1, 0);
@@ -580,16 +663,17 @@ __device__ __forceinline__ void eval_lpost(const Rows& rows, const Prior<T, P>& 
         rows.for_each([&](const T(&xs)[P]) { row_term<T, P, VALUE, GRAD>(xs, bs, g, v); });
     }
     if constexpr (GRAD) {
+        if constexpr (sizeof(T) == 4) {
+            group_sum_levels<G, P>(g);  // fused v_add_f32_dpp per level (-fno-slp-vectorize)
+        } else {
 #pragma unroll
-        for (int j = 0; j < P; ++j) g[j] = group_sum<G>(g[j]);  // fused v_add_f32_dpp per level (-fno-slp-vectorize)
+            for (int j = 0; j < P; ++j) g[j] = group_sum<G>(g[j]);
+        }
         vnmsub<T, P>(beta, pr.inv_var, g, grad);
     }
     if constexpr (VALUE) {
         ll = group_sum<G>((double)(v + rows.value_fixup()));
-        T quad = T(0);
-#pragma unroll
-        for (int j = 0; j < P; ++j) quad = fma_t(beta[j] * beta[j], pr.inv_var[j], quad);
-        lprior = pr.lprior_const - 0.5 * (double)quad;
+        lprior = pr.lprior_const - 0.5 * (double)vquad<T, P>(pr.inv_var, beta);
     }
 }
 

@@ -184,33 +184,24 @@ __global__ void __launch_bounds__(256) k_chain(ModelArgs<T, P> m, ChainArgs<T, P
                 } else if constexpr (KIND == KIND_MALA) {
                     // prop = advance(x) + sqrt(pre*dt) z ; advance(x) = x + 0.5*pre*dt*glp(x)
                     // a = lp' - ll + dprop(x,prop) - dprop(prop,x)           fit-np-mala.py:61-78
-                    T advx[P];
-#pragma unroll
-                    for (int j = 0; j < P; ++j) {
-                        advx[j] = fma_t(a.a[j], g[j], x[j]);
-                        xp[j] = fma_t(a.b[j], z[j], advx[j]);
-                    }
+                    T advx[P], advp[P];
+                    vfma_o<T, P>(a.a, g, x, advx);
+                    vfma_o<T, P>(a.b, z, advx, xp);
                     eval_lpost<T, P, G, true, true>(rows, m.prior, xp, gp, llp, lprp);
-                    T dq = T(0);
-#pragma unroll
-                    for (int j = 0; j < P; ++j) {
-                        const T advp = fma_t(a.a[j], gp[j], xp[j]);
-                        const T d1 = x[j] - advp;       // dprop(x, prop): new = x, old = prop
-                        const T d2 = xp[j] - advx[j];   // dprop(prop, x)
-                        dq = fma_t(a.c[j], d1 * d1 - d2 * d2, dq);
-                    }
+                    vfma_o<T, P>(a.a, gp, xp, advp);
+                    // dprop(x, prop) - dprop(prop, x): (x - advance(prop))^2 - (prop - advance(x))^2, weighted 1/(pre dt)
+                    const T dq = vdiffsq<T, P>(a.c, x, advp, xp, advx);
                     logr = (llp + lprp) - lp - 0.5 * (double)dq;
                 } else {  // HMC
                     // p ~ N(0, dmm); leapfrog l steps; a = alpi(prop) - alpi(x)     fit-np-hmc.py:65-87
                     T pm[P];
-                    T k0 = T(0);
 #pragma unroll
                     for (int j = 0; j < P; ++j) {
                         pm[j] = z[j] * a.a[j];
-                        k0 = fma_t(pm[j] * pm[j], a.c[j], k0);
                         xp[j] = x[j];
                         gp[j] = g[j];
                     }
+                    const T k0 = vquad<T, P>(a.c, pm);
                     const T heps = T(0.5) * a.step;
                     vfma_s<T, P>(heps, gp, pm);
                     T xk[P];  // k * position
@@ -224,12 +215,8 @@ __global__ void __launch_bounds__(256) k_chain(ModelArgs<T, P> m, ChainArgs<T, P
                     vfma_v<T, P>(a.d, pm, xk);
                     vscale<T, P>(ExpScale<T>::inv, xk, xp);
                     eval_lpost<T, P, G, true, true>(rows, m.prior, xp, gp, llp, lprp);
-                    T k1 = T(0);
-#pragma unroll
-                    for (int j = 0; j < P; ++j) {
-                        pm[j] = fma_t(heps, gp[j], pm[j]);
-                        k1 = fma_t(pm[j] * pm[j], a.c[j], k1);
-                    }
+                    vfma_s<T, P>(heps, gp, pm);
+                    const T k1 = vquad<T, P>(a.c, pm);
                     logr = ((llp + lprp) - lp) - 0.5 * ((double)k1 - (double)k0);
                 }
                 const bool acc = logu < logr;  // NaN -> reject, as `np.log(np.random.rand()) < a`

@@ -116,6 +116,30 @@ template <int KIND> __global__ void k(float* out, long long* cyc, float seed) {
 #define S(i) asm volatile("v_permlane32_swap_b32 %0, %1\n\ts_nop 0\n\tv_add_f32 %0, %0, %1" : "+v"(a[i]), "+v"(b[i]));
             REP16(S)
 #undef S
+        } else if constexpr (KIND == 25) {  // v_mul_lo_u32
+#define S(i) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b[i]));
+            REP16(S)
+#undef S
+        } else if constexpr (KIND == 26) {  // v_mul_hi_u32
+#define S(i) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b[i]));
+            REP16(S)
+#undef S
+        } else if constexpr (KIND == 27) {  // v_mad_u64_u32 (full 32x32 -> 64 product in one instruction)
+#define S(i) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(*(double*)&a[(i)&~1]) : "v"(b[i]), "v"(b[(i+1)&15]) : "vcc");
+            REP16(S)
+#undef S
+        } else if constexpr (KIND == 28) {  // v_log_f32
+#define S(i) asm volatile("v_log_f32 %0, %0" : "+v"(a[i]));
+            REP16(S)
+#undef S
+        } else if constexpr (KIND == 29) {  // v_sin_f32
+#define S(i) asm volatile("v_sin_f32 %0, %0" : "+v"(a[i]));
+            REP16(S)
+#undef S
+        } else if constexpr (KIND == 30) {  // v_add_f64
+#define S(i) asm volatile("v_add_f64 %0, %0, %1" : "+v"(*(double*)&a[(i)&~1]) : "v"(*(double*)&b[(i)&~1]));
+            REP16(S)
+#undef S
         } else if constexpr (KIND == 13) {  // f32 MFMA 16x16x4
             typedef float f4 __attribute__((ext_vector_type(4)));
             f4 acc0 = {a[0], a[1], a[2], a[3]}, acc1 = {a[4], a[5], a[6], a[7]}, acc2 = {a[8], a[9], a[10], a[11]}, acc3 = {a[12], a[13], a[14], a[15]};
@@ -200,6 +224,12 @@ int main() {
     run<22>("v_permlane16_swap indep", 16);
     run<23>("v_mov_b64 indep", 16);
     run<24>("swap32 + nop + add (2 inst)", 32);
+    run<25>("v_mul_lo_u32", 16);
+    run<26>("v_mul_hi_u32", 16);
+    run<27>("v_mad_u64_u32", 16);
+    run<28>("v_log_f32", 16);
+    run<29>("v_sin_f32", 16);
+    run<30>("v_add_f64", 16);
     run<13>("mfma_f32_16x16x4f32", 16);
     run<14>("mfma + 16 fmac each (2+32..)", 2 * (2 + 32));
     return 0;
