@@ -25,14 +25,19 @@ PRE = np.array([100.0, 1, 1, 1, 1, 1, 25, 1])
 MAP = np.array([-9.19131622, 0.09705401, 0.03112265, -0.00564495, -0.00062272, 0.0814371, 1.26032561, 0.03939102])
 
 
-def timed(cs, iters, thin, warm=1):
+def timed(cs, iters, thin, warm=1, repeats=1):
+    """Wall time of `iters` kept iterations; repeats > 1: the best of that many (short measurements)."""
     for _ in range(warm):
         cs.advance(1, thin, keep=False)
     cs.sync()
-    t0 = time.perf_counter()
-    out = cs.advance(iters, thin)
-    cs.sync()
-    return time.perf_counter() - t0, out
+    best, out = None, None
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        out = cs.advance(iters, thin)
+        cs.sync()
+        dt = time.perf_counter() - t0
+        best = dt if best is None or dt < best else best
+    return best, out
 
 
 def config1():
@@ -67,11 +72,11 @@ def config4(chains=1024, n=100000):
     init = np.zeros(8)
     k = la.hmcKernel(m.lpost, m.glp, eps=1e-3 / 22, l=50, dmm=np.ones(8) * (n / 200.0))
     cs = la.ChainSet(k, np.tile(init, (chains, 1)), seed=4)
-    dt, _ = timed(cs, 2, 1, warm=1)
+    dt, _ = timed(cs, 2, 1, warm=1, repeats=3)
     its = chains * 2
     return {"config": 4, "what": f"HMC L=50, n={n}, p=8, {chains} chains", "plan": cs.plan(), "it_per_s": its / dt,
             "grad_evals_per_s": its * 50 / dt, "x_pass_GBps_per_eval_stream": its * 50 * n * 8 * 4 / dt / 1e9,
-            "accept": float(cs.get_accepts().sum() / (chains * 3))}
+            "accept": float(cs.get_accepts().sum() / (chains * 7))}
 
 
 def config5(chains=1024, n=4096, p=128):
@@ -79,12 +84,12 @@ def config5(chains=1024, n=4096, p=128):
     m = la.LogReg(X, y, np.ones(p))
     k = la.hmcKernel(m.lpost, m.glp, eps=5e-3, l=50, dmm=np.ones(p))
     cs = la.ChainSet(k, np.zeros((chains, p)), seed=5)
-    dt, _ = timed(cs, 4, 1, warm=1)
+    dt, _ = timed(cs, 4, 1, warm=1, repeats=3)
     its = chains * 4
     fg = 4 * n * p + 5 * n + 2 * p
     return {"config": 5, "what": f"HMC L=50, n={n}, p={p}, {chains} chains (one GPU's shard of 8192)", "plan": cs.plan(),
             "it_per_s": its / dt, "grad_evals_per_s": its * 50 / dt, "tflops_algorithmic": its * 50 * fg / dt / 1e12,
-            "accept": float(cs.get_accepts().sum() / (chains * 5))}
+            "accept": float(cs.get_accepts().sum() / (chains * 13))}
 
 
 if __name__ == "__main__":
