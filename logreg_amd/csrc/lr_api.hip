@@ -69,6 +69,7 @@ struct lr_model {
     int P = 0;   // padded width (4, 8, 16, 32)
     int cus = 256;
     void* d_rows = nullptr;  // [n][P] signed rows, dtype
+    void* d_rows_tw = nullptr;  // float32, P <= 32: [ceil(n/2)][P][2] twisted row pairs (lr::ScalarRowPairs)
     double inv_var[kMaxP];
     double lprior_const = 0;
     const lr::InstTable* table = nullptr;
@@ -136,6 +137,7 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
         int64_t RS = (4 * want_waves + waves_per_slice - 1) / waves_per_slice;
         int64_t slice_len = (m->n + RS - 1) / RS;
         if (slice_len < 16 * NW) slice_len = 16 * NW;  // at least 16 rows per wave
+        slice_len = (slice_len + 1) & ~(int64_t)1;      // even: the float32 kernel walks row pairs
         RS = (m->n + slice_len - 1) / slice_len;
         out->mode = lr::MODE_STEPWISE;
         out->G = (int)RS;
@@ -172,9 +174,10 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
         else score += 10L * v.G;                                   // not filled: prefer large groups
         if (v.mode == lr::MODE_REG) score -= v.R;                  // exact-fit R before padded R
         // lane-per-chain with rows broadcast from the scalar unit has no replicated work and no
-        // reductions: measured fastest (2.0e8 it/s, 47 % of fp32 peak) once there are >= 4 waves per
-        // SIMD to hide the SMEM latency, provided the rows fit the 16 KB scalar cache
-        if (mode == LR_MODE_AUTO && group == 0 && v.mode == lr::MODE_GLOBAL && v.G == 1 && waves >= 4 * want_waves &&
+        // reductions: measured fastest once there are >= 3 waves per SIMD to hide the SMEM latency (HMC,
+        // n=200, p=8: 2.20 / 2.46 / 2.64e8 it/s at 2 / 4 / 8 waves per SIMD against 2.21e8 for rows in
+        // registers), provided the rows fit the 16 KB scalar cache
+        if (mode == LR_MODE_AUTO && group == 0 && v.mode == lr::MODE_GLOBAL && v.G == 1 && waves >= 3 * want_waves &&
             (size_t)m->n * m->P * m->esize() <= 16 * 1024)
             score = 4000000L;
         if (score > best_score) { best_score = score; best = i; }
@@ -193,6 +196,7 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
 template <typename T, int P> lr::ModelArgs<T, P> model_args(const lr_model* m) {
     lr::ModelArgs<T, P> a;
     a.rows = static_cast<const T*>(m->d_rows);
+    a.rows_tw = static_cast<const float*>(m->d_rows_tw);
     a.n = m->n;
     for (int j = 0; j < P; ++j) a.prior.inv_var[j] = (T)m->inv_var[j];
     a.prior.lprior_const = m->lprior_const;
@@ -277,6 +281,7 @@ int setup_tall(lr_model* m, const Plan& pl, int64_t C, lr::TallArgs<T, P>* pa) {
     auto carve = [&](size_t b) { unsigned char* r = w; w += b; return r; };
     std::memset(&a, 0, sizeof(a));
     a.rows = static_cast<const T*>(m->d_rows);
+    a.rows_tw = static_cast<const float*>(m->d_rows_tw);
     a.n = m->n;
     a.slice_len = pl.R;
     a.RS = RS;
@@ -567,6 +572,29 @@ int lr_model_create(const double* X, const double* y, int64_t n, int32_t p, cons
         delete m;
         return fail(LR_ERR_HIP, "hipMemcpy rows failed");
     }
+    if (m->P <= 32 && dtype == LR_F32) {
+        // the rows once more as twisted row pairs, for the kernels that take them through the scalar unit:
+        // pair k, coordinates (j, j+1), j even:  [k][j] = (A_j, B_{j+1}),  [k][j+1] = (A_{j+1}, B_j)  with
+        // A = row 2k, B = row 2k+1 (a zero row closes an odd n)
+        const float* hrows = reinterpret_cast<const float*>(host.data());
+        const int64_t npair = (n + 1) / 2;
+        const int PP = m->P;
+        std::vector<float> tw((size_t)npair * PP * 2, 0.0f);
+        auto at = [&](int64_t r, int j) { return r < n ? hrows[r * PP + j] : 0.0f; };
+        for (int64_t k = 0; k < npair; ++k)
+            for (int j = 0; j < PP; j += 2) {
+                float* q = tw.data() + ((size_t)k * PP + j) * 2;
+                q[0] = at(2 * k, j);
+                q[1] = at(2 * k + 1, j + 1);
+                q[2] = at(2 * k, j + 1);
+                q[3] = at(2 * k + 1, j);
+            }
+        if (hipMalloc(&m->d_rows_tw, tw.size() * 4) != hipSuccess ||
+            hipMemcpy(m->d_rows_tw, tw.data(), tw.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+            lr_model_destroy(m);
+            return fail(LR_ERR_NOMEM, "allocating the row-pair image (%zu bytes) failed", tw.size() * 4);
+        }
+    }
     if (m->P > 32) {  // wide models: bf16-piece block images for the exact-split matrix-core kernel
         const float* hrows = reinterpret_cast<const float*>(host.data());
         const int64_t nblk = (n + 31) / 32;
@@ -588,6 +616,7 @@ void lr_model_destroy(lr_model* m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
     if (m->d_rows) (void)hipFree(m->d_rows);
+    if (m->d_rows_tw) (void)hipFree(m->d_rows_tw);
     if (m->ws) (void)hipFree(m->ws);
     if (m->d_xblk) (void)hipFree(m->d_xblk);
     delete m;

@@ -511,45 +511,50 @@ template <int P, int R, int G> struct RegRowPairs {
 template <class Rows> struct is_row_pairs { static constexpr bool value = false; };
 template <int P, int R, int G> struct is_row_pairs<RegRowPairs<P, R, G>> { static constexpr bool value = true; };
 
+// one twisted row pair (see RegRowPairs): q[j] = (A_j, B_{j+1}), q[j+1] = (A_{j+1}, B_j); bb[j/2] = (b_j, b_{j+1})
+// is beta * ExpScale::k.  Gradient partial sums go to gp (straight) / hp (swapped), the value to vacc (log2 units).
+//   value: log sigma(t) = ln2 * (ts - log2(1 + 2^ts)) with ts = t log2(e): the SAME 1 + 2^ts the gradient
+//   needs, so the value costs one v_log per row on top.  ts is clamped at 100 (sigma(-t) < 2^-100 there:
+//   nothing changes) so that 2^ts stays finite; for ts -> -inf the expression tends to ts exactly.
+//   Cancellation at large ts costs an absolute ulp(ts) ~ 1e-6 per row, the size of the fp32 summation
+//   error of the value itself.
+// The row data may sit in VGPRs (RegRowPairs) or in SGPRs (ScalarRowPairs: scalar operands of the v_pk ops).
+template <int P, bool VALUE, bool GRAD>
+__device__ __forceinline__ void pair_term(const f32x2 (&q)[P], const f32x2 (&bb)[P / 2], f32x2 (&gp)[P / 2],
+                                          f32x2 (&hp)[P / 2], f32x2& vacc) {
+    typedef f32x2 f2;
+    f2 ts = q[0] * bb[0];
+    ts = __builtin_elementwise_fma(q[1], __builtin_shufflevector(bb[0], bb[0], 1, 0), ts);
+#pragma unroll
+    for (int j = 2; j < P; j += 2) {
+        ts = __builtin_elementwise_fma(q[j], bb[j / 2], ts);
+        ts = __builtin_elementwise_fma(q[j + 1], __builtin_shufflevector(bb[j / 2], bb[j / 2], 1, 0), ts);
+    }
+    if constexpr (VALUE) ts = f2{__builtin_fminf(ts.x, 100.0f), __builtin_fminf(ts.y, 100.0f)};
+    const f2 d = f2{ExpScale<float>::exp_scaled(ts.x), ExpScale<float>::exp_scaled(ts.y)} + f2{1.0f, 1.0f};
+    if constexpr (GRAD) {
+        const f2 w = {fast_rcp(d.x), fast_rcp(d.y)};  // sigma(-t); exp overflow -> rcp(inf) = 0
+#pragma unroll
+        for (int j = 0; j < P; j += 2) {
+            gp[j / 2] = __builtin_elementwise_fma(q[j], w, gp[j / 2]);
+            hp[j / 2] = __builtin_elementwise_fma(q[j + 1], w, hp[j / 2]);
+        }
+    }
+    if constexpr (VALUE) vacc += ts - f2{__builtin_amdgcn_logf(d.x), __builtin_amdgcn_logf(d.y)};
+}
+
 // all rows of a RegRowPairs lane: gradient partial sums into gp[P/2] = (g_j, g_{j+1}) pairs, value into v.
-// bb[j/2] = (b_j, b_{j+1}) is beta * ExpScale::k.
 template <int P, int R, int G, bool VALUE, bool GRAD>
-__device__ __forceinline__ void row_pairs_eval(const RegRowPairs<P, R, G>& rows,
-                                               const float __attribute__((ext_vector_type(2))) (&bb)[P / 2],
-                                               float __attribute__((ext_vector_type(2))) (&gp)[P / 2], float& v) {
-    typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void row_pairs_eval(const RegRowPairs<P, R, G>& rows, const f32x2 (&bb)[P / 2],
+                                               f32x2 (&gp)[P / 2], float& v) {
+    typedef f32x2 f2;
     f2 hp[P / 2];
 #pragma unroll
     for (int j = 0; j < P / 2; ++j) gp[j] = hp[j] = f2{0.0f, 0.0f};
-    // value: log sigma(t) = ln2 * (ts - log2(1 + 2^ts)) with ts = t log2(e): the SAME 1 + 2^ts the gradient
-    // needs, so the value costs one v_log per row on top (accumulated in log2 units, scaled once).  ts is
-    // clamped at 100 (sigma(-t) < 2^-100 there: nothing changes) so that 2^ts stays finite; for ts -> -inf the
-    // expression tends to ts exactly.  Cancellation at large ts costs an absolute ulp(ts) ~ 1e-6 per row,
-    // the size of the fp32 summation error of the value itself.
     f2 vacc = {0.0f, 0.0f};
     float vs = 0.0f;
 #pragma unroll
-    for (int k = 0; k < RegRowPairs<P, R, G>::RP; ++k) {
-        const f2(&q)[P] = rows.q[k];
-        f2 ts = q[0] * bb[0];
-        ts = __builtin_elementwise_fma(q[1], __builtin_shufflevector(bb[0], bb[0], 1, 0), ts);
-#pragma unroll
-        for (int j = 2; j < P; j += 2) {
-            ts = __builtin_elementwise_fma(q[j], bb[j / 2], ts);
-            ts = __builtin_elementwise_fma(q[j + 1], __builtin_shufflevector(bb[j / 2], bb[j / 2], 1, 0), ts);
-        }
-        if constexpr (VALUE) ts = f2{__builtin_fminf(ts.x, 100.0f), __builtin_fminf(ts.y, 100.0f)};
-        const f2 d = f2{ExpScale<float>::exp_scaled(ts.x), ExpScale<float>::exp_scaled(ts.y)} + f2{1.0f, 1.0f};
-        if constexpr (GRAD) {
-            const f2 w = {fast_rcp(d.x), fast_rcp(d.y)};  // sigma(-t); exp overflow -> rcp(inf) = 0
-#pragma unroll
-            for (int j = 0; j < P; j += 2) {
-                gp[j / 2] = __builtin_elementwise_fma(q[j], w, gp[j / 2]);
-                hp[j / 2] = __builtin_elementwise_fma(q[j + 1], w, hp[j / 2]);
-            }
-        }
-        if constexpr (VALUE) vacc += ts - f2{__builtin_amdgcn_logf(d.x), __builtin_amdgcn_logf(d.y)};
-    }
+    for (int k = 0; k < RegRowPairs<P, R, G>::RP; ++k) pair_term<P, VALUE, GRAD>(rows.q[k], bb, gp, hp, vacc);
     if constexpr (RegRowPairs<P, R, G>::ODD) {
         f2 acc = rows.s[0] * bb[0];
 #pragma unroll
@@ -622,6 +627,41 @@ template <typename T, int P, int PF = 1> struct ScalarRows {
     __device__ __forceinline__ T value_fixup() const { return T(0); }
 };
 
+// Lane-per-chain with the rows broadcast from the scalar unit as TWISTED ROW PAIRS: `base` is the pair image
+// built at model creation ([ceil(n/2)][P] f32x2, layout of RegRowPairs; an odd n is closed with a zero row),
+// [k0, k1) the pairs this wave works on.  Each pair is one s_load of 8 P bytes; its SGPR pairs are the
+// scalar operands of the v_pk_fma: 10.5 instead of 12 VALU instructions per row (see RegRowPairs).
+template <int P, int PF = 1> struct ScalarRowPairs {
+    typedef const __attribute__((address_space(4))) f32x2* cptr;
+    const float* base;
+    int64_t k0, k1;
+    int zero_rows;  // 1 when [k0, k1) ends with the zero row closing an odd n (value fix-up), else 0
+    template <class F> __device__ __forceinline__ void for_each_pair(F&& f) const {
+        cptr cb = (cptr)base;
+        int64_t k = k0;
+        if constexpr (PF > 1) {
+            for (; k + PF <= k1; k += PF) {
+                f32x2 q[PF][P];
+#pragma unroll
+                for (int u = 0; u < PF; ++u)
+#pragma unroll
+                    for (int j = 0; j < P; ++j) q[u][j] = cb[(k + u) * P + j];
+#pragma unroll
+                for (int u = 0; u < PF; ++u) f(q[u]);
+            }
+        }
+        for (; k < k1; ++k) {
+            f32x2 q[P];
+#pragma unroll
+            for (int j = 0; j < P; ++j) q[j] = cb[k * P + j];
+            f(q);
+        }
+    }
+    __device__ __forceinline__ float value_fixup() const { return float(zero_rows) * 0.693147180559945309f; }
+};
+template <class Rows> struct is_scalar_pairs { static constexpr bool value = false; };
+template <int P, int PF> struct is_scalar_pairs<ScalarRowPairs<P, PF>> { static constexpr bool value = true; };
+
 // ------------------------------------------------------------------------------------------
 // log-posterior value / gradient of one chain, cooperatively over the G lanes of its group.
 //   value = ll + lprior (double), grad = d/dbeta (T), both replicated in all lanes of the group.
@@ -658,6 +698,20 @@ __device__ __forceinline__ void eval_lpost(const Rows& rows, const Prior<T, P>& 
         for (int j = 0; j < P / 2; ++j) {
             g[2 * j] = gp[j].x;
             g[2 * j + 1] = gp[j].y;
+        }
+    } else if constexpr (is_scalar_pairs<Rows>::value) {
+        f32x2 bb[P / 2], gp[P / 2], hp[P / 2], vacc = {0.0f, 0.0f};
+#pragma unroll
+        for (int j = 0; j < P / 2; ++j) {
+            bb[j] = f32x2{bs[2 * j], bs[2 * j + 1]};
+            gp[j] = hp[j] = f32x2{0.0f, 0.0f};
+        }
+        rows.for_each_pair([&](const f32x2(&q)[P]) { pair_term<P, VALUE, GRAD>(q, bb, gp, hp, vacc); });
+        if constexpr (VALUE) v += (vacc.x + vacc.y) * ExpScale<float>::inv;
+#pragma unroll
+        for (int j = 0; j < P / 2; ++j) {
+            g[2 * j] = gp[j].x + hp[j].y;
+            g[2 * j + 1] = gp[j].y + hp[j].x;
         }
     } else {
         rows.for_each([&](const T(&xs)[P]) { row_term<T, P, VALUE, GRAD>(xs, bs, g, v); });

@@ -11,6 +11,7 @@ enum Mode { MODE_REG = 0, MODE_LDS = 1, MODE_GLOBAL = 2, MODE_MFMA = 3, MODE_STE
 
 template <typename T, int P> struct ModelArgs {
     const T* rows;  // [n][P] signed rows (2y-1)*x, zero-padded to P columns (device)
+    const float* rows_tw;  // float32 models, P <= 32: the same rows as twisted row pairs (ScalarRowPairs), else null
     int64_t n;
     Prior<T, P> prior;
 };
@@ -62,6 +63,9 @@ template <int P, int G, int R> struct RowsOf<float, P, G, MODE_REG, R> {
 template <typename T, int P, int R> struct RowsOf<T, P, 1, MODE_GLOBAL, R> {
     using type = ScalarRows<T, P>;  // lane-per-chain: rows broadcast through the scalar unit
 };
+template <int R> struct RowsOf<float, 4, 1, MODE_GLOBAL, R> { using type = ScalarRowPairs<4>; };
+template <int R> struct RowsOf<float, 8, 1, MODE_GLOBAL, R> { using type = ScalarRowPairs<8>; };
+template <int R> struct RowsOf<float, 16, 1, MODE_GLOBAL, R> { using type = ScalarRowPairs<16>; };  // P = 32: 64 SGPRs per pair
 
 template <typename T, int P, int G, int MODE, int R>
 __device__ __forceinline__ typename RowsOf<T, P, G, MODE, R>::type make_rows(const ModelArgs<T, P>& m, int gl,
@@ -77,6 +81,11 @@ __device__ __forceinline__ typename RowsOf<T, P, G, MODE, R>::type make_rows(con
         rows.base = smem;
         rows.n = m.n;
         rows.gl = gl;
+    } else if constexpr (is_scalar_pairs<typename RowsOf<T, P, G, MODE, R>::type>::value) {
+        rows.base = m.rows_tw;
+        rows.k0 = 0;
+        rows.k1 = (m.n + 1) / 2;
+        rows.zero_rows = (int)(m.n & 1);
     } else if constexpr (G == 1) {
         rows.base = m.rows;
         rows.i0 = 0;

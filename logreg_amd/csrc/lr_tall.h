@@ -46,6 +46,7 @@ template <int P, typename T> __device__ __forceinline__ T chain_sum(T v) {
 
 template <typename T, int P> struct TallArgs {
     const T* rows;  // [n][P] signed rows
+    const float* rows_tw;  // float32: the rows as twisted row pairs (lr::ScalarRowPairs); slices are even
     int64_t n, slice_len;
     int RS;
     Prior<T, P> prior;
@@ -100,12 +101,8 @@ __global__ void __launch_bounds__((64 * TallGeom<T, P>::NW)) k_tall_partial(Tall
     const bool live = chain < a.C;
     if (!live) chain = a.C - 1;
     const int rs = blockIdx.y;
-    const int64_t sub = (a.slice_len + NW - 1) / NW;
+    const int64_t sub = ((a.slice_len + NW - 1) / NW + 1) & ~(int64_t)1;  // even: row pairs never straddle waves
     const int64_t s0 = (int64_t)rs * a.slice_len, s1 = s0 + a.slice_len < a.n ? s0 + a.slice_len : a.n;
-    ScalarRows<T, P, (P * sizeof(T) <= 64 ? 4 : 2)> rows;
-    rows.base = a.rows;
-    rows.i0 = s0 + wave * sub;
-    rows.i1 = rows.i0 + sub < s1 ? rows.i0 + sub : s1;
     T bs[P], g[P];
     double gd[P];  // blocked summation: fp32 over 16 rows, then fp64 -- a sub-slice can be thousands of
                    // rows of strongly cancelling terms; a plain fp32 running sum loses ~sqrt(rows) ulps
@@ -116,22 +113,86 @@ __global__ void __launch_bounds__((64 * TallGeom<T, P>::NW)) k_tall_partial(Tall
         gd[j] = 0.0;
     }
     double v = 0.0;
-    int cnt = 0;
-    rows.for_each([&](const T(&xs)[P]) {
-        T vt = T(0);
-        row_term<T, P, VALUE, GRAD>(xs, bs, g, vt);
-        if constexpr (VALUE) v += (double)vt;
-        if constexpr (GRAD && sizeof(T) == 4) {
-            if (++cnt == 16) {
-                cnt = 0;
+    const int64_t i0 = s0 + wave * sub, i1 = i0 + sub < s1 ? i0 + sub : s1;
+    if constexpr (sizeof(T) == 4 && P <= 16) {
+        // float32: twisted row pairs through the scalar unit (slices and sub-slices are even)
+        ScalarRowPairs<P> rows;
+        rows.base = a.rows_tw;
+        rows.k0 = i0 / 2;
+        rows.k1 = i1 > i0 ? (i1 + 1) / 2 : rows.k0;
+        rows.zero_rows = i1 > i0 ? (int)(i1 & 1) : 0;
+        f32x2 bb[P / 2], gp[P / 2], hp[P / 2], vacc = {0.0f, 0.0f};
 #pragma unroll
-                for (int j = 0; j < P; ++j) {
-                    gd[j] += (double)g[j];
-                    g[j] = T(0);
+        for (int j = 0; j < P / 2; ++j) {
+            bb[j] = f32x2{bs[2 * j], bs[2 * j + 1]};
+            gp[j] = hp[j] = f32x2{0.0f, 0.0f};
+        }
+        auto flush = [&]() {
+#pragma unroll
+            for (int j = 0; j < P / 2; ++j) {
+                if constexpr (GRAD) {
+                    gd[2 * j] += (double)(gp[j].x + hp[j].y);
+                    gd[2 * j + 1] += (double)(gp[j].y + hp[j].x);
+                }
+                gp[j] = hp[j] = f32x2{0.0f, 0.0f};
+            }
+            if constexpr (VALUE) v += (double)(vacc.x + vacc.y);
+            vacc = f32x2{0.0f, 0.0f};
+        };
+        // blocks of 8 pairs (16 rows) between fp64 flushes; inside a block PFP pairs (64 SGPRs) are fetched
+        // per wait, so the SMEM latency (~500 cycles from L2) is paid once per PFP pairs and the pair terms
+        // of a batch interleave
+        typedef const __attribute__((address_space(4))) f32x2* cptr;
+        cptr cb = (cptr)rows.base;
+        constexpr int BLK = 8, PFP = P <= 4 ? 8 : (P <= 8 ? 4 : 2);
+        int64_t k = rows.k0;
+        for (; k + BLK <= rows.k1; k += BLK) {
+#pragma unroll
+            for (int u0 = 0; u0 < BLK; u0 += PFP) {
+                f32x2 q[PFP][P];
+#pragma unroll
+                for (int u = 0; u < PFP; ++u)
+#pragma unroll
+                    for (int j = 0; j < P; ++j) q[u][j] = cb[(k + u0 + u) * P + j];
+#pragma unroll
+                for (int u = 0; u < PFP; ++u) pair_term<P, VALUE, GRAD>(q[u], bb, gp, hp, vacc);
+                // one batch in flight: hoisting the next batch's loads above this point needs more than the
+                // ~100 SGPRs there are (34 spilled to VGPR lanes, +17 % instructions); the other waves of
+                // the SIMD cover the SMEM latency instead
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            flush();
+        }
+        for (; k < rows.k1; ++k) {
+            f32x2 q[P];
+#pragma unroll
+            for (int j = 0; j < P; ++j) q[j] = cb[k * P + j];
+            pair_term<P, VALUE, GRAD>(q, bb, gp, hp, vacc);
+        }
+        flush();
+        if constexpr (VALUE) v = (v + (double)rows.zero_rows) * (double)ExpScale<float>::inv;  // log2 units -> nats
+    } else {
+        ScalarRows<T, P, (P * sizeof(T) <= 64 ? 4 : 2)> rows;
+        rows.base = a.rows;
+        rows.i0 = i0;
+        rows.i1 = i1;
+        int cnt = 0;
+        rows.for_each([&](const T(&xs)[P]) {
+            T vt = T(0);
+            row_term<T, P, VALUE, GRAD>(xs, bs, g, vt);
+            if constexpr (VALUE) v += (double)vt;
+            if constexpr (GRAD && sizeof(T) == 4) {
+                if (++cnt == 16) {
+                    cnt = 0;
+#pragma unroll
+                    for (int j = 0; j < P; ++j) {
+                        gd[j] += (double)g[j];
+                        g[j] = T(0);
+                    }
                 }
             }
-        }
-    });
+        });
+    }
     if constexpr (GRAD) {
 #pragma unroll
         for (int j = 0; j < P; ++j) red_g[wave][lane][j] = (T)(gd[j] + (double)g[j]);
