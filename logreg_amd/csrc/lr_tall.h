@@ -235,7 +235,26 @@ __global__ void __launch_bounds__(256) k_tall_update(TallArgs<T, P> a, int phase
 
     auto reduced_grad = [&]() {  // likelihood partials in slice order + prior
         double s = 0.0;
-        for (int r = 0; r < a.RS; ++r) s += (double)a.part_g[((int64_t)r * a.C + chain) * P + j];
+        // slice order, 16 loads in flight (a plain loop issues them one L2 round trip at a time: this kernel is
+        // nothing but that latency)
+        const T* pg = a.part_g + chain * P + j;
+        const int64_t stride = a.C * P;
+        int r = 0;
+        for (; r + 16 <= a.RS; r += 16) {
+            T t[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) t[u] = pg[(r + u) * stride];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s += (double)t[u];
+        }
+        for (; r + 4 <= a.RS; r += 4) {
+            T t[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) t[u] = pg[(r + u) * stride];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s += (double)t[u];
+        }
+        for (; r < a.RS; ++r) s += (double)pg[r * stride];
         return (T)s - a.q1[ix] * ivj;
     };
     auto reduced_value = [&]() {  // lpost(q1) = sum of slice values + lprior(q1)
