@@ -128,8 +128,13 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
     if (for_eval && (mode == LR_MODE_MFMA || mode == LR_MODE_STEPWISE)) { mode = LR_MODE_AUTO; group = 0; }
     // tall data: neither VGPRs nor LDS can hold the rows -> stepwise engine (lr_tall.h): split the rows into
     // RS slices so that every evaluation occupies the whole chip with ~4 waves per SIMD
-    const bool fits_lds = (size_t)m->n * m->P * m->esize() <= kLdsBudget;
-    if (!for_eval && (mode == LR_MODE_STEPWISE || (mode == LR_MODE_AUTO && group == 0 && !fits_lds && m->n >= 8192))) {
+    // measured (tools/midn_sweep.py, HMC, p = 8, chain-rows/s): rows streamed from L2 by every group never beat
+    // the stepwise engine (n = 6000-8000: 0.4-1.0e12 vs 0.6-2.0e12), and LDS-resident rows lose to it once they
+    // take more than 64 KB (one workgroup per CU) and there are >= 2048 chains (n = 4000: 0.8e12 vs 1.1-1.8e12)
+    const size_t row_bytes = (size_t)m->n * m->P * m->esize();
+    const bool fits_lds = row_bytes <= kLdsBudget;
+    const bool prefer_stepwise = !fits_lds || (row_bytes > 64 * 1024 && C >= 2048);  // (never register-sized)
+    if (!for_eval && (mode == LR_MODE_STEPWISE || (mode == LR_MODE_AUTO && group == 0 && prefer_stepwise))) {
         // a workgroup = NW waves x 64 chains working on one slice (NW as lr::TallGeom: LDS-limited)
         const int raw = 2048 / (m->P * (int)m->esize());
         const int64_t NW = raw >= 16 ? 16 : (raw >= 8 ? 8 : 4);

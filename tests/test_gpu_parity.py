@@ -234,6 +234,23 @@ def test_tall_data_uses_stepwise_engine_and_matches_oracle(la):
         assert np.max(np.abs(out[:, ok] - ref["out"][:, ok])) < tol
 
 
+def test_planner_engine_choice_by_size(la):
+    """lr_plan's measured rules (tools/midn_sweep.py): registers while the rows fit them, LDS up to 64 KB of
+    rows (or up to the LDS size with few chains), the stepwise engine beyond; lane-per-chain scalar rows from
+    three waves per SIMD."""
+    def plan(n, C, p=8):
+        X, y, _ = la.synthetic_logreg(n, p, seed=n)
+        return la.LogReg(X, y, np.ones(p)).plan(C)
+    assert plan(200, 4096) == {"mode": "reg", "group": 16, "rows_per_lane": 13}
+    assert plan(200, 64)["group"] == 64
+    assert plan(200, 1 << 18)["mode"] == "global" and plan(200, 1 << 18)["group"] == 1
+    assert plan(1000, 4096)["mode"] == "lds"
+    assert plan(4000, 1024)["mode"] == "lds"        # 128 KB of rows, few chains
+    assert plan(4000, 4096)["mode"] == "stepwise"   # same rows, enough chains to fill the chip per slice
+    assert plan(6000, 64)["mode"] == "stepwise"     # beyond LDS
+    assert plan(300, 64, p=100)["mode"] == "stepwise"
+
+
 @pytest.mark.parametrize("engine", ["bf16x3", "fp32"])
 @pytest.mark.parametrize("p,n,C", [(128, 1000, 70), (100, 513, 64), (40, 300, 130)])
 def test_wide_models_run_on_the_matrix_cores(la, p, n, C, engine, monkeypatch):
