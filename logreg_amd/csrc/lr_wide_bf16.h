@@ -86,7 +86,7 @@ __global__ void __launch_bounds__((64 * NW)) k_wide_partial_bf16(TallArgs<float,
     using G = WideBf16Geom<P>;
     constexpr int NT = 64 * NW, CPB = 16 * NW;  // threads, chains per block
     // [buffer][piece q][tile T][chunk m][kg'][row][8]  (bf16), reused as the fp32 output tile
-    constexpr int SMEM = 2 * G::BUF > CPB * P * 2 ? 2 * G::BUF : CPB * P * 2;
+    constexpr int SMEM = 2 * G::BUF > CPB * (P + 4) * 2 ? 2 * G::BUF : CPB * (P + 4) * 2;
     __shared__ __attribute__((aligned(16))) uint16_t smem[SMEM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, kg = lane >> 4;
@@ -209,20 +209,22 @@ __global__ void __launch_bounds__((64 * NW)) k_wide_partial_bf16(TallArgs<float,
         if (b + 1 < nblk) deposit(buf ^ 1);
         __syncthreads();
     }
-    // epilogue: gradient register (mb' = 2m + h, r) of lane (c, kg) is coordinate 32m + 8kg + 4h + r
+    // epilogue: gradient register (mb' = 2m + h, r) of lane (c, kg) is coordinate 32m + 8kg + 4h + r.
+    // The LDS tile rows are P + 4 floats apart: with a stride of P (= 0 mod 64 banks) the 16 chains of a wave
+    // would all write the same banks (16-way conflict on every ds_write_b128).
+    constexpr int OT = P + 4;
+    static_assert(CPB * OT * 2 <= SMEM, "padded output tile must fit");
     float* otile = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int mb = 0; mb < G::MBP; ++mb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            otile[(16 * wave + c) * P + 32 * (mb >> 1) + 8 * kg + 4 * (mb & 1) + r] = gacc[mb][r];
+        *reinterpret_cast<f32x4*>(otile + (16 * wave + c) * OT + 32 * (mb >> 1) + 8 * kg + 4 * (mb & 1)) = gacc[mb];
     __syncthreads();
     {
         const int64_t chain0 = (int64_t)blockIdx.x * CPB;
         const int64_t nlive = a.C - chain0 < CPB ? a.C - chain0 : CPB;
         f32x4* dst = reinterpret_cast<f32x4*>(a.part_g + ((int64_t)rs * a.C + chain0) * P);
-        const f32x4* src = reinterpret_cast<const f32x4*>(otile);
-        for (int i = tid; i < (int)(nlive * P / 4); i += NT) dst[i] = src[i];
+        for (int i = tid; i < (int)(nlive * P / 4); i += NT)  // consumed once, by the update kernel: non-temporal
+            __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(otile + (i / (P / 4)) * OT + (i % (P / 4)) * 4), &dst[i]);
     }
     if constexpr (VALUE) {
         const double tot = ksum(vsum);
