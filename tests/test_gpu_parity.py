@@ -49,7 +49,7 @@ def make_kernel(la, model, kind):
     return la.mhKernel(model.lpost, la.rwProposal(KW["rwmh"]["scale"]))
 
 
-VARIANTS = [("reg", 64), ("reg", 32), ("reg", 16), ("lds", 1), ("lds", 8), ("lds", 64), ("global", 64)]
+VARIANTS = [("reg", 64), ("reg", 32), ("reg", 16), ("lds", 1), ("lds", 8), ("lds", 64), ("global", 64), ("global", 1)]
 
 
 # ------------------------------------------------------------------------------------------------
@@ -211,9 +211,9 @@ def test_stepwise_engine_matches_oracle(la, models, oracle_model, map_beta, kind
 
 
 def test_tall_data_uses_stepwise_engine_and_matches_oracle(la):
-    """n = 20000 rows (640 KB of rows: beyond VGPRs and LDS): AUTO selects the stepwise engine."""
+    """n = 20001 rows (640 KB of rows: beyond VGPRs and LDS): AUTO selects the stepwise engine."""
     from oracle.oracle import OracleModel
-    n, p, C = 20000, 8, 96
+    n, p, C = 20001, 8, 96  # odd: the pair image closes with a zero row
     X, y, _ = la.synthetic_logreg(n, p, seed=20240004)
     ps = np.array([10.0] + [1.0] * 7)
     orc = OracleModel(X, y, ps)
@@ -524,13 +524,14 @@ def test_register_row_pair_layouts_for_every_row_count(la, n):
     m = la.LogReg(X, y, ps)
     rng = np.random.default_rng(n)
     q0 = 0.2 * rng.standard_normal((C, p))
-    for group in (16, 32, 64):
+    for mode, group in (("reg", 16), ("reg", 32), ("reg", 64), ("global", 1)):  # global/1: pairs through the scalar unit
         try:
-            plan = m.plan(C, group, "reg")
+            plan = m.plan(C, group, mode)
         except la.LogregHipError:
             continue  # n does not fit this variant's registers
-        assert plan["mode"] == "reg" and plan["group"] == group and plan["group"] * plan["rows_per_lane"] >= n
-        r = m.eval(q0, group=group, mode="reg")
+        assert plan["mode"] == mode and plan["group"] == group
+        assert mode != "reg" or plan["group"] * plan["rows_per_lane"] >= n
+        r = m.eval(q0, group=group, mode=mode)
         np.testing.assert_allclose(r["lpost"], orc.lpost(q0), rtol=3e-6)
         assert np.max(np.abs(r["glp"] - orc.glp(q0))) < 3e-4
         for kind, kw, kern in (
@@ -540,7 +541,7 @@ def test_register_row_pair_layouts_for_every_row_count(la, n):
                 ("ul", dict(step=1e-2, scale=np.ones(p)), la.ulKernel(m.glp, dt=1e-2, pre=np.ones(p)))):
             ll0 = orc.lpost(q0) if kind in ("mala", "rwmh") else None
             ref = orc.run(kind, q0, thin=1, iters=2, seed=9, ll_state=ll0, threads=0, **kw)
-            out, info = la.mcmc(q0, kern, thin=1, iters=2, verb=False, seed=9, ll=ll0, group=group, mode="reg",
+            out, info = la.mcmc(q0, kern, thin=1, iters=2, verb=False, seed=9, ll=ll0, group=group, mode=mode,
                                 return_info=True)
             ok = ref["margin"] > 1e-3
             assert ok.mean() > 0.9, (kind, group)
