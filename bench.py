@@ -204,6 +204,9 @@ def main():
                          "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
                          "kernel_ms": kern_s * 1e3,
+                         # SURVEY.md section 8(d)'s own estimate of what the VALU + transcendental mix allows
+                         # (1.0e10 grad evals/s/GPU), reported beside the fraction of the nominal peak
+                         "frac_of_survey_ceiling": grad_evals / wall / world / 1.0e10,
                          "flops_per_grad_eval": fg, "grad_evals_per_launch": C * THIN * LEAP,
                          "algorithmic_hbm_bytes_per_launch": alg_bytes,
                          "hbm_GBps_algorithmic": alg_bytes / kern_s / 1e9,

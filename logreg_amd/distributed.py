@@ -11,6 +11,9 @@ The reference has no distributed code on this path; chains never interact (`mcmc
   `torch.distributed.gather` (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU
   tests).  With 7 direct xGMI links per GPU every sender has its own link into rank 0.
 
+* when only pooled posterior summaries are wanted, `reduce_moments` exchanges (2p + 1) float64 sufficient
+  statistics per rank with one all-reduce instead of moving any samples.
+
 `run_sharded` takes the per-rank compute as a callable so the sharding/gather logic is testable
 without a GPU (tests inject the CPU oracle); `mcmc_sharded` binds it to the fused HIP kernels.
 """
@@ -45,6 +48,28 @@ def gather_samples(local, n_chains: int, dst: int = 0, group=None):
     if rank != dst:
         return None
     return torch.cat([b[:, : hi - lo, :] for b, (lo, hi) in zip(bufs, sizes)], dim=1)
+
+
+def reduce_moments(local, group=None):
+    """Pooled posterior mean and SD (ddof = 1, as `scipy.stats.describe` in fit-np-hmc.py:113-117) over the
+    samples of ALL ranks from one all-reduce of sufficient statistics: count, sum and sum of squares per
+    parameter, accumulated in float64.  `local` is this rank's `[iters, C_r, p]` block (tensor on the rank's
+    device, or ndarray).  Every rank gets `{"n", "mean", "sd"}`; no samples move."""
+    import torch
+    import torch.distributed as dist
+    t = local if isinstance(local, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(local))
+    x = t.reshape(-1, t.shape[-1]).to(torch.float64)
+    # centre on a common pivot (rank 0's first sample) so that sum-of-squares cancellation stays harmless
+    pivot = x[0].clone() if x.shape[0] else torch.zeros(t.shape[-1], dtype=torch.float64, device=t.device)
+    dist.broadcast(pivot, src=0, group=group)
+    d = x - pivot
+    stats = torch.cat([torch.tensor([float(x.shape[0])], dtype=torch.float64, device=t.device), d.sum(0), (d * d).sum(0)])
+    dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
+    p = t.shape[-1]
+    n, s1, s2 = stats[0], stats[1:1 + p], stats[1 + p:]
+    mean_d = s1 / n
+    var = (s2 - n * mean_d * mean_d) / (n - 1)
+    return {"n": int(n.item()), "mean": (pivot + mean_d).cpu().numpy(), "sd": var.clamp_min(0).sqrt().cpu().numpy()}
 
 
 def run_sharded(init, run_block, n_chains: int | None = None, dst: int = 0, group=None, device=None):

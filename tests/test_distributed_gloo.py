@@ -37,8 +37,13 @@ def _worker(rank, world, port, C, tmp):
     def run_block(block, chain_offset):
         return m.run("hmc", block, step=1e-3, l=5, scale=dmm, thin=2, iters=3, seed=31, chain_offset=chain_offset)["out"]
     out = run_sharded(init, run_block)
+    # the no-samples-moved alternative: pooled mean / SD from one all-reduce of sufficient statistics
+    from logreg_amd.distributed import reduce_moments, shard_bounds
+    lo, hi = shard_bounds(C, world, rank)
+    mom = reduce_moments(run_block(init[lo:hi], lo))
     if rank == 0:
         np.save(os.path.join(tmp, "gathered.npy"), out.numpy())
+        np.savez(os.path.join(tmp, "moments.npz"), **mom)
     else:
         assert out is None
     dist.barrier()
@@ -61,3 +66,8 @@ def test_sharded_run_equals_single_process_run(tmp_path, C):
     ref = m.run("hmc", init, step=1e-3, l=5, scale=dmm, thin=2, iters=3, seed=31)["out"]
     assert got.shape == (3, C, 8)
     np.testing.assert_array_equal(got, ref)  # bit-exact: chain ids are global
+    mom = np.load(tmp_path / "moments.npz")
+    flat = ref.reshape(-1, 8)
+    assert int(mom["n"]) == flat.shape[0]
+    np.testing.assert_allclose(mom["mean"], flat.mean(0), rtol=1e-12)
+    np.testing.assert_allclose(mom["sd"], flat.std(0, ddof=1), rtol=1e-9)
