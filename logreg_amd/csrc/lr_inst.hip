@@ -30,7 +30,7 @@ constexpr int P = LR_P;
     X(MODE_GLOBAL, 1, 0)
 #elif LR_DTYPE == 0 && LR_P == 16
 #define LR_VARIANTS(X) \
-    X(MODE_REG, 64, 8) X(MODE_LDS, 1, 0) X(MODE_LDS, 8, 0) X(MODE_LDS, 64, 0) X(MODE_GLOBAL, 64, 0) X(MODE_GLOBAL, 1, 0)
+    X(MODE_REG, 64, 8) X(MODE_REG, 32, 7) X(MODE_REG, 32, 8) X(MODE_LDS, 1, 0) X(MODE_LDS, 8, 0) X(MODE_LDS, 64, 0) X(MODE_GLOBAL, 64, 0) X(MODE_GLOBAL, 1, 0)
 #elif LR_DTYPE == 0 && LR_P == 32
 #define LR_VARIANTS(X) X(MODE_REG, 64, 4) X(MODE_LDS, 8, 0) X(MODE_LDS, 64, 0) X(MODE_GLOBAL, 64, 0) X(MODE_GLOBAL, 1, 0)
 #else  // float64: validation-grade path, no register-resident variants

@@ -249,6 +249,7 @@ def test_planner_engine_choice_by_size(la):
     assert plan(4000, 4096)["mode"] == "stepwise"   # same rows, enough chains to fill the chip per slice
     assert plan(6000, 64)["mode"] == "stepwise"     # beyond LDS
     assert plan(300, 64, p=100)["mode"] == "stepwise"
+    assert plan(200, 4096, p=12) == {"mode": "reg", "group": 32, "rows_per_lane": 7}
 
 
 @pytest.mark.parametrize("engine", ["bf16x3", "fp32"])
@@ -489,10 +490,10 @@ def test_errors_are_loud(la, models, map_beta):
 
 
 def test_other_parameter_counts_use_padded_kernels(la, oracle_model):
-    """p = 3, 11, 20: padded to 4 / 16 / 32 columns; padded coordinates are frozen at 0."""
+    """p = 3, 11, 12, 20: padded to 4 / 16 / 16 / 32 columns; padded coordinates are frozen at 0."""
     from oracle.oracle import OracleModel
     rng = np.random.default_rng(8)
-    for p, n in ((3, 50), (11, 300), (20, 1000)):
+    for p, n in ((3, 50), (11, 300), (12, 200), (20, 1000)):  # (12, 200): the 32-lane register variant of P = 16
         X, y, _ = la.synthetic_logreg(n, p, seed=p)
         ps = np.full(p, 2.0)
         orc = OracleModel(X, y, ps)
