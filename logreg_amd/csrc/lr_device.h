@@ -659,6 +659,9 @@ template <int P, int PF = 1> struct ScalarRowPairs {
     }
     __device__ __forceinline__ float value_fixup() const { return float(zero_rows) * 0.693147180559945309f; }
 };
+template <class Rows> struct is_scalar_rows { static constexpr bool value = false; };
+template <typename T, int P, int PF> struct is_scalar_rows<ScalarRows<T, P, PF>> { static constexpr bool value = true; };
+constexpr int kSeqRows = 512;  // rows one lane may sum sequentially in fp32 (lane-per-chain variants)
 template <class Rows> struct is_scalar_pairs { static constexpr bool value = false; };
 template <int P, int PF> struct is_scalar_pairs<ScalarRowPairs<P, PF>> { static constexpr bool value = true; };
 
@@ -706,12 +709,62 @@ __device__ __forceinline__ void eval_lpost(const Rows& rows, const Prior<T, P>& 
             bb[j] = f32x2{bs[2 * j], bs[2 * j + 1]};
             gp[j] = hp[j] = f32x2{0.0f, 0.0f};
         }
-        rows.for_each_pair([&](const f32x2(&q)[P]) { pair_term<P, VALUE, GRAD>(q, bb, gp, hp, vacc); });
-        if constexpr (VALUE) v += (vacc.x + vacc.y) * ExpScale<float>::inv;
+        // one lane sums ALL rows of its chain: beyond kSeqRows the fp32 running sums are flushed to fp64 block
+        // by block (a forced lane-per-chain run at n = 9001 lost 3e-5 of lpost without it; the planner itself
+        // picks this variant only for rows <= 16 KB)
+        if (rows.k1 - rows.k0 <= kSeqRows / 2) {
+            rows.for_each_pair([&](const f32x2(&q)[P]) { pair_term<P, VALUE, GRAD>(q, bb, gp, hp, vacc); });
+            if constexpr (VALUE) v += (vacc.x + vacc.y) * ExpScale<float>::inv;
 #pragma unroll
-        for (int j = 0; j < P / 2; ++j) {
-            g[2 * j] = gp[j].x + hp[j].y;
-            g[2 * j + 1] = gp[j].y + hp[j].x;
+            for (int j = 0; j < P / 2; ++j) {
+                g[2 * j] = gp[j].x + hp[j].y;
+                g[2 * j + 1] = gp[j].y + hp[j].x;
+            }
+        } else {
+            double gd[P], vd = 0.0;
+#pragma unroll
+            for (int j = 0; j < P; ++j) gd[j] = 0.0;
+            Rows sub = rows;
+            for (int64_t kb = rows.k0; kb < rows.k1; kb += kSeqRows / 2) {
+                sub.k0 = kb;
+                sub.k1 = kb + kSeqRows / 2 < rows.k1 ? kb + kSeqRows / 2 : rows.k1;
+                sub.for_each_pair([&](const f32x2(&q)[P]) { pair_term<P, VALUE, GRAD>(q, bb, gp, hp, vacc); });
+#pragma unroll
+                for (int j = 0; j < P / 2; ++j) {
+                    gd[2 * j] += (double)(gp[j].x + hp[j].y);
+                    gd[2 * j + 1] += (double)(gp[j].y + hp[j].x);
+                    gp[j] = hp[j] = f32x2{0.0f, 0.0f};
+                }
+                vd += (double)(vacc.x + vacc.y);
+                vacc = f32x2{0.0f, 0.0f};
+            }
+#pragma unroll
+            for (int j = 0; j < P; ++j) g[j] = (float)gd[j];
+            if constexpr (VALUE) v += (float)(vd * (double)ExpScale<float>::inv);
+        }
+    } else if constexpr (G == 1 && sizeof(T) == 4 && is_scalar_rows<Rows>::value) {
+        if (rows.i1 - rows.i0 <= kSeqRows) {
+            rows.for_each([&](const T(&xs)[P]) { row_term<T, P, VALUE, GRAD>(xs, bs, g, v); });
+        } else {  // as above, for the row-at-a-time scalar form (P = 32)
+            double gd[P], vd = 0.0;
+#pragma unroll
+            for (int j = 0; j < P; ++j) gd[j] = 0.0;
+            Rows sub = rows;
+            for (int64_t ib = rows.i0; ib < rows.i1; ib += kSeqRows) {
+                sub.i0 = ib;
+                sub.i1 = ib + kSeqRows < rows.i1 ? ib + kSeqRows : rows.i1;
+                T vb = T(0);
+                sub.for_each([&](const T(&xs)[P]) { row_term<T, P, VALUE, GRAD>(xs, bs, g, vb); });
+#pragma unroll
+                for (int j = 0; j < P; ++j) {
+                    gd[j] += (double)g[j];
+                    g[j] = T(0);
+                }
+                vd += (double)vb;
+            }
+#pragma unroll
+            for (int j = 0; j < P; ++j) g[j] = (T)gd[j];
+            if constexpr (VALUE) v += (T)vd;
         }
     } else {
         rows.for_each([&](const T(&xs)[P]) { row_term<T, P, VALUE, GRAD>(xs, bs, g, v); });

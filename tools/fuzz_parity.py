@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Randomised parity fuzz (GPU): random n, p, chain counts, kernels and engines against the CPU oracle.
+usage: fuzz_parity.py [cases] [seed]      -- prints failures and a summary; exit code 1 on any failure."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import logreg_amd as la
+from oracle.oracle import OracleModel
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+fails, done, skipped = [], 0, 0
+t0 = time.time()
+for case in range(cases):
+    p = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 12, 16, 17, 24, 32, 33, 40, 64, 100, 128]))
+    n = int(rng.choice([1, 2, 3, 7, 16, 33, 64, 100, 199, 200, 201, 255, 256, 257, 400, 513, 1000, 2500, 5001, 9001]))
+    if p > 32:
+        n = min(n, 1000)
+    C = int(rng.choice([1, 2, 15, 16, 17, 63, 64, 65, 130, 300]))
+    kind = str(rng.choice(["hmc", "mala", "rwmh", "ul"]))
+    X, y, _ = la.synthetic_logreg(n, p, seed=1000 + case, beta_sd=0.3 / np.sqrt(p))
+    ps = rng.uniform(0.5, 3.0, p)
+    orc = OracleModel(X, y, ps)
+    m = la.LogReg(X, y, ps)
+    modes = [("auto", 0)]
+    if p <= 32:
+        modes += [("lds", 8), ("lds", 64), ("global", 64), ("global", 1), ("stepwise", 0)]
+        for g in (16, 32, 64):
+            try:
+                m.plan(C, g, "reg"); modes.append(("reg", g))
+            except la.LogregHipError:
+                pass
+    mode, group = modes[int(rng.integers(len(modes)))]
+    sc = 1.0 / np.sqrt(max(n, 4))
+    q0 = 0.3 * sc * rng.standard_normal((C, p))
+    scale = rng.uniform(0.5, 2.0, p)
+    if kind == "hmc":
+        L = int(rng.integers(1, 8)); eps = 0.3 * sc
+        kern = la.hmcKernel(m.lpost, m.glp, eps=eps, l=L, dmm=scale); kw = dict(step=eps, l=L, scale=scale)
+    elif kind == "mala":
+        dt = 0.05 * sc * sc
+        kern = la.malaKernel(m.lpost, m.glp, dt=dt, pre=scale); kw = dict(step=dt, scale=scale)
+    elif kind == "ul":
+        dt = 0.05 * sc * sc
+        kern = la.ulKernel(m.glp, dt=dt, pre=scale); kw = dict(step=dt, scale=scale)
+    else:
+        sd = 0.3 * sc * scale
+        kern = la.mhKernel(m.lpost, la.rwProposal(sd)); kw = dict(scale=sd)
+    ll0 = orc.lpost(q0) if kind in ("mala", "rwmh") else None
+    thin, iters = int(rng.integers(1, 3)), int(rng.integers(1, 3))
+    tag = f"case {case}: n={n} p={p} C={C} {kind} {mode}/{group} thin={thin} iters={iters}"
+    try:
+        ref = orc.run(kind, q0, thin=thin, iters=iters, seed=case, ll_state=ll0, threads=0, **kw)
+        out, info = la.mcmc(q0, kern, thin=thin, iters=iters, verb=False, seed=case, ll=ll0, mode=mode, group=group,
+                            return_info=True)
+        r = m.eval(q0, mode=mode if mode != "stepwise" else "auto", group=group if mode != "stepwise" else 0)
+    except la.LogregHipError as e:
+        skipped += 1
+        print("SKIP", tag, "->", str(e)[:80]); continue
+    done += 1
+    ok = ref["margin"] > 2e-3
+    lp_ref = orc.lpost(q0)
+    errs = []
+    if not np.allclose(r["lpost"], lp_ref, rtol=3e-5, atol=3e-5 * n ** 0.5):
+        errs.append("lpost %.3g" % np.max(np.abs(r["lpost"] - lp_ref)))
+    gtol = 2e-4 * np.sqrt(n) * max(1.0, np.abs(X).max())
+    if np.max(np.abs(r["glp"] - orc.glp(q0))) > gtol:
+        errs.append("glp %.3g" % np.max(np.abs(r["glp"] - orc.glp(q0))))
+    if ok.any():
+        if not np.array_equal(info["accepts"][ok], ref["accepts"][ok].astype(np.uint32)):
+            errs.append("accepts differ in %d chains" % int((info["accepts"][ok] != ref["accepts"][ok]).sum()))
+        d = np.max(np.abs(out[:, ok] - ref["out"][:, ok]))
+        if not d < 2e-3 * sc * 3 + 1e-5:
+            errs.append("states %.3g" % d)
+    if not np.isfinite(out).all():
+        errs.append("non-finite output")
+    if errs:
+        fails.append(tag + " :: " + "; ".join(errs)); print("FAIL", fails[-1], flush=True)
+print(f"fuzz: {done} cases run, {skipped} skipped, {len(fails)} failed, {time.time() - t0:.0f}s")
+sys.exit(1 if fails else 0)
