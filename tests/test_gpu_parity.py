@@ -605,3 +605,17 @@ def test_wide_bf16_split_stays_in_the_fp32_error_class(la, monkeypatch):
     print("rel lpost err / abs grad err: bf16x3", err["1"], "fp32-mfma", err["0"])
     assert err["1"][0] < 3e-6 and err["0"][0] < 3e-6
     assert err["1"][1] < 3.0 * err["0"][1] + 1e-4
+
+
+def test_randomised_parity_fuzz():
+    """tools/fuzz_parity.py: random n (1..9001), p (1..128), chain counts, kernels and engines (every forced
+    variant that accepts the shape) against the oracle -- model values, accept decisions and states."""
+    import os
+    import subprocess
+    import sys
+    from conftest import REPO
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "fuzz_parity.py"), "80", "7"], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " 0 failed" in r.stdout
+
