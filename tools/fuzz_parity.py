@@ -74,6 +74,19 @@ for case in range(cases):
             errs.append("states %.3g" % d)
     if not np.isfinite(out).all():
         errs.append("non-finite output")
+    if rng.random() < 0.4:  # chunk and shard invariance: bit-exact (global chain id and iteration in the Philox counter)
+        again = la.mcmc(q0, kern, thin=thin, iters=iters, verb=False, seed=case, ll=ll0, mode=mode, group=group, chunk=1)
+        if not np.array_equal(again, out):
+            errs.append("chunk=1 differs")
+        if C > 1 and mode != "stepwise" and p <= 32:  # (stepwise slicing depends on the chain count by design)
+            h = C // 2
+            pl = info["plan"]
+            a = la.mcmc(q0[:h], kern, thin=thin, iters=iters, verb=False, seed=case, ll=None if ll0 is None else ll0[:h],
+                        mode=pl["mode"], group=pl["group"])
+            b = la.mcmc(q0[h:], kern, thin=thin, iters=iters, verb=False, seed=case, ll=None if ll0 is None else ll0[h:],
+                        mode=pl["mode"], group=pl["group"], chain_offset=h)
+            if not np.array_equal(np.concatenate([a, b], axis=1), out):
+                errs.append("shards differ")
     if errs:
         fails.append(tag + " :: " + "; ".join(errs)); print("FAIL", fails[-1], flush=True)
 print(f"fuzz: {done} cases run, {skipped} skipped, {len(fails)} failed, {time.time() - t0:.0f}s")
