@@ -147,24 +147,115 @@ template <int G, typename T> __device__ __forceinline__ T group_sum(T v) {
     return v;
 }
 
+// v_permlane{16,32}_swap on M register pairs in one statement (one hazard pad for all of them).
+//   swap16: a <- [a.r0, b.r0, a.r2, b.r2], b <- [a.r1, b.r1, a.r3, b.r3]   (r = 16-lane row)
+//   swap32: a <- [a.lo, b.lo],             b <- [a.hi, b.hi]               (lo/hi = 32-lane half)
+template <int WIDTH, int M> __device__ __forceinline__ void swap_pairs(float (&a)[M], float (&b)[M]) {
+    static_assert(WIDTH == 16 || WIDTH == 32, "row or half swap");
+    static_assert(M == 1 || M == 2 || M == 4 || M % 8 == 0, "pairs per call");
+    // the hazard pad must sit INSIDE the statement (hipcc neither sees the permlane nor keeps its own
+    // instructions out from between two asm statements): one pad per statement of up to 8 swaps
+#define LR_SW16 "v_permlane16_swap_b32 "
+#define LR_SW32 "v_permlane32_swap_b32 "
+#define LR_SWAP1(OP, i) asm volatile("s_nop 1\n\t" OP "%0, %1\n\ts_nop 0" : "+v"(a[i]), "+v"(b[i]))
+#define LR_SWAP2(OP, i) \
+    asm volatile("s_nop 1\n\t" OP "%0, %2\n\t" OP "%1, %3\n\ts_nop 0" : "+v"(a[i]), "+v"(a[i + 1]), "+v"(b[i]), "+v"(b[i + 1]))
+#define LR_SWAP4(OP, i)                                                                                                  \
+    asm volatile("s_nop 1\n\t" OP "%0, %4\n\t" OP "%1, %5\n\t" OP "%2, %6\n\t" OP "%3, %7\n\ts_nop 0"                 \
+                 : "+v"(a[i]), "+v"(a[i + 1]), "+v"(a[i + 2]), "+v"(a[i + 3]), "+v"(b[i]), "+v"(b[i + 1]), "+v"(b[i + 2]), \
+                   "+v"(b[i + 3]))
+#define LR_SWAP8(OP, i)                                                                                                   \
+    asm volatile("s_nop 1\n\t" OP "%0, %8\n\t" OP "%1, %9\n\t" OP "%2, %10\n\t" OP "%3, %11\n\t" OP "%4, %12\n\t" OP      \
+                 "%5, %13\n\t" OP "%6, %14\n\t" OP "%7, %15\n\ts_nop 0"                                                  \
+                 : "+v"(a[i]), "+v"(a[i + 1]), "+v"(a[i + 2]), "+v"(a[i + 3]), "+v"(a[i + 4]), "+v"(a[i + 5]),            \
+                   "+v"(a[i + 6]), "+v"(a[i + 7]), "+v"(b[i]), "+v"(b[i + 1]), "+v"(b[i + 2]), "+v"(b[i + 3]),            \
+                   "+v"(b[i + 4]), "+v"(b[i + 5]), "+v"(b[i + 6]), "+v"(b[i + 7]))
+    if constexpr (WIDTH == 16) {
+        if constexpr (M == 1) LR_SWAP1(LR_SW16, 0);
+        else if constexpr (M == 2) LR_SWAP2(LR_SW16, 0);
+        else if constexpr (M == 4) LR_SWAP4(LR_SW16, 0);
+        else {
+#pragma unroll
+            for (int i = 0; i < M; i += 8) LR_SWAP8(LR_SW16, i);
+        }
+    } else {
+        if constexpr (M == 1) LR_SWAP1(LR_SW32, 0);
+        else if constexpr (M == 2) LR_SWAP2(LR_SW32, 0);
+        else if constexpr (M == 4) LR_SWAP4(LR_SW32, 0);
+        else {
+#pragma unroll
+            for (int i = 0; i < M; i += 8) LR_SWAP8(LR_SW32, i);
+        }
+    }
+#undef LR_SWAP1
+#undef LR_SWAP2
+#undef LR_SWAP4
+#undef LR_SWAP8
+#undef LR_SW16
+#undef LR_SW32
+}
+
 // N independent float values at once, LEVEL-major: between a value's write and its next DPP read there
 // are N-1 other instructions, so no hazard padding and no dependency stall.  The scheduling barriers pin
 // that order: left alone, the scheduler sometimes serialises the reduction value by value (32 dependent
 // v_add_f32_dpp separated by s_nop: measured 10 % of the whole HMC kernel), depending on register
 // pressure elsewhere in the kernel.
+// Groups wider than a 16-lane row: the cross-row levels run FIRST, as a transposing reduce-scatter -- a
+// permlane swap of (v[j], v[j + n/2]) followed by one add leaves the row sums of v[j] in one half of the
+// rows and those of v[j + n/2] in the other, in ONE register -- so the four in-row DPP levels work on N/2
+// (G = 32) or N/4 (G = 64) registers, and two (one) swap levels hand every lane all N totals back:
+// 4 N instructions instead of 8 N (G = 64) / 6 N (G = 32).
 template <int G, int N> __device__ __forceinline__ void group_sum_levels(float (&v)[N]) {
     static_assert(G == 1 || G == 2 || G == 4 || G == 8 || G == 16 || G == 32 || G == 64, "bad group");
-#define LR_LEVEL(COND, EXPR)                       \
+#define LR_LEVEL(COND, CNT, EXPR)                  \
     if constexpr (COND) {                          \
         __builtin_amdgcn_sched_barrier(0);         \
-        _Pragma("unroll") for (int j = 0; j < N; ++j) v[j] = EXPR; \
+        _Pragma("unroll") for (int j = 0; j < (CNT); ++j) v[j] = EXPR; \
     }
-    LR_LEVEL(G >= 16, v[j] + dpp_mov<0x140>(v[j]))
-    LR_LEVEL(G >= 8, v[j] + dpp_mov<0x141>(v[j]))
-    LR_LEVEL(G >= 4, v[j] + dpp_mov<0x4E>(v[j]))
-    LR_LEVEL(G >= 2, v[j] + dpp_mov<0xB1>(v[j]))
-    LR_LEVEL(G >= 32, swap16_sum(v[j]))
-    LR_LEVEL(G >= 64, swap32_sum(v[j]))
+    constexpr bool X32 = G >= 64 && N % 4 == 0, X16 = G >= 32 && N % (G >= 64 ? 4 : 2) == 0 && (G < 64 || X32);
+    constexpr int N1 = X32 ? N / 2 : N;   // registers after the half-swap level
+    constexpr int N2 = X16 ? N1 / 2 : N1;  // registers after the row-swap level
+    if constexpr (X32) {  // v[j] <- sum over the two halves of v[j] (lanes 0-31) | of v[j + N/2] (lanes 32-63)
+        float a[N / 2], b[N / 2];
+#pragma unroll
+        for (int j = 0; j < N / 2; ++j) { a[j] = v[j]; b[j] = v[j + N / 2]; }
+        swap_pairs<32>(a, b);
+#pragma unroll
+        for (int j = 0; j < N / 2; ++j) v[j] = a[j] + b[j];
+    }
+    if constexpr (X16) {  // v[j] <- sum over the row pair of v[j] (even rows) | of v[j + N1/2] (odd rows)
+        float a[N1 / 2], b[N1 / 2];
+#pragma unroll
+        for (int j = 0; j < N1 / 2; ++j) { a[j] = v[j]; b[j] = v[j + N1 / 2]; }
+        swap_pairs<16>(a, b);
+#pragma unroll
+        for (int j = 0; j < N1 / 2; ++j) v[j] = a[j] + b[j];
+    }
+    LR_LEVEL(G >= 16, N2, v[j] + dpp_mov<0x140>(v[j]))
+    LR_LEVEL(G >= 8, N2, v[j] + dpp_mov<0x141>(v[j]))
+    LR_LEVEL(G >= 4, N2, v[j] + dpp_mov<0x4E>(v[j]))
+    LR_LEVEL(G >= 2, N2, v[j] + dpp_mov<0xB1>(v[j]))
+    if constexpr (X16) {  // hand the totals back: even rows hold value j, odd rows value j + N1/2
+        __builtin_amdgcn_sched_barrier(0);
+        float a[N1 / 2], b[N1 / 2];
+#pragma unroll
+        for (int j = 0; j < N1 / 2; ++j) a[j] = b[j] = v[j];
+        swap_pairs<16>(a, b);
+#pragma unroll
+        for (int j = 0; j < N1 / 2; ++j) { v[j] = a[j]; v[j + N1 / 2] = b[j]; }
+    } else {
+        LR_LEVEL(G >= 32, N, swap16_sum(v[j]))
+    }
+    if constexpr (X32) {
+        float a[N / 2], b[N / 2];
+#pragma unroll
+        for (int j = 0; j < N / 2; ++j) a[j] = b[j] = v[j];
+        swap_pairs<32>(a, b);
+#pragma unroll
+        for (int j = 0; j < N / 2; ++j) { v[j] = a[j]; v[j + N / 2] = b[j]; }
+    } else {
+        LR_LEVEL(G >= 64, N, swap32_sum(v[j]))
+    }
 #undef LR_LEVEL
     if constexpr (G >= 2) __builtin_amdgcn_sched_barrier(0);
 }

@@ -78,9 +78,9 @@ for case in range(cases):
         again = la.mcmc(q0, kern, thin=thin, iters=iters, verb=False, seed=case, ll=ll0, mode=mode, group=group, chunk=1)
         if not np.array_equal(again, out):
             errs.append("chunk=1 differs")
-        if C > 1 and mode != "stepwise" and p <= 32:  # (stepwise slicing depends on the chain count by design)
+        pl = info["plan"]
+        if C > 1 and pl["mode"] != "stepwise":  # (stepwise slicing depends on the chain count by design)
             h = C // 2
-            pl = info["plan"]
             a = la.mcmc(q0[:h], kern, thin=thin, iters=iters, verb=False, seed=case, ll=None if ll0 is None else ll0[:h],
                         mode=pl["mode"], group=pl["group"])
             b = la.mcmc(q0[h:], kern, thin=thin, iters=iters, verb=False, seed=case, ll=None if ll0 is None else ll0[h:],
