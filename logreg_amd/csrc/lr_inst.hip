@@ -22,7 +22,8 @@ constexpr int P = LR_P;
 // power-of-two fallbacks.
 #if LR_DTYPE == 0 && LR_P == 8
 #define LR_VARIANTS(X)                                                                                \
-    X(MODE_REG, 64, 4) X(MODE_REG, 32, 7) X(MODE_REG, 32, 8) X(MODE_REG, 16, 13) X(MODE_REG, 16, 16) \
+    X(MODE_REG, 64, 4) X(MODE_REG, 32, 7) X(MODE_REG, 32, 8) X(MODE_REG, 16, 13) X(MODE_REG, 16, 16) X(MODE_REG, 32, 16) \
+    X(MODE_REG, 64, 8) X(MODE_REG, 64, 12) X(MODE_REG, 64, 16) \
     X(MODE_LDS, 1, 0) X(MODE_LDS, 8, 0) X(MODE_LDS, 64, 0) X(MODE_GLOBAL, 64, 0) X(MODE_GLOBAL, 1, 0)
 #elif LR_DTYPE == 0 && LR_P == 4
 #define LR_VARIANTS(X) \

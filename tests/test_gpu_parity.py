@@ -235,7 +235,7 @@ def test_tall_data_uses_stepwise_engine_and_matches_oracle(la):
 
 
 def test_planner_engine_choice_by_size(la):
-    """lr_plan's measured rules (tools/midn_sweep.py): registers while the rows fit them, LDS up to 64 KB of
+    """lr_plan's measured rules (tools/midn_sweep.py): registers while the rows fit them (n <= 1024 at p = 8), LDS up to 64 KB of
     rows (or up to the LDS size with few chains), the stepwise engine beyond; lane-per-chain scalar rows from
     three waves per SIMD."""
     def plan(n, C, p=8):
@@ -244,7 +244,10 @@ def test_planner_engine_choice_by_size(la):
     assert plan(200, 4096) == {"mode": "reg", "group": 16, "rows_per_lane": 13}
     assert plan(200, 64)["group"] == 64
     assert plan(200, 1 << 18)["mode"] == "global" and plan(200, 1 << 18)["group"] == 1
-    assert plan(1000, 4096)["mode"] == "lds"
+    assert plan(300, 4096) == {"mode": "reg", "group": 32, "rows_per_lane": 16}
+    assert plan(600, 4096) == {"mode": "reg", "group": 64, "rows_per_lane": 12}
+    assert plan(1000, 4096) == {"mode": "reg", "group": 64, "rows_per_lane": 16}
+    assert plan(1500, 4096)["mode"] == "lds"
     assert plan(4000, 1024)["mode"] == "lds"        # 128 KB of rows, few chains
     assert plan(4000, 4096)["mode"] == "stepwise"   # same rows, enough chains to fill the chip per slice
     assert plan(6000, 64)["mode"] == "stepwise"     # beyond LDS
@@ -512,7 +515,7 @@ def test_other_parameter_counts_use_padded_kernels(la, oracle_model):
             assert np.max(np.abs(out[0, ok] - ref["out"][0, ok])) < (2e-3 if dtype == "float32" else 1e-9)
 
 
-@pytest.mark.parametrize("n", [1, 2, 17, 64, 208, 250, 256])
+@pytest.mark.parametrize("n", [1, 2, 17, 64, 208, 250, 256, 511, 700, 1023])
 def test_register_row_pair_layouts_for_every_row_count(la, n):
     """Rows live in VGPRs as twisted row pairs (+ one unpaired row when the per-lane count is odd):
     exercise even and odd rows-per-lane, ragged last rows and all-padding lanes for every register

@@ -58,7 +58,9 @@ for case in range(cases):
         skipped += 1
         print("SKIP", tag, "->", str(e)[:80]); continue
     done += 1
-    ok = ref["margin"] > 2e-3
+    # decisions are compared where the oracle's |a - log u| clears the fp32 resolution of the log-density
+    # (|ll| ~ 0.7 n: ulp-level sums of n terms; 2e-3 up to n = 1000, growing with n)
+    ok = ref["margin"] > 2e-3 * max(1.0, n / 1000.0)
     lp_ref = orc.lpost(q0)
     errs = []
     if not np.allclose(r["lpost"], lp_ref, rtol=3e-5, atol=3e-5 * n ** 0.5):
