@@ -19,7 +19,7 @@ constexpr int P = LR_P;
 
 // Variant table: X(mode, lanes-per-chain G, rows-per-lane R).  REG variants keep R*P <= 128
 // VGPRs of data per lane; exact R for Pima's n = 200 (G*R >= 200: 64x4, 32x7, 16x13) plus
-// power-of-two fallbacks.
+// larger fallbacks up to the 128-register budget (n <= 64 * 128 / P).
 #if LR_DTYPE == 0 && LR_P == 8
 #define LR_VARIANTS(X)                                                                                \
     X(MODE_REG, 64, 4) X(MODE_REG, 32, 7) X(MODE_REG, 32, 8) X(MODE_REG, 16, 13) X(MODE_REG, 16, 16) X(MODE_REG, 32, 16) \
@@ -27,8 +27,8 @@ constexpr int P = LR_P;
     X(MODE_LDS, 1, 0) X(MODE_LDS, 8, 0) X(MODE_LDS, 64, 0) X(MODE_GLOBAL, 64, 0) X(MODE_GLOBAL, 1, 0)
 #elif LR_DTYPE == 0 && LR_P == 4
 #define LR_VARIANTS(X) \
-    X(MODE_REG, 64, 8) X(MODE_REG, 16, 16) X(MODE_LDS, 1, 0) X(MODE_LDS, 8, 0) X(MODE_LDS, 64, 0) X(MODE_GLOBAL, 64, 0) \
-    X(MODE_GLOBAL, 1, 0)
+    X(MODE_REG, 64, 8) X(MODE_REG, 16, 16) X(MODE_REG, 16, 32) X(MODE_REG, 32, 32) X(MODE_REG, 64, 32) X(MODE_LDS, 1, 0) \
+    X(MODE_LDS, 8, 0) X(MODE_LDS, 64, 0) X(MODE_GLOBAL, 64, 0) X(MODE_GLOBAL, 1, 0)
 #elif LR_DTYPE == 0 && LR_P == 16
 #define LR_VARIANTS(X) \
     X(MODE_REG, 64, 8) X(MODE_REG, 32, 7) X(MODE_REG, 32, 8) X(MODE_LDS, 1, 0) X(MODE_LDS, 8, 0) X(MODE_LDS, 64, 0) X(MODE_GLOBAL, 64, 0) X(MODE_GLOBAL, 1, 0)
