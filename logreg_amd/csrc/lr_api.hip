@@ -84,13 +84,18 @@ namespace {
 struct Plan { int mode, G, R; size_t lds_bytes; };
 
 // wide models: 0 = fp32-MFMA kernel (LOGREG_WIDE_BF16=0), 1 = bf16x3 with 4 waves (64 chains) per workgroup,
-// 2 = bf16x3 with 8 waves (128 chains) per workgroup -- chosen by chain count (measured, lr_wide_bf16.h)
-int wide_engine(int64_t C) {
+// 2 = bf16x3 with 8 waves (128 chains) per workgroup.  Measured (tools/wide_nsweep.py, wide_sweep.py): the
+// 128-chain workgroup halves the staging per chain but needs twice the row slices to fill the chip, so it wins only
+// when there are >= 4096 chains AND its slices still hold >= 512 rows (4096 chains: n = 2048 35.6 vs 36.6 us per
+// step for 4 vs 8 waves, n = 4096 equal, n = 8192 102 vs 85; n = 512: 18.9 vs 25.9)
+int wide_engine(const lr_model* m, int64_t C) {
     const char* env = std::getenv("LOGREG_WIDE_BF16");
     if (env) return std::atoi(env);
-    return C >= 4096 ? 2 : 1;
+    if (C < 4096) return 1;
+    const int64_t blocks2 = (C + 127) / 128, rs2 = (m->cus + blocks2 - 1) / blocks2;
+    return m->n / rs2 >= 512 ? 2 : 1;
 }
-int64_t wide_chains_per_block(int64_t C) { return wide_engine(C) == 2 ? 128 : 64; }
+int64_t wide_chains_per_block(const lr_model* m, int64_t C) { return wide_engine(m, C) == 2 ? 128 : 64; }
 
 // Choose the kernel variant.  REG (rows in VGPRs) whenever the data fit (G*R >= n), then LDS,
 // then GLOBAL.  Group size: the smallest available G that still gives every SIMD a wavefront
@@ -105,7 +110,7 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
         // GEMM over blocks of 64 chains x row slices (lr_wide.h).  ~2 workgroups per CU.
         if (mode != LR_MODE_AUTO && mode != LR_MODE_STEPWISE)
             return fail(LR_ERR_UNSUPPORTED, "p=%d > 32 runs on the stepwise engine only (mode=%d requested)", m->p, mode);
-        const int64_t cpb = wide_chains_per_block(C);
+        const int64_t cpb = wide_chains_per_block(m, C);
         const int64_t blocks = (C + cpb - 1) / cpb;
         // measured (tools/wide_sweep.py): 2 workgroups per CU pay off only when each still gets >= 32
         // row tiles (8192 chains: 96 vs 77 TFLOP/s); with less work 1 per CU wins (1024 chains: 51 vs 44)
@@ -114,7 +119,7 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
         // bf16 kernels (48-64 KB of LDS: 2-3 workgroups per CU would fit): one per CU -- the fewest row
         // slices -- measured fastest (8192 chains: 188 / 170 / 155 TFLOP/s at 1 / 2 / 3 per CU)
         const int64_t per_cu = env && std::atoi(env) > 0 ? std::atoi(env)
-                               : (wide_engine(C) != 0 ? 1 : (tiles_at_2 >= 32 ? 2 : 1));
+                               : (wide_engine(m, C) != 0 ? 1 : (tiles_at_2 >= 32 ? 2 : 1));
         int64_t RS = (per_cu * m->cus + blocks - 1) / blocks;
         int64_t slice_len = (m->n + RS - 1) / RS;
         slice_len = (slice_len + 31) / 32 * 32;  // whole 32-row blocks (the bf16 kernel's K = 32)
@@ -306,7 +311,7 @@ int setup_tall(lr_model* m, const Plan& pl, int64_t C, lr::TallArgs<T, P>* pa) {
     {
         // wide models: the exact-split bf16 matrix-core kernel (lr_wide_bf16.h) is the default -- same fp32
         // tolerances, 1.5x the fp32-MFMA kernel; LOGREG_WIDE_BF16=0 selects the fp32-MFMA kernel (lr_wide.h)
-        a.wide_bf16 = (m->P > 32 && m->d_xblk) ? wide_engine(C) : 0;
+        a.wide_bf16 = (m->P > 32 && m->d_xblk) ? wide_engine(m, C) : 0;
         a.xblk = static_cast<const uint16_t*>(m->d_xblk);
     }
     return LR_OK;
