@@ -672,7 +672,20 @@ template <typename T, int P, int G> struct StridedRows {  // LDS or global: same
     int64_t n;
     int gl;
     template <class F> __device__ __forceinline__ void for_each(F&& f) const {
-        for (int64_t i = gl; i < n; i += G) {
+        // four rows are fetched before the first is used: with one load batch per row the loop is one LDS / L2
+        // round trip per row, which nothing else in the wave covers
+        constexpr int UB = sizeof(T) * P <= 64 ? 4 : 2;
+        int64_t i = gl;
+        for (; i + (UB - 1) * G < n; i += UB * G) {
+            T xs[UB][P];
+#pragma unroll
+            for (int u = 0; u < UB; ++u)
+#pragma unroll
+                for (int j = 0; j < P; ++j) xs[u][j] = base[(i + u * G) * P + j];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) f(xs[u]);
+        }
+        for (; i < n; i += G) {
             T xs[P];
 #pragma unroll
             for (int j = 0; j < P; ++j) xs[j] = base[i * P + j];
