@@ -15,10 +15,21 @@ chain states are resident in HBM before the timed region starts.
 Prints ONE JSON line (rank 0).  Multi-GPU: chains are sharded (weak scaling: 4096 per GPU, the
 Philox counter carries the global chain id) and the kept samples are gathered to rank 0 over
 RCCL inside the timed region.
+
+At N = 1 the line also carries, outside the timed region:
+  cpu_baseline   the float64 C oracle (OpenMP over chains) on a bounded sample of the same workload ("port")
+  reference_cpu  the reference's own NumPy script, as measured in BASELINE.md (1 core)
+  ess            ESS per kept draw from a separate 512-draw run (Geyer), scaled to the timed throughput
+  extra.configs  BASELINE.json configs 3, 4, 5 on this GPU (one GPU's shard where the config is multi-GPU),
+                 each with its own roofline block
+
+`--dry-run` exercises the launch plumbing without a GPU (gloo instead of RCCL, no kernels): rank/world parsing,
+shard offsets, the gather and the max-over-ranks reduction -- what tests/test_host_logic.py runs on CPU.
 """
 from __future__ import annotations
 
 import argparse
+import ctypes as Ct
 import json
 import os
 import sys
@@ -32,8 +43,13 @@ sys.path.insert(0, REPO)
 N_ROWS, N_PAR, LEAP, EPS, THIN = 200, 8, 50, 0.1, 20
 CHAINS_PER_GPU = 4096
 SEED = 42
-PEAK_FP32_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector == FP32-input MFMA peak
+PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector == FP32-input MFMA peak
+PEAK_BF16_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
 HBM_PEAK_GBS = 8000.0
+# the reference's own script timed in BASELINE.md section 2 (Python/fit-np-hmc.py, Pima n=200 p=8, eps=1e-3 L=50)
+REFERENCE_CPU = {"it_per_s": 1368.0, "grad_evals_per_s": 6.98e4, "min_ess_per_s": 24.8, "cores": 1,
+                 "what": "unmodified Python/fit-np-hmc.py (NumPy), 1 chain, 1 core Xeon SPR 2.1 GHz, 146.2 s for 200 000 "
+                         "HMC iterations: BASELINE.md section 2"}
 
 
 def flops_per_grad_eval(n, p):  # F_g = 4np + 5n + 2p
@@ -80,6 +96,142 @@ def cpu_baseline(X, y, pscale, init, target_s=12.0):
             "grad_evals_per_s": chains * iters * (LEAP + 1) / dt}
 
 
+class Timer:
+    """HIP events on the stream the kernels are launched on (torch.cuda.Event would see torch's stream only)."""
+
+    def __init__(self, L, check, dev, stream):
+        self.L, self.check, self.dev, self.stream = L, check, dev, stream
+        self.e0, self.e1 = Ct.c_void_p(), Ct.c_void_p()
+        check(L.lr_event_create(dev, Ct.byref(self.e0)))
+        check(L.lr_event_create(dev, Ct.byref(self.e1)))
+
+    def start(self):
+        self.check(self.L.lr_event_record(self.dev, self.e0, self.stream))
+
+    def stop_ms(self) -> float:
+        self.check(self.L.lr_event_record(self.dev, self.e1, self.stream))
+        ms = Ct.c_float()
+        self.check(self.L.lr_event_elapsed_ms(self.dev, self.e0, self.e1, Ct.byref(ms)))
+        return float(ms.value)
+
+
+def _timed_chainset(la, timer, cs, iters, thin, repeats=3):
+    """Best-of-`repeats` HIP-event time (ms) of one advance(iters, thin, keep=False) after one warm-up."""
+    cs.advance(1, thin, keep=False)
+    cs.sync()
+    best = None
+    for _ in range(repeats):
+        timer.start()
+        cs.advance(iters, thin, keep=False)
+        ms = timer.stop_ms()
+        best = ms if best is None or ms < best else best
+    return best
+
+
+def extra_configs(la, L, check, dev, stream):
+    """BASELINE.json configs 3, 4, 5 on ONE GPU, timed with HIP events on the launch stream (bounded: a few ms of
+    GPU time each).  Step sizes: config 3 the reference's; configs 4/5 the tuned ones of
+    tests/golden/fullsize_cfg{4,5}.json (acceptance 0.75-0.85: the MH test does real work)."""
+    timer = Timer(L, check, dev, stream)
+    res = []
+    # ---- config 3: MALA, thin 1000, 8192 chains = one GPU's shard of 65 536 (real Pima data)
+    X, y = la.load_pima()
+    pre = np.array([100.0, 1, 1, 1, 1, 1, 25, 1])
+    bmap = np.array([-9.19131622, 0.09705401, 0.03112265, -0.00564495, -0.00062272, 0.0814371, 1.26032561, 0.03939102])
+    m = la.LogReg(X, y, np.array([10.0, 1, 1, 1, 1, 1, 1, 1]), device=dev)
+    k = la.malaKernel(m.lpost, m.glp, dt=1e-5, pre=pre)
+    C3 = 8192
+    cs = la.ChainSet(k, np.tile(bmap, (C3, 1)), seed=3, stream=stream)
+    ms = _timed_chainset(la, timer, cs, 2, 1000)
+    its = C3 * 2000
+    fg = flops_per_grad_eval(200, 8)
+    ach = its * fg / (ms * 1e-3) / 1e12
+    res.append({"config": 3, "workload": "MALA dt=1e-5 pre=[100,1,..,25,1] on Pima n=200 p=8, thin 1000, 8192 chains "
+                "(one GPU's shard of 65 536)", "kernel_variant": cs.plan(), "chain_iterations_per_s": its / (ms * 1e-3),
+                "grad_evals_per_s": its / (ms * 1e-3), "accept_rate": float(cs.get_accepts().sum() / (C3 * 7000)),
+                "launch_ms": ms, "reference_cpu_it_per_s": 4930.0,
+                "roofline": {"bound": "valu_fp32", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                             "frac": ach / PEAK_FP32_TFLOPS, "flops_per_iteration": fg,
+                             "note": "1 fused value+gradient evaluation per iteration (F_g flops counted; the value's "
+                                     "log and the Philox/Box-Muller work, ~60 % of the instructions, are not)"}})
+    # ---- configs 4 and 5: stepwise engines at full size, tuned step sizes from the committed fixtures
+    for cfg in (4, 5):
+        fix = json.load(open(os.path.join(REPO, "tests", "golden", f"fullsize_cfg{cfg}.json")))
+        n, p, C = fix["n"], fix["p"], 1024
+        X, y, _ = la.synthetic_logreg(n, p, seed=fix["data_seed"], beta_sd=fix["beta_sd"])
+        m = la.LogReg(X, y, np.array(fix["pscale"]), device=dev)
+        k = la.hmcKernel(m.lpost, m.glp, eps=fix["eps"], l=fix["l"], dmm=np.array(fix["dmm"]))
+        rng = np.random.Generator(np.random.Philox(4000 + cfg))
+        q0 = np.array(fix["map"]) + np.array(fix["laplace_sd"]) * rng.standard_normal((C, p))
+        cs = la.ChainSet(k, q0, seed=5, stream=stream)
+        iters = 4
+        ms = _timed_chainset(la, timer, cs, iters, 1)
+        evals = iters * fix["l"]  # per chain: L evaluations per iteration (the carried gradient saves the L+1-th)
+        per_eval_s = ms * 1e-3 / evals
+        fg = flops_per_grad_eval(n, p)
+        ach = C * fg / per_eval_s / 1e12
+        acc = float(cs.get_accepts().sum() / (C * (3 * iters + 1)))
+        row = {"config": cfg, "workload": f"HMC L={fix['l']} eps={fix['eps']} unit mass, synthetic n={n} p={p}, {C} chains"
+               + (" (one GPU's shard of 8192)" if cfg == 5 else ""), "kernel_variant": cs.plan(),
+               "chain_iterations_per_s": C * iters / (ms * 1e-3), "grad_evals_per_s": C * evals / (ms * 1e-3),
+               "accept_rate": acc, "us_per_evaluation_all_chains": per_eval_s * 1e6,
+               "timing": "HIP events around 4 iterations = 200 x (partial kernel + update kernel); per-evaluation time "
+                         "includes both kernels and the launch boundaries between them"}
+        if cfg == 4:
+            xbytes = 4 * n * (p + 1)
+            row["roofline"] = {"bound": "valu_fp32", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ach / PEAK_FP32_TFLOPS, "flops_per_grad_eval": fg,
+                               "x_pass_bytes": xbytes, "x_pass_GBps": xbytes / per_eval_s / 1e9,
+                               "hbm_frac": xbytes / per_eval_s / (HBM_PEAK_GBS * 1e9),
+                               "note": "SURVEY 8(d): report both; 1024 chains share every X pass (1.03 flop/B per chain "
+                                       "x 1024), so the fp32 vector ALU is the operative bound, not HBM"}
+        else:
+            row["roofline"] = {"bound": "mfma", "pipe": "bf16 MFMA (v_mfma_f32_16x16x32_bf16), fp32 accumulate",
+                               "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
+                               "frac_of_fp32_peak": ach / PEAK_FP32_TFLOPS, "flops_per_grad_eval": fg,
+                               "wide_precision": os.environ.get("LOGREG_WIDE_PRECISION", "default"),
+                               "note": "algorithmic flops counted once (SURVEY 8(d)); split-bf16 piece products are not counted"}
+        res.append(row)
+    return res
+
+
+def ess_per_draw(la, model, kern, q0, dev):
+    """ESS per kept draw (thin 20) from a SEPARATE run of 256 chains x 512 kept draws, Geyer IPS per chain."""
+    cs = la.ChainSet(kern, q0[:256], seed=SEED + 7)
+    cs.advance(1, 200, keep=False)
+    s = cs.advance(512, THIN).to_host()
+    ess = la.ess_pooled(s, max_chains=None)
+    return ess / (s.shape[0] * s.shape[1]), s.shape
+
+
+def dry_run(a, rank, world):
+    """Launch plumbing without a GPU: gloo group, shard offsets, gather to rank 0, max over ranks."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo")
+    C = a.chains
+    lo = rank * C  # weak scaling: chain_offset of this rank
+    out = torch.full((a.steps, C, N_PAR), float(rank))
+    t0 = time.perf_counter()
+    if world > 1:
+        gathered = [torch.empty_like(out) for _ in range(world)] if rank == 0 else None
+        dist.gather(out, gathered, dst=0)
+        dist.barrier()
+    wall = time.perf_counter() - t0
+    tw = torch.tensor([wall], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        ok = world == 1 or all(float(g[0, 0, 0]) == r for r, g in enumerate(gathered))
+        print(json.dumps({"dry_run": True, "metric": "MCMC iterations/sec x chains for HMC (L=50) on n=200,p=8", "value": None,
+                          "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "chain_offsets": [r * C for r in range(world)],
+                          "this_rank_offset": lo, "gather_ok": bool(ok), "scaling": "weak"}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -90,6 +242,8 @@ def main():
     ap.add_argument("--mode", default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ess", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the configs 3/4/5 sub-results")
+    ap.add_argument("--dry-run", action="store_true", help="launch plumbing only (gloo, no GPU work)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -98,6 +252,8 @@ def main():
     if world != a.gpus:
         if rank == 0:
             print(f"warning: WORLD_SIZE={world} != --gpus {a.gpus}; using WORLD_SIZE", file=sys.stderr)
+    if a.dry_run:
+        return dry_run(a, rank, world)
     dist = None
     if world > 1 or os.environ.get("LOGREG_BENCH_FORCE_DIST") == "1":  # the env var exercises the RCCL path at N=1
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -123,7 +279,6 @@ def main():
     model = la.LogReg(X, y, pscale, dtype="float32", device=dev)
     kern = la.hmcKernel(model.lpost, model.glp, eps=EPS, l=LEAP, dmm=np.ones(N_PAR))
     L = _lib.load()
-    import ctypes as Ct
     stream = Ct.c_void_p()
     _lib.check(L.lr_stream_create(dev, Ct.byref(stream)))
     cs = la.ChainSet(kern, q0, seed=SEED, chain_offset=rank * C, group=a.group, mode=a.mode, stream=stream)
@@ -137,9 +292,7 @@ def main():
         one_step(i, True)
     cs.sync()
 
-    ev0, ev1 = Ct.c_void_p(), Ct.c_void_p()
-    _lib.check(L.lr_event_create(dev, Ct.byref(ev0)))
-    _lib.check(L.lr_event_create(dev, Ct.byref(ev1)))
+    timer = Timer(L, _lib.check, dev, stream)
     gathered = None
     if dist is not None:
         import torch
@@ -150,10 +303,10 @@ def main():
         torch.cuda.synchronize()
     acc0 = cs.get_accepts().astype(np.int64).sum()
     t0 = time.perf_counter()
-    _lib.check(L.lr_event_record(dev, ev0, stream))
+    timer.start()
     for i in range(a.steps):
         one_step(i, True)
-    _lib.check(L.lr_event_record(dev, ev1, stream))
+    _lib.check(L.lr_event_record(dev, timer.e1, stream))
     cs.sync()
     if dist is not None:
         dist.gather(tout, gathered, dst=0)  # RCCL gather of the thinned samples to rank 0
@@ -161,7 +314,8 @@ def main():
         dist.barrier()
     t1 = time.perf_counter()
     ms = Ct.c_float()
-    _lib.check(L.lr_event_elapsed_ms(dev, ev0, ev1, Ct.byref(ms)))
+    _lib.check(L.lr_event_elapsed_ms(dev, timer.e0, timer.e1, Ct.byref(ms)))
+    kernel_ms_total = float(ms.value)
     wall = t1 - t0
     acc = cs.get_accepts().astype(np.int64).sum() - acc0
     if dist is not None:
@@ -175,13 +329,14 @@ def main():
     if rank == 0:
         iters_total = world * C * a.steps * THIN
         grad_evals = iters_total * LEAP  # executed: the gradient at the current state is carried, L per iteration
-        kern_s = ms.value / 1e3 / a.steps  # average launch duration from HIP events on the launch stream
+        kern_s = kernel_ms_total / 1e3 / a.steps  # average launch duration from HIP events on the launch stream
         fg = flops_per_grad_eval(N_ROWS, N_PAR)
         achieved = C * THIN * LEAP * fg / kern_s / 1e12
         alg_bytes = C * N_PAR * 4 * 3 + C * 4 + N_ROWS * N_PAR * 4  # state r/w + sample + accepts + X once
+        value = iters_total / wall
         line = {
             "metric": "MCMC iterations/sec x chains for HMC (L=50) on n=200,p=8",
-            "value": iters_total / wall,
+            "value": value,
             "unit": "chain-iterations/s",
             "n_gpus": world,
             "steps": a.steps,
@@ -189,7 +344,8 @@ def main():
             "ms_per_step": 1e3 * wall / a.steps,
             "higher_is_better": True,
             "scaling": "weak",
-            "vs_baseline": None,
+            # BASELINE.md's number for this metric: the reference's own fit-np-hmc.py, 1 368 it/s x 1 chain (1 core)
+            "vs_baseline": value / REFERENCE_CPU["it_per_s"],
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "HMC L=50 eps=0.1 unit-mass, n=200 p=8 synthetic logistic regression, "
@@ -198,9 +354,10 @@ def main():
                        "kernel_variant": plan, "parallelism": f"chains sharded x{world}" + (" + RCCL gather" if world > 1 else "")},
             "grad_evals_per_s": grad_evals / wall,
             "accept_rate": acc / iters_total,
-            # compute-bound: priced against the dense fp32 peak (157.3 TFLOP/s: the fp32-input MFMA peak and the
-            # fp32 vector-ALU peak are the same number and the same multipliers); `pipe` says which one runs
-            "roofline": {"bound": "mfma", "pipe": "fp32 vector ALU (v_pk_fma_f32) + transcendental unit",
+            "reference_cpu": REFERENCE_CPU,
+            # compute-bound on the fp32 VECTOR ALU (MFMA busy = 0 in the PMC passes): priced against the dense fp32
+            # peak, 157.3 TFLOP/s (the guide's figure for v_pk_fma_f32 and for fp32-input MFMA alike)
+            "roofline": {"bound": "valu_fp32", "pipe": "fp32 vector ALU (v_pk_fma_f32) + transcendental unit",
                          "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
                          "kernel_ms": kern_s * 1e3,
@@ -210,28 +367,36 @@ def main():
                          "flops_per_grad_eval": fg, "grad_evals_per_launch": C * THIN * LEAP,
                          "algorithmic_hbm_bytes_per_launch": alg_bytes,
                          "hbm_GBps_algorithmic": alg_bytes / kern_s / 1e9,
-                         "note": "X lives in VGPRs for the whole launch: the path is compute-bound on the fp32 "
-                                 "multipliers (dense fp32 peak 157.3 TFLOP/s, shared by v_pk_fma_f32 and fp32-input "
-                                 "MFMA), not HBM-bound (8 TB/s: see hbm_frac); see DESIGN.md section 5"},
+                         "note": "X lives in VGPRs for the whole launch: the path is compute-bound on the fp32 vector "
+                                 "ALU, not HBM-bound (8 TB/s: see hbm_frac) and not on the matrix cores; DESIGN.md section 5"},
         }
         # HBM traffic of the same launch from the committed rocprofv3 PMC passes (profiles/), if they
         # were taken for this kernel variant and shape
-        try:
-            tr = json.load(open(os.path.join(REPO, "profiles", "r1_traffic.json")))
-            if tr["kernel_variant"] == plan and tr["chains"] == C and tr["thin"] == THIN:
-                line["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
-                line["roofline"]["traffic_source"] = "profiles/r1_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)"
-                line["roofline"]["hbm_GBps_measured"] = tr["hbm_bytes_per_launch"] / kern_s / 1e9
-                line["roofline"]["hbm_frac"] = tr["hbm_bytes_per_launch"] / kern_s / (HBM_PEAK_GBS * 1e9)
-        except (OSError, KeyError, ValueError):
-            pass
+        for name in ("r2_traffic.json", "r1_traffic.json"):
+            try:
+                tr = json.load(open(os.path.join(REPO, "profiles", name)))
+                if tr["kernel_variant"] == plan and tr["chains"] == C and tr["thin"] == THIN:
+                    line["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+                    line["roofline"]["traffic_source"] = f"profiles/{name} (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)"
+                    line["roofline"]["hbm_GBps_measured"] = tr["hbm_bytes_per_launch"] / kern_s / 1e9
+                    line["roofline"]["hbm_frac"] = tr["hbm_bytes_per_launch"] / kern_s / (HBM_PEAK_GBS * 1e9)
+                    break
+            except (OSError, KeyError, ValueError):
+                pass
         if not a.no_ess:
-            samples = out.to_host()  # rank 0's chains, [steps, C, p]
-            ess = la.ess_pooled(samples, max_chains=64)
-            line["min_ess_per_s"] = float(world * ess.min() / wall)
-            line["ess_note"] = "Geyer IPS per chain, summed over chains (64-chain subsample scaled), rank 0 x n_gpus"
+            eff, shape = ess_per_draw(la, model, kern, q0, dev)
+            draws_per_s = world * C * a.steps / wall
+            line["min_ess_per_s"] = float(eff.min() * draws_per_s)
+            line["ess"] = {"ess_per_kept_draw_min": float(eff.min()), "ess_per_kept_draw_max": float(eff.max()),
+                           "kept_draws_per_s": draws_per_s,
+                           "estimator": f"Geyer initial-positive-sequence per chain on a separate run of {shape[1]} chains x "
+                                        f"{shape[0]} kept draws (thin {THIN}), outside the timed region; min over the {N_PAR} "
+                                        "parameters; ESS/s = ESS per kept draw x kept draws/s of the timed run",
+                           "reference_min_ess_per_s": REFERENCE_CPU["min_ess_per_s"]}
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(X, y, pscale, init)
+        if world == 1 and not a.no_extra:
+            line["extra"] = {"configs": extra_configs(la, L, _lib.check, dev, stream)}
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -50,8 +50,11 @@ enum { LR_F32 = 0, LR_F64 = 1 };
 /* where the data rows live / which pipe does the matvecs: REG/LDS/GLOBAL use the vector ALU with rows in
  * VGPRs / LDS / memory; MFMA uses the fp32 matrix cores with rows in VGPRs (p = 8, small n; there `group`
  * selects the row-split ways S in {1,4} instead of lanes per chain); STEPWISE is the tall-data engine: two
- * small kernels per log-posterior evaluation, the rows split into slices across the whole chip (`group` is
- * ignored; lr_plan reports the slice count as group_out and the slice length as rows_out) */
+ * small kernels per log-posterior evaluation, the rows split into slices across the whole chip (`group` = 0
+ * lets the library choose the slice count from the chain count, `group` > 0 requests that many slices; lr_plan
+ * reports the slice count as group_out and the slice length as rows_out).  Slice partials are summed in slice
+ * order, so launches of different chain counts are bit-identical only under the same slice count: a sharded
+ * run that wants bit-exact agreement with the one-GPU run passes the one-GPU plan's group_out explicitly */
 enum { LR_MODE_AUTO = -1, LR_MODE_REG = 0, LR_MODE_LDS = 1, LR_MODE_GLOBAL = 2, LR_MODE_MFMA = 3, LR_MODE_STEPWISE = 4 };
 
 typedef struct lr_model lr_model;
@@ -67,9 +70,19 @@ typedef struct lr_run_opts {
     int32_t mode;         /* LR_MODE_*: where the data rows live during the launch */
     int32_t on_device;    /* see conventions */
     void* stream;         /* hipStream_t when on_device = 1 */
+    /* streaming posterior statistics (optional; see "Streaming statistics" below) */
+    double* stats;        /* NULL, or [stats_slots][C][2][p] running (mean, M2) per batch of kept samples */
+    int64_t stats_batch;  /* B >= 1: kept samples per batch slot */
+    int64_t stats_first;  /* index, within the statistics window, of this call's first kept sample */
+    int64_t stats_slots;  /* slots in the buffer: stats_first + iters <= stats_slots * stats_batch */
 } lr_run_opts;
 
 LR_API const char* lr_last_error(void);
+/* content hash of the sources this library was compiled from (logreg_amd/build.py: source_hash): the binding
+ * refuses a library whose id differs from the sources beside it */
+LR_API const char* lr_build_id(void);
+/* sizeof(lr_run_opts) as this library was compiled: a binding in another language checks its struct layout */
+LR_API int lr_sizeof_run_opts(void);
 LR_API int lr_device_count(void);
 /* number of compute units of `device` (<0 on error) */
 LR_API int lr_device_cus(int device);
@@ -119,6 +132,38 @@ LR_API int lr_run_ul(lr_model* m, void* state, double dt, const double* pre, con
 /* hmcKernel(lpi, glpi, eps, l, dmm) with its own mhKernel: fit-np-hmc.py:56-87 */
 LR_API int lr_run_hmc(lr_model* m, void* state, double eps, int32_t l, const double* dmm,
                       const lr_run_opts* opts, void* out, uint32_t* accepts);
+
+/*
+ * lpost, glp and the NEGATIVE Hessian of lpost at ONE beta, in float64 arithmetic whatever the model's dtype:
+ *     hess = X^T W X + diag(1 / prior_sd^2),  W = diag(sigma(eta) (1 - sigma(eta)))       [p,p], symmetric
+ * One pass over the rows on the device.  Serves the warm start that replaces the reference's SciPy call
+ * `minimize(-lpost, init, jac=-glp, method='BFGS')` (fit-np-hmc.py:49) with Newton's method, the closed-form
+ * Hessian being the one of the reference's JAX variant (fit-jax-hmc.py:61-79).  beta [p], grad [p], hess [p,p]
+ * and lpost are HOST doubles; any output may be NULL.  Synchronous.
+ */
+LR_API int lr_hessian(lr_model* m, const double* beta, double* lpost, double* grad, double* hess, void* stream);
+
+/*
+ * Streaming statistics: the on-device replacement for keeping every thinned sample when only a posterior summary
+ * is wanted.  The reference post-processes the full [iters, p] matrix: scipy.stats.describe in
+ * fit-np-hmc.py:113-117 and smfsb::mcmcSummary in Python/analyse.R:17-19; with 65 536 chains that matrix is tens
+ * of GB.  When opts->stats is set every lr_run_* call folds each kept sample into the running (mean, M2) of its
+ * batch slot (Welford; the first sample of a slot initialises it, so the buffer needs no clearing):
+ *     stats[b][c][0][j] = mean, stats[b][c][1][j] = sum of squared deviations, of parameter j of chain c over
+ *     the kept samples [b*B, (b+1)*B) of the statistics window
+ * lr_stats_reduce turns the buffer (DEVICE memory) into chain-pooled sums, rows of `sums` [LR_STATS_ROWS][p]
+ * (HOST doubles), with n = kept samples per chain, nb = n / B full batches, piv = pivot[j]:
+ *     0  sum_c n (mean_c - piv)              1  sum_c n (mean_c - piv)^2       2  sum_c M2_c
+ *     3  sum_h (mean_h - piv)   over the 2C half-chains (first / second nb/2 batches; nb even, else 0)
+ *     4  sum_h (mean_h - piv)^2              5  sum_h M2_h / (n_h - 1)
+ *     6  sum_c sum_b (batchmean_cb - mean_c)^2   over the full batches
+ * Sums are additive over chain shards (one all-reduce across GPUs); logreg_amd/diagnostics.py turns them into
+ * mean, sd (ddof = 1), split-R-hat and batch-means ESS.  `pivot` only has to be near the posterior (it removes
+ * cancellation from the squared sums); every shard must pass the same one.
+ */
+#define LR_STATS_ROWS 7
+LR_API int lr_stats_reduce(int device, const double* stats, int64_t n_chains, int32_t p, int64_t batch, int64_t kept,
+                           const double* pivot, double* sums, void* stream);
 
 /*
  * Which kernel variant the library would launch for (model, n_chains, group, mode):

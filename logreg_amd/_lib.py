@@ -12,6 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "liblogreg_hip.so")
 
 LR_F32, LR_F64 = 0, 1
+STATS_ROWS = 7  # LR_STATS_ROWS
 MODE_AUTO, MODE_REG, MODE_LDS, MODE_GLOBAL, MODE_MFMA, MODE_STEPWISE = -1, 0, 1, 2, 3, 4
 MODE_NAMES = {MODE_REG: "reg", MODE_LDS: "lds", MODE_GLOBAL: "global", MODE_MFMA: "mfma", MODE_STEPWISE: "stepwise"}
 MODE_BY_NAME = {"auto": MODE_AUTO, "reg": MODE_REG, "lds": MODE_LDS, "global": MODE_GLOBAL, "mfma": MODE_MFMA, "stepwise": MODE_STEPWISE}
@@ -24,7 +25,8 @@ class LogregHipError(RuntimeError):
 class RunOpts(C.Structure):
     _fields_ = [("n_chains", C.c_int64), ("chain_offset", C.c_int64), ("thin", C.c_int64), ("iters", C.c_int64),
                 ("iter_offset", C.c_int64), ("seed", C.c_uint64), ("group", C.c_int32), ("mode", C.c_int32),
-                ("on_device", C.c_int32), ("stream", C.c_void_p)]
+                ("on_device", C.c_int32), ("stream", C.c_void_p),
+                ("stats", C.c_void_p), ("stats_batch", C.c_int64), ("stats_first", C.c_int64), ("stats_slots", C.c_int64)]
 
 
 # name -> (restype, argtypes); every symbol include/logreg_hip.h declares
@@ -32,6 +34,8 @@ _vp, _dp, _i32, _i64, _u64 = C.c_void_p, C.POINTER(C.c_double), C.c_int32, C.c_i
 _op = C.POINTER(RunOpts)
 SYMBOLS = {
     "lr_last_error": (C.c_char_p, []),
+    "lr_build_id": (C.c_char_p, []),
+    "lr_sizeof_run_opts": (C.c_int, []),
     "lr_device_count": (C.c_int, []),
     "lr_device_cus": (C.c_int, [C.c_int]),
     "lr_model_create": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _i32, _i32, C.POINTER(_vp)]),
@@ -42,6 +46,8 @@ SYMBOLS = {
     "lr_run_mala": (C.c_int, [_vp, _vp, _vp, C.c_double, _vp, _op, _vp, _vp]),
     "lr_run_ul": (C.c_int, [_vp, _vp, C.c_double, _vp, _op, _vp, _vp]),
     "lr_run_hmc": (C.c_int, [_vp, _vp, C.c_double, _i32, _vp, _op, _vp, _vp]),
+    "lr_hessian": (C.c_int, [_vp, _vp, _dp, _vp, _vp, _vp]),
+    "lr_stats_reduce": (C.c_int, [C.c_int, _vp, _i64, _i32, _i64, _i64, _vp, _vp, _vp]),
     "lr_plan": (C.c_int, [_vp, _i64, _i32, _i32, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
     "lr_malloc": (C.c_int, [C.c_int, _u64, C.POINTER(_vp)]),
     "lr_free": (C.c_int, [C.c_int, _vp]),
@@ -65,13 +71,13 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        from . import build as _build
+    from . import build as _build
+    if _build.needs_build():  # missing, or older than a kernel source / the header: never run stale kernels
         try:
             _build.build(verbose=False)
         except Exception as e:  # no hipcc / compile error: loud, no fallback
             raise LogregHipError(
-                f"liblogreg_hip.so is missing ({LIB_PATH}) and could not be built: {e}. "
+                f"liblogreg_hip.so is missing or stale ({LIB_PATH}) and could not be built: {e}. "
                 "Run `python -m logreg_amd.build`. There is no CPU fallback.") from e
     try:
         L = C.CDLL(LIB_PATH)
@@ -81,6 +87,12 @@ def load():
         fn = getattr(L, name)  # AttributeError if the ABI and the binding drift apart
         fn.restype = res
         fn.argtypes = args
+    have, want = L.lr_build_id().decode(), _build.source_hash()
+    if have != want:
+        raise LogregHipError(f"{LIB_PATH} was built from other sources (build id {have}, sources {want}); "
+                             "run `python -m logreg_amd.build --force`")
+    if L.lr_sizeof_run_opts() != C.sizeof(RunOpts):
+        raise LogregHipError(f"lr_run_opts is {L.lr_sizeof_run_opts()} bytes in the library, {C.sizeof(RunOpts)} in the binding")
     _lib = L
     return L
 

@@ -45,11 +45,33 @@ def _sources():
     return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))] + [os.path.join(INCLUDE, "logreg_hip.h")]
 
 
+BUILD_ID_FILE = os.path.join(LIBDIR, "build_id.txt")
+
+
+def source_hash() -> str:
+    """Content hash of every kernel source, the ABI header and the compile flags: the library carries it
+    (`lr_build_id()`), so a stale .so is recognised whatever the file times say (the library is git-ignored and
+    travels to the GPU box inside a snapshot whose mtimes mean nothing)."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in _sources():
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(f for f in COMMON if not os.path.isabs(f)).encode())  # flags without the -I paths
+    return h.hexdigest()[:16]
+
+
+def built_id() -> str | None:
+    try:
+        with open(BUILD_ID_FILE) as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
 def needs_build() -> bool:
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(s) > t for s in _sources())
+    return not os.path.exists(LIB) or built_id() != source_hash()
 
 
 def _run(cmd):
@@ -80,7 +102,8 @@ def build(force: bool = False, jobs: int | None = None, verbose: bool = True) ->
                           os.path.join(CSRC, "lr_inst_wide.hip"), "-o", obj])
     api_obj = os.path.join(OBJDIR, "lr_api.o")
     objs.append(api_obj)
-    jobs_list.append([hipcc, *COMMON, "-c", os.path.join(CSRC, "lr_api.hip"), "-o", api_obj])
+    bid = source_hash()
+    jobs_list.append([hipcc, *COMMON, f'-DLR_BUILD_ID="{bid}"', "-c", os.path.join(CSRC, "lr_api.hip"), "-o", api_obj])
     jobs = jobs or min(len(jobs_list), max(1, (os.cpu_count() or 2)))
     if verbose:
         print(f"[logreg_amd.build] compiling {len(jobs_list)} units for {ARCH} with {jobs} jobs", flush=True)
@@ -89,6 +112,8 @@ def build(force: bool = False, jobs: int | None = None, verbose: bool = True) ->
             if warn.strip() and verbose:
                 print(warn, file=sys.stderr)
     _run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB, *objs])
+    with open(BUILD_ID_FILE, "w") as f:
+        f.write(bid + "\n")
     if verbose:
         print(f"[logreg_amd.build] wrote {LIB}", flush=True)
     return LIB

@@ -14,6 +14,8 @@
 
 #include "lr_inst.h"
 #include "lr_kernels.h"
+#include "lr_hessian.h"
+#include "lr_stats.h"
 #include "lr_tall.h"
 #include "lr_wide_bf16.h"
 
@@ -74,8 +76,11 @@ struct lr_model {
     double lprior_const = 0;
     const lr::InstTable* table = nullptr;
     void* d_xblk = nullptr;  // wide models: per-32-row-block bf16-piece images of the rows (lr_wide_bf16.h)
-    void* ws = nullptr;  // stepwise-engine workspace (grow-only, owned by the handle)
-    size_t ws_bytes = 0;
+    // stepwise-engine workspaces, one per stream (grow-only, owned by the handle): calls enqueued on ONE stream
+    // run in order, so they may share a workspace; calls on different streams overlap on the device and get
+    // disjoint ones (two ChainSets of one model on two streams, or an eval on the NULL stream beside a run)
+    struct Ws { hipStream_t stream; void* p; size_t bytes; };
+    std::vector<Ws> ws;
     size_t esize() const { return dtype == LR_F32 ? 4 : 8; }
 };
 
@@ -121,6 +126,7 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
         const int64_t per_cu = env && std::atoi(env) > 0 ? std::atoi(env)
                                : (wide_engine(m, C) != 0 ? 1 : (tiles_at_2 >= 32 ? 2 : 1));
         int64_t RS = (per_cu * m->cus + blocks - 1) / blocks;
+        if (group > 0) RS = group;  // explicit slice count: pins the summation order whatever the chain count
         int64_t slice_len = (m->n + RS - 1) / RS;
         slice_len = (slice_len + 31) / 32 * 32;  // whole 32-row blocks (the bf16 kernel's K = 32)
         RS = (m->n + slice_len - 1) / slice_len;
@@ -145,6 +151,7 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
         const int64_t NW = raw >= 16 ? 16 : (raw >= 8 ? 8 : 4);
         const int64_t waves_per_slice = NW * ((C + 63) / 64);
         int64_t RS = (4 * want_waves + waves_per_slice - 1) / waves_per_slice;
+        if (mode == LR_MODE_STEPWISE && group > 0) RS = group;  // explicit slice count (see the wide branch)
         int64_t slice_len = (m->n + RS - 1) / RS;
         if (slice_len < 16 * NW) slice_len = 16 * NW;  // at least 16 rows per wave
         slice_len = (slice_len + 1) & ~(int64_t)1;      // even: the float32 kernel walks row pairs
@@ -265,6 +272,7 @@ int do_chain_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs, c
         ca.d[j] = (T)(rs.b[j] * ks);
         ca.e[j] = (T)(m->inv_var[j] / ks);
     }
+    ca.stats = lr::StatsArgs{o->stats, o->stats_batch, o->stats_first};
     lr::LaunchCfg cfg{pl.mode, pl.G, pl.R, rs.kind, st, pl.lds_bytes};
     const int rc = m->table->launch_chain(&cfg, o->n_chains, &ma, &ca);
     if (rc != 0) return fail(rc == -3 ? LR_ERR_UNSUPPORTED : LR_ERR_HIP, "chain launch failed (%d): %s", rc,
@@ -273,21 +281,37 @@ int do_chain_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs, c
 }
 
 template <typename T, int P>
-int setup_tall(lr_model* m, const Plan& pl, int64_t C, lr::TallArgs<T, P>* pa) {
+int setup_tall(lr_model* m, const Plan& pl, hipStream_t st, int64_t C, lr::TallArgs<T, P>* pa) {
     lr::TallArgs<T, P>& a = *pa;
     const int RS = pl.G;
     auto align = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t vec = align((size_t)C * P * sizeof(T)), dbl = align((size_t)C * sizeof(double));
     const size_t need = 4 * vec + 2 * dbl + align((size_t)C * 4) + align((size_t)RS * C * P * sizeof(T)) +
                         align((size_t)RS * C * sizeof(double));
-    if (need > m->ws_bytes) {
-        if (m->ws) (void)hipFree(m->ws);
-        m->ws = nullptr;
-        m->ws_bytes = 0;
-        if (hipMalloc(&m->ws, need) != hipSuccess) return fail(LR_ERR_NOMEM, "stepwise workspace of %zu bytes", need);
-        m->ws_bytes = need;
+    lr_model::Ws* slot = nullptr;
+    for (auto& e : m->ws)
+        if (e.stream == st) slot = &e;
+    if (!slot) {
+        if (m->ws.size() >= 16) {  // a caller cycling through streams: drop every workspace once all work is done
+            if (hipDeviceSynchronize() != hipSuccess) return fail(LR_ERR_HIP, "hipDeviceSynchronize failed");
+            for (auto& e : m->ws)
+                if (e.p) (void)hipFree(e.p);
+            m->ws.clear();
+        }
+        m->ws.push_back({st, nullptr, 0});
+        slot = &m->ws.back();
     }
-    unsigned char* w = static_cast<unsigned char*>(m->ws);
+    if (need > slot->bytes) {
+        if (slot->p) {
+            // work already enqueued on this stream may still use the old block: hipFree waits for the device
+            (void)hipFree(slot->p);
+        }
+        slot->p = nullptr;
+        slot->bytes = 0;
+        if (hipMalloc(&slot->p, need) != hipSuccess) return fail(LR_ERR_NOMEM, "stepwise workspace of %zu bytes", need);
+        slot->bytes = need;
+    }
+    unsigned char* w = static_cast<unsigned char*>(slot->p);
     auto carve = [&](size_t b) { unsigned char* r = w; w += b; return r; };
     std::memset(&a, 0, sizeof(a));
     a.rows = static_cast<const T*>(m->d_rows);
@@ -322,7 +346,7 @@ template <typename T, int P>
 int do_eval_stepwise_t(lr_model* m, const Plan& pl, hipStream_t st, int64_t C, const void* beta, void* ll, void* lprior,
                        void* lpost, void* grad) {
     lr::TallArgs<T, P> a;
-    int rc = setup_tall<T, P>(m, pl, C, &a);
+    int rc = setup_tall<T, P>(m, pl, st, C, &a);
     if (rc) return rc;
     a.state = static_cast<T*>(const_cast<void*>(beta));
     a.ev_ll = static_cast<T*>(ll);
@@ -342,7 +366,7 @@ int do_stepwise_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs
                   double* lp_state, void* out, uint32_t* accepts) {
     const int64_t C = o->n_chains;
     lr::TallArgs<T, P> a;
-    int rc = setup_tall<T, P>(m, pl, C, &a);
+    int rc = setup_tall<T, P>(m, pl, st, C, &a);
     if (rc) return rc;
     a.state = static_cast<T*>(state);
     a.lp_state = lp_state;
@@ -359,6 +383,7 @@ int do_stepwise_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs
         a.b[j] = (T)rs.b[j];
         a.c[j] = (T)rs.c[j];
     }
+    a.stats = lr::StatsArgs{o->stats, o->stats_batch, o->stats_first};
     const lr::InstTable* t = m->table;
     auto U = [&](int phase, int64_t iter, int64_t out_row, int bn) {
         if (!rc) rc = t->launch_tall_update(st, rs.kind, phase, iter, out_row, bn, &a);
@@ -457,6 +482,14 @@ int check_opts(const lr_model* m, const lr_run_opts* o, bool run) {
         if (o->chain_offset < 0 || o->iter_offset < 0) return fail(LR_ERR_INVALID, "offsets must be >= 0");
         if ((uint64_t)(o->chain_offset + o->n_chains) > 0xFFFFFFFFull)
             return fail(LR_ERR_INVALID, "global chain ids must fit 32 bits");
+        if (o->stats) {
+            if (o->stats_batch < 1 || o->stats_first < 0 || o->stats_slots < 1)
+                return fail(LR_ERR_INVALID, "stats needs stats_batch >= 1, stats_first >= 0, stats_slots >= 1");
+            if (o->stats_first + o->iters > o->stats_slots * o->stats_batch)
+                return fail(LR_ERR_INVALID, "stats buffer too small: kept samples %lld..%lld need more than %lld slots of %lld",
+                            (long long)o->stats_first, (long long)(o->stats_first + o->iters), (long long)o->stats_slots,
+                            (long long)o->stats_batch);
+        }
     }
     return LR_OK;
 }
@@ -488,17 +521,25 @@ int run_common(lr_model* m, const RunSpec& rs, const lr_run_opts* o, void* state
     const size_t es = m->esize();
     const size_t sbytes = (size_t)o->n_chains * m->p * es;
     const size_t obytes = out ? (size_t)o->iters * o->n_chains * m->p * es : 0;
-    DevBuf ds, dl, dout, dacc;
+    DevBuf ds, dl, dout, dacc, dstats;
     if (ds.alloc(sbytes) || dl.alloc(o->n_chains * sizeof(double)) || dout.alloc(obytes) ||
         dacc.alloc(o->n_chains * sizeof(uint32_t)))
         return fail(LR_ERR_NOMEM, "device allocation failed (%zu bytes of samples)", obytes);
+    lr_run_opts od = *o;  // device-side view of the options: the statistics buffer is staged like the other arrays
+    const size_t stbytes = o->stats ? (size_t)o->stats_slots * o->n_chains * 2 * m->p * sizeof(double) : 0;
+    if (o->stats) {
+        if (dstats.alloc(stbytes)) return fail(LR_ERR_NOMEM, "device allocation failed (%zu bytes of statistics)", stbytes);
+        LR_HIP(hipMemcpy(dstats.p, o->stats, stbytes, hipMemcpyHostToDevice));
+        od.stats = static_cast<double*>(dstats.p);
+    }
     LR_HIP(hipMemcpy(ds.p, state, sbytes, hipMemcpyHostToDevice));
     if (threaded) LR_HIP(hipMemcpy(dl.p, lp_state, o->n_chains * sizeof(double), hipMemcpyHostToDevice));
     if (accepts) LR_HIP(hipMemcpy(dacc.p, accepts, o->n_chains * sizeof(uint32_t), hipMemcpyHostToDevice));
-    rc = do_chain(m, pl, nullptr, rs, o, ds.p, threaded ? (double*)dl.p : nullptr, out ? dout.p : nullptr,
+    rc = do_chain(m, pl, nullptr, rs, &od, ds.p, threaded ? (double*)dl.p : nullptr, out ? dout.p : nullptr,
                   accepts ? (uint32_t*)dacc.p : nullptr);
     if (rc) return rc;
     LR_HIP(hipDeviceSynchronize());
+    if (o->stats) LR_HIP(hipMemcpy(o->stats, dstats.p, stbytes, hipMemcpyDeviceToHost));
     LR_HIP(hipMemcpy(state, ds.p, sbytes, hipMemcpyDeviceToHost));
     if (threaded) LR_HIP(hipMemcpy(lp_state, dl.p, o->n_chains * sizeof(double), hipMemcpyDeviceToHost));
     if (out) LR_HIP(hipMemcpy(out, dout.p, obytes, hipMemcpyDeviceToHost));
@@ -519,6 +560,12 @@ int positive_vec(const char* name, const double* v, int p) {
 extern "C" {
 
 const char* lr_last_error(void) { return g_err; }
+
+#ifndef LR_BUILD_ID
+#define LR_BUILD_ID "unversioned"
+#endif
+const char* lr_build_id(void) { return LR_BUILD_ID; }
+int lr_sizeof_run_opts(void) { return (int)sizeof(lr_run_opts); }
 
 int lr_device_count(void) {
     int n = 0;
@@ -627,7 +674,8 @@ void lr_model_destroy(lr_model* m) {
     (void)hipSetDevice(m->device);
     if (m->d_rows) (void)hipFree(m->d_rows);
     if (m->d_rows_tw) (void)hipFree(m->d_rows_tw);
-    if (m->ws) (void)hipFree(m->ws);
+    for (auto& e : m->ws)
+        if (e.p) (void)hipFree(e.p);
     if (m->d_xblk) (void)hipFree(m->d_xblk);
     delete m;
 }
@@ -645,6 +693,9 @@ int lr_model_info(const lr_model* m, int64_t* n, int32_t* p, int32_t* dtype, int
 int lr_plan(const lr_model* m, int64_t n_chains, int32_t group, int32_t mode, int32_t* mode_out, int32_t* group_out,
             int32_t* rows_out) {
     if (!m) return fail(LR_ERR_INVALID, "model is NULL");
+    if (n_chains <= 0) return fail(LR_ERR_INVALID, "n_chains must be positive (got %lld)", (long long)n_chains);
+    if (group < 0 || group > 64 || (group & (group - 1)))
+        return fail(LR_ERR_INVALID, "group must be 0 or a power of two <= 64 (got %d)", group);
     Plan pl;
     const int rc = make_plan(m, n_chains, group, mode, &pl);
     if (rc) return rc;
@@ -740,6 +791,83 @@ int lr_run_hmc(lr_model* m, void* state, double eps, int32_t l, const double* dm
         rs.c[j] = 1.0 / dmm[j];
     }
     return run_common(m, rs, o, state, nullptr, out, accepts);
+}
+
+int lr_hessian(lr_model* m, const double* beta, double* lpost, double* grad, double* hess, void* stream) {
+    if (!m) return fail(LR_ERR_INVALID, "model is NULL");
+    if (!beta) return fail(LR_ERR_INVALID, "beta is NULL");
+    LR_HIP(hipSetDevice(m->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int p = m->p, NE = p * (p + 1) / 2, width = NE + p + 1;
+    const int64_t nblocks = (m->n + lr::kHessRows - 1) / lr::kHessRows;
+    DevBuf scratch;
+    if (scratch.alloc(((size_t)nblocks * width + width + p) * sizeof(double))) return fail(LR_ERR_NOMEM, "lr_hessian scratch");
+    double* d_part = static_cast<double*>(scratch.p);
+    double* d_sums = d_part + (size_t)nblocks * width;
+    double* d_beta = d_sums + width;
+    LR_HIP(hipMemcpyAsync(d_beta, beta, (size_t)p * sizeof(double), hipMemcpyHostToDevice, st));
+    const size_t lds = ((size_t)lr::kHessRows * p + 3 * lr::kHessRows + p) * sizeof(double);
+    if (m->dtype == LR_F32)
+        hipLaunchKernelGGL((lr::k_hess_partial<float>), dim3((unsigned)nblocks), dim3(256), lds, st,
+                           static_cast<const float*>(m->d_rows), m->n, m->P, p, d_beta, d_part);
+    else
+        hipLaunchKernelGGL((lr::k_hess_partial<double>), dim3((unsigned)nblocks), dim3(256), lds, st,
+                           static_cast<const double*>(m->d_rows), m->n, m->P, p, d_beta, d_part);
+    LR_HIP(hipGetLastError());
+    hipLaunchKernelGGL(lr::k_hess_final, dim3((width + 255) / 256), dim3(256), 0, st, d_part, nblocks, width, d_sums);
+    LR_HIP(hipGetLastError());
+    std::vector<double> h(width);
+    LR_HIP(hipMemcpyAsync(h.data(), d_sums, (size_t)width * sizeof(double), hipMemcpyDeviceToHost, st));
+    LR_HIP(hipStreamSynchronize(st));
+    if (hess) {
+        int e = 0;
+        for (int a = 0; a < p; ++a)
+            for (int c = a; c < p; ++c, ++e) hess[a * p + c] = hess[c * p + a] = h[e];
+        for (int j = 0; j < p; ++j) hess[j * p + j] += m->inv_var[j];
+    }
+    if (grad)
+        for (int j = 0; j < p; ++j) grad[j] = h[NE + j] - beta[j] * m->inv_var[j];
+    if (lpost) {
+        double quad = 0.0;
+        for (int j = 0; j < p; ++j) quad += beta[j] * beta[j] * m->inv_var[j];
+        *lpost = h[NE + p] + m->lprior_const - 0.5 * quad;
+    }
+    return LR_OK;
+}
+
+int lr_stats_reduce(int device, const double* stats, int64_t n_chains, int32_t p, int64_t batch, int64_t kept,
+                    const double* pivot, double* sums, void* stream) {
+    if (!stats || !pivot || !sums) return fail(LR_ERR_INVALID, "NULL argument");
+    if (n_chains <= 0 || p <= 0 || p > kMaxP || batch < 1 || kept < 0)
+        return fail(LR_ERR_INVALID, "lr_stats_reduce: need n_chains > 0, 0 < p <= %d, batch >= 1, kept >= 0", kMaxP);
+    LR_HIP(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    int PW = 1;
+    while (PW < p) PW *= 2;
+    const int CY = 256 / PW;
+    const int64_t nblocks = (n_chains + CY - 1) / CY;
+    const size_t part_bytes = (size_t)nblocks * lr::kStatsRows * p * sizeof(double);
+    const size_t tail_bytes = (size_t)(lr::kStatsRows + 1) * p * sizeof(double);  // final sums + the pivot
+    DevBuf scratch;
+    if (scratch.alloc(part_bytes + tail_bytes)) return fail(LR_ERR_NOMEM, "lr_stats_reduce scratch");
+    double* d_part = static_cast<double*>(scratch.p);
+    double* d_sums = d_part + (size_t)nblocks * lr::kStatsRows * p;
+    double* d_piv = d_sums + (size_t)lr::kStatsRows * p;
+    LR_HIP(hipMemcpyAsync(d_piv, pivot, (size_t)p * sizeof(double), hipMemcpyHostToDevice, st));
+    const dim3 grid((unsigned)nblocks), block(PW, CY);
+    switch (PW) {
+#define LR_STATS_CASE(W) \
+    case W: hipLaunchKernelGGL((lr::k_stats_partial<W>), grid, block, 0, st, stats, n_chains, (int)p, batch, kept, d_piv, d_part); break;
+        LR_STATS_CASE(1) LR_STATS_CASE(2) LR_STATS_CASE(4) LR_STATS_CASE(8) LR_STATS_CASE(16) LR_STATS_CASE(32)
+        LR_STATS_CASE(64) LR_STATS_CASE(128)
+#undef LR_STATS_CASE
+    }
+    LR_HIP(hipGetLastError());
+    hipLaunchKernelGGL(lr::k_stats_final, dim3((lr::kStatsRows * p + 255) / 256), dim3(256), 0, st, d_part, nblocks, (int)p, d_sums);
+    LR_HIP(hipGetLastError());
+    LR_HIP(hipMemcpyAsync(sums, d_sums, (size_t)lr::kStatsRows * p * sizeof(double), hipMemcpyDeviceToHost, st));
+    LR_HIP(hipStreamSynchronize(st));
+    return LR_OK;
 }
 
 // ---- device memory / stream / event helpers -------------------------------------------------------

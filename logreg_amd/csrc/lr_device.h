@@ -671,11 +671,14 @@ template <typename T, int P, int G> struct StridedRows {  // LDS or global: same
     const T* base;  // row-major [n][P]
     int64_t n;
     int gl;
-    template <class F> __device__ __forceinline__ void for_each(F&& f) const {
+    template <class F> __device__ __forceinline__ void for_each(F&& f) const { for_each_in(0, n, f); }
+    // the lane's rows inside [lo, hi), lo a multiple of G
+    template <class F> __device__ __forceinline__ void for_each_in(int64_t lo, int64_t hi, F&& f) const {
         // four rows are fetched before the first is used: with one load batch per row the loop is one LDS / L2
         // round trip per row, which nothing else in the wave covers
         constexpr int UB = sizeof(T) * P <= 64 ? 4 : 2;
-        int64_t i = gl;
+        const int64_t n = hi;
+        int64_t i = lo + gl;
         for (; i + (UB - 1) * G < n; i += UB * G) {
             T xs[UB][P];
 #pragma unroll
@@ -763,11 +766,46 @@ template <int P, int PF = 1> struct ScalarRowPairs {
     }
     __device__ __forceinline__ float value_fixup() const { return float(zero_rows) * 0.693147180559945309f; }
 };
+template <class Rows> struct is_strided_rows { static constexpr bool value = false; };
+template <typename T, int P, int G> struct is_strided_rows<StridedRows<T, P, G>> { static constexpr bool value = true; };
 template <class Rows> struct is_scalar_rows { static constexpr bool value = false; };
 template <typename T, int P, int PF> struct is_scalar_rows<ScalarRows<T, P, PF>> { static constexpr bool value = true; };
 constexpr int kSeqRows = 512;  // rows one lane may sum sequentially in fp32 (lane-per-chain variants)
 template <class Rows> struct is_scalar_pairs { static constexpr bool value = false; };
 template <int P, int PF> struct is_scalar_pairs<ScalarRowPairs<P, PF>> { static constexpr bool value = true; };
+
+// ------------------------------------------------------------------------------------------
+// streaming posterior statistics (include/logreg_hip.h "Streaming statistics"): fold kept sample number `idx`
+// of the statistics window into the running (mean, M2) of its batch slot.  stats [slots][C][2][p] doubles.
+// Called once per kept sample by the lane(s) that own the chain's coordinates; `slot_of` returns the
+// (mean, M2) pair of one coordinate.
+struct StatsArgs {
+    double* buf;       // null = off
+    int64_t batch;     // kept samples per slot
+    int64_t first;     // window index of the launch's first kept sample
+};
+__device__ __forceinline__ void stats_fold(double* mean_p, double* m2_p, int64_t k_in_slot, double inv_count, double x) {
+    double mean = x, m2 = 0.0;
+    if (k_in_slot != 0) {  // Welford
+        mean = *mean_p;
+        m2 = *m2_p;
+        const double d = x - mean;
+        mean += d * inv_count;
+        m2 += d * (x - mean);
+    }
+    *mean_p = mean;
+    *m2_p = m2;
+}
+template <typename T, int P>
+__device__ __forceinline__ void stats_update(const StatsArgs& st, int64_t kept_in_launch, int64_t C, int64_t chain, int p,
+                                             const T (&x)[P]) {
+    const int64_t idx = st.first + kept_in_launch, b = idx / st.batch, k = idx - b * st.batch;
+    const double inv = 1.0 / (double)(k + 1);
+    double* s = st.buf + ((b * C + chain) * 2) * p;
+#pragma unroll
+    for (int j = 0; j < P; ++j)
+        if (j < p) stats_fold(s + j, s + p + j, k, inv, (double)x[j]);
+}
 
 // ------------------------------------------------------------------------------------------
 // log-posterior value / gradient of one chain, cooperatively over the G lanes of its group.
@@ -788,6 +826,7 @@ __device__ __forceinline__ void eval_lpost(const Rows& rows, const Prior<T, P>& 
 #pragma unroll
     for (int j = 0; j < P; ++j) g[j] = T(0);
     T v = T(0);
+    double vwide = 0.0;  // value part already accumulated in fp64 (blocked lane-per-chain sums)
     T bs[P];
     if constexpr (PRESCALED) {
 #pragma unroll
@@ -844,7 +883,7 @@ __device__ __forceinline__ void eval_lpost(const Rows& rows, const Prior<T, P>& 
             }
 #pragma unroll
             for (int j = 0; j < P; ++j) g[j] = (float)gd[j];
-            if constexpr (VALUE) v += (float)(vd * (double)ExpScale<float>::inv);
+            if constexpr (VALUE) vwide = vd * (double)ExpScale<float>::inv;
         }
     } else if constexpr (G == 1 && sizeof(T) == 4 && is_scalar_rows<Rows>::value) {
         if (rows.i1 - rows.i0 <= kSeqRows) {
@@ -868,7 +907,29 @@ __device__ __forceinline__ void eval_lpost(const Rows& rows, const Prior<T, P>& 
             }
 #pragma unroll
             for (int j = 0; j < P; ++j) g[j] = (T)gd[j];
-            if constexpr (VALUE) v += (T)vd;
+            if constexpr (VALUE) vwide = vd;
+        }
+    } else if constexpr (sizeof(T) == 4 && is_strided_rows<Rows>::value) {
+        if (rows.n <= (int64_t)kSeqRows * G) {
+            rows.for_each([&](const T(&xs)[P]) { row_term<T, P, VALUE, GRAD>(xs, bs, g, v); });
+        } else {  // LDS / global rows with few lanes per chain (lds G = 1 reaches n = 4096 at p = 4): as above
+            double gd[P], vd = 0.0;
+#pragma unroll
+            for (int j = 0; j < P; ++j) gd[j] = 0.0;
+            for (int64_t ib = 0; ib < rows.n; ib += (int64_t)kSeqRows * G) {
+                const int64_t ie = ib + (int64_t)kSeqRows * G < rows.n ? ib + (int64_t)kSeqRows * G : rows.n;
+                T vb = T(0);
+                rows.for_each_in(ib, ie, [&](const T(&xs)[P]) { row_term<T, P, VALUE, GRAD>(xs, bs, g, vb); });
+#pragma unroll
+                for (int j = 0; j < P; ++j) {
+                    gd[j] += (double)g[j];
+                    g[j] = T(0);
+                }
+                vd += (double)vb;
+            }
+#pragma unroll
+            for (int j = 0; j < P; ++j) g[j] = (T)gd[j];
+            if constexpr (VALUE) vwide = vd;
         }
     } else {
         rows.for_each([&](const T(&xs)[P]) { row_term<T, P, VALUE, GRAD>(xs, bs, g, v); });
@@ -883,7 +944,7 @@ __device__ __forceinline__ void eval_lpost(const Rows& rows, const Prior<T, P>& 
         vnmsub<T, P>(beta, pr.inv_var, g, grad);
     }
     if constexpr (VALUE) {
-        ll = group_sum<G>((double)(v + rows.value_fixup()));
+        ll = group_sum<G>((double)(v + rows.value_fixup()) + vwide);
         lprior = pr.lprior_const - 0.5 * (double)vquad<T, P>(pr.inv_var, beta);
     }
 }

@@ -48,6 +48,7 @@ template <typename T, int P> struct ChainArgs {
     T step;  // HMC eps
     T a[P], b[P], c[P];
     T d[P], e[P];  // HMC: d = b * ExpScale<T>::k, e = prior inv_var / ExpScale<T>::k (trajectory in scaled units)
+    StatsArgs stats;  // streaming (mean, M2) per batch of kept samples; buf = null: off
 };
 
 // --------------------------------------------------------------------------------------------
@@ -246,6 +247,7 @@ __global__ void __launch_bounds__(256) k_chain(ModelArgs<T, P> m, ChainArgs<T, P
             for (int j = 0; j < P; ++j)
                 if (j < a.p) o[j] = x[j];
         }
+        if (a.stats.buf && writer) stats_update<T, P>(a.stats, it, a.C, chain, a.p, x);
     }
     if (writer) {
 #pragma unroll

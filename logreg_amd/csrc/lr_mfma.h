@@ -274,6 +274,14 @@ __global__ void __launch_bounds__(256) k_chain_mfma(ModelArgs<float, 8> m, Chain
             for (int h = 0; h < 2; ++h)
                 if (k + 4 * h < a.p) o[k + 4 * h] = x[h];
         }
+        if (a.stats.buf && writer) {  // the lane owns coordinates k and k + 4
+            const int64_t idx = a.stats.first + it, sb = idx / a.stats.batch, sk = idx - sb * a.stats.batch;
+            const double inv = 1.0 / (double)(sk + 1);
+            double* s = a.stats.buf + ((sb * a.C + chain) * 2) * a.p;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                if (k + 4 * h < a.p) stats_fold(s + k + 4 * h, s + a.p + k + 4 * h, sk, inv, (double)x[h]);
+        }
     }
     if (writer) {
 #pragma unroll

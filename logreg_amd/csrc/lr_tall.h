@@ -77,6 +77,7 @@ template <typename T, int P> struct TallArgs {
     int p, l;
     T step;
     T a[P], b[P], c[P];
+    StatsArgs stats;  // streaming statistics of the kept samples (lr_device.h); buf = null: off
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -376,6 +377,11 @@ __global__ void __launch_bounds__(256) k_tall_update(TallArgs<T, P> a, int phase
             }
         }
         if (out_row >= 0 && live && j < a.p && a.out) a.out[(out_row * a.C + chain) * a.p + j] = x;
+        if (out_row >= 0 && live && j < a.p && a.stats.buf) {  // lane = coordinate: one (mean, M2) pair each
+            const int64_t idx = a.stats.first + out_row, sb = idx / a.stats.batch, sk = idx - sb * a.stats.batch;
+            double* s = a.stats.buf + ((sb * a.C + chain) * 2) * a.p;
+            stats_fold(s + j, s + a.p + j, sk, 1.0 / (double)(sk + 1), (double)x);
+        }
         if (begin_next) begin((uint64_t)iter + 1, x, g);
         return;
     }

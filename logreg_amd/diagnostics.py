@@ -10,6 +10,10 @@ This module supplies what the BASELINE metric "ESS/sec" needs:
 * `ess_pooled(samples)`-- many-chain ESS: sum of per-chain Geyer ESS (chains are independent).
 * `summarise(samples)` -- mean / sd / ESS / MCSE per parameter, pooled over chains.
 * `describe(out)`      -- `scipy.stats.describe`-shaped summary (mean, variance with ddof=1).
+* `summary_from_sums(sums, ...)` -- mean / sd / split-R-hat / batch-means ESS from the chain-pooled sums the DEVICE
+                          accumulates while sampling (`lr_stats_reduce`, include/logreg_hip.h): many-chain runs
+                          never materialise `[iters, C, p]`; `batch_sums(samples, ...)` is the NumPy statement of
+                          the same sums (tests, and host-side samples).
 """
 from __future__ import annotations
 
@@ -116,3 +120,76 @@ def describe(out: np.ndarray) -> dict:
         "mean": flat.mean(axis=0),
         "variance": flat.var(axis=0, ddof=1),
     }
+
+
+STATS_ROWS = 7  # LR_STATS_ROWS, include/logreg_hip.h
+
+
+def choose_batches(iters: int, max_batches: int = 32) -> tuple[int, int]:
+    """(batch length B, slots) for `iters` kept samples: the largest EVEN batch count <= max_batches that divides
+    `iters` (so the two halves of split-R-hat are whole batches and nothing is left over); if none does, B =
+    iters // max_batches with the remainder in one extra partial slot (it enters mean/sd only)."""
+    iters = int(iters)
+    for nb in range(max_batches - max_batches % 2, 1, -2):
+        if iters % nb == 0:
+            return iters // nb, nb
+    B = max(1, iters // max_batches)
+    return B, -(-iters // B)
+
+
+def batch_sums(samples: np.ndarray, batch: int, pivot) -> np.ndarray:
+    """NumPy statement of `lr_stats_reduce` (include/logreg_hip.h): `[iters, C, p]` samples -> sums `[7, p]`."""
+    s = np.asarray(samples, dtype=np.float64)
+    n, C, p = s.shape
+    piv = np.asarray(pivot, dtype=np.float64)
+    nb = n // batch
+    out = np.zeros((STATS_ROWS, p))
+    mean_c = s.mean(axis=0)
+    out[0] = (n * (mean_c - piv)).sum(axis=0)
+    out[1] = (n * (mean_c - piv) ** 2).sum(axis=0)
+    out[2] = ((s - mean_c) ** 2).sum(axis=(0, 1))
+    full = s[: nb * batch]
+    if nb >= 2 and nb % 2 == 0:
+        h = nb * batch // 2
+        halves = np.concatenate([full[:h], full[h:]], axis=1)  # [h, 2C, p]
+        mh = halves.mean(axis=0)
+        out[3] = (mh - piv).sum(axis=0)
+        out[4] = ((mh - piv) ** 2).sum(axis=0)
+        out[5] = halves.var(axis=0, ddof=1).sum(axis=0) if h > 1 else 0.0
+    if nb >= 2:
+        bmean = full.reshape(nb, batch, C, p).mean(axis=1)
+        out[6] = ((bmean - full.mean(axis=0)) ** 2).sum(axis=(0, 1))
+    return out
+
+
+def summary_from_sums(sums, n_chains: int, kept: int, batch: int, pivot) -> dict:
+    """Posterior summary from chain-pooled sums (rows as in include/logreg_hip.h; sums of several chain shards
+    simply add).  Returns mean, sd (ddof = 1 over all draws, as `scipy.stats.describe` in fit-np-hmc.py:113-117),
+    rhat (split-R-hat, BDA3: the two halves of every chain), ess (batch means, pooled over chains: what
+    `smfsb::mcmcSummary` reports per chain in Python/analyse.R:17-19), mcse = sd / sqrt(ess)."""
+    S = np.asarray(sums, dtype=np.float64)
+    piv = np.asarray(pivot, dtype=np.float64)
+    C, n = int(n_chains), int(kept)
+    N = C * n
+    nb = n // batch
+    mean_d = S[0] / N
+    var = (S[2] + S[1] - N * mean_d * mean_d) / max(N - 1, 1)
+    res = {"n": N, "chains": C, "mean": piv + mean_d, "sd": np.sqrt(np.maximum(var, 0.0))}
+    nan = np.full(S.shape[1], np.nan)
+    if nb >= 2 and nb % 2 == 0:
+        h = nb * batch // 2
+        W = S[5] / (2 * C)
+        Bv = h * (S[4] - S[3] ** 2 / (2 * C)) / (2 * C - 1)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            res["rhat"] = np.sqrt(((h - 1) / h * W + Bv / h) / W)
+    else:
+        res["rhat"] = nan
+    if nb >= 2:
+        s2_within = S[2] / max(N - C, 1)
+        sigma2_bm = batch * S[6] / (C * (nb - 1))
+        with np.errstate(divide="ignore", invalid="ignore"):
+            res["ess"] = N * s2_within / sigma2_bm
+        res["mcse"] = res["sd"] / np.sqrt(res["ess"])
+    else:
+        res["ess"], res["mcse"] = nan, nan
+    return res

@@ -14,8 +14,13 @@ The reference has no distributed code on this path; chains never interact (`mcmc
 * when only pooled posterior summaries are wanted, `reduce_moments` exchanges (2p + 1) float64 sufficient
   statistics per rank with one all-reduce instead of moving any samples.
 
+* `reduce_stats` goes one step further: the statistics themselves are accumulated ON THE DEVICE while sampling
+  (`ChainSet.enable_stats`), reduced over the rank's chains by `lr_stats_reduce`, and 7p + 1 doubles per rank are
+  all-reduced: posterior mean / sd / split-R-hat / ESS of 65 536 chains without ever storing `[iters, C, p]`.
+
 `run_sharded` takes the per-rank compute as a callable so the sharding/gather logic is testable
-without a GPU (tests inject the CPU oracle); `mcmc_sharded` binds it to the fused HIP kernels.
+without a GPU (tests inject the CPU oracle); `mcmc_sharded` binds it to the fused HIP kernels through a
+`ChainSet` factory that the CPU tests replace as well.
 """
 from __future__ import annotations
 
@@ -72,6 +77,22 @@ def reduce_moments(local, group=None):
     return {"n": int(n.item()), "mean": (pivot + mean_d).cpu().numpy(), "sd": var.clamp_min(0).sqrt().cpu().numpy()}
 
 
+def reduce_stats(sums, n_chains_local: int, group=None, device=None):
+    """All-reduce (SUM) the chain-pooled statistics sums of every rank's shard -- the `[7, p]` array of
+    `ChainSet.stats_sums()` (device accumulators reduced over the rank's chains by `lr_stats_reduce`) -- plus the
+    chain count: 7p + 1 float64 per rank cross xGMI, no samples.  Every rank gets `(sums_total, n_chains_total)`;
+    feed them to `diagnostics.summary_from_sums`.  All ranks must have used the same pivot and batch length."""
+    import torch
+    import torch.distributed as dist
+    flat = np.concatenate([np.asarray(sums, dtype=np.float64).ravel(), [float(n_chains_local)]])
+    t = torch.as_tensor(flat)
+    if device is not None:
+        t = t.to(device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    flat = t.cpu().numpy()
+    return flat[:-1].reshape(np.shape(sums)), int(round(flat[-1]))
+
+
 def run_sharded(init, run_block, n_chains: int | None = None, dst: int = 0, group=None, device=None):
     """Shard `init [C, p]` over the ranks of the initialised process group, call
     `run_block(init_block, chain_offset) -> ndarray | tensor [iters, C_r, p]` on each rank and
@@ -90,23 +111,90 @@ def run_sharded(init, run_block, n_chains: int | None = None, dst: int = 0, grou
     return gather_samples(out, C, dst=dst, group=group)
 
 
-def mcmc_sharded(init, make_kernel, thin=10, iters=10000, seed=0, dst=0, group=None, local_device=None, **kw):
+def _as_tensor(arr, device):
+    """Samples of one shard as a torch tensor: a DeviceArray is viewed in place on its GPU (and cloned, so the
+    tensor owns its memory); anything else goes through NumPy (CPU tests)."""
+    import torch
+    if hasattr(arr, "__cuda_array_interface__"):
+        return torch.as_tensor(arr, device=f"cuda:{device}").clone()
+    return torch.as_tensor(np.ascontiguousarray(arr))
+
+
+def mcmc_sharded(init, make_kernel, thin=10, iters=10000, seed=0, dst=0, group=None, local_device=None,
+                 chunk=None, summary_only=False, max_batches=16, plan="local", chainset_factory=None, **kw):
     """Many-chain `mcmc` across all ranks (one process per GPU, launched with torchrun).
 
-    `make_kernel(device) -> FusedKernel` builds the rank's model + kernel on its own GPU.
-    Returns the gathered `[iters, C, p]` tensor on rank `dst` (on that rank's GPU), else None."""
+    `make_kernel(device) -> FusedKernel` builds the rank's model + kernel on its own GPU.  Rank r runs the
+    contiguous chain block `shard_bounds(C, world, r)` with its GLOBAL chain ids in the Philox counter, in chunked
+    launches like `mcmc()`; an empty shard (more ranks than chains) runs nothing and still takes part in the
+    collective.
+
+    Returns the gathered `[iters, C, p]` tensor on rank `dst` (on that rank's GPU), else None -- or, with
+    `summary_only=True`, on EVERY rank the posterior summary dict of all chains from one all-reduce of the
+    on-device statistics (`reduce_stats`); no samples are stored or moved.
+
+    `plan="global"` pins the kernel variant to the one a single GPU would pick for all C chains, which makes the
+    output bit-identical to the one-GPU run (summation order depends on the variant); the default "local" lets
+    every rank plan for its own shard size (statistically identical, fastest).
+    `chainset_factory(kernel, block, seed, chain_offset=..., **kw)` defaults to `ChainSet` (tests inject a CPU one).
+    """
     import os
     import torch
     import torch.distributed as dist
-    from .kernels import ChainSet
+    from .diagnostics import choose_batches, summary_from_sums
+    from .kernels import ChainSet, _auto_chunk
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
     if local_device is None:
-        local_device = int(os.environ.get("LOCAL_RANK", dist.get_rank(group)))
+        local_device = int(os.environ.get("LOCAL_RANK", rank))
+    factory = ChainSet if chainset_factory is None else chainset_factory
+    init = np.asarray(init, dtype=np.float64)
+    C, p = init.shape
+    lo, hi = shard_bounds(C, world, rank)
     kernel = make_kernel(local_device)
+    if plan == "global" and "mode" not in kw and hasattr(kernel, "model"):
+        pl = kernel.model.plan(C)
+        kw = dict(kw, mode=pl["mode"], group=pl["group"])
+    elif plan not in ("local", "global"):
+        raise ValueError("plan must be 'local' or 'global'")
+    cs = factory(kernel, init[lo:hi], seed, chain_offset=lo, **kw) if hi > lo else None
+    if chunk is None:
+        chunk = _auto_chunk(kernel, hi - lo, thin, iters) if hasattr(kernel, "params") else iters
+    pivot = init[0]
 
-    def run_block(block, chain_offset):
-        cs = ChainSet(kernel, block, seed, chain_offset=chain_offset, **kw)
-        out = cs.advance(iters, thin)
-        cs.sync()
-        t = torch.as_tensor(out, device=f"cuda:{local_device}").clone()  # own the memory beyond `out`
-        return t
-    return run_sharded(init, run_block, dst=dst, group=group)
+    if summary_only:
+        batch, slots = choose_batches(iters, max_batches)
+        sums = np.zeros((7, p))
+        if cs is not None:
+            cs.enable_stats(batch, slots, pivot=pivot)
+            done = 0
+            while done < iters:
+                k = min(chunk, iters - done)
+                cs.advance(k, thin, keep=False)
+                cs.sync()
+                done += k
+            sums = cs.stats_sums()
+        dev = f"cuda:{local_device}" if dist.get_backend(group) == "nccl" else None
+        tot, ctot = reduce_stats(sums, hi - lo, group=group, device=dev)
+        acc = np.array([float(cs.get_accepts().sum()) if cs is not None else 0.0])
+        t = torch.as_tensor(acc)
+        t = t.to(dev) if dev else t
+        dist.all_reduce(t, group=group)
+        res = summary_from_sums(tot, ctot, iters, batch, pivot)
+        res.update(accept_rate=float(t.item()) / (C * iters * thin), batch=batch)
+        return res
+
+    if cs is None:
+        local = np.zeros((iters, 0, p), dtype=np.float32)
+    else:
+        outs, done = [], 0
+        while done < iters:  # chunked like mcmc(): bounded launches, identical samples
+            k = min(chunk, iters - done)
+            outs.append(_as_tensor(cs.advance(k, thin), local_device))
+            cs.sync()
+            done += k
+        local = torch.cat(outs, dim=0) if len(outs) > 1 else outs[0]
+    if not isinstance(local, torch.Tensor):
+        local = torch.as_tensor(local)
+        if dist.get_backend(group) == "nccl":
+            local = local.to(f"cuda:{local_device}")
+    return gather_samples(local, C, dst=dst, group=group)

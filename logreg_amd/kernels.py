@@ -231,20 +231,66 @@ class ChainSet:
         self.acc = DeviceArray(m.device, (self.C,), np.uint32)
         self.acc.zero_()
         check(_lib.load().lr_stream_sync(m.device, None))
+        # streaming statistics (enable_stats): device buffer [slots, C, 2, p], batch length, kept samples folded in
+        self.stats = None
+        self.stats_batch = 0
+        self.stats_kept = 0
+        self.pivot = st[0].astype(np.float64)  # any point near the posterior; shards of one run must share it
 
     def plan(self):
         return self.model.plan(self.C, self.group, _lib.MODE_NAMES.get(self.mode, "auto"))
 
-    def advance(self, iters: int, thin: int, keep: bool = True, out: DeviceArray | None = None):
+    def enable_stats(self, batch: int, slots: int, pivot=None):
+        """Start a statistics window: from now on every kept sample is folded, on the device, into the running
+        (mean, M2) of its batch of `batch` kept samples (include/logreg_hip.h "Streaming statistics"); `slots`
+        batches are provided for.  The window restarts at the current state."""
+        m = self.model
+        if self.stats is not None:
+            self.stats.free()
+        self.stats = DeviceArray(m.device, (int(slots), self.C, 2, m.p), np.float64)
+        self.stats_batch = int(batch)
+        self.stats_kept = 0
+        if pivot is not None:
+            self.pivot = np.asarray(pivot, dtype=np.float64).copy()
+
+    def advance(self, iters: int, thin: int, keep: bool = True, out: DeviceArray | None = None, stats: bool | None = None):
+        """One fused launch: iters*thin iterations per chain.  keep: return the thinned samples `[iters, C, p]`
+        (a DeviceArray); stats (default: on when enable_stats was called): fold the kept samples into the
+        streaming statistics -- with keep=False nothing of size iters*C*p is ever allocated."""
         m = self.model
         if keep and out is None:
             out = DeviceArray(m.device, (iters, self.C, m.p), m.np_dtype)
         opts = RunOpts(n_chains=self.C, chain_offset=self.chain_offset, thin=int(thin), iters=int(iters),
                        iter_offset=self.iter_offset, seed=self.seed, group=self.group, mode=self.mode, on_device=1,
                        stream=self.stream)
+        use_stats = self.stats is not None if stats is None else bool(stats)
+        if use_stats:
+            if self.stats is None:
+                raise ValueError("advance(stats=True) needs enable_stats(batch, slots) first")
+            opts.stats, opts.stats_batch = self.stats.ptr, self.stats_batch
+            opts.stats_first, opts.stats_slots = self.stats_kept, self.stats.shape[0]
         self.kernel.launch(opts, self.state.ptr, self.lp.ptr, out.ptr if keep else None, self.acc.ptr)
         self.iter_offset += int(iters) * int(thin)
+        if use_stats:
+            self.stats_kept += int(iters)
         return out if keep else None
+
+    def stats_sums(self) -> np.ndarray:
+        """Chain-pooled sums `[7, p]` of the statistics window (`lr_stats_reduce`: a device reduction over the
+        chains; only 7p doubles cross PCIe).  Sums of chain shards add: see distributed.reduce_stats."""
+        if self.stats is None:
+            raise ValueError("no statistics window: call enable_stats first")
+        m = self.model
+        piv = np.ascontiguousarray(self.pivot, dtype=np.float64)
+        sums = np.empty((_lib.STATS_ROWS, m.p), dtype=np.float64)
+        check(_lib.load().lr_stats_reduce(m.device, self.stats.ptr, self.C, m.p, self.stats_batch, self.stats_kept,
+                                          piv.ctypes.data, sums.ctypes.data, self.stream))
+        return sums
+
+    def stats_summary(self) -> dict:
+        """mean / sd / split-R-hat / batch-means ESS / MCSE of the window, from the device accumulators."""
+        from .diagnostics import summary_from_sums
+        return summary_from_sums(self.stats_sums(), self.C, self.stats_kept, self.stats_batch, self.pivot)
 
     def sync(self):
         check(_lib.load().lr_stream_sync(self.model.device, self.stream))
@@ -264,24 +310,50 @@ class ChainSet:
     # -- checkpoint / resume (the reference has none: a run is all-or-nothing).  Because the random
     # stream is counter-based, (state, threaded ll, iteration counter, seed, chain offset) IS the
     # complete sampler state: a resumed run continues bit-for-bit.
+    def _fingerprint(self) -> dict:
+        """What a resumed run must share with the saved one for the continuation to be bit-exact: model shape and
+        arithmetic type, a hash of the data block, and the kernel's parameters."""
+        m, k = self.model, self.kernel
+        par = {name: np.broadcast_to(np.asarray(v, dtype=np.float64), (m.p,) if np.ndim(v) else ()).copy()
+               for name, v in sorted(k.params.items())}
+        return {"kind": k.kind, "n": np.int64(m.n), "p": np.int64(m.p), "dtype": np.dtype(m.np_dtype).name,
+                "data_hash": m.data_hash, **{"param_" + name: v for name, v in par.items()}}
+
     def checkpoint(self) -> dict:
         self.sync()
         return {"state": self.state.to_host(), "ll": self.lp.to_host(), "accepts": self.acc.to_host(),
                 "iter_offset": np.int64(self.iter_offset), "seed": np.uint64(self.seed),
-                "chain_offset": np.int64(self.chain_offset), "kind": self.kernel.kind}
+                "chain_offset": np.int64(self.chain_offset), **self._fingerprint()}
 
-    def save(self, path: str):
+    def save(self, path: str) -> str:
+        """Write the checkpoint as an .npz archive; returns the path actually written (np.savez appends
+        ".npz" to a name without it), so `ChainSet.resume(kernel, cs.save("ckpt"))` works."""
+        path = str(path)
+        if not path.endswith(".npz"):
+            path += ".npz"
         np.savez(path, **self.checkpoint())
         return path
 
     @classmethod
     def resume(cls, kernel: "FusedKernel", ckpt, group: int = 0, mode: str = "auto", stream=None) -> "ChainSet":
-        if isinstance(ckpt, str):
-            ckpt = dict(np.load(ckpt, allow_pickle=False))
+        if isinstance(ckpt, (str, bytes)) or hasattr(ckpt, "__fspath__"):
+            path = str(ckpt)
+            if not path.endswith(".npz"):
+                path += ".npz"
+            ckpt = dict(np.load(path, allow_pickle=False))
         if str(ckpt["kind"]) != kernel.kind:
             raise ValueError(f"checkpoint is for a {ckpt['kind']} kernel, got {kernel.kind}")
         cs = cls(kernel, ckpt["state"], int(ckpt["seed"]), chain_offset=int(ckpt["chain_offset"]), ll=ckpt["ll"],
                  group=group, mode=mode, stream=stream)
+        want = cs._fingerprint()
+        for key, val in want.items():
+            if key not in ckpt:
+                continue  # checkpoints written before the fingerprint existed carry only `kind`
+            have = ckpt[key]
+            same = np.array_equal(np.asarray(have), np.asarray(val)) if key.startswith("param_") else str(have) == str(val)
+            if not same:
+                raise ValueError(f"checkpoint does not match this kernel/model: {key} = {have!r} in the checkpoint, "
+                                 f"{val!r} here (a resumed run would silently stop being the continuation)")
         cs.iter_offset = int(ckpt["iter_offset"])
         cs.acc.copy_from(np.asarray(ckpt["accepts"], dtype=np.uint32))
         return cs
@@ -297,7 +369,7 @@ def _auto_chunk(kernel: FusedKernel, C: int, thin: int, iters: int) -> int:
 
 
 def mcmc(init, kernel, thin=10, iters=10000, verb=True, *, seed=None, chunk=None, chain_offset=0, ll=None,
-         group=0, mode="auto", return_info=False):
+         group=0, mode="auto", return_info=False, summary_only=False, max_batches=16):
     """Run a chain (or C chains): `mat[i]` = state after (i+1)*thin iterations (fit-np-hmc.py:89-103).
 
     Fused kernels run on the device; `init` of shape [p] returns a float64 `[iters, p]` matrix
@@ -305,6 +377,10 @@ def mcmc(init, kernel, thin=10, iters=10000, verb=True, *, seed=None, chunk=None
     with the threaded log-density at -inf as the reference does (fit-np-mala.py:82) unless
     `ll=` is given.  `seed=None` draws the Philox key from NumPy's global RNG, so
     `np.random.seed(s)` before the call makes a run reproducible, like the reference.
+
+    `summary_only=True` (fused kernels): no sample matrix at all -- the kept samples are folded into on-device
+    running statistics and the call returns a dict (mean, sd, rhat, ess, mcse, accept_rate, ...): what the
+    reference computes from the full matrix afterwards (fit-np-hmc.py:113-117, analyse.R:17-19).
     """
     if not isinstance(kernel, FusedKernel):
         return _mcmc_generic(init, kernel, thin, iters, verb)
@@ -316,6 +392,26 @@ def mcmc(init, kernel, thin=10, iters=10000, verb=True, *, seed=None, chunk=None
     m = kernel.model
     if chunk is None:
         chunk = _auto_chunk(kernel, cs.C, thin, iters)
+    if summary_only:
+        from .diagnostics import choose_batches
+        batch, slots = choose_batches(iters, max_batches)
+        cs.enable_stats(batch, slots)
+        if verb:
+            print(str(iters) + " iterations")
+        done = 0
+        while done < iters:
+            k = min(chunk, iters - done)
+            cs.advance(k, thin, keep=False)
+            cs.sync()
+            done += k
+            if verb:
+                print(str(done), end=" ", flush=True)
+        if verb:
+            print("\nDone.", flush=True)
+        res = cs.stats_summary()
+        res.update(accept_rate=float(cs.get_accepts().sum() / (cs.C * iters * thin)), batch=batch, seed=seed,
+                   plan=cs.plan(), state=cs.get_state())
+        return res
     mat = np.empty((iters, cs.C, m.p), dtype=m.np_dtype)
     if verb:
         print(str(iters) + " iterations")

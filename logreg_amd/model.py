@@ -128,6 +128,8 @@ class LogReg:
         except KeyError:
             raise ValueError(f"dtype must be float32 or float64, got {dtype!r}") from None
         self.device = int(device)
+        import hashlib
+        self.data_hash = hashlib.sha256(X.tobytes() + y.tobytes() + self.pscale.tobytes()).hexdigest()[:16]
         h = C.c_void_p()
         check(L.lr_model_create(X.ctypes.data, y.ctypes.data, self.n, self.p, self.pscale.ctypes.data,
                                 self.dtype_id, self.device, C.byref(h)))
@@ -164,6 +166,18 @@ class LogReg:
         check(_lib.load().lr_plan(self.handle, int(chains), int(group), _lib.MODE_BY_NAME[mode], C.byref(m),
                                   C.byref(g), C.byref(r)))
         return {"mode": _lib.MODE_NAMES[m.value], "group": g.value, "rows_per_lane": r.value}
+
+    def hessian(self, beta):
+        """(lpost, glp [p], H [p,p]) at one beta, H = -d2 lpost / d beta2 = X^T W X + diag(1/pscale^2), computed on
+        the device in float64 in one pass over the rows (`lr_hessian`)."""
+        b = np.ascontiguousarray(beta, dtype=np.float64)
+        if b.shape != (self.p,):
+            raise ValueError(f"beta must have shape ({self.p},); got {b.shape}")
+        lp = C.c_double()
+        g = np.empty(self.p)
+        H = np.empty((self.p, self.p))
+        check(_lib.load().lr_hessian(self.handle, b.ctypes.data, C.byref(lp), g.ctypes.data, H.ctypes.data, None))
+        return lp.value, g, H
 
     # ------------------------------------------------------------------------------------------
     def eval(self, beta, want=("ll", "lprior", "lpost", "glp"), group: int = 0, mode: str = "auto") -> dict:

@@ -71,3 +71,103 @@ def test_sharded_run_equals_single_process_run(tmp_path, C):
     assert int(mom["n"]) == flat.shape[0]
     np.testing.assert_allclose(mom["mean"], flat.mean(0), rtol=1e-12)
     np.testing.assert_allclose(mom["sd"], flat.std(0, ddof=1), rtol=1e-9)
+
+
+# ------------------------------------------------------------------------------------------------
+# mcmc_sharded ITSELF (chunked launches, global chain ids, ragged and empty shards, gather, and the
+# statistics all-reduce) with a CPU ChainSet injected through its factory argument: same interface as
+# logreg_amd.kernels.ChainSet, the float64 oracle as the engine.
+class _OracleChainSet:
+    def __init__(self, kernel, block, seed, chain_offset=0, **kw):
+        self.k, self.seed, self.chain_offset = kernel, seed, chain_offset
+        self.state = np.array(block, dtype=np.float64)
+        self.iter_offset = 0
+        self.acc = np.zeros(self.state.shape[0], dtype=np.uint64)
+        self.kept, self.batch, self.pivot = None, 0, None
+        self.launches = 0
+
+    def enable_stats(self, batch, slots, pivot=None):
+        self.kept, self.batch, self.pivot = [], batch, np.asarray(pivot)
+
+    def advance(self, iters, thin, keep=True, stats=None):
+        r = self.k.oracle.run("hmc", self.state, thin=thin, iters=iters, seed=self.seed, chain_offset=self.chain_offset,
+                              iter_offset=self.iter_offset, **self.k.kw)
+        self.state, self.iter_offset = r["state"], self.iter_offset + iters * thin
+        self.acc += r["accepts"]
+        self.launches += 1
+        if self.kept is not None:
+            self.kept.append(r["out"])
+        return r["out"].astype(np.float32) if keep else None
+
+    def sync(self):
+        pass
+
+    def get_accepts(self):
+        return self.acc
+
+    def stats_sums(self):
+        from logreg_amd.diagnostics import batch_sums
+        return batch_sums(np.concatenate(self.kept), self.batch, self.pivot)
+
+
+def _worker_mcmc_sharded(rank, world, port, C, tmp):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import types
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle.oracle import OracleModel
+    from logreg_amd.data import load_pima
+    from logreg_amd.distributed import mcmc_sharded
+    X, y = load_pima()
+    dmm = 1.0 / np.array([100.0, 1, 1, 1, 1, 1, 25, 1])
+    init = np.load(os.path.join(tmp, "init.npy"))
+
+    def make_kernel(dev):  # what FusedKernel exposes to mcmc_sharded: kind, params, model.n/.p
+        return types.SimpleNamespace(kind="hmc", params={"l": 5}, model=types.SimpleNamespace(n=200, p=8),
+                                     oracle=OracleModel(X, y, [10, 1, 1, 1, 1, 1, 1, 1]), kw=dict(step=1e-3, l=5, scale=dmm))
+    made = []
+
+    def factory(*a, **k):
+        made.append(_OracleChainSet(*a, **k))
+        return made[-1]
+    out = mcmc_sharded(init, make_kernel, thin=2, iters=8, seed=31, chunk=3, chainset_factory=factory)
+    assert (made[0].launches == 3) if made else (C < world and rank >= C)  # 8 kept samples in chunks of 3, 3, 2
+    summ = mcmc_sharded(init, make_kernel, thin=2, iters=8, seed=31, summary_only=True, max_batches=4, chainset_factory=factory)
+    if rank == 0:
+        np.save(os.path.join(tmp, "gathered.npy"), out.numpy())
+    else:
+        assert out is None
+    np.savez(os.path.join(tmp, f"summary{rank}.npz"), **{k: v for k, v in summ.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("C", [7, 1])
+def test_mcmc_sharded_driver_on_cpu(tmp_path, C):
+    """world_size 2; C = 7: ragged shards (4 + 3); C = 1: rank 1's shard is EMPTY and still joins the collectives."""
+    import torch.multiprocessing as mp
+    from oracle.oracle import OracleModel
+    from logreg_amd.data import load_pima
+    from logreg_amd.diagnostics import split_rhat
+    X, y = load_pima()
+    m = OracleModel(X, y, [10, 1, 1, 1, 1, 1, 1, 1])
+    dmm = 1.0 / np.array([100.0, 1, 1, 1, 1, 1, 25, 1])
+    rng = np.random.default_rng(1)
+    init = np.array([-9.19, 0.097, 0.031, -0.0056, -0.0006, 0.0814, 1.26, 0.0394]) + 0.01 * rng.standard_normal((C, 8))
+    np.save(tmp_path / "init.npy", init)
+    mp.spawn(_worker_mcmc_sharded, args=(2, _free_port(), C, str(tmp_path)), nprocs=2, join=True)
+    ref = m.run("hmc", init, step=1e-3, l=5, scale=dmm, thin=2, iters=8, seed=31)
+    got = np.load(tmp_path / "gathered.npy")
+    assert got.shape == (8, C, 8)
+    np.testing.assert_array_equal(got, ref["out"].astype(np.float32))  # chunked + sharded = monolithic, bit for bit
+    flat = ref["out"].reshape(-1, 8)
+    for rank in range(2):  # every rank holds the summary of ALL chains
+        s = np.load(tmp_path / f"summary{rank}.npz")
+        assert int(s["n"]) == flat.shape[0] and int(s["chains"]) == C
+        np.testing.assert_allclose(s["mean"], flat.mean(0), rtol=1e-12)
+        np.testing.assert_allclose(s["sd"], flat.std(0, ddof=1), rtol=1e-8)
+        np.testing.assert_allclose(s["rhat"], split_rhat(ref["out"]), rtol=1e-8)
+        assert float(s["accept_rate"]) == pytest.approx(ref["accepts"].sum() / (C * 16))

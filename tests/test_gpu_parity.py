@@ -452,14 +452,37 @@ def test_generic_composition_with_device_closures_replays_reference_draws(la, mo
     np.testing.assert_allclose(out, np.array(g["hmc"]["states"])[:12], rtol=1e-7, atol=1e-9)
 
 
-def test_device_map_finder_matches_bfgs_fixture(la, models, map_beta):  # F2, section 8(f) item 1
+def test_device_map_finder_matches_bfgs_fixture(la, models, map_beta, pima, oracle_model):  # F2, section 8(f) item 1
+    """Newton with the closed-form Hessian kernel (lr_hessian: X^T W X + prior, one pass, float64)."""
     g = load_golden("map.json")
-    beta, info = la.find_map(models["float64"], np.zeros(8))
-    assert info["converged"] and info["lpost"] == pytest.approx(g["lpost_map"], abs=1e-7)
-    np.testing.assert_allclose(beta, map_beta, atol=2e-4)
-    beta32, info32 = la.find_map(models["float32"], np.zeros(8))
-    assert info32["lpost"] == pytest.approx(g["lpost_map"], abs=2e-3)
-    assert np.max(np.abs(beta32 - map_beta) / POST_SD) < 0.05
+    X, _ = pima
+    for dtype in ("float64", "float32"):
+        m = models[dtype]
+        lp, gr, H = m.hessian(map_beta)
+        mu = 1.0 / (1.0 + np.exp(-X @ map_beta))
+        H_ref = (X * (mu * (1 - mu))[:, None]).T @ X + np.diag(1.0 / PSCALE ** 2)
+        np.testing.assert_allclose(H, H_ref, rtol=1e-12 if dtype == "float64" else 1e-6)
+        assert lp == pytest.approx(g["lpost_map"], abs=1e-9 if dtype == "float64" else 1e-4)
+        np.testing.assert_allclose(gr, oracle_model.glp(map_beta), atol=1e-8 if dtype == "float64" else 1e-2)
+        beta, info = la.find_map(m, np.zeros(8))
+        assert info["converged"] and info["iterations"] < 15
+        # float32 models store the ROWS in float32 (the arithmetic of lr_hessian is float64 either way)
+        assert np.max(np.abs(beta - map_beta) / POST_SD) < (1e-4 if dtype == "float64" else 1e-3)
+        assert info["lpost"] == pytest.approx(g["lpost_map"], abs=1e-7 if dtype == "float64" else 1e-4)
+        np.testing.assert_allclose(info["sd"], np.sqrt(np.diag(np.linalg.inv(H_ref))), rtol=1e-3)
+
+
+@pytest.mark.parametrize("cfg", [4, 5])
+def test_device_map_finder_on_the_full_size_designs(la, cfg):
+    """Configs 4 and 5 (n = 100 000 / p = 128): MAP and Laplace sd against the float64 NumPy Newton of the fixtures."""
+    fix = load_golden(f"fullsize_cfg{cfg}.json")
+    X, y, _ = la.synthetic_logreg(fix["n"], fix["p"], seed=fix["data_seed"], beta_sd=fix["beta_sd"])
+    m = la.LogReg(X, y, np.array(fix["pscale"]))
+    beta, info = la.find_map(m)
+    lsd = np.array(fix["laplace_sd"])
+    assert info["converged"] and info["iterations"] < 15
+    assert np.max(np.abs(beta - np.array(fix["map"])) / lsd) < 1e-3
+    np.testing.assert_allclose(info["sd"], lsd, rtol=1e-4)
 
 
 @pytest.mark.parametrize("kind", ["hmc", "mala", "rwmh"])
@@ -622,3 +645,51 @@ def test_randomised_parity_fuzz():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " 0 failed" in r.stdout
 
+
+
+@pytest.mark.parametrize("n,p", [(6001, 8), (600, 40)])
+def test_two_chainsets_of_one_model_on_two_streams(la, n, p):
+    """The stepwise engine's workspace is per (model, stream): two ChainSets of ONE model advancing concurrently on
+    two non-blocking streams -- and a model.eval() on the NULL stream in between -- must not touch each other's
+    state.  Bit-exact against the same two runs executed one after the other."""
+    import ctypes as C
+    from logreg_amd import _lib
+    Cn = 256
+    X, y, _ = la.synthetic_logreg(n, p, seed=5, beta_sd=0.5 / np.sqrt(p))
+    ps = np.ones(p)
+    m = la.LogReg(X, y, ps)
+    k = la.hmcKernel(m.lpost, m.glp, eps=0.01, l=20, dmm=np.ones(p))
+    rng = np.random.default_rng(8)
+    qa, qb = 0.05 * rng.standard_normal((Cn, p)), 0.05 * rng.standard_normal((Cn, p))
+    L = _lib.load()
+
+    def run(concurrent):
+        streams = []
+        for _ in range(2):
+            s = C.c_void_p()
+            _lib.check(L.lr_stream_create(0, C.byref(s)))
+            streams.append(s)
+        a = la.ChainSet(k, qa, seed=1, mode="stepwise", stream=streams[0])
+        b = la.ChainSet(k, qb, seed=2, mode="stepwise", stream=streams[1])
+        outs = [[], []]
+        for step in range(3):
+            outs[0].append(a.advance(2, 2))
+            if not concurrent:
+                a.sync()
+            outs[1].append(b.advance(2, 2))
+            if concurrent and step == 1:
+                m.eval(qa[:64])  # NULL stream, while both runs are in flight (wide models: stepwise lr_eval)
+            if not concurrent:
+                b.sync()
+        a.sync()
+        b.sync()
+        res = [np.concatenate([o.to_host() for o in oo]) for oo in outs]
+        for s in streams:
+            _lib.check(L.lr_stream_destroy(0, s))
+        return res
+
+    assert m.plan(Cn)["mode"] == "stepwise"
+    seq = run(False)
+    con = run(True)
+    assert np.array_equal(seq[0], con[0]) and np.array_equal(seq[1], con[1])
+    assert not np.array_equal(seq[0], seq[1])

@@ -25,4 +25,13 @@ if rank == 0:
     assert got.shape == (7, 1000, 8), got.shape
     assert np.array_equal(got, ref), "sharded run differs from the single-process run"
     print("sharded_smoke ok: world", world, "gathered", got.shape, "bit-exact vs single process")
+# the no-samples path: on-device statistics of every rank's shard, one all-reduce of 7p + 1 doubles over RCCL
+summ = mcmc_sharded(init, make_kernel, thin=5, iters=8, seed=11, summary_only=True, max_batches=4, plan="global")
+if rank == 0:
+    ref = la.mcmc(init, make_kernel(lr), thin=5, iters=8, seed=11, verb=False).astype(np.float64)
+    flat = ref.reshape(-1, 8)
+    assert summ["n"] == flat.shape[0]
+    assert np.allclose(summ["mean"], flat.mean(0), rtol=1e-9) and np.allclose(summ["sd"], flat.std(0, ddof=1), rtol=1e-6)
+    assert np.allclose(summ["rhat"], la.split_rhat(ref), rtol=1e-6)
+    print("sharded_smoke ok: summary_only over", summ["chains"], "chains: mean", np.round(summ["mean"], 4))
 dist.barrier(); dist.destroy_process_group()
