@@ -75,7 +75,23 @@ typedef struct lr_run_opts {
     int64_t stats_batch;  /* B >= 1: kept samples per batch slot */
     int64_t stats_first;  /* index, within the statistics window, of this call's first kept sample */
     int64_t stats_slots;  /* slots in the buffer: stats_first + iters <= stats_slots * stats_batch */
+    int32_t precision;    /* LR_PREC_*: arithmetic of HMC's INTERIOR leapfrog gradients (see below) */
+    int32_t reserved;     /* must be 0 */
 } lr_run_opts;
+
+/*
+ * Interior-gradient precision of lr_run_hmc.  The L - 1 gradient evaluations strictly inside a trajectory only
+ * steer it: the leapfrog map stays volume-preserving and reversible for any deterministic force, and the
+ * Metropolis test uses the log-posterior at the two END points, which is always evaluated in the model's full
+ * precision (as are the end-point half-kicks).  So the interior evaluations may be cheaper without biasing the
+ * sampler; the only possible cost is acceptance rate.
+ *   LR_PREC_AUTO   library's choice: LR_PREC_BF16 where a reduced-precision kernel exists (wide models,
+ *                  32 < p <= 128: rows in one bf16 piece, beta in two, on the bf16 matrix pipe), else full
+ *   LR_PREC_FULL   every evaluation in the model's dtype (bit-comparable with the float64 oracle step by step)
+ *   LR_PREC_BF16   request the reduced-precision interior kernels (ignored where none exists)
+ * RWMH, MALA and UL ignore the field (every evaluation of theirs enters an accept ratio or is the sample itself).
+ */
+enum { LR_PREC_AUTO = 0, LR_PREC_FULL = 1, LR_PREC_BF16 = 2 };
 
 LR_API const char* lr_last_error(void);
 /* content hash of the sources this library was compiled from (logreg_amd/build.py: source_hash): the binding

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(HERE, "lib", "liblogreg_hip.so")
 
 LR_F32, LR_F64 = 0, 1
 STATS_ROWS = 7  # LR_STATS_ROWS
+PREC_BY_NAME = {"auto": 0, "full": 1, "bf16": 2}  # LR_PREC_*
 MODE_AUTO, MODE_REG, MODE_LDS, MODE_GLOBAL, MODE_MFMA, MODE_STEPWISE = -1, 0, 1, 2, 3, 4
 MODE_NAMES = {MODE_REG: "reg", MODE_LDS: "lds", MODE_GLOBAL: "global", MODE_MFMA: "mfma", MODE_STEPWISE: "stepwise"}
 MODE_BY_NAME = {"auto": MODE_AUTO, "reg": MODE_REG, "lds": MODE_LDS, "global": MODE_GLOBAL, "mfma": MODE_MFMA, "stepwise": MODE_STEPWISE}
@@ -26,7 +27,8 @@ class RunOpts(C.Structure):
     _fields_ = [("n_chains", C.c_int64), ("chain_offset", C.c_int64), ("thin", C.c_int64), ("iters", C.c_int64),
                 ("iter_offset", C.c_int64), ("seed", C.c_uint64), ("group", C.c_int32), ("mode", C.c_int32),
                 ("on_device", C.c_int32), ("stream", C.c_void_p),
-                ("stats", C.c_void_p), ("stats_batch", C.c_int64), ("stats_first", C.c_int64), ("stats_slots", C.c_int64)]
+                ("stats", C.c_void_p), ("stats_batch", C.c_int64), ("stats_first", C.c_int64), ("stats_slots", C.c_int64),
+                ("precision", C.c_int32), ("reserved", C.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/logreg_hip.h declares

@@ -27,7 +27,11 @@ ARCH = "gfx950"
 # into v_pk_add_f32 and lose the fused v_add_f32_dpp form (16 more instructions per evaluation)
 # -amdgpu-sched-strategy=max-ilp: the kernels run one or two waves per SIMD by design, so latency hiding has
 # to come from instruction-level parallelism, not occupancy (HMC hot loop: +7 % over the default strategy)
-COMMON = ["--offload-arch=" + ARCH, "-O3", "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall",
+# -falign-loops=64: the 1.4 KB leapfrog loop of the fused HMC kernel runs one wave per SIMD, nothing hides its
+# instruction fetch; when an unrelated edit elsewhere in the file moved the loop head to an address = 4 mod 8 the
+# kernel lost 10 % (0.444 -> 0.489 ms per launch, identical instructions).  With every loop head on a 64-byte
+# line the time no longer depends on what precedes the loop (8 / 16 / 32 / 64 / 128: 0.451 / 0.442 / 0.450 / 0.443 / 0.447 ms).
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-fno-slp-vectorize", "-falign-loops=64", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall",
           "-Wno-unused-function", "-I", CSRC, "-I", INCLUDE] + os.environ.get("LOGREG_HIPCC_FLAGS", "").split()
 
 INSTANCES = [(dt, dtype_id, ctype, p) for dt, dtype_id, ctype in (("f32", 0, "float"), ("f64", 1, "double"))

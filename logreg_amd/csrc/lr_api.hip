@@ -76,6 +76,7 @@ struct lr_model {
     double lprior_const = 0;
     const lr::InstTable* table = nullptr;
     void* d_xblk = nullptr;  // wide models: per-32-row-block bf16-piece images of the rows (lr_wide_bf16.h)
+    void* d_xblk1 = nullptr;  // wide models: single-piece round-to-nearest images (interior leapfrog steps)
     // stepwise-engine workspaces, one per stream (grow-only, owned by the handle): calls enqueued on ONE stream
     // run in order, so they may share a workspace; calls on different streams overlap on the device and get
     // disjoint ones (two ChainSets of one model on two streams, or an eval on the NULL stream beside a run)
@@ -337,6 +338,7 @@ int setup_tall(lr_model* m, const Plan& pl, hipStream_t st, int64_t C, lr::TallA
         // tolerances, 1.5x the fp32-MFMA kernel; LOGREG_WIDE_BF16=0 selects the fp32-MFMA kernel (lr_wide.h)
         a.wide_bf16 = (m->P > 32 && m->d_xblk) ? wide_engine(m, C) : 0;
         a.xblk = static_cast<const uint16_t*>(m->d_xblk);
+        a.xblk1 = static_cast<const uint16_t*>(m->d_xblk1);
     }
     return LR_OK;
 }
@@ -391,6 +393,13 @@ int do_stepwise_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs
     auto K = [&](int v, int g) {
         if (!rc) rc = t->launch_tall_partial(st, v, g, &a);
     };
+    // interior leapfrog gradients (HMC): reduced precision where the policy allows and a kernel exists
+    const bool bf16_interior = rs.kind == lr::KIND_HMC && o->precision != LR_PREC_FULL && m->d_xblk1 != nullptr;
+    auto KI = [&]() {
+        a.interior = bf16_interior ? 1 : 0;
+        K(0, 1);
+        a.interior = 0;
+    };
     const int kind = rs.kind;
     U(lr::PH_LOAD, 0, -1, 0);
     if (kind == lr::KIND_HMC) K(1, 1);
@@ -400,7 +409,7 @@ int do_stepwise_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs
     for (int64_t tt = 0; tt < total && !rc; ++tt) {
         if (kind == lr::KIND_HMC) {
             for (int i = 0; i < rs.l - 1; ++i) {
-                K(0, 1);
+                KI();
                 U(lr::PH_MID, 0, -1, 0);
             }
             K(1, 1);
@@ -482,6 +491,8 @@ int check_opts(const lr_model* m, const lr_run_opts* o, bool run) {
         if (o->chain_offset < 0 || o->iter_offset < 0) return fail(LR_ERR_INVALID, "offsets must be >= 0");
         if ((uint64_t)(o->chain_offset + o->n_chains) > 0xFFFFFFFFull)
             return fail(LR_ERR_INVALID, "global chain ids must fit 32 bits");
+        if (o->precision < LR_PREC_AUTO || o->precision > LR_PREC_BF16 || o->reserved != 0)
+            return fail(LR_ERR_INVALID, "precision must be LR_PREC_AUTO/FULL/BF16 and reserved 0");
         if (o->stats) {
             if (o->stats_batch < 1 || o->stats_first < 0 || o->stats_slots < 1)
                 return fail(LR_ERR_INVALID, "stats needs stats_batch >= 1, stats_first >= 0, stats_slots >= 1");
@@ -664,6 +675,15 @@ int lr_model_create(const double* X, const double* y, int64_t n, int32_t p, cons
             lr_model_destroy(m);
             return fail(LR_ERR_NOMEM, "allocating the bf16 block images (%zu bytes) failed", img.size() * 2);
         }
+        const size_t elems_blk1 = m->P == 64 ? (size_t)lr::WideBf16Geom<64>::BUF1 : (size_t)lr::WideBf16Geom<128>::BUF1;
+        std::vector<uint16_t> img1((size_t)nblk * elems_blk1);
+        if (m->P == 64) lr::wide_bf16_prepare_rne<64>(hrows, n, img1.data());
+        else lr::wide_bf16_prepare_rne<128>(hrows, n, img1.data());
+        if (hipMalloc(&m->d_xblk1, img1.size() * 2) != hipSuccess ||
+            hipMemcpy(m->d_xblk1, img1.data(), img1.size() * 2, hipMemcpyHostToDevice) != hipSuccess) {
+            lr_model_destroy(m);
+            return fail(LR_ERR_NOMEM, "allocating the single-piece bf16 block images (%zu bytes) failed", img1.size() * 2);
+        }
     }
     *out = m;
     return LR_OK;
@@ -677,6 +697,7 @@ void lr_model_destroy(lr_model* m) {
     for (auto& e : m->ws)
         if (e.p) (void)hipFree(e.p);
     if (m->d_xblk) (void)hipFree(m->d_xblk);
+    if (m->d_xblk1) (void)hipFree(m->d_xblk1);
     delete m;
 }
 

@@ -14,6 +14,15 @@ inline int check(hipError_t e) { return e == hipSuccess ? 0 : -2; }
 int launch_tall_partial(hipStream_t st, int want_value, int /*want_grad*/, const void* tall_args) {
     const auto& a = *static_cast<const TallArgs<float, P>*>(tall_args);
     const dim3 grid((unsigned)((a.C + 63) / 64), (unsigned)a.RS), block(256);
+    if (a.interior && !want_value && a.wide_bf16 >= 1 && a.xblk1) {  // reduced-precision interior leapfrog step
+        if (a.wide_bf16 == 2) {
+            const dim3 gridb((unsigned)((a.C + 127) / 128), (unsigned)a.RS), blockb(512);
+            hipLaunchKernelGGL((k_wide_partial_bf16i<P, 8>), gridb, blockb, 0, st, a);
+        } else {
+            hipLaunchKernelGGL((k_wide_partial_bf16i<P, 4>), grid, block, 0, st, a);
+        }
+        return check(hipGetLastError());
+    }
     if (a.wide_bf16 == 2) {  // 8 waves x 16 chains per workgroup
         const dim3 gridb((unsigned)((a.C + 127) / 128), (unsigned)a.RS), blockb(512);
         if (want_value) hipLaunchKernelGGL((k_wide_partial_bf16<P, true, 8>), gridb, blockb, 0, st, a);

@@ -74,6 +74,8 @@ template <typename T, int P> struct TallArgs {
     uint64_t seed;
     int wide_bf16;  // wide models: 0 = fp32 MFMA partial kernel, 1 = exact-split bf16 MFMA partial kernel
     const uint16_t* xblk;  // wide bf16: per-32-row-block LDS images of the split rows (lr_wide_bf16.h)
+    const uint16_t* xblk1;  // wide bf16: single-piece (round-to-nearest) images for interior leapfrog steps
+    int interior;  // this launch is an interior HMC gradient evaluation that may run in reduced precision
     int p, l;
     T step;
     T a[P], b[P], c[P];

@@ -211,7 +211,7 @@ class ChainSet:
     """
 
     def __init__(self, kernel: FusedKernel, init, seed: int, chain_offset: int = 0, ll=None, group: int = 0,
-                 mode: str = "auto", stream=None):
+                 mode: str = "auto", stream=None, precision: str = "auto"):
         self.kernel = kernel
         self.model = kernel.model
         m = self.model
@@ -224,6 +224,8 @@ class ChainSet:
         self.iter_offset = 0
         self.group = int(group)
         self.mode = _lib.MODE_BY_NAME[mode]
+        # arithmetic of HMC's interior leapfrog gradients (include/logreg_hip.h LR_PREC_*): "auto" | "full" | "bf16"
+        self.precision = _lib.PREC_BY_NAME[precision]
         self.stream = stream
         self.state = DeviceArray.from_host(m.device, st)
         lp0 = np.full(self.C, -np.inf) if ll is None else np.broadcast_to(np.asarray(ll, dtype=np.float64), (self.C,))
@@ -262,7 +264,7 @@ class ChainSet:
             out = DeviceArray(m.device, (iters, self.C, m.p), m.np_dtype)
         opts = RunOpts(n_chains=self.C, chain_offset=self.chain_offset, thin=int(thin), iters=int(iters),
                        iter_offset=self.iter_offset, seed=self.seed, group=self.group, mode=self.mode, on_device=1,
-                       stream=self.stream)
+                       stream=self.stream, precision=self.precision)
         use_stats = self.stats is not None if stats is None else bool(stats)
         if use_stats:
             if self.stats is None:
@@ -335,7 +337,8 @@ class ChainSet:
         return path
 
     @classmethod
-    def resume(cls, kernel: "FusedKernel", ckpt, group: int = 0, mode: str = "auto", stream=None) -> "ChainSet":
+    def resume(cls, kernel: "FusedKernel", ckpt, group: int = 0, mode: str = "auto", stream=None,
+               precision: str = "auto") -> "ChainSet":
         if isinstance(ckpt, (str, bytes)) or hasattr(ckpt, "__fspath__"):
             path = str(ckpt)
             if not path.endswith(".npz"):
@@ -344,7 +347,7 @@ class ChainSet:
         if str(ckpt["kind"]) != kernel.kind:
             raise ValueError(f"checkpoint is for a {ckpt['kind']} kernel, got {kernel.kind}")
         cs = cls(kernel, ckpt["state"], int(ckpt["seed"]), chain_offset=int(ckpt["chain_offset"]), ll=ckpt["ll"],
-                 group=group, mode=mode, stream=stream)
+                 group=group, mode=mode, stream=stream, precision=precision)
         want = cs._fingerprint()
         for key, val in want.items():
             if key not in ckpt:
@@ -369,7 +372,7 @@ def _auto_chunk(kernel: FusedKernel, C: int, thin: int, iters: int) -> int:
 
 
 def mcmc(init, kernel, thin=10, iters=10000, verb=True, *, seed=None, chunk=None, chain_offset=0, ll=None,
-         group=0, mode="auto", return_info=False, summary_only=False, max_batches=16):
+         group=0, mode="auto", return_info=False, summary_only=False, max_batches=16, precision="auto"):
     """Run a chain (or C chains): `mat[i]` = state after (i+1)*thin iterations (fit-np-hmc.py:89-103).
 
     Fused kernels run on the device; `init` of shape [p] returns a float64 `[iters, p]` matrix
@@ -388,7 +391,7 @@ def mcmc(init, kernel, thin=10, iters=10000, verb=True, *, seed=None, chunk=None
     single = init.ndim == 1
     if seed is None:
         seed = int(np.random.randint(0, 2**31 - 1))
-    cs = ChainSet(kernel, init, seed, chain_offset=chain_offset, ll=ll, group=group, mode=mode)
+    cs = ChainSet(kernel, init, seed, chain_offset=chain_offset, ll=ll, group=group, mode=mode, precision=precision)
     m = kernel.model
     if chunk is None:
         chunk = _auto_chunk(kernel, cs.C, thin, iters)

@@ -15,8 +15,8 @@ Writes tests/golden/fullsize_cfg4.json / fullsize_cfg5.json:
     map, laplace_sd           Newton MAP (float64 NumPy) and sqrt(diag((-H)^-1))
     eps, l, dmm               HMC settings, eps tuned to an acceptance rate inside 0.6-0.95
     accept, accept_se         acceptance rate of the long oracle run
-    mean, sd, ess, mcse       pooled posterior summary of the long oracle run
-    ess_sq, se_sd             ESS of the squared deviations and the SD's standard error sd / sqrt(2 ESS_sq)
+    mean, sd                  pooled posterior summary of the long oracle run (after `dropped` warm-up iterations)
+    mcse, se_sd               their standard errors, from the spread between the independent chains
 """
 from __future__ import annotations
 
@@ -32,13 +32,13 @@ REPO = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, REPO)
 
 from logreg_amd.data import synthetic_logreg  # noqa: E402  (NumPy only)
-from logreg_amd.diagnostics import ess_pooled, summarise  # noqa: E402  (NumPy only)
+from logreg_amd.diagnostics import summarise  # noqa: E402  (NumPy only)
 from oracle.oracle import OracleModel, max_threads  # noqa: E402
 
 CONFIGS = {
-    4: dict(n=100000, p=8, seed=20240004, beta_sd=0.5, pscale=[10.0] + [1.0] * 7, l=50, chains=128, iters=250,
+    4: dict(n=100000, p=8, seed=20240004, beta_sd=0.5, pscale=[10.0] + [1.0] * 7, l=50, chains=128, iters=250, drop=50,
             eps_grid=[0.004, 0.006, 0.008, 0.010]),
-    5: dict(n=4096, p=128, seed=20240005, beta_sd=0.1, pscale=[1.0] * 128, l=50, chains=128, iters=400,
+    5: dict(n=4096, p=128, seed=20240005, beta_sd=0.1, pscale=[1.0] * 128, l=50, chains=128, iters=400, drop=50,
             eps_grid=[0.008, 0.012, 0.016, 0.020]),
 }
 
@@ -82,19 +82,23 @@ def make(cfg_id: int):
     t0 = time.time()
     r = orc.run("hmc", init, step=eps, l=c["l"], scale=dmm, thin=1, iters=c["iters"], seed=20240000 + cfg_id, threads=thr)
     dt = time.time() - t0
-    out = r["out"][10:]  # starts are Laplace draws; drop 10 iterations anyway
+    out = r["out"][c["drop"]:]  # starts are Laplace draws about the MAP; the posterior mean sits up to 0.2 sd away
     s = summarise(out, max_chains=None)
-    # the SD's own standard error needs the ESS of the SQUARED deviations (HMC draws can be antithetic for the
-    # mean -- ESS above the draw count -- while their squares are not): se(sd) = sd / sqrt(2 ESS_sq)
-    ess_sq = ess_pooled((out - s["mean"]) ** 2, max_chains=None)
+    # Standard errors from the spread BETWEEN the independent chains (no autocorrelation estimate involved: Geyer's
+    # truncation on chains of a few hundred draws overstates the ESS): per-chain means m_c and second moments
+    # v_c = mean((x - pooled mean)^2);  se(mean) = sd_c(m_c)/sqrt(C),  se(sd) = sd_c(v_c)/sqrt(C) / (2 sd).
+    C = out.shape[1]
+    m_c = out.mean(axis=0)
+    v_c = ((out - s["mean"]) ** 2).mean(axis=0)
+    mcse = m_c.std(axis=0, ddof=1) / np.sqrt(C)
+    se_sd = v_c.std(axis=0, ddof=1) / np.sqrt(C) / (2 * s["sd"])
     ndraw = c["chains"] * c["iters"]
     acc = float(r["accepts"].sum() / ndraw)
     fix = {"config": cfg_id, "n": c["n"], "p": p, "data_seed": c["seed"], "beta_sd": c["beta_sd"], "pscale": c["pscale"],
            "eps": eps, "l": c["l"], "dmm": dmm.tolist(), "map": bmap.tolist(), "laplace_sd": lsd.tolist(),
            "oracle_chains": c["chains"], "oracle_iters": c["iters"], "oracle_seed": 20240000 + cfg_id,
            "accept": acc, "accept_se": float(np.sqrt(acc * (1 - acc) / ndraw)), "mean": s["mean"].tolist(),
-           "sd": s["sd"].tolist(), "ess": s["ess"].tolist(), "mcse": s["mcse"].tolist(),
-           "ess_sq": ess_sq.tolist(), "se_sd": (s["sd"] / np.sqrt(2 * ess_sq)).tolist(),
+           "sd": s["sd"].tolist(), "ess_geyer": s["ess"].tolist(), "mcse": mcse.tolist(), "se_sd": se_sd.tolist(), "dropped": c["drop"],
            "source": "oracle/lr_oracle.c float64, orc_run HMC on the Philox stream; tests/golden/make_fullsize_fixtures.py",
            "oracle_wall_s": dt}
     path = os.path.join(HERE, f"fullsize_cfg{cfg_id}.json")

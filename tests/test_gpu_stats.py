@@ -90,7 +90,7 @@ def test_summary_only_mcmc_never_builds_the_sample_matrix(la, pima, map_beta):
     Cn = 2048
     q0 = np.tile(map_beta, (Cn, 1))
     np.random.seed(3)
-    warm = la.mcmc(q0, k, thin=500, iters=1, verb=False, seed=11)[0]
+    warm = la.mcmc(q0, k, thin=2000, iters=1, verb=False, seed=11)[0]
     res = la.mcmc(warm, k, thin=20, iters=64, verb=False, seed=12, summary_only=True)
     samples = la.mcmc(warm, k, thin=20, iters=64, verb=False, seed=12)
     flat = samples.reshape(-1, 8).astype(np.float64)
@@ -98,7 +98,7 @@ def test_summary_only_mcmc_never_builds_the_sample_matrix(la, pima, map_beta):
     np.testing.assert_allclose(res["sd"], flat.std(0, ddof=1), rtol=1e-6)
     np.testing.assert_allclose(res["rhat"], la.split_rhat(samples), rtol=1e-6)
     assert res["n"] == Cn * 64 and res["batch"] == 4
-    assert np.all(np.abs(res["rhat"] - 1) < 0.02)
+    assert np.all(np.abs(res["rhat"] - 1) < 0.03)
     # batch-means ESS (batches of 4 kept samples) against Geyer's estimator on the same samples: same order
     geyer = la.ess_pooled(samples, max_chains=128)
     assert np.all(res["ess"] > 0.5 * geyer) and np.all(res["ess"] < 2.0 * geyer)

@@ -52,7 +52,7 @@ for case in range(cases):
     try:
         ref = orc.run(kind, q0, thin=thin, iters=iters, seed=case, ll_state=ll0, threads=0, **kw)
         out, info = la.mcmc(q0, kern, thin=thin, iters=iters, verb=False, seed=case, ll=ll0, mode=mode, group=group,
-                            return_info=True)
+                            return_info=True, precision="full")
         r = m.eval(q0, mode=mode if mode != "stepwise" else "auto", group=group if mode != "stepwise" else 0)
     except la.LogregHipError as e:
         skipped += 1
@@ -77,16 +77,17 @@ for case in range(cases):
     if not np.isfinite(out).all():
         errs.append("non-finite output")
     if rng.random() < 0.4:  # chunk and shard invariance: bit-exact (global chain id and iteration in the Philox counter)
-        again = la.mcmc(q0, kern, thin=thin, iters=iters, verb=False, seed=case, ll=ll0, mode=mode, group=group, chunk=1)
+        again = la.mcmc(q0, kern, thin=thin, iters=iters, verb=False, seed=case, ll=ll0, mode=mode, group=group, chunk=1,
+                        precision="full")
         if not np.array_equal(again, out):
             errs.append("chunk=1 differs")
         pl = info["plan"]
         if C > 1 and pl["mode"] != "stepwise":  # (stepwise slicing depends on the chain count by design)
             h = C // 2
             a = la.mcmc(q0[:h], kern, thin=thin, iters=iters, verb=False, seed=case, ll=None if ll0 is None else ll0[:h],
-                        mode=pl["mode"], group=pl["group"])
+                        mode=pl["mode"], group=pl["group"], precision="full")
             b = la.mcmc(q0[h:], kern, thin=thin, iters=iters, verb=False, seed=case, ll=None if ll0 is None else ll0[h:],
-                        mode=pl["mode"], group=pl["group"], chain_offset=h)
+                        mode=pl["mode"], group=pl["group"], chain_offset=h, precision="full")
             if not np.array_equal(np.concatenate([a, b], axis=1), out):
                 errs.append("shards differ")
     if errs:
