@@ -31,7 +31,12 @@ ARCH = "gfx950"
 # instruction fetch; when an unrelated edit elsewhere in the file moved the loop head to an address = 4 mod 8 the
 # kernel lost 10 % (0.444 -> 0.489 ms per launch, identical instructions).  With every loop head on a 64-byte
 # line the time no longer depends on what precedes the loop (8 / 16 / 32 / 64 / 128: 0.451 / 0.442 / 0.450 / 0.443 / 0.447 ms).
-COMMON = ["--offload-arch=" + ARCH, "-O3", "-fno-slp-vectorize", "-falign-loops=64", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall",
+# -amdgpu-mfma-vgpr-form: MFMA results in VGPRs.  In the AGPR form the register allocator rotated the 32 gradient
+# accumulators of the wide kernels through VGPRs on every trip of the block loop (48 v_accvgpr_read + 32
+# v_accvgpr_write per 24 MFMAs: 184 -> 104 instructions per block with the flag); no kernel here needs more than
+# 256 registers, so the accumulator file buys nothing.
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-fno-slp-vectorize", "-falign-loops=64", "-mllvm", "-amdgpu-sched-strategy=max-ilp",
+          "-mllvm", "-amdgpu-mfma-vgpr-form", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall",
           "-Wno-unused-function", "-I", CSRC, "-I", INCLUDE] + os.environ.get("LOGREG_HIPCC_FLAGS", "").split()
 
 INSTANCES = [(dt, dtype_id, ctype, p) for dt, dtype_id, ctype in (("f32", 0, "float"), ("f64", 1, "double"))

@@ -287,7 +287,21 @@ int setup_tall(lr_model* m, const Plan& pl, hipStream_t st, int64_t C, lr::TallA
     const int RS = pl.G;
     auto align = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t vec = align((size_t)C * P * sizeof(T)), dbl = align((size_t)C * sizeof(double));
-    const size_t need = 4 * vec + 2 * dbl + align((size_t)C * 4) + align((size_t)RS * C * P * sizeof(T)) +
+    // wide models, interior leapfrog steps with few chains: the row-split kernel (lr_wide_bf16.h) wants one chain
+    // tile of 16 per workgroup and as many row slices as fill the chip; each slice a multiple of 128 rows
+    int RS_i = 0;
+    int64_t slice_len_i = 0;
+    if (m->P > 32 && m->d_xblk1 && !std::getenv("LOGREG_WIDE_NO_ROWSPLIT")) {
+        const int64_t tiles = (C + 15) / 16;
+        if (tiles <= m->cus) {
+            int64_t want = m->cus / tiles;
+            if (want < 1) want = 1;
+            slice_len_i = ((m->n + want - 1) / want + 127) / 128 * 128;
+            RS_i = (int)((m->n + slice_len_i - 1) / slice_len_i);
+        }
+    }
+    const int RSmax = RS_i > RS ? RS_i : RS;
+    const size_t need = 4 * vec + 2 * dbl + align((size_t)C * 4) + align((size_t)RSmax * C * P * sizeof(T)) +
                         align((size_t)RS * C * sizeof(double));
     lr_model::Ws* slot = nullptr;
     for (auto& e : m->ws)
@@ -329,7 +343,9 @@ int setup_tall(lr_model* m, const Plan& pl, hipStream_t st, int64_t C, lr::TallA
     a.lp = (double*)carve(dbl);
     a.aux = (double*)carve(dbl);
     a.nacc = (uint32_t*)carve(align((size_t)C * 4));
-    a.part_g = (T*)carve(align((size_t)RS * C * P * sizeof(T)));
+    a.part_g = (T*)carve(align((size_t)RSmax * C * P * sizeof(T)));
+    a.RS_i = RS_i;
+    a.slice_len_i = slice_len_i;
     a.part_v = (double*)carve(align((size_t)RS * C * sizeof(double)));
     a.C = C;
     a.p = m->p;
@@ -395,6 +411,8 @@ int do_stepwise_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs
     };
     // interior leapfrog gradients (HMC): reduced precision where the policy allows and a kernel exists
     const bool bf16_interior = rs.kind == lr::KIND_HMC && o->precision != LR_PREC_FULL && m->d_xblk1 != nullptr;
+    const int RS_exact = a.RS, RS_mid = bf16_interior && a.RS_i > 0 ? a.RS_i : a.RS;
+    if (!bf16_interior) a.RS_i = 0;
     auto KI = [&]() {
         a.interior = bf16_interior ? 1 : 0;
         K(0, 1);
@@ -410,7 +428,9 @@ int do_stepwise_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs
         if (kind == lr::KIND_HMC) {
             for (int i = 0; i < rs.l - 1; ++i) {
                 KI();
+                a.RS = RS_mid;  // the update sums as many slice partials as the partial kernel just wrote
                 U(lr::PH_MID, 0, -1, 0);
+                a.RS = RS_exact;
             }
             K(1, 1);
         } else if (kind == lr::KIND_MALA) {

@@ -76,6 +76,8 @@ template <typename T, int P> struct TallArgs {
     const uint16_t* xblk;  // wide bf16: per-32-row-block LDS images of the split rows (lr_wide_bf16.h)
     const uint16_t* xblk1;  // wide bf16: single-piece (round-to-nearest) images for interior leapfrog steps
     int interior;  // this launch is an interior HMC gradient evaluation that may run in reduced precision
+    int RS_i;               // row-split interior kernel (k_wide_partial_bf16r): slices, 0 = not used for this run
+    int64_t slice_len_i;    //   and rows per slice (a multiple of 128: 4 waves x whole 32-row blocks)
     int p, l;
     T step;
     T a[P], b[P], c[P];

@@ -256,13 +256,22 @@ __global__ void __launch_bounds__((64 * NW)) k_wide_partial_bf16(TallArgs<float,
 // perturbed by 2^-9 relative -- a smooth Hamiltonian next door -- and the acceptance rate at BASELINE config 5
 // (n = 4096, p = 128, eps = 0.02, L = 50) moves from 0.757 to 0.75x (tests/test_gpu_fullsize.py measures it).
 // The reference has no counterpart (fit-np-hmc.py:65-87 computes every glp in float64).
+// Staging: the 8 KB block images go from L2/HBM straight into LDS with the LDS-DMA load (global_load_lds_dwordx4:
+// wave-uniform LDS base + lane x 16 B, no staging VGPRs, no ds_write pass), a PASS of kPassBytes (4 blocks at
+// P = 128) at a time into one of two buffers: the DMA of pass g + 1 runs under the arithmetic of pass g, and there
+// is ONE barrier per pass instead of one per 32-row block (config 5's slices of 8 blocks: 2 barriers, was 8 --
+// with the per-block barrier the loop paid the global-load latency of every block: 11.3 us per launch).
 template <int P, int NW>
 __global__ void __launch_bounds__((64 * NW)) k_wide_partial_bf16i(TallArgs<float, P> a) {
     using G = WideBf16Geom<P>;
     constexpr int NT = 64 * NW, CPB = 16 * NW;
-    constexpr int SMEM = 2 * G::BUF1 > CPB * (P + 4) * 2 ? 2 * G::BUF1 : CPB * (P + 4) * 2;
-    __shared__ __attribute__((aligned(16))) uint16_t smem[SMEM];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int kPassBytes = 32768, BLK_BYTES = G::BUF1 * 2;
+    constexpr int SB = kPassBytes / BLK_BYTES;  // blocks per pass
+    constexpr int PASS_EL = kPassBytes / 2;     // bf16 elements per buffer
+    constexpr int SMEM = 2 * PASS_EL > CPB * (P + 4) * 2 ? 2 * PASS_EL : CPB * (P + 4) * 2;
+    __shared__ __attribute__((aligned(1024))) uint16_t smem[SMEM];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, kg = lane >> 4;
     int64_t chain = (int64_t)blockIdx.x * CPB + 16 * wave + c;
     const bool live = chain < a.C;
@@ -270,25 +279,21 @@ __global__ void __launch_bounds__((64 * NW)) k_wide_partial_bf16i(TallArgs<float
     const int rs = blockIdx.y;
     const int64_t s0 = (int64_t)rs * a.slice_len, s1 = s0 + a.slice_len < a.n ? s0 + a.slice_len : a.n;
     const int64_t nblk = s1 > s0 ? (s1 - s0 + 31) / 32 : 0;
-
-    // staging of block 0 is issued first: its latency overlaps the beta split below
-    constexpr int NCH = G::BUF1 * 2 / 16;
-    constexpr int CHUNKS = (NCH + NT - 1) / NT;
-    u32x4 stage[CHUNKS];
+    const int64_t npass = (nblk + SB - 1) / SB;
     const int64_t blk0 = s0 / 32;
-    auto fetch = [&](int64_t b) {
-        const u32x4* src = reinterpret_cast<const u32x4*>(a.xblk1 + (blk0 + b) * (int64_t)G::BUF1);
-#pragma unroll
-        for (int i = 0; i < CHUNKS; ++i)
-            if (NT * (i + 1) <= NCH || tid + NT * i < NCH) stage[i] = src[tid + NT * i];
+
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    auto issue = [&](int64_t g) {  // pass g -> buffer g & 1; 1 KB per wave-instruction, chunks dealt round-robin to the waves
+        const int64_t b0 = g * SB;
+        const int nb = (int)(nblk - b0 < SB ? nblk - b0 : SB);
+        const char* src = reinterpret_cast<const char*>(a.xblk1 + (blk0 + b0) * (int64_t)G::BUF1);
+        char* dst = reinterpret_cast<char*>(smem) + (g & 1) * kPassBytes;
+        const int nchunk = nb * (BLK_BYTES / 1024);
+        for (int ch = wave; ch < nchunk; ch += NW)
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + ch * 1024 + lane * 16), (lptr_t)(dst + ch * 1024), 16, 0, 0);
     };
-    auto deposit = [&](int buf) {
-        u32x4* dst = reinterpret_cast<u32x4*>(smem + buf * G::BUF1);
-#pragma unroll
-        for (int i = 0; i < CHUNKS; ++i)
-            if (NT * (i + 1) <= NCH || tid + NT * i < NCH) dst[tid + NT * i] = stage[i];
-    };
-    if (nblk > 0) fetch(0);
+    if (npass > 0) issue(0);  // in flight under the beta split below
 
     // beta = hi + lo (two round-to-nearest bf16 pieces) of the lane's coordinates 32 m + 8 kg + i, times log2(e)
     u32x4 bq[G::M32][2];
@@ -319,41 +324,47 @@ __global__ void __launch_bounds__((64 * NW)) k_wide_partial_bf16i(TallArgs<float
 #pragma unroll
     for (int mb = 0; mb < G::MBP; ++mb) gacc[mb] = f32x4{0, 0, 0, 0};
 
-    if (nblk > 0) deposit(0);
-    __syncthreads();
-    for (int64_t b = 0; b < nblk; ++b) {
-        const int buf = (int)(b & 1);
-        const uint16_t* base = smem + buf * G::BUF1;
-        if (b + 1 < nblk) fetch(b + 1);
-        // ---- eta for the two tiles: X (1 piece) x beta (hi, lo)
-        uint32_t wq[4];
-#pragma unroll
-        for (int T = 0; T < 2; ++T) {
-            f32x4 e0 = {0, 0, 0, 0}, e1 = {0, 0, 0, 0};
-#pragma unroll
-            for (int m = 0; m < G::M32; ++m) {
-                const u32x4 xa = *reinterpret_cast<const u32x4*>(base + G::tile1(T, m) + eta_off);
-                e0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(xa), as_bf16x8(bq[m][0]), e0, 0, 0, 0);
-                e1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(xa), as_bf16x8(bq[m][1]), e1, 0, 0, 0);
-            }
-            float w[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) w[r] = fast_rcp(1.0f + __builtin_amdgcn_exp2f(e0[r] + e1[r]));
-            wq[2 * T] = pack_rne(w[0], w[1]);  // K-slot 8 kg + 4 T + r <-> row 4 kg + r of tile T
-            wq[2 * T + 1] = pack_rne(w[2], w[3]);
-        }
-        const u32x4 wv = {wq[0], wq[1], wq[2], wq[3]};
-        // ---- grad += Xs^T . W
-#pragma unroll
-        for (int mb = 0; mb < G::MBP; ++mb) {
-            const u32x2 t0 = lds_read_tr16(base + G::tile1(0, mb >> 1) + tr_off[mb & 1]);
-            const u32x2 t1 = lds_read_tr16(base + G::tile1(1, mb >> 1) + tr_off[mb & 1]);
-            const u32x4 xg = {t0[0], t0[1], t1[0], t1[1]};
-            gacc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(xg), as_bf16x8(wv), gacc[mb], 0, 0, 0);
-        }
-        if (b + 1 < nblk) deposit(buf ^ 1);
+    for (int64_t g = 0; g < npass; ++g) {
+        // pass g has landed (every wave waits for its own DMA, the barrier for everybody's), and all waves are done
+        // reading the other buffer (pass g - 1), which the DMA of pass g + 1 may now overwrite
+        // (builtin, not inline asm: a kernel containing inline asm makes the register allocator assume AGPRs may be
+        // needed, selects the AGPR form of every MFMA and then shuffles the 32 gradient accumulators through VGPRs
+        // on each trip -- 80 v_accvgpr moves per block)
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), lgkmcnt / expcnt untouched
         __syncthreads();
+        if (g + 1 < npass) issue(g + 1);
+        const int nb = (int)(nblk - g * SB < SB ? nblk - g * SB : SB);
+        for (int bi = 0; bi < nb; ++bi) {
+            const uint16_t* base = smem + (g & 1) * PASS_EL + bi * G::BUF1;
+            // ---- eta for the two tiles: X (1 piece) x beta (hi, lo)
+            uint32_t wq[4];
+#pragma unroll
+            for (int T = 0; T < 2; ++T) {
+                f32x4 e0 = {0, 0, 0, 0}, e1 = {0, 0, 0, 0};
+#pragma unroll
+                for (int m = 0; m < G::M32; ++m) {
+                    const u32x4 xa = *reinterpret_cast<const u32x4*>(base + G::tile1(T, m) + eta_off);
+                    e0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(xa), as_bf16x8(bq[m][0]), e0, 0, 0, 0);
+                    e1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(xa), as_bf16x8(bq[m][1]), e1, 0, 0, 0);
+                }
+                float w[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) w[r] = fast_rcp(1.0f + __builtin_amdgcn_exp2f(e0[r] + e1[r]));
+                wq[2 * T] = pack_rne(w[0], w[1]);  // K-slot 8 kg + 4 T + r <-> row 4 kg + r of tile T
+                wq[2 * T + 1] = pack_rne(w[2], w[3]);
+            }
+            const u32x4 wv = {wq[0], wq[1], wq[2], wq[3]};
+            // ---- grad += Xs^T . W
+#pragma unroll
+            for (int mb = 0; mb < G::MBP; ++mb) {
+                const u32x2 t0 = lds_read_tr16(base + G::tile1(0, mb >> 1) + tr_off[mb & 1]);
+                const u32x2 t1 = lds_read_tr16(base + G::tile1(1, mb >> 1) + tr_off[mb & 1]);
+                const u32x4 xg = {t0[0], t0[1], t1[0], t1[1]};
+                gacc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(xg), as_bf16x8(wv), gacc[mb], 0, 0, 0);
+            }
+        }
     }
+    __syncthreads();  // the output tile aliases the staging buffers
     constexpr int OT = P + 4;
     static_assert(CPB * OT * 2 <= SMEM, "padded output tile must fit");
     float* otile = reinterpret_cast<float*>(smem);
@@ -367,6 +378,149 @@ __global__ void __launch_bounds__((64 * NW)) k_wide_partial_bf16i(TallArgs<float
         f32x4* dst = reinterpret_cast<f32x4*>(a.part_g + ((int64_t)rs * a.C + chain0) * P);
         for (int i = tid; i < (int)(nlive * P / 4); i += NT)
             __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(otile + (i / (P / 4)) * OT + (i % (P / 4)) * 4), &dst[i]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// ROW-SPLIT form of the interior-step kernel, for few chains (ceil(C / 16) <= CUs, i.e. C <= 4096 on MI355X).
+// Measured on config 5 (1024 chains, 16 row slices x 16 chain blocks): of the 15 us per evaluation, 4.7 us were
+// the 8 MB of slice partials leaving the chip (16 slices x 1024 chains x 128 coordinates x 4 B) and another ~2 us
+// the update kernel reading them back -- more than the 3.9 us of matrix work.  Here a workgroup is ONE chain tile
+// (16 chains) whose 4 waves take different ROWS of the slice and add their gradients through LDS before anything
+// leaves the CU: 4 slices instead of 16, 2 MB of partials instead of 8.  The waves share nothing while they
+// run, so the row loop has no barrier at all: every wave streams its own 8 KB block images L2 -> LDS with the
+// LDS-DMA load into a private ring of 4 buffers (3 blocks in flight ahead of the one being consumed) and waits
+// with counted vmcnt.  (The DMA is issued from inline asm: told about it, the compiler guards every
+// ds_read_b64_tr_b16 with vmcnt(0) -- it cannot see that the transposing reads touch another ring slot -- and
+// the prefetch would never run ahead.)  Price: the tile's rows are not shared between waves any more, 4x the
+// L2 -> LDS traffic (64 MB per evaluation), which the DMA ring hides under the MFMAs.
+template <int BYTES> __device__ __forceinline__ void wait_vm_blocks(int younger) {
+    // wait until at most `younger` block images (BYTES / 1024 DMA instructions each) are still in flight
+    constexpr int per = BYTES / 1024;
+    static_assert(3 * per <= 63, "vmcnt is a 6-bit field");
+    if (younger >= 3) __builtin_amdgcn_s_waitcnt(0x0F70 | ((3 * per) & 15) | (((3 * per) >> 4) << 14));
+    else if (younger == 2) __builtin_amdgcn_s_waitcnt(0x0F70 | ((2 * per) & 15) | (((2 * per) >> 4) << 14));
+    else if (younger == 1) __builtin_amdgcn_s_waitcnt(0x0F70 | (per & 15) | ((per >> 4) << 14));
+    else __builtin_amdgcn_s_waitcnt(0x0F70);
+}
+
+template <int P>
+__global__ void __launch_bounds__(256) k_wide_partial_bf16r(TallArgs<float, P> a) {
+    using G = WideBf16Geom<P>;
+    constexpr int BLK_BYTES = G::BUF1 * 2, NBUF = 4, RING_BYTES = NBUF * BLK_BYTES;  // per wave: 32 KB at P = 128
+    constexpr int OT = P + 4;
+    static_assert(16 * OT * 4 <= RING_BYTES, "a wave's output tile lives in its own ring");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[4 * RING_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, kg = lane >> 4;
+    const int64_t chain0 = (int64_t)blockIdx.x * 16;
+    int64_t chain = chain0 + c;
+    if (chain >= a.C) chain = a.C - 1;
+    const int rs = blockIdx.y;
+    const int64_t s0 = (int64_t)rs * a.slice_len_i, s1 = s0 + a.slice_len_i < a.n ? s0 + a.slice_len_i : a.n;
+    const int nblk_slice = s1 > s0 ? (int)((s1 - s0 + 31) / 32) : 0;
+    const int per_wave = (nblk_slice + 3) / 4;
+    const int wb0 = wave * per_wave;
+    const int wnb = nblk_slice - wb0 < 0 ? 0 : (nblk_slice - wb0 < per_wave ? nblk_slice - wb0 : per_wave);
+    const int64_t blk0 = s0 / 32 + wb0;
+    unsigned char* ring = smem + wave * RING_BYTES;
+    const uint32_t ring_lds = (uint32_t)(uintptr_t)ring;  // LDS byte address (generic -> local keeps the low 32 bits)
+
+    auto issue = [&](int b) {  // block b of this wave -> ring slot b % NBUF
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(a.xblk1 + (blk0 + b) * (int64_t)G::BUF1) + lane * 16;
+        const uint32_t dst = ring_lds + (uint32_t)((b & (NBUF - 1)) * BLK_BYTES);
+#pragma unroll
+        for (int ch = 0; ch < BLK_BYTES / 1024; ++ch) {
+            uint32_t keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(src + ch * 1024), "s"(dst + ch * 1024)
+                         : "memory");
+        }
+    };
+#pragma unroll
+    for (int b = 0; b < NBUF - 1; ++b)
+        if (b < wnb) issue(b);
+
+    // beta = hi + lo (two round-to-nearest bf16 pieces) of the lane's coordinates 32 m + 8 kg + i, times log2(e)
+    u32x4 bq[G::M32][2];
+#pragma unroll
+    for (int m = 0; m < G::M32; ++m) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.q1 + chain * P + 32 * m + 8 * kg);
+        const f32x4 v0 = src[0], v1 = src[1];
+        float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        uint32_t hi[4], lo[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float x0 = x[2 * i] * ExpScale<float>::k, x1 = x[2 * i + 1] * ExpScale<float>::k;
+            hi[i] = pack_rne(x0, x1);
+            const float h0 = __builtin_bit_cast(float, hi[i] << 16), h1 = __builtin_bit_cast(float, hi[i] & 0xFFFF0000u);
+            lo[i] = pack_rne(x0 - h0, x1 - h1);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int j = (kg & 1) ? (i ^ 2) : i;  // odd kg: halves swapped, as the eta read delivers them
+            bq[m][0][i] = hi[j];
+            bq[m][1][i] = lo[j];
+        }
+    }
+    const int eta_off = G::elem(kg, c, 0) & ~7;
+    const int ri = (lane & 15) >> 2, ci = lane & 3;
+    const int tr_off[2] = {G::elem(ci, 4 * kg + ri, 0), G::elem(ci, 4 * kg + ri, 4)};
+    f32x4 gacc[G::MBP];
+#pragma unroll
+    for (int mb = 0; mb < G::MBP; ++mb) gacc[mb] = f32x4{0, 0, 0, 0};
+
+    for (int b = 0; b < wnb; ++b) {
+        // slot (b - 1) % NBUF was read during the previous trip and those reads have returned (their MFMAs
+        // issued): refill it with block b + NBUF - 1, then wait for block b with the younger ones still in flight
+        if (b + NBUF - 1 < wnb) issue(b + NBUF - 1);
+        const int last = b + NBUF - 1 < wnb ? b + NBUF - 1 : wnb - 1;
+        wait_vm_blocks<BLK_BYTES>(last - b);
+        const uint16_t* base = reinterpret_cast<const uint16_t*>(ring + (b & (NBUF - 1)) * BLK_BYTES);
+        uint32_t wq[4];
+#pragma unroll
+        for (int T = 0; T < 2; ++T) {
+            f32x4 e0 = {0, 0, 0, 0}, e1 = {0, 0, 0, 0};
+#pragma unroll
+            for (int m = 0; m < G::M32; ++m) {
+                const u32x4 xa = *reinterpret_cast<const u32x4*>(base + G::tile1(T, m) + eta_off);
+                e0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(xa), as_bf16x8(bq[m][0]), e0, 0, 0, 0);
+                e1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(xa), as_bf16x8(bq[m][1]), e1, 0, 0, 0);
+            }
+            float w[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w[r] = fast_rcp(1.0f + __builtin_amdgcn_exp2f(e0[r] + e1[r]));
+            wq[2 * T] = pack_rne(w[0], w[1]);
+            wq[2 * T + 1] = pack_rne(w[2], w[3]);
+        }
+        const u32x4 wv = {wq[0], wq[1], wq[2], wq[3]};
+#pragma unroll
+        for (int mb = 0; mb < G::MBP; ++mb) {
+            const u32x2 t0 = lds_read_tr16(base + G::tile1(0, mb >> 1) + tr_off[mb & 1]);
+            const u32x2 t1 = lds_read_tr16(base + G::tile1(1, mb >> 1) + tr_off[mb & 1]);
+            const u32x4 xg = {t0[0], t0[1], t1[0], t1[1]};
+            gacc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(xg), as_bf16x8(wv), gacc[mb], 0, 0, 0);
+        }
+    }
+    // the four waves' gradients of the tile, summed in wave order (deterministic) and written once
+    float* otile = reinterpret_cast<float*>(ring);
+#pragma unroll
+    for (int mb = 0; mb < G::MBP; ++mb)
+        *reinterpret_cast<f32x4*>(otile + c * OT + 32 * (mb >> 1) + 8 * kg + 4 * (mb & 1)) = gacc[mb];
+    __syncthreads();
+    {
+        const int64_t nlive = a.C - chain0 < 16 ? a.C - chain0 : 16;
+        f32x4* dst = reinterpret_cast<f32x4*>(a.part_g + ((int64_t)rs * a.C + chain0) * P);
+        for (int i = tid; i < (int)(nlive * P / 4); i += 256) {
+            const int off = (i / (P / 4)) * OT + (i % (P / 4)) * 4;
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(smem + 0 * RING_BYTES + off * 4);
+            const f32x4 w1 = *reinterpret_cast<const f32x4*>(smem + 1 * RING_BYTES + off * 4);
+            const f32x4 w2 = *reinterpret_cast<const f32x4*>(smem + 2 * RING_BYTES + off * 4);
+            const f32x4 w3 = *reinterpret_cast<const f32x4*>(smem + 3 * RING_BYTES + off * 4);
+            __builtin_nontemporal_store((w0 + w1) + (w2 + w3), &dst[i]);
+        }
     }
 }
 
