@@ -289,20 +289,26 @@ int setup_tall(lr_model* m, const Plan& pl, hipStream_t st, int64_t C, lr::TallA
     const size_t vec = align((size_t)C * P * sizeof(T)), dbl = align((size_t)C * sizeof(double));
     // wide models, interior leapfrog steps with few chains: the row-split kernel (lr_wide_bf16.h) wants one chain
     // tile of 16 per workgroup and as many row slices as fill the chip; each slice a multiple of 128 rows
-    int RS_i = 0;
+    int RS_i = 0, rs_waves = 4;
     int64_t slice_len_i = 0;
     if (m->P > 32 && m->d_xblk1 && !std::getenv("LOGREG_WIDE_NO_ROWSPLIT")) {
         const int64_t tiles = (C + 15) / 16;
         if (tiles <= m->cus) {
             int64_t want = m->cus / tiles;
             if (want < 1) want = 1;
-            slice_len_i = ((m->n + want - 1) / want + 127) / 128 * 128;
+            const char* envw = std::getenv("LOGREG_WIDE_ROWSPLIT_WAVES");
+            rs_waves = envw ? std::atoi(envw) : 8;
+            if (rs_waves != 4) rs_waves = 8;
+            const int64_t quantum = 32 * rs_waves;
+            slice_len_i = ((m->n + want - 1) / want + quantum - 1) / quantum * quantum;
             RS_i = (int)((m->n + slice_len_i - 1) / slice_len_i);
         }
     }
     const int RSmax = RS_i > RS ? RS_i : RS;
-    const size_t need = 4 * vec + 2 * dbl + align((size_t)C * 4) + align((size_t)RSmax * C * P * sizeof(T)) +
-                        align((size_t)RS * C * sizeof(double));
+    const size_t pg = align((size_t)RSmax * C * P * sizeof(T)), cv = align((size_t)2 * P * sizeof(T));
+    // (second state pair + second partial buffer + constants: the fused interior steps of the row-split kernel)
+    const size_t need = 4 * vec + 2 * dbl + align((size_t)C * 4) + pg + align((size_t)RS * C * sizeof(double)) +
+                        (RS_i > 0 ? 2 * vec + pg : 0) + cv;
     lr_model::Ws* slot = nullptr;
     for (auto& e : m->ws)
         if (e.stream == st) slot = &e;
@@ -343,10 +349,17 @@ int setup_tall(lr_model* m, const Plan& pl, hipStream_t st, int64_t C, lr::TallA
     a.lp = (double*)carve(dbl);
     a.aux = (double*)carve(dbl);
     a.nacc = (uint32_t*)carve(align((size_t)C * 4));
-    a.part_g = (T*)carve(align((size_t)RSmax * C * P * sizeof(T)));
+    a.part_g = (T*)carve(pg);
     a.RS_i = RS_i;
     a.slice_len_i = slice_len_i;
+    a.rowsplit_waves = rs_waves;
     a.part_v = (double*)carve(align((size_t)RS * C * sizeof(double)));
+    a.cvec = (const T*)carve(cv);
+    if (RS_i > 0) {  // alternates, parked in the *_in fields until do_stepwise_t starts ping-ponging
+        a.q1_in = (const T*)carve(vec);
+        a.pm_in = (const T*)carve(vec);
+        a.part_in = (const T*)carve(pg);
+    }
     a.C = C;
     a.p = m->p;
     {
@@ -418,6 +431,11 @@ int do_stepwise_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs
         K(0, 1);
         a.interior = 0;
     };
+    const bool fuse = bf16_interior && a.RS_i > 0 && a.RS_i <= 4 && !std::getenv("LOGREG_WIDE_NO_FUSE");  // kFuseSlices
+    T* qb[2] = {a.q1, const_cast<T*>(a.q1_in)};
+    T* pb[2] = {a.pm, const_cast<T*>(a.pm_in)};
+    T* gb[2] = {a.part_g, const_cast<T*>(a.part_in)};
+    int cs = 0, cg = 0;  // which of the pairs holds the current state / the latest partials
     const int kind = rs.kind;
     U(lr::PH_LOAD, 0, -1, 0);
     if (kind == lr::KIND_HMC) K(1, 1);
@@ -426,11 +444,37 @@ int do_stepwise_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs
     const int64_t total = o->iters * o->thin;
     for (int64_t tt = 0; tt < total && !rc; ++tt) {
         if (kind == lr::KIND_HMC) {
-            for (int i = 0; i < rs.l - 1; ++i) {
-                KI();
-                a.RS = RS_mid;  // the update sums as many slice partials as the partial kernel just wrote
-                U(lr::PH_MID, 0, -1, 0);
-                a.RS = RS_exact;
+            if (fuse) {
+                // row-split interior kernel: every launch but the first finishes the previous leapfrog step in its
+                // own prologue (state and partial buffers ping-pong), so the L - 1 interior steps are L - 1
+                // launches plus ONE update at the end instead of 2 (L - 1) launches
+                for (int i = 0; i < rs.l - 1; ++i) {
+                    if (i > 0) {
+                        a.q1_in = qb[cs];
+                        a.pm_in = pb[cs];
+                        a.part_in = gb[cg];
+                        cs ^= 1;
+                        cg ^= 1;
+                        a.q1 = qb[cs];
+                        a.pm = pb[cs];
+                        a.part_g = gb[cg];
+                    }
+                    a.fuse_mid = i > 0;
+                    KI();
+                    a.fuse_mid = 0;
+                }
+                if (rs.l > 1) {
+                    a.RS = RS_mid;
+                    U(lr::PH_MID, 0, -1, 0);
+                    a.RS = RS_exact;
+                }
+            } else {
+                for (int i = 0; i < rs.l - 1; ++i) {
+                    KI();
+                    a.RS = RS_mid;  // the update sums as many slice partials as the partial kernel just wrote
+                    U(lr::PH_MID, 0, -1, 0);
+                    a.RS = RS_exact;
+                }
             }
             K(1, 1);
         } else if (kind == lr::KIND_MALA) {

@@ -17,7 +17,8 @@ int launch_tall_partial(hipStream_t st, int want_value, int /*want_grad*/, const
     if (a.interior && !want_value && a.wide_bf16 >= 1 && a.xblk1) {  // reduced-precision interior leapfrog step
         if (a.RS_i > 0) {  // few chains: one chain tile per workgroup, rows split over its waves
             const dim3 gridr((unsigned)((a.C + 15) / 16), (unsigned)a.RS_i);
-            hipLaunchKernelGGL((k_wide_partial_bf16r<P>), gridr, block, 0, st, a);
+            if (a.rowsplit_waves == 8) hipLaunchKernelGGL((k_wide_partial_bf16r<P, 8>), gridr, dim3(512), 0, st, a);
+            else hipLaunchKernelGGL((k_wide_partial_bf16r<P, 4>), gridr, block, 0, st, a);
         } else if (a.wide_bf16 == 2) {
             const dim3 gridb((unsigned)((a.C + 127) / 128), (unsigned)a.RS), blockb(512);
             hipLaunchKernelGGL((k_wide_partial_bf16i<P, 8>), gridb, blockb, 0, st, a);

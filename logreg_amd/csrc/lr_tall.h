@@ -76,8 +76,17 @@ template <typename T, int P> struct TallArgs {
     const uint16_t* xblk;  // wide bf16: per-32-row-block LDS images of the split rows (lr_wide_bf16.h)
     const uint16_t* xblk1;  // wide bf16: single-piece (round-to-nearest) images for interior leapfrog steps
     int interior;  // this launch is an interior HMC gradient evaluation that may run in reduced precision
+    // fused interior step (k_wide_partial_bf16r, fuse_mid = 1): the kernel first finishes the PREVIOUS leapfrog step
+    // itself -- kick with the slice partials in part_in, drift -- from the state in (q1_in, pm_in), stores the new state
+    // to (q1, pm) (slice 0 only; ping-pong buffers, so nobody reads what is being written) and then evaluates there
+    const T* part_in;
+    const T* q1_in;
+    const T* pm_in;
+    const T* cvec;          // [2][P]: drift factors b[j] = eps / dmm[j], prior precisions (device copy for per-lane reads)
+    int fuse_mid;
     int RS_i;               // row-split interior kernel (k_wide_partial_bf16r): slices, 0 = not used for this run
-    int64_t slice_len_i;    //   and rows per slice (a multiple of 128: 4 waves x whole 32-row blocks)
+    int64_t slice_len_i;    //   and rows per slice (a multiple of 32 * rowsplit_waves: whole 32-row blocks per wave)
+    int rowsplit_waves;     //   4 or 8 waves per workgroup
     int p, l;
     T step;
     T a[P], b[P], c[P];
@@ -312,6 +321,10 @@ __global__ void __launch_bounds__(256) k_tall_update(TallArgs<T, P> a, int phase
             a.x[ix] = x;
             a.q1[ix] = x;
             if (j == 0) a.nacc[chain] = 0;
+        }
+        if (a.cvec && chain == 0) {  // per-coordinate constants where a lane can fetch them with an ordinary load
+            const_cast<T*>(a.cvec)[j] = bj;
+            const_cast<T*>(a.cvec)[P + j] = ivj;
         }
         return;
     }

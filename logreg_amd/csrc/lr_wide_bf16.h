@@ -404,13 +404,15 @@ template <int BYTES> __device__ __forceinline__ void wait_vm_blocks(int younger)
     else __builtin_amdgcn_s_waitcnt(0x0F70);
 }
 
-template <int P>
-__global__ void __launch_bounds__(256) k_wide_partial_bf16r(TallArgs<float, P> a) {
+template <int P, int NW>
+__global__ void __launch_bounds__((64 * NW)) k_wide_partial_bf16r(TallArgs<float, P> a) {
     using G = WideBf16Geom<P>;
-    constexpr int BLK_BYTES = G::BUF1 * 2, NBUF = 4, RING_BYTES = NBUF * BLK_BYTES;  // per wave: 32 KB at P = 128
+    // NW = 4: one wave per SIMD, ring of 4 block images per wave; NW = 8: two waves per SIMD (each hides the other's
+    // LDS -> MFMA latency, which is what a block costs at one wave per SIMD), ring of 2
+    constexpr int BLK_BYTES = G::BUF1 * 2, NBUF = NW == 4 ? 4 : 2, RING_BYTES = NBUF * BLK_BYTES;
     constexpr int OT = P + 4;
     static_assert(16 * OT * 4 <= RING_BYTES, "a wave's output tile lives in its own ring");
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[4 * RING_BYTES];
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NW * RING_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, kg = lane >> 4;
@@ -420,7 +422,7 @@ __global__ void __launch_bounds__(256) k_wide_partial_bf16r(TallArgs<float, P> a
     const int rs = blockIdx.y;
     const int64_t s0 = (int64_t)rs * a.slice_len_i, s1 = s0 + a.slice_len_i < a.n ? s0 + a.slice_len_i : a.n;
     const int nblk_slice = s1 > s0 ? (int)((s1 - s0 + 31) / 32) : 0;
-    const int per_wave = (nblk_slice + 3) / 4;
+    const int per_wave = (nblk_slice + NW - 1) / NW;
     const int wb0 = wave * per_wave;
     const int wnb = nblk_slice - wb0 < 0 ? 0 : (nblk_slice - wb0 < per_wave ? nblk_slice - wb0 : per_wave);
     const int64_t blk0 = s0 / 32 + wb0;
@@ -443,13 +445,74 @@ __global__ void __launch_bounds__(256) k_wide_partial_bf16r(TallArgs<float, P> a
     for (int b = 0; b < NBUF - 1; ++b)
         if (b < wnb) issue(b);
 
+    // fused previous step (k_tall_update's PH_MID done here):  g1 = sum of the slice partials (slice order, fp64)
+    // - q ivar;  p += eps g1;  q += (eps / m) p.  The four waves hold the SAME 16 chains, so the work is dealt out:
+    // wave w does the 32-coordinate chunk m = w (every load issued before the first use: one memory round trip),
+    // leaves the new position in LDS for the others and -- slice 0 only -- in the state buffers for the next launch.
+    // Identical arithmetic in the RS_i workgroups of a tile.
+    constexpr int kFuseSlices = 4;  // the host fuses only when RS_i <= kFuseSlices
+    __shared__ __attribute__((aligned(16))) float qnew[16][P];
+    if (a.fuse_mid) {
+        if (wave < G::M32) {
+            const int m = wave;
+            const int64_t at = chain * P + 32 * m + 8 * kg;
+            f32x4 pg[kFuseSlices][2], vq[2], vp[2], vb[2], vi[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int r = 0; r < kFuseSlices; ++r)
+                    if (r < a.RS_i) pg[r][h] = *reinterpret_cast<const f32x4*>(a.part_in + ((int64_t)r * a.C) * P + at + 4 * h);
+                vq[h] = *reinterpret_cast<const f32x4*>(a.q1_in + at + 4 * h);
+                vp[h] = *reinterpret_cast<const f32x4*>(a.pm_in + at + 4 * h);
+                vb[h] = *reinterpret_cast<const f32x4*>(a.cvec + 32 * m + 8 * kg + 4 * h);
+                vi[h] = *reinterpret_cast<const f32x4*>(a.cvec + P + 32 * m + 8 * kg + 4 * h);
+            }
+            f32x4 xn[2], pn[2];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                double gs = 0.0;
+#pragma unroll
+                for (int r = 0; r < kFuseSlices; ++r)
+                    if (r < a.RS_i) gs += (double)pg[r][e >> 2][e & 3];
+                const float g1 = (float)gs - vq[e >> 2][e & 3] * vi[e >> 2][e & 3];
+                const float pmn = fma_t(a.step, g1, vp[e >> 2][e & 3]);
+                pn[e >> 2][e & 3] = pmn;
+                xn[e >> 2][e & 3] = fma_t(vb[e >> 2][e & 3], pmn, vq[e >> 2][e & 3]);
+            }
+            *reinterpret_cast<f32x4*>(&qnew[c][32 * m + 8 * kg]) = xn[0];
+            *reinterpret_cast<f32x4*>(&qnew[c][32 * m + 8 * kg + 4]) = xn[1];
+            if (rs == 0 && chain0 + c < a.C) {
+                *reinterpret_cast<f32x4*>(a.q1 + at) = xn[0];
+                *reinterpret_cast<f32x4*>(a.q1 + at + 4) = xn[1];
+                *reinterpret_cast<f32x4*>(a.pm + at) = pn[0];
+                *reinterpret_cast<f32x4*>(a.pm + at + 4) = pn[1];
+            }
+        }
+        __syncthreads();
+    }
     // beta = hi + lo (two round-to-nearest bf16 pieces) of the lane's coordinates 32 m + 8 kg + i, times log2(e)
     u32x4 bq[G::M32][2];
 #pragma unroll
     for (int m = 0; m < G::M32; ++m) {
-        const f32x4* src = reinterpret_cast<const f32x4*>(a.q1 + chain * P + 32 * m + 8 * kg);
-        const f32x4 v0 = src[0], v1 = src[1];
-        float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        const int64_t at = chain * P + 32 * m + 8 * kg;
+        float x[8];
+        if (a.fuse_mid) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(&qnew[c][32 * m + 8 * kg]);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(&qnew[c][32 * m + 8 * kg + 4]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                x[e] = v0[e];
+                x[4 + e] = v1[e];
+            }
+        } else {
+            const f32x4* src = reinterpret_cast<const f32x4*>(a.q1 + at);
+            const f32x4 v0 = src[0], v1 = src[1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                x[e] = v0[e];
+                x[4 + e] = v1[e];
+            }
+        }
         uint32_t hi[4], lo[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -513,13 +576,12 @@ __global__ void __launch_bounds__(256) k_wide_partial_bf16r(TallArgs<float, P> a
     {
         const int64_t nlive = a.C - chain0 < 16 ? a.C - chain0 : 16;
         f32x4* dst = reinterpret_cast<f32x4*>(a.part_g + ((int64_t)rs * a.C + chain0) * P);
-        for (int i = tid; i < (int)(nlive * P / 4); i += 256) {
+        for (int i = tid; i < (int)(nlive * P / 4); i += 64 * NW) {
             const int off = (i / (P / 4)) * OT + (i % (P / 4)) * 4;
-            const f32x4 w0 = *reinterpret_cast<const f32x4*>(smem + 0 * RING_BYTES + off * 4);
-            const f32x4 w1 = *reinterpret_cast<const f32x4*>(smem + 1 * RING_BYTES + off * 4);
-            const f32x4 w2 = *reinterpret_cast<const f32x4*>(smem + 2 * RING_BYTES + off * 4);
-            const f32x4 w3 = *reinterpret_cast<const f32x4*>(smem + 3 * RING_BYTES + off * 4);
-            __builtin_nontemporal_store((w0 + w1) + (w2 + w3), &dst[i]);
+            f32x4 acc = *reinterpret_cast<const f32x4*>(smem + off * 4);
+#pragma unroll
+            for (int w = 1; w < NW; ++w) acc += *reinterpret_cast<const f32x4*>(smem + w * RING_BYTES + off * 4);  // wave order
+            __builtin_nontemporal_store(acc, &dst[i]);
         }
     }
 }
