@@ -17,6 +17,7 @@
 #include "lr_hessian.h"
 #include "lr_stats.h"
 #include "lr_tall.h"
+#include "lr_tall_mx.h"
 #include "lr_wide_bf16.h"
 
 LR_DECLARE_INST(f32_p4)
@@ -58,6 +59,12 @@ const lr::InstTable* find_table(int dtype, int P) {
     return nullptr;
 }
 
+// tuning / A-B switches: set to a non-zero number to turn the named feature off
+bool env_on(const char* name) {
+    const char* v = std::getenv(name);
+    return v && std::atoi(v) != 0;
+}
+
 constexpr int kMaxP = 128;
 constexpr size_t kLdsBudget = 160 * 1024;
 
@@ -77,6 +84,7 @@ struct lr_model {
     const lr::InstTable* table = nullptr;
     void* d_xblk = nullptr;  // wide models: per-32-row-block bf16-piece images of the rows (lr_wide_bf16.h)
     void* d_xblk1 = nullptr;  // wide models: single-piece round-to-nearest images (interior leapfrog steps)
+    void* d_xmx = nullptr;    // float32, P = 8: two-piece bf16 tile images for interior leapfrog steps (lr_tall_mx.h)
     // stepwise-engine workspaces, one per stream (grow-only, owned by the handle): calls enqueued on ONE stream
     // run in order, so they may share a workspace; calls on different streams overlap on the device and get
     // disjoint ones (two ChainSets of one model on two streams, or an eval on the NULL stream beside a run)
@@ -156,6 +164,7 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
         int64_t slice_len = (m->n + RS - 1) / RS;
         if (slice_len < 16 * NW) slice_len = 16 * NW;  // at least 16 rows per wave
         slice_len = (slice_len + 1) & ~(int64_t)1;      // even: the float32 kernel walks row pairs
+        if (m->d_xmx) slice_len = (slice_len + 31) / 32 * 32;  // whole tile pairs: the matrix-pipe interior kernel
         RS = (m->n + slice_len - 1) / slice_len;
         out->mode = lr::MODE_STEPWISE;
         out->G = (int)RS;
@@ -291,7 +300,7 @@ int setup_tall(lr_model* m, const Plan& pl, hipStream_t st, int64_t C, lr::TallA
     // tile of 16 per workgroup and as many row slices as fill the chip; each slice a multiple of 128 rows
     int RS_i = 0, rs_waves = 4;
     int64_t slice_len_i = 0;
-    if (m->P > 32 && m->d_xblk1 && !std::getenv("LOGREG_WIDE_NO_ROWSPLIT")) {
+    if (m->P > 32 && m->d_xblk1 && !env_on("LOGREG_WIDE_NO_ROWSPLIT")) {
         const int64_t tiles = (C + 15) / 16;
         if (tiles <= m->cus) {
             int64_t want = m->cus / tiles;
@@ -304,11 +313,21 @@ int setup_tall(lr_model* m, const Plan& pl, hipStream_t st, int64_t C, lr::TallA
             RS_i = (int)((m->n + slice_len_i - 1) / slice_len_i);
         }
     }
+    if (m->P == 8 && m->d_xmx) {
+        // narrow models, interior leapfrog steps on the matrix pipe (lr_tall_mx.h): 4-wave workgroups of 64 chains;
+        // slices fine enough for ~4 waves per SIMD, each at least 256 rows, whole tile pairs
+        const int64_t blocks = (C + 63) / 64;
+        int64_t want = (4LL * 4 * m->cus + 4 * blocks - 1) / (4 * blocks);
+        if (want < 1) want = 1;
+        slice_len_i = ((m->n + want - 1) / want + 31) / 32 * 32;
+        if (slice_len_i < 256) slice_len_i = 256;
+        RS_i = (int)((m->n + slice_len_i - 1) / slice_len_i);
+    }
     const int RSmax = RS_i > RS ? RS_i : RS;
     const size_t pg = align((size_t)RSmax * C * P * sizeof(T)), cv = align((size_t)2 * P * sizeof(T));
     // (second state pair + second partial buffer + constants: the fused interior steps of the row-split kernel)
     const size_t need = 4 * vec + 2 * dbl + align((size_t)C * 4) + pg + align((size_t)RS * C * sizeof(double)) +
-                        (RS_i > 0 ? 2 * vec + pg : 0) + cv;
+                        (RS_i > 0 && m->P > 32 ? 2 * vec + pg : 0) + cv;
     lr_model::Ws* slot = nullptr;
     for (auto& e : m->ws)
         if (e.stream == st) slot = &e;
@@ -355,7 +374,7 @@ int setup_tall(lr_model* m, const Plan& pl, hipStream_t st, int64_t C, lr::TallA
     a.rowsplit_waves = rs_waves;
     a.part_v = (double*)carve(align((size_t)RS * C * sizeof(double)));
     a.cvec = (const T*)carve(cv);
-    if (RS_i > 0) {  // alternates, parked in the *_in fields until do_stepwise_t starts ping-ponging
+    if (RS_i > 0 && m->P > 32) {  // alternates, parked in the *_in fields until do_stepwise_t starts ping-ponging
         a.q1_in = (const T*)carve(vec);
         a.pm_in = (const T*)carve(vec);
         a.part_in = (const T*)carve(pg);
@@ -368,6 +387,7 @@ int setup_tall(lr_model* m, const Plan& pl, hipStream_t st, int64_t C, lr::TallA
         a.wide_bf16 = (m->P > 32 && m->d_xblk) ? wide_engine(m, C) : 0;
         a.xblk = static_cast<const uint16_t*>(m->d_xblk);
         a.xblk1 = static_cast<const uint16_t*>(m->d_xblk1);
+        a.xmx = static_cast<const uint16_t*>(m->d_xmx);
     }
     return LR_OK;
 }
@@ -423,7 +443,8 @@ int do_stepwise_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs
         if (!rc) rc = t->launch_tall_partial(st, v, g, &a);
     };
     // interior leapfrog gradients (HMC): reduced precision where the policy allows and a kernel exists
-    const bool bf16_interior = rs.kind == lr::KIND_HMC && o->precision != LR_PREC_FULL && m->d_xblk1 != nullptr;
+    const bool bf16_interior = rs.kind == lr::KIND_HMC && o->precision != LR_PREC_FULL &&
+                               (m->d_xblk1 != nullptr || (m->d_xmx != nullptr && !env_on("LOGREG_TALL_NO_MX")));
     const int RS_exact = a.RS, RS_mid = bf16_interior && a.RS_i > 0 ? a.RS_i : a.RS;
     if (!bf16_interior) a.RS_i = 0;
     auto KI = [&]() {
@@ -431,7 +452,7 @@ int do_stepwise_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs
         K(0, 1);
         a.interior = 0;
     };
-    const bool fuse = bf16_interior && a.RS_i > 0 && a.RS_i <= 4 && !std::getenv("LOGREG_WIDE_NO_FUSE");  // kFuseSlices
+    const bool fuse = P > 32 && bf16_interior && a.RS_i > 0 && a.RS_i <= 4 && !env_on("LOGREG_WIDE_NO_FUSE");  // kFuseSlices
     T* qb[2] = {a.q1, const_cast<T*>(a.q1_in)};
     T* pb[2] = {a.pm, const_cast<T*>(a.pm_in)};
     T* gb[2] = {a.part_g, const_cast<T*>(a.part_in)};
@@ -727,6 +748,17 @@ int lr_model_create(const double* X, const double* y, int64_t n, int32_t p, cons
             return fail(LR_ERR_NOMEM, "allocating the row-pair image (%zu bytes) failed", tw.size() * 4);
         }
     }
+    if (m->P == 8 && dtype == LR_F32) {  // narrow models: two-piece bf16 tile images (interior HMC steps on the matrix pipe)
+        const float* hrows = reinterpret_cast<const float*>(host.data());
+        const int64_t ntile = (n + 31) / 32 * 2;
+        std::vector<uint16_t> img((size_t)ntile * lr::kMxTileElems);
+        lr::tall_mx_prepare(hrows, n, img.data());
+        if (hipMalloc(&m->d_xmx, img.size() * 2) != hipSuccess ||
+            hipMemcpy(m->d_xmx, img.data(), img.size() * 2, hipMemcpyHostToDevice) != hipSuccess) {
+            lr_model_destroy(m);
+            return fail(LR_ERR_NOMEM, "allocating the bf16 tile images (%zu bytes) failed", img.size() * 2);
+        }
+    }
     if (m->P > 32) {  // wide models: bf16-piece block images for the exact-split matrix-core kernel
         const float* hrows = reinterpret_cast<const float*>(host.data());
         const int64_t nblk = (n + 31) / 32;
@@ -762,6 +794,7 @@ void lr_model_destroy(lr_model* m) {
         if (e.p) (void)hipFree(e.p);
     if (m->d_xblk) (void)hipFree(m->d_xblk);
     if (m->d_xblk1) (void)hipFree(m->d_xblk1);
+    if (m->d_xmx) (void)hipFree(m->d_xmx);
     delete m;
 }
 

@@ -75,6 +75,7 @@ template <typename T, int P> struct TallArgs {
     int wide_bf16;  // wide models: 0 = fp32 MFMA partial kernel, 1 = exact-split bf16 MFMA partial kernel
     const uint16_t* xblk;  // wide bf16: per-32-row-block LDS images of the split rows (lr_wide_bf16.h)
     const uint16_t* xblk1;  // wide bf16: single-piece (round-to-nearest) images for interior leapfrog steps
+    const uint16_t* xmx;    // narrow models (P = 8, float32): two-piece bf16 tile images (lr_tall_mx.h), else null
     int interior;  // this launch is an interior HMC gradient evaluation that may run in reduced precision
     // fused interior step (k_wide_partial_bf16r, fuse_mid = 1): the kernel first finishes the PREVIOUS leapfrog step
     // itself -- kick with the slice partials in part_in, drift -- from the state in (q1_in, pm_in), stores the new state
@@ -111,10 +112,15 @@ __global__ void __launch_bounds__((64 * TallGeom<T, P>::NW)) k_tall_partial(Tall
     // wave-uniform by construction; readfirstlane makes it PROVABLY uniform so the row addresses
     // stay scalar and the rows are fetched with s_load (not 64-fold redundant vector loads)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int64_t chain = (int64_t)blockIdx.x * 64 + lane;
+    // grid = (row slices, chain blocks): workgroups are dealt to the 8 XCDs round-robin by linear id, so with the
+    // SLICE index fastest every XCD works on its own eighth of the slices for all chain blocks and its L2 holds an
+    // eighth of the rows; with the chain block fastest (round 1) every XCD streamed all of X through its 4 MB L2
+    // for every evaluation (FETCH_SIZE 25 MB per launch against 3.6 MB of rows)
+    const int cb = blockIdx.y;
+    int64_t chain = (int64_t)cb * 64 + lane;
     const bool live = chain < a.C;
     if (!live) chain = a.C - 1;
-    const int rs = blockIdx.y;
+    const int rs = blockIdx.x;
     const int64_t sub = ((a.slice_len + NW - 1) / NW + 1) & ~(int64_t)1;  // even: row pairs never straddle waves
     const int64_t s0 = (int64_t)rs * a.slice_len, s1 = s0 + a.slice_len < a.n ? s0 + a.slice_len : a.n;
     T bs[P], g[P];
@@ -219,7 +225,7 @@ __global__ void __launch_bounds__((64 * TallGeom<T, P>::NW)) k_tall_partial(Tall
             double s = 0.0;
 #pragma unroll
             for (int w = 0; w < NW; ++w) s += (double)red_g[w][c][j];
-            const int64_t ch = (int64_t)blockIdx.x * 64 + c;
+            const int64_t ch = (int64_t)cb * 64 + c;
             if (ch < a.C) a.part_g[((int64_t)rs * a.C + ch) * P + j] = (T)s;
         }
     }

@@ -1,0 +1,175 @@
+// lr_tall_mx.h -- INTERIOR-step partial kernel of the stepwise engine for NARROW tall models (padded p = 8,
+// float32) on the bf16 matrix pipe: the counterpart of lr_wide_bf16.h's interior kernels for data with many rows
+// and few columns (BASELINE config 4: n = 100 000, p = 8).
+//
+// Why.  The fp32 vector kernel (k_tall_partial) spends 10.5 VALU instructions per row and 64 chains; it sits at
+// ~0.5 of the fp32 vector peak and cannot go further.  Of those instructions only the two
+// transcendentals of the sigmoid have to be VALU work: the 2 x 8 multiply-adds per row and chain are a GEMM with a
+// tiny inner dimension.  For the L - 1 INTERIOR gradient evaluations of an HMC trajectory (any deterministic force
+// keeps the leapfrog map volume-preserving and reversible; the Metropolis test uses the exact end-point values --
+// see include/logreg_hip.h, LR_PREC_*) the GEMMs move to v_mfma_f32_16x16x32_bf16 and the VALU keeps exp, rcp and
+// a bf16 pack: 26 instructions per 32 rows x 16 chains instead of 84.
+//
+// K = 32 of the MFMA is filled with PIECES, not coordinates (p = 8 would leave it three quarters empty):
+//   x = xh + xl, beta = bh + bl (two round-to-nearest bf16 pieces each: 16 significand bits), and
+//   eta = sum_j (xh_j + xl_j)(bh_j + bl_j) takes all four piece products of every coordinate from 2 x 16 K-slots.
+// Lane l = (c, kg) of a wave (c = l & 15: chain, kg = l >> 4) OWNS coordinates a = kg and b = kg + 4.
+//   eta tile (16 rows x 16 chains), two K = 16 MFMAs (v_mfma_f32_16x16x16_bf16) into one accumulator:
+//                                    A (lane (row, kg)) = [xh_a xl_a xh_b xl_b]          (K-slots 4 kg .. 4 kg + 3)
+//                                    B (lane (c,   kg)) = [bh_a bh_a bh_b bh_b], then [bl_a bl_a bl_b bl_b]
+//                                    D (lane (c, kg), r) = eta[row 4 kg + r][chain c]
+//   w = sigma(-eta) on the accumulator registers of two tiles, rounded to ONE bf16 piece = B of the gradient MFMA
+//       (K-slot 8 kg + i <-> i < 4: tile 0 row 4 kg + i; i >= 4: tile 1 row 4 kg + i - 4: the lane's own outputs)
+//   grad tile (K = 32 rows):  A (lane (m', kg)) = the 8 rows of slot group kg, element m' & 3 of coordinate group
+//                             m' >> 2, i.e. M-row 4 kg'' + r' = (xh_a, xl_a, xh_b, xl_b)[r'] of group kg'' -- exactly
+//                             what ds_read_b64_tr_b16 delivers from the SAME image the eta operand is read from
+//                             D (lane (c, kg), r) = sum_rows w (xh_a, xl_a, xh_b, xl_b)[r] of the lane's own group:
+//                             g_a = D0 + D1, g_b = D2 + D3 -- the lane's own coordinates, no data movement.
+// Image (built once at model creation, 32 bytes per row like the fp32 rows): per 16-row tile
+//   [kg''][row'][4 bf16],  row' = (row + 8 (kg'' >> 1)) & 15   (the swizzle that keeps the transposing reads of a
+//   half-wave on distinct banks; the eta reads, 8 bytes per lane, are conflict-free with or without it).
+// Workgroup = NW waves x 16 chains sharing one row slice; the slice streams L2 -> LDS in chunks of kChunkTiles
+// tiles with the LDS-DMA load (inline asm: see lr_wide_bf16.h for why), two chunks of LDS (32 KB per workgroup:
+// four workgroups per CU), one barrier per chunk.
+#pragma once
+#include <cstring>
+
+#include "lr_tall.h"
+
+namespace lr {
+
+typedef float mx_f32x4 __attribute__((ext_vector_type(4)));
+typedef float mx_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 mx_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 mx_bf16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t mx_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t mx_u32x2 __attribute__((ext_vector_type(2)));
+typedef short mx_s16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kMxTileElems = 4 * 16 * 4;  // bf16 elements per 16-row tile image (512 bytes)
+constexpr int kMxChunkTiles = 32;         // tiles per staged chunk: 16 KB, 512 rows (an even number: tile pairs)
+
+__host__ __device__ constexpr int mx_elem(int kg, int row) { return kg * 64 + ((row + 8 * (kg >> 1)) & 15) * 4; }
+
+__device__ __forceinline__ uint32_t mx_pack_rne(float a, float b) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(mx_f32x2{a, b}, mx_bf16x2));
+}
+__device__ __forceinline__ mx_u32x2 mx_read_tr16(const uint16_t* p) {
+    return __builtin_bit_cast(mx_u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) mx_s16x4*)(p)));
+}
+
+template <int NW>
+__global__ void __launch_bounds__((64 * NW)) k_tall_partial_mx(TallArgs<float, 8> a) {
+    constexpr int CHUNK_BYTES = kMxChunkTiles * kMxTileElems * 2;  // 32 KB
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * CHUNK_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, kg = lane >> 4;
+    // grid = (row slices, chain blocks): slice index fastest, so that an XCD (workgroups are dealt round-robin by
+    // linear id) streams only its own eighth of the rows, for all chain blocks, through its L2 (see k_tall_partial)
+    int64_t chain = (int64_t)blockIdx.y * (16 * NW) + 16 * wave + c;
+    const bool live = chain < a.C;
+    if (!live) chain = a.C - 1;
+    const int rs = blockIdx.x;
+    // its own slicing (RS_i slices of slice_len_i rows, whole tile pairs): finer than the fp32 kernel's, so that
+    // every SIMD holds ~4 of these 4-wave workgroups' waves and the LDS -> MFMA -> exp -> rcp -> MFMA chain of one
+    // tile pair is covered by the other waves (one wave per SIMD: 350 cycles per pair; the VALU work is 170)
+    const int64_t s0 = (int64_t)rs * a.slice_len_i, s1 = s0 + a.slice_len_i < a.n ? s0 + a.slice_len_i : a.n;
+    const int64_t tile0 = s0 / 16;
+    const int64_t ntile = s1 > s0 ? ((s1 - s0 + 31) / 32) * 2 : 0;  // tiles of this slice (even; the image is zero-padded)
+    const int64_t nchunk = (ntile + kMxChunkTiles - 1) / kMxChunkTiles;
+    const uint32_t smem_lds = (uint32_t)(uintptr_t)smem;
+
+    auto issue = [&](int64_t g) {  // chunk g -> buffer g & 1; 1 KB per wave-instruction, dealt round-robin to the waves
+        const int64_t t0 = g * kMxChunkTiles;
+        const int nt = (int)(ntile - t0 < kMxChunkTiles ? ntile - t0 : kMxChunkTiles);
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(a.xmx + (tile0 + t0) * (int64_t)kMxTileElems) + lane * 16;
+        const uint32_t dst = smem_lds + (uint32_t)((g & 1) * CHUNK_BYTES);
+        const int nkb = nt / 2;  // 1 KB = 2 tiles
+        for (int ch = wave; ch < nkb; ch += NW) {
+            uint32_t keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(src + ch * 1024), "s"(dst + ch * 1024)
+                         : "memory");
+        }
+    };
+    if (nchunk > 0) issue(0);
+
+    // beta pieces of the lane's coordinates a = kg, b = kg + 4, times log2(e): B operands of the two K = 16 eta MFMAs
+    // (K-slots 4 kg .. 4 kg + 3 of lane (c, kg):  [bh_a bh_a bh_b bh_b]  and  [bl_a bl_a bl_b bl_b]  against
+    //  A = [xh_a xl_a xh_b xl_b], the 8 bytes the image holds per (row, kg): no register shuffling per tile)
+    const float qa = a.q1[chain * 8 + kg] * ExpScale<float>::k, qb = a.q1[chain * 8 + kg + 4] * ExpScale<float>::k;
+    const uint32_t ha = mx_pack_rne(qa, qa), hb = mx_pack_rne(qb, qb);
+    const float la = qa - __builtin_bit_cast(float, ha << 16), lb = qb - __builtin_bit_cast(float, hb << 16);
+    const mx_u32x2 bh = {ha, hb}, bl = {mx_pack_rne(la, la), mx_pack_rne(lb, lb)};
+
+    const int eta_off = mx_elem(kg, c);                                            // lane (row c, kg): its 4 elements
+    const int tr_off = mx_elem(lane & 3, 4 * kg + ((lane & 15) >> 2));             // lane (kg, ri, ci): chunk ci, row 4 kg + ri
+    mx_f32x4 gacc = {0, 0, 0, 0};
+
+    for (int64_t g = 0; g < nchunk; ++g) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // own share of chunk g has landed ...
+        __syncthreads();                     // ... everybody's has, and nobody still reads the other buffer
+        if (g + 1 < nchunk) issue(g + 1);
+        const uint16_t* base = reinterpret_cast<const uint16_t*>(smem + (g & 1) * CHUNK_BYTES);
+        const int nt = (int)(ntile - g * kMxChunkTiles < kMxChunkTiles ? ntile - g * kMxChunkTiles : kMxChunkTiles);
+        for (int t = 0; t < nt; t += 2) {
+            const uint16_t* tp = base + t * kMxTileElems;
+            uint32_t wq[4];
+#pragma unroll
+            for (int T = 0; T < 2; ++T) {
+                const mx_s16x4 xa = *reinterpret_cast<const mx_s16x4*>(tp + T * kMxTileElems + eta_off);
+                mx_f32x4 e = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(xa, __builtin_bit_cast(mx_s16x4, bh), mx_f32x4{0, 0, 0, 0}, 0, 0, 0);
+                e = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(xa, __builtin_bit_cast(mx_s16x4, bl), e, 0, 0, 0);
+                const mx_f32x2 d0 = mx_f32x2{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])} + mx_f32x2{1.0f, 1.0f};
+                const mx_f32x2 d1 = mx_f32x2{__builtin_amdgcn_exp2f(e[2]), __builtin_amdgcn_exp2f(e[3])} + mx_f32x2{1.0f, 1.0f};
+                wq[2 * T] = mx_pack_rne(fast_rcp(d0.x), fast_rcp(d0.y));
+                wq[2 * T + 1] = mx_pack_rne(fast_rcp(d1.x), fast_rcp(d1.y));
+            }
+            const mx_u32x2 t0 = mx_read_tr16(tp + tr_off), t1 = mx_read_tr16(tp + kMxTileElems + tr_off);
+            const mx_u32x4 xg = {t0[0], t0[1], t1[0], t1[1]}, wv = {wq[0], wq[1], wq[2], wq[3]};
+            gacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mx_bf16x8, xg), __builtin_bit_cast(mx_bf16x8, wv), gacc, 0, 0, 0);
+        }
+    }
+    if (live) {
+        float* dst = a.part_g + ((int64_t)rs * a.C + chain) * 8;
+        dst[kg] = gacc[0] + gacc[1];
+        dst[kg + 4] = gacc[2] + gacc[3];
+    }
+}
+
+// Host side: the tile images.  rows: [n][8] fp32 signed rows.  out: [ceil(n/32) * 2][kMxTileElems] bf16 bit patterns.
+inline uint16_t mx_bf16_rne(float x) {
+    uint32_t b;
+    memcpy(&b, &x, 4);
+    return (uint16_t)((b + 0x7FFFu + ((b >> 16) & 1u)) >> 16);
+}
+inline float mx_bf16_to_f32(uint16_t h) {
+    const uint32_t b = (uint32_t)h << 16;
+    float x;
+    memcpy(&x, &b, 4);
+    return x;
+}
+inline void tall_mx_prepare(const float* rows, int64_t n, uint16_t* out) {
+    const int64_t ntile = (n + 31) / 32 * 2;
+    for (int64_t t = 0; t < ntile; ++t) {
+        uint16_t* base = out + t * (int64_t)kMxTileElems;
+        for (int e = 0; e < kMxTileElems; ++e) base[e] = 0;
+        for (int r = 0; r < 16; ++r) {
+            const int64_t row = 16 * t + r;
+            if (row >= n) continue;
+            for (int kg = 0; kg < 4; ++kg) {
+                const float xa = rows[row * 8 + kg], xb = rows[row * 8 + kg + 4];
+                const uint16_t ha = mx_bf16_rne(xa), hb = mx_bf16_rne(xb);
+                uint16_t* q = base + mx_elem(kg, r);
+                q[0] = ha;
+                q[1] = mx_bf16_rne(xa - mx_bf16_to_f32(ha));
+                q[2] = hb;
+                q[3] = mx_bf16_rne(xb - mx_bf16_to_f32(hb));
+            }
+        }
+    }
+}
+
+}  // namespace lr

@@ -189,7 +189,7 @@ def test_stepwise_engine_matches_oracle(la, models, oracle_model, map_beta, kind
     # ~1e-3 sd per iteration from spread-out starts); float64: a free-running multi-iteration run
     iters, thin = (1, 1) if dtype == "float32" else ((3, 2) if kind != "mala" else (2, 1))
     ref = oracle_model.run(kind, q0, thin=thin, iters=iters, seed=8, ll_state=ll0, threads=0, **KW[kind])
-    out, info = la.mcmc(q0, k, thin=thin, iters=iters, verb=False, seed=8, ll=ll0, mode="stepwise", return_info=True)
+    out, info = la.mcmc(q0, k, thin=thin, iters=iters, verb=False, seed=8, ll=ll0, mode="stepwise", return_info=True, precision="full")
     clear = ref["margin"] > (1e-3 if dtype == "float32" else 1e-7)
     assert clear.mean() > 0.9
     assert np.array_equal(info["accepts"][clear], ref["accepts"][clear].astype(np.uint32))
@@ -198,15 +198,16 @@ def test_stepwise_engine_matches_oracle(la, models, oracle_model, map_beta, kind
     if dtype == "float32":  # and a longer run must agree with the fused float32 kernels to fp32 noise
         iters, thin = 3, 2
         fused = la.mcmc(q0, k, thin=thin, iters=iters, verb=False, seed=8, ll=ll0)
-        out = la.mcmc(q0, k, thin=thin, iters=iters, verb=False, seed=8, ll=ll0, mode="stepwise")
+        out = la.mcmc(q0, k, thin=thin, iters=iters, verb=False, seed=8, ll=ll0, mode="stepwise", precision="full")
         same = np.max(np.abs(out - fused) / POST_SD, axis=(0, 2)) < 2e-2
         assert same.mean() > (0.97 if kind != "mala" else 0.8)
     # chunking and sharding stay bit-exact in this engine too
-    again = la.mcmc(q0, k, thin=thin, iters=iters, verb=False, seed=8, ll=ll0, mode="stepwise", chunk=1)
+    again = la.mcmc(q0, k, thin=thin, iters=iters, verb=False, seed=8, ll=ll0, mode="stepwise", chunk=1, precision="full")
     assert np.array_equal(out, again)
-    a = la.mcmc(q0[:100], k, thin=thin, iters=iters, verb=False, seed=8, ll=None if ll0 is None else ll0[:100], mode="stepwise")
+    a = la.mcmc(q0[:100], k, thin=thin, iters=iters, verb=False, seed=8, ll=None if ll0 is None else ll0[:100], mode="stepwise",
+                precision="full")
     b = la.mcmc(q0[100:], k, thin=thin, iters=iters, verb=False, seed=8, ll=None if ll0 is None else ll0[100:], mode="stepwise",
-                chain_offset=100)
+                chain_offset=100, precision="full")
     assert np.array_equal(out, np.concatenate([a, b], axis=1))
 
 
@@ -227,7 +228,7 @@ def test_tall_data_uses_stepwise_engine_and_matches_oracle(la):
         r = m.eval(q0[:16])
         np.testing.assert_allclose(r["lpost"], orc.lpost(q0[:16]), rtol=5e-6 if dtype == "float32" else 1e-12)
         out, info = la.mcmc(q0, la.hmcKernel(m.lpost, m.glp, eps=2e-4, l=6, dmm=dmm), thin=1, iters=2, verb=False,
-                            seed=12, return_info=True)
+                            seed=12, return_info=True, precision="full")
         ok = ref["margin"] > (5e-3 if dtype == "float32" else 1e-7)
         assert ok.mean() > 0.9
         assert np.array_equal(info["accepts"][ok], ref["accepts"][ok].astype(np.uint32))
