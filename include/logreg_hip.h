@@ -188,6 +188,15 @@ LR_API int lr_stats_reduce(int device, const double* stats, int64_t n_chains, in
 LR_API int lr_plan(const lr_model* m, int64_t n_chains, int32_t group, int32_t mode, int32_t* mode_out,
                    int32_t* group_out, int32_t* rows_out);
 
+/*
+ * The variant lr_run_<kind> would launch for these options (n_chains, group, mode, precision are read): unlike
+ * lr_plan it knows the kernel family -- HMC runs whose interior gradients may use the bf16 matrix pipe
+ * (LR_PREC_AUTO / LR_PREC_BF16) are planned onto the fused matrix-core kernels when there are enough chains.
+ */
+enum { LR_KIND_RWMH = 0, LR_KIND_MALA = 1, LR_KIND_HMC = 2, LR_KIND_UL = 3 };
+LR_API int lr_plan_run(const lr_model* m, int32_t kind, const lr_run_opts* opts, int32_t* mode_out, int32_t* group_out,
+                       int32_t* rows_out);
+
 /* device memory + stream + event helpers so a host language needs no other GPU runtime */
 LR_API int lr_malloc(int device, uint64_t bytes, void** dptr);
 LR_API int lr_free(int device, void* dptr);

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(HERE, "lib", "liblogreg_hip.so")
 LR_F32, LR_F64 = 0, 1
 STATS_ROWS = 7  # LR_STATS_ROWS
 PREC_BY_NAME = {"auto": 0, "full": 1, "bf16": 2}  # LR_PREC_*
+KIND_BY_NAME = {"rwmh": 0, "mala": 1, "hmc": 2, "ul": 3}  # LR_KIND_*
 MODE_AUTO, MODE_REG, MODE_LDS, MODE_GLOBAL, MODE_MFMA, MODE_STEPWISE = -1, 0, 1, 2, 3, 4
 MODE_NAMES = {MODE_REG: "reg", MODE_LDS: "lds", MODE_GLOBAL: "global", MODE_MFMA: "mfma", MODE_STEPWISE: "stepwise"}
 MODE_BY_NAME = {"auto": MODE_AUTO, "reg": MODE_REG, "lds": MODE_LDS, "global": MODE_GLOBAL, "mfma": MODE_MFMA, "stepwise": MODE_STEPWISE}
@@ -50,6 +51,7 @@ SYMBOLS = {
     "lr_run_hmc": (C.c_int, [_vp, _vp, C.c_double, _i32, _vp, _op, _vp, _vp]),
     "lr_hessian": (C.c_int, [_vp, _vp, _dp, _vp, _vp, _vp]),
     "lr_stats_reduce": (C.c_int, [C.c_int, _vp, _i64, _i32, _i64, _i64, _vp, _vp, _vp]),
+    "lr_plan_run": (C.c_int, [_vp, _i32, _op, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
     "lr_plan": (C.c_int, [_vp, _i64, _i32, _i32, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
     "lr_malloc": (C.c_int, [C.c_int, _u64, C.POINTER(_vp)]),
     "lr_free": (C.c_int, [C.c_int, _vp]),

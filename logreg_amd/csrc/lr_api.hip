@@ -114,11 +114,34 @@ int64_t wide_chains_per_block(const lr_model* m, int64_t C) { return wide_engine
 // Choose the kernel variant.  REG (rows in VGPRs) whenever the data fit (G*R >= n), then LDS,
 // then GLOBAL.  Group size: the smallest available G that still gives every SIMD a wavefront
 // (C*G/64 >= 4*CUs), else the largest; an explicit `group` request is honoured exactly.
-int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool for_eval = false) {
+// `hmc_bf16`: the run is HMC and its interior leapfrog gradients may use the bf16 matrix pipe (LR_PREC_AUTO / BF16)
+int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool for_eval = false, bool hmc_bf16 = false) {
     const lr::InstTable* t = m->table;
     const int64_t want_waves = 4LL * m->cus;
     int best = -1;
     long best_score = -1;
+    if (hmc_bf16 && !for_eval && mode == LR_MODE_AUTO && group == 0 && m->dtype == LR_F32 && m->P == 8 &&
+        !env_on("LOGREG_NO_MFMA_INTERIOR")) {
+        // register-resident data, many chains: the fused matrix-core kernel with bf16 interior steps (lr_mfma.h).
+        // Measured (bench.py workload, chain-iterations/s, reg 16x13 | mfma S=4 | mfma S=1):
+        //    4096: 1.83e8 | 1.68e8 | 0.82e8      6144: 1.56e8 | 1.84e8 | --        8192: 1.99e8 | 2.44e8 | 1.63e8
+        //   12288: 2.06e8 | 2.77e8 | 2.45e8     16384: 2.10e8 | 2.79e8 | 3.23e8   65536: 2.19e8 |   --   | 4.12e8
+        // S = 4 (rows split over the 4 waves of a workgroup) needs two workgroups per CU to hide its
+        // MFMA -> exp -> rcp -> MFMA -> LDS latency chain; S = 1 (16 chains per wave) needs a wave per SIMD.
+        int want_S = 0;
+        if (C >= 64LL * m->cus && m->n <= 16 * 13) want_S = 1;
+        else if (C >= 24LL * m->cus && m->n <= 16 * 4 * 4) want_S = 4;
+        for (int i = 0; want_S && i < t->nvariants; ++i) {
+            const lr::Variant& v = t->variants[i];
+            if (v.mode == lr::MODE_MFMA && v.G == want_S && (int64_t)16 * v.G * v.R >= m->n) {
+                out->mode = v.mode;
+                out->G = v.G;
+                out->R = v.R;
+                out->lds_bytes = 0;
+                return LR_OK;
+            }
+        }
+    }
     if (m->P > 32) {
         // wide models (32 < p <= 128): only the stepwise engine exists; its partial kernel is an MFMA
         // GEMM over blocks of 64 chains x row slices (lr_wide.h).  ~2 workgroups per CU.
@@ -283,6 +306,7 @@ int do_chain_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs, c
         ca.e[j] = (T)(m->inv_var[j] / ks);
     }
     ca.stats = lr::StatsArgs{o->stats, o->stats_batch, o->stats_first};
+    ca.interior_bf16 = rs.kind == lr::KIND_HMC && pl.mode == lr::MODE_MFMA && o->precision != LR_PREC_FULL;
     lr::LaunchCfg cfg{pl.mode, pl.G, pl.R, rs.kind, st, pl.lds_bytes};
     const int rc = m->table->launch_chain(&cfg, o->n_chains, &ma, &ca);
     if (rc != 0) return fail(rc == -3 ? LR_ERR_UNSUPPORTED : LR_ERR_HIP, "chain launch failed (%d): %s", rc,
@@ -609,7 +633,7 @@ int run_common(lr_model* m, const RunSpec& rs, const lr_run_opts* o, void* state
     if (threaded && !lp_state) return fail(LR_ERR_INVALID, "lp_state is required for RWMH/MALA");
     LR_HIP(hipSetDevice(m->device));
     Plan pl;
-    rc = make_plan(m, o->n_chains, o->group, o->mode, &pl);
+    rc = make_plan(m, o->n_chains, o->group, o->mode, &pl, false, rs.kind == lr::KIND_HMC && o->precision != LR_PREC_FULL);
     if (rc) return rc;
     if (o->iters == 0) return LR_OK;
     if (o->on_device) return do_chain(m, pl, (hipStream_t)o->stream, rs, o, state, threaded ? lp_state : nullptr, out, accepts);
@@ -816,6 +840,19 @@ int lr_plan(const lr_model* m, int64_t n_chains, int32_t group, int32_t mode, in
         return fail(LR_ERR_INVALID, "group must be 0 or a power of two <= 64 (got %d)", group);
     Plan pl;
     const int rc = make_plan(m, n_chains, group, mode, &pl);
+    if (rc) return rc;
+    if (mode_out) *mode_out = pl.mode;
+    if (group_out) *group_out = pl.G;
+    if (rows_out) *rows_out = pl.R;
+    return LR_OK;
+}
+
+int lr_plan_run(const lr_model* m, int32_t kind, const lr_run_opts* o, int32_t* mode_out, int32_t* group_out, int32_t* rows_out) {
+    int rc = check_opts(m, o, false);
+    if (rc) return rc;
+    if (kind < LR_KIND_RWMH || kind > LR_KIND_UL) return fail(LR_ERR_INVALID, "kind must be one of LR_KIND_*");
+    Plan pl;
+    rc = make_plan(m, o->n_chains, o->group, o->mode, &pl, false, kind == LR_KIND_HMC && o->precision != LR_PREC_FULL);
     if (rc) return rc;
     if (mode_out) *mode_out = pl.mode;
     if (group_out) *group_out = pl.G;

@@ -49,6 +49,7 @@ template <typename T, int P> struct ChainArgs {
     T a[P], b[P], c[P];
     T d[P], e[P];  // HMC: d = b * ExpScale<T>::k, e = prior inv_var / ExpScale<T>::k (trajectory in scaled units)
     StatsArgs stats;  // streaming (mean, M2) per batch of kept samples; buf = null: off
+    int interior_bf16;  // HMC, matrix-core variants: interior leapfrog gradients from bf16 operands (LR_PREC_*)
 };
 
 // --------------------------------------------------------------------------------------------

@@ -31,10 +31,32 @@ namespace lr {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+typedef float mf_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 mf_bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 mf_bf16x8 __attribute__((ext_vector_type(8)));
+typedef short mf_s16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t mf_u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t mf_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t mf_pack_rne(float a, float b) {  // two fp32 -> packed bf16 (v_cvt_pk_bf16_f32, RNE)
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(mf_f32x2{a, b}, mf_bf16x2));
+}
+__device__ __forceinline__ float mf_hi_f32(uint32_t packed) { return __builtin_bit_cast(float, packed << 16); }
+
 template <int NTW, int S> struct MfmaRows {
     float xa[NTW][2];
     float xg[NTW][4];
     int pad_rows;  // rows >= n among this lane's eta rows (each adds log sigma(0) = -log 2)
+    // INTERIOR leapfrog steps on the bf16 matrix pipe (the scheme of lr_tall_mx.h with the rows in registers):
+    //   x = xh + xl, beta = bh + bl (two round-to-nearest bf16 pieces each); lane (c, k) owns coordinates a = k, b = k + 4
+    //   eta tile:  A (lane (row, k)) = [xh_a xl_a xh_b xl_b],  B = [bh_a bh_a bh_b bh_b] then [bl_a bl_a bl_b bl_b]
+    //              (two v_mfma_f32_16x16x16_bf16 into one accumulator: all four piece products of every coordinate)
+    //   grad tile pair (K = 32 rows):  B = w = sigma(-eta) of the lane's own 2 x 4 accumulator values, one bf16 piece;
+    //              A (lane (m', k')) = element m' & 3 of (xh_a xl_a xh_b xl_b) of group m' >> 2, rows of slot group k'
+    //              D (lane (c, k), r) = sum_rows w (xh_a, xl_a, xh_b, xl_b)[r]:  g_a = D0 + D1, g_b = D2 + D3
+    static constexpr int NPAIR = (NTW + 1) / 2;
+    mf_u32x2 xe[NTW];
+    mf_u32x4 xq[NPAIR];
+    int ntile_live;  // this wave's tiles that contain at least one real row (all-padding tiles are skipped)
 
     __device__ __forceinline__ void load(const float* __restrict__ rows, int64_t n, int wave, int lane) {
         const int c = lane & 15, k = lane >> 4;
@@ -54,6 +76,66 @@ template <int NTW, int S> struct MfmaRows {
                 if (rg >= n) ++pad_rows;
             }
         }
+        // bf16 operands of the interior steps
+        auto piece = [&](int64_t row, int coord, int lo) {  // bf16 bit pattern of the hi / lo piece of X[row][coord]
+            const float x = row < n ? rows[row * 8 + coord] : 0.0f;
+            const uint32_t h = mf_pack_rne(x, x) & 0xFFFFu;
+            if (!lo) return h;
+            return mf_pack_rne(x - mf_hi_f32(h), 0.0f) & 0xFFFFu;
+        };
+        ntile_live = 0;
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const int64_t base = 16 * ((int64_t)t * S + wave);
+            if (base < n) ntile_live = t + 1;
+            xe[t] = mf_u32x2{piece(base + c, k, 0) | (piece(base + c, k, 1) << 16),
+                             piece(base + c, k + 4, 0) | (piece(base + c, k + 4, 1) << 16)};
+        }
+        const int grp = c >> 2, el = c & 3;  // gradient A operand: M-row c = 4 grp + el -> element el of group grp
+        const int gcoord = grp + 4 * (el >> 1), glo = el & 1;
+#pragma unroll
+        for (int pi = 0; pi < NPAIR; ++pi) {
+            uint32_t v[8];
+#pragma unroll
+            for (int sl = 0; sl < 8; ++sl) {
+                const int t = 2 * pi + (sl >> 2);
+                const int64_t row = 16 * ((int64_t)t * S + wave) + 4 * k + (sl & 3);
+                v[sl] = t < NTW ? piece(row, gcoord, glo) : 0u;
+            }
+            xq[pi] = mf_u32x4{v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16)};
+        }
+    }
+
+    // interior-step gradient (likelihood part, this wave's tiles) for the lane's two coordinates
+    __device__ __forceinline__ void eval_bf16(const float (&q2)[2], float (&gl)[2]) const {
+        const float qa = q2[0] * ExpScale<float>::k, qb = q2[1] * ExpScale<float>::k;
+        const uint32_t ha = mf_pack_rne(qa, qa), hb = mf_pack_rne(qb, qb);
+        const float la = qa - mf_hi_f32(ha), lb = qb - mf_hi_f32(hb);
+        const mf_u32x2 bh = {ha, hb}, bl = {mf_pack_rne(la, la), mf_pack_rne(lb, lb)};
+        f32x4 gacc = {0, 0, 0, 0};
+#pragma unroll
+        for (int pi = 0; pi < NPAIR; ++pi) {
+            if (2 * pi < ntile_live) {  // wave-uniform
+                uint32_t wq[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int T = 0; T < 2; ++T) {
+                    const int t = 2 * pi + T;
+                    if (t < NTW && t < ntile_live) {
+                        f32x4 e = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(mf_s16x4, xe[t]), __builtin_bit_cast(mf_s16x4, bh),
+                                                                            f32x4{0, 0, 0, 0}, 0, 0, 0);
+                        e = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(mf_s16x4, xe[t]), __builtin_bit_cast(mf_s16x4, bl), e, 0, 0, 0);
+                        const mf_f32x2 d0 = mf_f32x2{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])} + mf_f32x2{1.0f, 1.0f};
+                        const mf_f32x2 d1 = mf_f32x2{__builtin_amdgcn_exp2f(e[2]), __builtin_amdgcn_exp2f(e[3])} + mf_f32x2{1.0f, 1.0f};
+                        wq[2 * T] = mf_pack_rne(fast_rcp(d0.x), fast_rcp(d0.y));
+                        wq[2 * T + 1] = mf_pack_rne(fast_rcp(d1.x), fast_rcp(d1.y));
+                    }
+                }
+                const mf_u32x4 wv = {wq[0], wq[1], wq[2], wq[3]};
+                gacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mf_bf16x8, xq[pi]), __builtin_bit_cast(mf_bf16x8, wv), gacc, 0, 0, 0);
+            }
+        }
+        gl[0] = gacc[0] + gacc[1];
+        gl[1] = gacc[2] + gacc[3];
     }
 
     // likelihood part for the lane's two coordinates over THIS wave's tiles:
@@ -151,6 +233,23 @@ __global__ void __launch_bounds__(256) k_chain_mfma(ModelArgs<float, 8> m, Chain
         grad[0] = gl[0] - q2[0] * inv_var[0];
         grad[1] = gl[1] - q2[1] * inv_var[1];
     };
+    // interior leapfrog step: gradient only, from the bf16 operands (LR_PREC_BF16 / AUTO), else the exact evaluation
+    auto evaluate_interior = [&](const float (&q2)[2], float (&grad)[2]) {
+        float gl[2];
+        rows.eval_bf16(q2, gl);
+        if constexpr (S > 1) {
+            red[step_parity][wave][lane][0] = gl[0];
+            red[step_parity][wave][lane][1] = gl[1];
+            __syncthreads();
+            gl[0] = (red[step_parity][0][lane][0] + red[step_parity][1][lane][0]) +
+                    (red[step_parity][2][lane][0] + red[step_parity][3][lane][0]);
+            gl[1] = (red[step_parity][0][lane][1] + red[step_parity][1][lane][1]) +
+                    (red[step_parity][2][lane][1] + red[step_parity][3][lane][1]);
+            step_parity ^= 1;
+        }
+        grad[0] = gl[0] - q2[0] * inv_var[0];
+        grad[1] = gl[1] - q2[1] * inv_var[1];
+    };
     using True = std::integral_constant<bool, true>;
     using False = std::integral_constant<bool, false>;
     auto lprior_of = [&](const float (&q2)[2]) {
@@ -236,13 +335,23 @@ __global__ void __launch_bounds__(256) k_chain_mfma(ModelArgs<float, 8> m, Chain
                     const float heps = 0.5f * a.step;
                     pm[0] = fma_t(heps, gp[0], pm[0]);
                     pm[1] = fma_t(heps, gp[1], pm[1]);
-                    for (int i = 0; i < a.l - 1; ++i) {
-                        xp[0] = fma_t(kb[0], pm[0], xp[0]);
-                        xp[1] = fma_t(kb[1], pm[1], xp[1]);
-                        double d0;
-                        evaluate(False{}, xp, gp, d0);
-                        pm[0] = fma_t(a.step, gp[0], pm[0]);
-                        pm[1] = fma_t(a.step, gp[1], pm[1]);
+                    if (a.interior_bf16) {
+                        for (int i = 0; i < a.l - 1; ++i) {
+                            xp[0] = fma_t(kb[0], pm[0], xp[0]);
+                            xp[1] = fma_t(kb[1], pm[1], xp[1]);
+                            evaluate_interior(xp, gp);
+                            pm[0] = fma_t(a.step, gp[0], pm[0]);
+                            pm[1] = fma_t(a.step, gp[1], pm[1]);
+                        }
+                    } else {
+                        for (int i = 0; i < a.l - 1; ++i) {
+                            xp[0] = fma_t(kb[0], pm[0], xp[0]);
+                            xp[1] = fma_t(kb[1], pm[1], xp[1]);
+                            double d0;
+                            evaluate(False{}, xp, gp, d0);
+                            pm[0] = fma_t(a.step, gp[0], pm[0]);
+                            pm[1] = fma_t(a.step, gp[1], pm[1]);
+                        }
                     }
                     xp[0] = fma_t(kb[0], pm[0], xp[0]);
                     xp[1] = fma_t(kb[1], pm[1], xp[1]);

@@ -240,7 +240,12 @@ class ChainSet:
         self.pivot = st[0].astype(np.float64)  # any point near the posterior; shards of one run must share it
 
     def plan(self):
-        return self.model.plan(self.C, self.group, _lib.MODE_NAMES.get(self.mode, "auto"))
+        """The kernel variant `advance` launches for this chain set (family- and precision-aware: `lr_plan_run`)."""
+        opts = RunOpts(n_chains=self.C, group=self.group, mode=self.mode, precision=self.precision)
+        m, g, r = C.c_int32(), C.c_int32(), C.c_int32()
+        check(_lib.load().lr_plan_run(self.model.handle, _lib.KIND_BY_NAME[self.kernel.kind], C.byref(opts), C.byref(m),
+                                      C.byref(g), C.byref(r)))
+        return {"mode": _lib.MODE_NAMES[m.value], "group": g.value, "rows_per_lane": r.value}
 
     def enable_stats(self, batch: int, slots: int, pivot=None):
         """Start a statistics window: from now on every kept sample is folded, on the device, into the running

@@ -94,7 +94,8 @@ def test_every_kernel_variant_evaluates_the_same_model(models, oracle_model, mod
 
 # ------------------------------------------------------------------------------------------------
 def one_step(la, model, kind, q0, seed, iter_offset=0, ll=None, group=0, mode="auto"):
-    cs = la.ChainSet(make_kernel(la, model, kind), q0, seed=seed, ll=ll, group=group, mode=mode)
+    # precision="full": every gradient in the model's own arithmetic (step-level comparison with the float64 oracle)
+    cs = la.ChainSet(make_kernel(la, model, kind), q0, seed=seed, ll=ll, group=group, mode=mode, precision="full")
     cs.iter_offset = iter_offset
     out = cs.advance(1, 1).to_host()[0].astype(np.float64)
     return out, cs.get_accepts(), cs.get_ll()
@@ -161,7 +162,7 @@ def test_matrix_core_variant_invariances_and_short_run(la, models, oracle_model,
     rng = np.random.default_rng(2)
     q0 = map_beta + 0.3 * POST_SD * rng.standard_normal((C, 8))
     k = make_kernel(la, models["float32"], "hmc")
-    kw = dict(thin=3, iters=6, verb=False, seed=99, group=ways, mode="mfma")
+    kw = dict(thin=3, iters=6, verb=False, seed=99, group=ways, mode="mfma", precision="full")
     full = la.mcmc(q0, k, **kw)
     assert np.array_equal(full, la.mcmc(q0, k, **kw))
     assert np.array_equal(full, la.mcmc(q0, k, chunk=4, **kw))
@@ -172,6 +173,18 @@ def test_matrix_core_variant_invariances_and_short_run(la, models, oracle_model,
     ok = ref["margin"] > 2e-3
     assert ok.mean() > 0.9
     assert np.max(np.abs(full[:, ok, :] - ref["out"][:, ok, :]) / POST_SD) < 2e-3
+    # default policy: the L - 1 interior gradients of a trajectory come from bf16 operands on the bf16 matrix pipe
+    # (two-piece rows and beta, one-piece w); end points exact.  Same invariances, trajectories close to the exact ones.
+    kw["precision"] = "auto"
+    mixed = la.mcmc(q0, k, **kw)
+    assert np.array_equal(mixed, la.mcmc(q0, k, chunk=4, **kw))
+    a = la.mcmc(q0[:50], k, **kw)
+    b = la.mcmc(q0[50:], k, chain_offset=50, **kw)
+    assert np.array_equal(mixed, np.concatenate([a, b], axis=1))
+    assert not np.array_equal(mixed, full)
+    wide_ok = ref["margin"] > 0.1
+    print("mfma bf16-interior vs oracle:", np.max(np.abs(mixed[:, wide_ok, :] - ref["out"][:, wide_ok, :]) / POST_SD), "sd")
+    assert np.max(np.abs(mixed[:, wide_ok, :] - ref["out"][:, wide_ok, :]) / POST_SD) < 5e-2
 
 
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
@@ -254,6 +267,20 @@ def test_planner_engine_choice_by_size(la):
     assert plan(6000, 64)["mode"] == "stepwise"     # beyond LDS
     assert plan(300, 64, p=100)["mode"] == "stepwise"
     assert plan(200, 4096, p=12) == {"mode": "reg", "group": 32, "rows_per_lane": 7}
+    # family-aware planning (lr_plan_run): HMC whose interior gradients may use the bf16 matrix pipe moves to the
+    # fused matrix-core kernels once there are enough chains to hide their latency chain; "full" precision never does
+    X, y, _ = la.synthetic_logreg(200, 8, seed=200)
+    m = la.LogReg(X, y, np.ones(8))
+    hmc = la.hmcKernel(m.lpost, m.glp, eps=0.1, l=10, dmm=np.ones(8))
+    mala = la.malaKernel(m.lpost, m.glp, dt=1e-3, pre=np.ones(8))
+
+    def run_plan(kernel, C, **kw):
+        return la.ChainSet(kernel, np.zeros((C, 8)), seed=0, **kw).plan()
+    assert run_plan(hmc, 4096) == {"mode": "reg", "group": 16, "rows_per_lane": 13}
+    assert run_plan(hmc, 8192) == {"mode": "mfma", "group": 4, "rows_per_lane": 4}
+    assert run_plan(hmc, 16384) == {"mode": "mfma", "group": 1, "rows_per_lane": 13}
+    assert run_plan(hmc, 16384, precision="full") == {"mode": "reg", "group": 16, "rows_per_lane": 13}
+    assert run_plan(mala, 16384) == {"mode": "reg", "group": 16, "rows_per_lane": 13}
 
 
 @pytest.mark.parametrize("engine", ["bf16x3", "fp32"])
