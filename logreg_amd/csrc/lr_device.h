@@ -475,6 +475,57 @@ template <typename T, int P> __device__ __forceinline__ void vscale(T s, const T
     }
 }
 
+// 16 lanes per chain, 8 values: REDUCE-SCATTER instead of the all-reduce above.  The butterfly all-reduce costs
+// 8 adds per level x 4 levels = 32 v_add_f32_dpp and leaves all 8 totals in all 16 lanes -- where the caller then
+// repeats the same leapfrog update 16 times.  Here the first two levels halve the values a lane carries (bank-masked
+// DPP adds: a lane only receives the values it keeps), the last two finish two values per lane:
+//   level 1  row_mirror       lanes 0-7 keep v0..v3, lanes 8-15 keep v4..v7           8 adds (bank_mask 0x3 / 0xc)
+//   level 2  row_half_mirror  lanes 0-3 | 4-7 | 8-11 | 12-15 keep (v0,v1) | (v2,v3) | (v4,v5) | (v6,v7)   4 adds
+//   level 3, 4  quad_perm [2,3,0,1], [1,0,3,2] on the two remaining values                                 4 adds
+// 16 adds; every lane of quad q ends with the totals of values 2q and 2q + 1 (bit-identical in the quad's 4 lanes).
+// Inline asm: the bank-masked form (disabled lanes keep the destination) has no builtin that the DPP combiner would
+// fuse, and the compiler pads no hazards inside asm -- the leading s_nop and the instruction order below keep two
+// wait states between a VALU write of a register and its DPP read.
+__device__ __forceinline__ void group16_reduce_scatter8(const float (&v)[8], float& u0, float& u1) {
+    float r0, r1, r2, r3, s0, s1;
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %8, %8 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %1, %9, %9 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %2, %10, %10 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %3, %11, %11 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %0, %12, %12 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %1, %13, %13 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %2, %14, %14 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %3, %15, %15 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %4, %0, %0 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %5, %1, %1 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %4, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %5, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %6, %4, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %7, %5, %5 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %6, %6, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %7, %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"  // the caller's next instruction may be a DPP read of u1 (the compiler pads nothing after asm)
+        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(s0), "=&v"(s1), "=&v"(u0), "=&v"(u1)
+        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+}
+// the reverse: every lane of a 16-lane row gets the pair held by quad q (its lane 4q) for q = 0..3: 8 v_mov_b32_dpp row_share
+__device__ __forceinline__ void group16_allgather_pairs(const f32x2& mine, f32x2 (&all)[4]) {
+    const float fx = mine.x, fy = mine.y;  // (bit_cast straight from a vector-element lvalue reads element 0 for both)
+    const int mx = __builtin_bit_cast(int, fx), my = __builtin_bit_cast(int, fy);
+    all[0] = f32x2{__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, mx, 0x150, 0xF, 0xF, true)),
+                   __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, my, 0x150, 0xF, 0xF, true))};
+    all[1] = f32x2{__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, mx, 0x154, 0xF, 0xF, true)),
+                   __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, my, 0x154, 0xF, 0xF, true))};
+    all[2] = f32x2{__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, mx, 0x158, 0xF, 0xF, true)),
+                   __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, my, 0x158, 0xF, 0xF, true))};
+    all[3] = f32x2{__builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, mx, 0x15C, 0xF, 0xF, true)),
+                   __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, my, 0x15C, 0xF, 0xF, true))};
+}
+
 // exp(t) given ts = t * kScale<T> (float: the log2(e) factor is folded into beta once per
 // evaluation instead of once per row; double: kScale = 1)
 template <typename T> struct ExpScale;

@@ -128,6 +128,50 @@ __global__ void __launch_bounds__(256) k_eval(ModelArgs<T, P> m, EvalArgs<T> a) 
 }
 
 // --------------------------------------------------------------------------------------------
+// HMC interior leapfrog loop for the 16-lanes-per-chain register kernel (float, P = 8): l - 1 x (drift, gradient,
+// kick) with the position and momentum of a chain DISTRIBUTED over its 16 lanes -- quad q owns coordinates 2q, 2q + 1
+// -- instead of replicated in all of them.  Per step: all-gather the position (8 v_mov_b32_dpp row_share), the row
+// pass (unchanged), a reduce-scatter of the 8 gradient sums (16 v_add_f32_dpp instead of the all-reduce's 32) and
+// kick + drift on ONE coordinate pair (3 v_pk_fma_f32 instead of 12): 27 instructions where there were 44, of ~190.
+// On entry xk = k * position (all lanes), pm = momentum after the first half kick; on exit both are replicated again.
+template <int R>
+__device__ __forceinline__ void hmc_interior_rs16(const RegRowPairs<8, R, 16>& rows, const float (&d)[8], const float (&e)[8],
+                                                  float step, int nsteps, float (&xk)[8], float (&pm)[8]) {
+    const int q = (threadIdx.x >> 2) & 3;
+    auto pick = [&](const float (&v)[8]) {
+        const float x01 = q & 1 ? v[2] : v[0], x23 = q & 1 ? v[6] : v[4];
+        const float y01 = q & 1 ? v[3] : v[1], y23 = q & 1 ? v[7] : v[5];
+        return f32x2{q & 2 ? x23 : x01, q & 2 ? y23 : y01};
+    };
+    const f32x2 dq = pick(d), eq = pick(e), st = {step, step};
+    f32x2 xq = pick(xk), pq = pick(pm);
+    f32x2 bb[4];
+    for (int i = 0; i < nsteps; ++i) {
+        xq = __builtin_elementwise_fma(dq, pq, xq);  // drift
+        group16_allgather_pairs(xq, bb);
+        f32x2 gpp[4];
+        float unused = 0.0f;
+        row_pairs_eval<8, R, 16, false, true>(rows, bb, gpp, unused);
+        const float gv[8] = {gpp[0].x, gpp[0].y, gpp[1].x, gpp[1].y, gpp[2].x, gpp[2].y, gpp[3].x, gpp[3].y};
+        float u0, u1;
+        group16_reduce_scatter8(gv, u0, u1);
+        const f32x2 gq = __builtin_elementwise_fma(-xq, eq, f32x2{u0, u1});  // + prior:  g - (k q)(ivar / k)
+        pq = __builtin_elementwise_fma(st, gq, pq);                          // kick
+    }
+    xq = __builtin_elementwise_fma(dq, pq, xq);  // the last drift (its gradient is the end-point evaluation)
+    group16_allgather_pairs(xq, bb);
+    f32x2 pp[4];
+    group16_allgather_pairs(pq, pp);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        xk[2 * j] = bb[j].x;
+        xk[2 * j + 1] = bb[j].y;
+        pm[2 * j] = pp[j].x;
+        pm[2 * j + 1] = pp[j].y;
+    }
+}
+
+// --------------------------------------------------------------------------------------------
 // the chain kernel
 template <typename T, int P, int G, int MODE, int R, int KIND>
 __global__ void __launch_bounds__(256) k_chain(ModelArgs<T, P> m, ChainArgs<T, P> a) {
@@ -217,13 +261,17 @@ __global__ void __launch_bounds__(256) k_chain(ModelArgs<T, P> m, ChainArgs<T, P
                     vfma_s<T, P>(heps, gp, pm);
                     T xk[P];  // k * position
                     vscale<T, P>(ExpScale<T>::k, xp, xk);
-                    for (int i = 0; i < a.l - 1; ++i) {
-                        vfma_v<T, P>(a.d, pm, xk);  // drift
-                        double d0, d1;
-                        eval_lpost<T, P, G, false, true, true>(rows, prior_k, xk, gp, d0, d1);
-                        vfma_s<T, P>(a.step, gp, pm);  // kick
+                    if constexpr (G == 16 && P == 8 && sizeof(T) == 4 && MODE == MODE_REG) {
+                        hmc_interior_rs16<R>(rows, a.d, a.e, a.step, a.l - 1, xk, pm);  // includes the last drift
+                    } else {
+                        for (int i = 0; i < a.l - 1; ++i) {
+                            vfma_v<T, P>(a.d, pm, xk);  // drift
+                            double d0, d1;
+                            eval_lpost<T, P, G, false, true, true>(rows, prior_k, xk, gp, d0, d1);
+                            vfma_s<T, P>(a.step, gp, pm);  // kick
+                        }
+                        vfma_v<T, P>(a.d, pm, xk);
                     }
-                    vfma_v<T, P>(a.d, pm, xk);
                     vscale<T, P>(ExpScale<T>::inv, xk, xp);
                     eval_lpost<T, P, G, true, true>(rows, m.prior, xp, gp, llp, lprp);
                     vfma_s<T, P>(heps, gp, pm);
