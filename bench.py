@@ -173,24 +173,31 @@ def extra_configs(la, L, check, dev, stream):
         acc = float(cs.get_accepts().sum() / (C * (3 * iters + 1)))
         row = {"config": cfg, "workload": f"HMC L={fix['l']} eps={fix['eps']} unit mass, synthetic n={n} p={p}, {C} chains"
                + (" (one GPU's shard of 8192)" if cfg == 5 else ""), "kernel_variant": cs.plan(),
+               "interior_precision": "auto (bf16 matrix pipe for the L-1 interior gradients; end points exact)",
                "chain_iterations_per_s": C * iters / (ms * 1e-3), "grad_evals_per_s": C * evals / (ms * 1e-3),
                "accept_rate": acc, "us_per_evaluation_all_chains": per_eval_s * 1e6,
-               "timing": "HIP events around 4 iterations = 200 x (partial kernel + update kernel); per-evaluation time "
-                         "includes both kernels and the launch boundaries between them"}
+               "timing": "HIP events around 4 HMC iterations = 200 log-posterior-gradient evaluations of all chains (every "
+                         "kernel launch of the stepwise engine and the boundaries between them included)"}
+        # what the sigmoid alone costs: 2 transcendental VALU ops (quarter rate: 8 cycles per wave-instruction) per row and chain
+        trans_floor_s = n * C * 2 / 64 * 8 / (1024 * 2.4e9)
         if cfg == 4:
             xbytes = 4 * n * (p + 1)
-            row["roofline"] = {"bound": "valu_fp32", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / PEAK_FP32_TFLOPS, "flops_per_grad_eval": fg,
+            row["roofline"] = {"bound": "valu_trans", "pipe": "interior steps: exp + rcp of the sigmoid on the vector ALU, multiply-adds "
+                               "on the bf16 matrix pipe (lr_tall_mx.h); end points: fp32 vector ALU",
+                               "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS,
+                               "flops_per_grad_eval": fg, "transcendental_floor_us": trans_floor_s * 1e6,
+                               "frac_of_transcendental_floor": trans_floor_s / per_eval_s,
                                "x_pass_bytes": xbytes, "x_pass_GBps": xbytes / per_eval_s / 1e9,
                                "hbm_frac": xbytes / per_eval_s / (HBM_PEAK_GBS * 1e9),
-                               "note": "SURVEY 8(d): report both; 1024 chains share every X pass (1.03 flop/B per chain "
-                                       "x 1024), so the fp32 vector ALU is the operative bound, not HBM"}
+                               "note": "SURVEY 8(d): report both; algorithmic flops are priced against the fp32 vector peak (the pipe "
+                                       "the fp32 formulation needs), but the interior multiply-adds run on the matrix pipe, so the "
+                                       "operative bound is the transcendental unit; 1024 chains share every X pass: HBM is idle"}
         else:
             row["roofline"] = {"bound": "mfma", "pipe": "bf16 MFMA (v_mfma_f32_16x16x32_bf16), fp32 accumulate",
                                "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
                                "frac_of_fp32_peak": ach / PEAK_FP32_TFLOPS, "flops_per_grad_eval": fg,
-                               "wide_precision": os.environ.get("LOGREG_WIDE_PRECISION", "default"),
-                               "note": "algorithmic flops counted once (SURVEY 8(d)); split-bf16 piece products are not counted"}
+                               "note": "algorithmic flops counted once (SURVEY 8(d)); at 1024 chains an evaluation is 2.15 GFLOP = "
+                                       "0.9 us of the bf16 pipe: launch, prologue and epilogue dominate (DESIGN.md section 5)"}
         res.append(row)
     return res
 

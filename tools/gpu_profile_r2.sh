@@ -16,6 +16,6 @@ for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_B
 done
 cd $ROOT
 python3 tools/summarize_prof.py $OUT $OUT/summary.txt > /dev/null
-tail -1 $OUT/trace.log > $OUT/bench_line.json
+grep "^{" $OUT/trace.log | tail -1 > $OUT/bench_line.json
 # the rocpd databases are tens of MB per pass (gpurun merges at most 64 MiB back): keep the summaries only
 rm -rf $OUT/trace $OUT/pmc_*/
