@@ -11,8 +11,10 @@
  * Conventions
  *   - every function returns 0 on success, a negative lr_status on failure;
  *     lr_last_error() returns a thread-local message for the last failure on this thread.
- *   - a model handle is bound to one device; calls on one handle must be serialised by the
- *     caller; different handles may be used from different threads/processes.
+ *   - a model handle is bound to one device; HOST calls on one handle must be serialised by the
+ *     caller; different handles may be used from different threads/processes.  The DEVICE work of
+ *     on_device calls issued on different streams may overlap: the scratch state of the stepwise engine
+ *     is kept per (handle, stream), so two chain sets of one model on two streams do not disturb each other.
  *   - "dtype" is the arithmetic type the device path computes in and the element type of every
  *     `void*` array below: LR_F32 (float) or LR_F64 (double).  Model inputs and kernel tuning
  *     vectors are always host doubles (they are tiny and converted once).
@@ -145,7 +147,8 @@ LR_API int lr_run_mala(lr_model* m, void* state, double* lp_state, double dt, co
 /* ulKernel(glpi, dt, pre): fit-np-ul.py:61-68 (no accept step; accepts counts iterations) */
 LR_API int lr_run_ul(lr_model* m, void* state, double dt, const double* pre, const lr_run_opts* opts,
                      void* out, uint32_t* accepts);
-/* hmcKernel(lpi, glpi, eps, l, dmm) with its own mhKernel: fit-np-hmc.py:56-87 */
+/* hmcKernel(lpi, glpi, eps, l, dmm) with its own mhKernel: fit-np-hmc.py:56-87
+ * (opts->precision selects the arithmetic of the l - 1 interior leapfrog gradients: LR_PREC_*) */
 LR_API int lr_run_hmc(lr_model* m, void* state, double eps, int32_t l, const double* dmm,
                       const lr_run_opts* opts, void* out, uint32_t* accepts);
 
