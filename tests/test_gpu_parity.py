@@ -682,6 +682,11 @@ def test_randomised_parity_fuzz():
                        text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " 0 failed" in r.stdout
+    # the same generator with the default interior-gradient policy (reduced-precision interior leapfrog steps)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "fuzz_parity.py"), "60", "11", "auto"], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " 0 failed" in r.stdout
 
 
 

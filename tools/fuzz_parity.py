@@ -9,6 +9,9 @@ from oracle.oracle import OracleModel
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+# third argument "auto": HMC cases run with the default interior-gradient policy (bf16 matrix-pipe interior steps
+# where a kernel exists) and are compared with the oracle at the looser tolerances such trajectories allow
+PREC = sys.argv[3] if len(sys.argv) > 3 else "full"
 fails, done, skipped = [], 0, 0
 t0 = time.time()
 for case in range(cases):
@@ -52,7 +55,7 @@ for case in range(cases):
     try:
         ref = orc.run(kind, q0, thin=thin, iters=iters, seed=case, ll_state=ll0, threads=0, **kw)
         out, info = la.mcmc(q0, kern, thin=thin, iters=iters, verb=False, seed=case, ll=ll0, mode=mode, group=group,
-                            return_info=True, precision="full")
+                            return_info=True, precision=PREC)
         r = m.eval(q0, mode=mode if mode != "stepwise" else "auto", group=group if mode != "stepwise" else 0)
     except la.LogregHipError as e:
         skipped += 1
@@ -61,6 +64,9 @@ for case in range(cases):
     # decisions are compared where the oracle's |a - log u| clears the fp32 resolution of the log-density
     # (|ll| ~ 0.7 n: ulp-level sums of n terms; 2e-3 up to n = 1000, growing with n)
     ok = ref["margin"] > 2e-3 * max(1.0, n / 1000.0)
+    loose = PREC != "full" and kind == "hmc"
+    if loose:
+        ok = ref["margin"] > 0.25
     lp_ref = orc.lpost(q0)
     errs = []
     if not np.allclose(r["lpost"], lp_ref, rtol=3e-5, atol=3e-5 * n ** 0.5):
@@ -72,22 +78,22 @@ for case in range(cases):
         if not np.array_equal(info["accepts"][ok], ref["accepts"][ok].astype(np.uint32)):
             errs.append("accepts differ in %d chains" % int((info["accepts"][ok] != ref["accepts"][ok]).sum()))
         d = np.max(np.abs(out[:, ok] - ref["out"][:, ok]))
-        if not d < 2e-3 * sc * 3 + 1e-5:
+        if not d < (2e-3 if not loose else 6e-2) * sc * 3 + 1e-5:
             errs.append("states %.3g" % d)
     if not np.isfinite(out).all():
         errs.append("non-finite output")
     if rng.random() < 0.4:  # chunk and shard invariance: bit-exact (global chain id and iteration in the Philox counter)
         again = la.mcmc(q0, kern, thin=thin, iters=iters, verb=False, seed=case, ll=ll0, mode=mode, group=group, chunk=1,
-                        precision="full")
+                        precision=PREC)
         if not np.array_equal(again, out):
             errs.append("chunk=1 differs")
         pl = info["plan"]
         if C > 1 and pl["mode"] != "stepwise":  # (stepwise slicing depends on the chain count by design)
             h = C // 2
             a = la.mcmc(q0[:h], kern, thin=thin, iters=iters, verb=False, seed=case, ll=None if ll0 is None else ll0[:h],
-                        mode=pl["mode"], group=pl["group"], precision="full")
+                        mode=pl["mode"], group=pl["group"], precision=PREC)
             b = la.mcmc(q0[h:], kern, thin=thin, iters=iters, verb=False, seed=case, ll=None if ll0 is None else ll0[h:],
-                        mode=pl["mode"], group=pl["group"], chain_offset=h, precision="full")
+                        mode=pl["mode"], group=pl["group"], chain_offset=h, precision=PREC)
             if not np.array_equal(np.concatenate([a, b], axis=1), out):
                 errs.append("shards differ")
     if errs:
