@@ -337,7 +337,7 @@ int setup_tall(lr_model* m, const Plan& pl, hipStream_t st, int64_t C, lr::TallA
             RS_i = (int)((m->n + slice_len_i - 1) / slice_len_i);
         }
     }
-    if (m->P == 8 && m->d_xmx) {
+    if (m->P <= 32 && m->d_xmx) {
         // narrow models, interior leapfrog steps on the matrix pipe (lr_tall_mx.h): 4-wave workgroups of 64 chains;
         // slices fine enough for ~4 waves per SIMD, each at least 256 rows, whole tile pairs
         const int64_t blocks = (C + 63) / 64;
@@ -772,11 +772,13 @@ int lr_model_create(const double* X, const double* y, int64_t n, int32_t p, cons
             return fail(LR_ERR_NOMEM, "allocating the row-pair image (%zu bytes) failed", tw.size() * 4);
         }
     }
-    if (m->P == 8 && dtype == LR_F32) {  // narrow models: two-piece bf16 tile images (interior HMC steps on the matrix pipe)
+    if (m->P >= 8 && m->P <= 32 && dtype == LR_F32) {  // narrow models: two-piece bf16 tile images (interior HMC steps on the matrix pipe)
         const float* hrows = reinterpret_cast<const float*>(host.data());
         const int64_t ntile = (n + 31) / 32 * 2;
-        std::vector<uint16_t> img((size_t)ntile * lr::kMxTileElems);
-        lr::tall_mx_prepare(hrows, n, img.data());
+        std::vector<uint16_t> img((size_t)ntile * (m->P / 8) * lr::kMxSetElems);
+        if (m->P == 8) lr::tall_mx_prepare<8>(hrows, n, img.data());
+        else if (m->P == 16) lr::tall_mx_prepare<16>(hrows, n, img.data());
+        else lr::tall_mx_prepare<32>(hrows, n, img.data());
         if (hipMalloc(&m->d_xmx, img.size() * 2) != hipSuccess ||
             hipMemcpy(m->d_xmx, img.data(), img.size() * 2, hipMemcpyHostToDevice) != hipSuccess) {
             lr_model_destroy(m);

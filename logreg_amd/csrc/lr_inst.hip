@@ -5,6 +5,8 @@
 #include "lr_tall.h"
 #if LR_DTYPE == 0 && LR_P == 8
 #include "lr_mfma.h"
+#endif
+#if LR_DTYPE == 0 && LR_P >= 8
 #include "lr_tall_mx.h"
 #endif
 
@@ -125,10 +127,10 @@ int launch_chain(const LaunchCfg* cfg, int64_t C, const void* model_args, const 
 int launch_tall_partial(hipStream_t st, int want_value, int want_grad, const void* tall_args) {
     const auto& a = *static_cast<const TallArgs<T, P>*>(tall_args);
     const dim3 grid((unsigned)a.RS, (unsigned)((a.C + 63) / 64)), block(64 * TallGeom<T, P>::NW);  // slices fastest: XCD locality
-#if LR_DTYPE == 0 && LR_P == 8
+#if LR_DTYPE == 0 && LR_P >= 8
     if (a.interior && !want_value && a.xmx && a.RS_i > 0) {  // reduced-precision interior leapfrog step on the bf16 matrix pipe
         const dim3 gridm((unsigned)a.RS_i, (unsigned)((a.C + 63) / 64));
-        hipLaunchKernelGGL((k_tall_partial_mx<4>), gridm, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((k_tall_partial_mx<P, 4>), gridm, dim3(256), 0, st, a);
         return check(hipGetLastError());
     }
 #endif

@@ -1,5 +1,5 @@
-// lr_tall_mx.h -- INTERIOR-step partial kernel of the stepwise engine for NARROW tall models (padded p = 8,
-// float32) on the bf16 matrix pipe: the counterpart of lr_wide_bf16.h's interior kernels for data with many rows
+// lr_tall_mx.h -- INTERIOR-step partial kernel of the stepwise engine for NARROW tall models (padded p = 8, 16 or 32,
+// float32; written out below for p = 8: wider models repeat the scheme per set of 8 coordinates) on the bf16 matrix pipe: the counterpart of lr_wide_bf16.h's interior kernels for data with many rows
 // and few columns (BASELINE config 4: n = 100 000, p = 8).
 //
 // Why.  The fp32 vector kernel (k_tall_partial) spends 10.5 VALU instructions per row and 64 chains; it sits at
@@ -46,8 +46,17 @@ typedef uint32_t mx_u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t mx_u32x2 __attribute__((ext_vector_type(2)));
 typedef short mx_s16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kMxTileElems = 4 * 16 * 4;  // bf16 elements per 16-row tile image (512 bytes)
-constexpr int kMxChunkTiles = 32;         // tiles per staged chunk: 16 KB, 512 rows (an even number: tile pairs)
+constexpr int kMxSetElems = 4 * 16 * 4;   // bf16 elements of one coordinate set (8 coordinates) of a 16-row tile: 512 bytes
+constexpr int kMxChunkBytes = 16384;      // staged chunk: 512 rows at P = 8, 256 at P = 16, 128 at P = 32 (whole tile pairs)
+// P = 8 s coordinates: lane (., kg) handles, for every set s < P / 8, the pair a = 8 s + kg, b = 8 s + kg + 4; a tile image is
+// [s][kg][row'][4 bf16] and everything below runs once per set (eta: 2 more MFMAs into the same accumulator; gradient: one
+// more MFMA and accumulator per set).
+template <int P> struct MxGeom {
+    static_assert(P == 8 || P == 16 || P == 32, "coordinate sets of 8");
+    static constexpr int NS = P / 8;
+    static constexpr int TILE = NS * kMxSetElems;              // bf16 elements per tile image
+    static constexpr int CHUNK_TILES = kMxChunkBytes / (TILE * 2);
+};
 
 __host__ __device__ constexpr int mx_elem(int kg, int row) { return kg * 64 + ((row + 8 * (kg >> 1)) & 15) * 4; }
 
@@ -58,9 +67,11 @@ __device__ __forceinline__ mx_u32x2 mx_read_tr16(const uint16_t* p) {
     return __builtin_bit_cast(mx_u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) mx_s16x4*)(p)));
 }
 
-template <int NW>
-__global__ void __launch_bounds__((64 * NW)) k_tall_partial_mx(TallArgs<float, 8> a) {
-    constexpr int CHUNK_BYTES = kMxChunkTiles * kMxTileElems * 2;  // 32 KB
+template <int P, int NW>
+__global__ void __launch_bounds__((64 * NW)) k_tall_partial_mx(TallArgs<float, P> a) {
+    using G = MxGeom<P>;
+    constexpr int NS = G::NS, kMxTileElems = G::TILE, kMxChunkTiles = G::CHUNK_TILES;
+    constexpr int CHUNK_BYTES = kMxChunkBytes;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * CHUNK_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -85,7 +96,7 @@ __global__ void __launch_bounds__((64 * NW)) k_tall_partial_mx(TallArgs<float, 8
         const int nt = (int)(ntile - t0 < kMxChunkTiles ? ntile - t0 : kMxChunkTiles);
         const unsigned char* src = reinterpret_cast<const unsigned char*>(a.xmx + (tile0 + t0) * (int64_t)kMxTileElems) + lane * 16;
         const uint32_t dst = smem_lds + (uint32_t)((g & 1) * CHUNK_BYTES);
-        const int nkb = nt / 2;  // 1 KB = 2 tiles
+        const int nkb = nt * (kMxTileElems * 2) / 1024;  // 1 KB per wave-instruction (nt is even: whole KB at every P)
         for (int ch = wave; ch < nkb; ch += NW) {
             uint32_t keep;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -96,17 +107,24 @@ __global__ void __launch_bounds__((64 * NW)) k_tall_partial_mx(TallArgs<float, 8
     };
     if (nchunk > 0) issue(0);
 
-    // beta pieces of the lane's coordinates a = kg, b = kg + 4, times log2(e): B operands of the two K = 16 eta MFMAs
+    // beta pieces of the lane's coordinates a = 8 s + kg, b = 8 s + kg + 4, times log2(e): B operands of the K = 16 eta MFMAs
     // (K-slots 4 kg .. 4 kg + 3 of lane (c, kg):  [bh_a bh_a bh_b bh_b]  and  [bl_a bl_a bl_b bl_b]  against
-    //  A = [xh_a xl_a xh_b xl_b], the 8 bytes the image holds per (row, kg): no register shuffling per tile)
-    const float qa = a.q1[chain * 8 + kg] * ExpScale<float>::k, qb = a.q1[chain * 8 + kg + 4] * ExpScale<float>::k;
-    const uint32_t ha = mx_pack_rne(qa, qa), hb = mx_pack_rne(qb, qb);
-    const float la = qa - __builtin_bit_cast(float, ha << 16), lb = qb - __builtin_bit_cast(float, hb << 16);
-    const mx_u32x2 bh = {ha, hb}, bl = {mx_pack_rne(la, la), mx_pack_rne(lb, lb)};
+    //  A = [xh_a xl_a xh_b xl_b], the 8 bytes the image holds per (set, row, kg): no register shuffling per tile)
+    mx_u32x2 bh[NS], bl[NS];
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+        const float qa = a.q1[chain * P + 8 * st + kg] * ExpScale<float>::k, qb = a.q1[chain * P + 8 * st + kg + 4] * ExpScale<float>::k;
+        const uint32_t ha = mx_pack_rne(qa, qa), hb = mx_pack_rne(qb, qb);
+        const float la = qa - __builtin_bit_cast(float, ha << 16), lb = qb - __builtin_bit_cast(float, hb << 16);
+        bh[st] = mx_u32x2{ha, hb};
+        bl[st] = mx_u32x2{mx_pack_rne(la, la), mx_pack_rne(lb, lb)};
+    }
 
     const int eta_off = mx_elem(kg, c);                                            // lane (row c, kg): its 4 elements
     const int tr_off = mx_elem(lane & 3, 4 * kg + ((lane & 15) >> 2));             // lane (kg, ri, ci): chunk ci, row 4 kg + ri
-    mx_f32x4 gacc = {0, 0, 0, 0};
+    mx_f32x4 gacc[NS];
+#pragma unroll
+    for (int st = 0; st < NS; ++st) gacc[st] = mx_f32x4{0, 0, 0, 0};
 
     for (int64_t g = 0; g < nchunk; ++g) {
         __builtin_amdgcn_s_waitcnt(0x0F70);  // own share of chunk g has landed ...
@@ -119,27 +137,38 @@ __global__ void __launch_bounds__((64 * NW)) k_tall_partial_mx(TallArgs<float, 8
             uint32_t wq[4];
 #pragma unroll
             for (int T = 0; T < 2; ++T) {
-                const mx_s16x4 xa = *reinterpret_cast<const mx_s16x4*>(tp + T * kMxTileElems + eta_off);
-                mx_f32x4 e = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(xa, __builtin_bit_cast(mx_s16x4, bh), mx_f32x4{0, 0, 0, 0}, 0, 0, 0);
-                e = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(xa, __builtin_bit_cast(mx_s16x4, bl), e, 0, 0, 0);
+                mx_f32x4 e = {0, 0, 0, 0};
+#pragma unroll
+                for (int st = 0; st < NS; ++st) {
+                    const mx_s16x4 xa = *reinterpret_cast<const mx_s16x4*>(tp + T * kMxTileElems + st * kMxSetElems + eta_off);
+                    e = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(xa, __builtin_bit_cast(mx_s16x4, bh[st]), e, 0, 0, 0);
+                    e = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(xa, __builtin_bit_cast(mx_s16x4, bl[st]), e, 0, 0, 0);
+                }
                 const mx_f32x2 d0 = mx_f32x2{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])} + mx_f32x2{1.0f, 1.0f};
                 const mx_f32x2 d1 = mx_f32x2{__builtin_amdgcn_exp2f(e[2]), __builtin_amdgcn_exp2f(e[3])} + mx_f32x2{1.0f, 1.0f};
                 wq[2 * T] = mx_pack_rne(fast_rcp(d0.x), fast_rcp(d0.y));
                 wq[2 * T + 1] = mx_pack_rne(fast_rcp(d1.x), fast_rcp(d1.y));
             }
-            const mx_u32x2 t0 = mx_read_tr16(tp + tr_off), t1 = mx_read_tr16(tp + kMxTileElems + tr_off);
-            const mx_u32x4 xg = {t0[0], t0[1], t1[0], t1[1]}, wv = {wq[0], wq[1], wq[2], wq[3]};
-            gacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mx_bf16x8, xg), __builtin_bit_cast(mx_bf16x8, wv), gacc, 0, 0, 0);
+            const mx_u32x4 wv = {wq[0], wq[1], wq[2], wq[3]};
+#pragma unroll
+            for (int st = 0; st < NS; ++st) {
+                const mx_u32x2 t0 = mx_read_tr16(tp + st * kMxSetElems + tr_off), t1 = mx_read_tr16(tp + kMxTileElems + st * kMxSetElems + tr_off);
+                const mx_u32x4 xg = {t0[0], t0[1], t1[0], t1[1]};
+                gacc[st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mx_bf16x8, xg), __builtin_bit_cast(mx_bf16x8, wv), gacc[st], 0, 0, 0);
+            }
         }
     }
     if (live) {
-        float* dst = a.part_g + ((int64_t)rs * a.C + chain) * 8;
-        dst[kg] = gacc[0] + gacc[1];
-        dst[kg + 4] = gacc[2] + gacc[3];
+        float* dst = a.part_g + ((int64_t)rs * a.C + chain) * P;
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+            dst[8 * st + kg] = gacc[st][0] + gacc[st][1];
+            dst[8 * st + kg + 4] = gacc[st][2] + gacc[st][3];
+        }
     }
 }
 
-// Host side: the tile images.  rows: [n][8] fp32 signed rows.  out: [ceil(n/32) * 2][kMxTileElems] bf16 bit patterns.
+// Host side: the tile images.  rows: [n][P] fp32 signed rows.  out: [ceil(n/32) * 2][MxGeom<P>::TILE] bf16 bit patterns.
 inline uint16_t mx_bf16_rne(float x) {
     uint32_t b;
     memcpy(&b, &x, 4);
@@ -151,23 +180,25 @@ inline float mx_bf16_to_f32(uint16_t h) {
     memcpy(&x, &b, 4);
     return x;
 }
-inline void tall_mx_prepare(const float* rows, int64_t n, uint16_t* out) {
+template <int P> inline void tall_mx_prepare(const float* rows, int64_t n, uint16_t* out) {
+    using G = MxGeom<P>;
     const int64_t ntile = (n + 31) / 32 * 2;
     for (int64_t t = 0; t < ntile; ++t) {
-        uint16_t* base = out + t * (int64_t)kMxTileElems;
-        for (int e = 0; e < kMxTileElems; ++e) base[e] = 0;
+        uint16_t* base = out + t * (int64_t)G::TILE;
+        for (int e = 0; e < G::TILE; ++e) base[e] = 0;
         for (int r = 0; r < 16; ++r) {
             const int64_t row = 16 * t + r;
             if (row >= n) continue;
-            for (int kg = 0; kg < 4; ++kg) {
-                const float xa = rows[row * 8 + kg], xb = rows[row * 8 + kg + 4];
-                const uint16_t ha = mx_bf16_rne(xa), hb = mx_bf16_rne(xb);
-                uint16_t* q = base + mx_elem(kg, r);
-                q[0] = ha;
-                q[1] = mx_bf16_rne(xa - mx_bf16_to_f32(ha));
-                q[2] = hb;
-                q[3] = mx_bf16_rne(xb - mx_bf16_to_f32(hb));
-            }
+            for (int st = 0; st < G::NS; ++st)
+                for (int kg = 0; kg < 4; ++kg) {
+                    const float xa = rows[row * P + 8 * st + kg], xb = rows[row * P + 8 * st + kg + 4];
+                    const uint16_t ha = mx_bf16_rne(xa), hb = mx_bf16_rne(xb);
+                    uint16_t* q = base + st * kMxSetElems + mx_elem(kg, r);
+                    q[0] = ha;
+                    q[1] = mx_bf16_rne(xa - mx_bf16_to_f32(ha));
+                    q[2] = hb;
+                    q[3] = mx_bf16_rne(xb - mx_bf16_to_f32(hb));
+                }
         }
     }
 }
