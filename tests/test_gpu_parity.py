@@ -736,3 +736,30 @@ def test_two_chainsets_of_one_model_on_two_streams(la, n, p):
     con = run(True)
     assert np.array_equal(seq[0], con[0]) and np.array_equal(seq[1], con[1])
     assert not np.array_equal(seq[0], seq[1])
+
+
+def test_wide_many_chains_use_the_chain_split_interior_kernel(la):
+    """More chain tiles than CUs (C > 16 x 256): the interior steps of wide models run on k_wide_partial_bf16i
+    (workgroups of 4/8 waves x 16 chains sharing staged row blocks, LDS-DMA passes) instead of the row-split kernel.
+    A 64-chain subset against the oracle: decisions away from near-ties, trajectories within the reduced-precision
+    tolerance; exact mode at the exact tolerance; reruns bit-identical."""
+    from oracle.oracle import OracleModel
+    n, p, C = 700, 64, 4200
+    X, y, _ = la.synthetic_logreg(n, p, seed=77, beta_sd=0.1)
+    ps = np.full(p, 1.5)
+    orc = OracleModel(X, y, ps)
+    m = la.LogReg(X, y, ps)
+    b = 0.1 * np.random.default_rng(5).standard_normal((C, p))
+    k = la.hmcKernel(m.lpost, m.glp, eps=0.02, l=8, dmm=np.ones(p))
+    ref = orc.run("hmc", b[:64], step=0.02, l=8, scale=np.ones(p), thin=1, iters=2, seed=4, threads=0)
+    full, fi = la.mcmc(b, k, thin=1, iters=2, verb=False, seed=4, return_info=True, precision="full")
+    ok = ref["margin"] > 2e-3
+    assert np.array_equal(fi["accepts"][:64][ok], ref["accepts"][ok].astype(np.uint32))
+    assert np.max(np.abs(full[:, :64][:, ok] - ref["out"][:, ok])) < 5e-4
+    mixed, mi = la.mcmc(b, k, thin=1, iters=2, verb=False, seed=4, return_info=True)
+    wide_ok = ref["margin"] > 0.2
+    assert np.array_equal(mi["accepts"][:64][wide_ok], ref["accepts"][wide_ok].astype(np.uint32))
+    assert np.max(np.abs(mixed[:, :64][:, wide_ok] - ref["out"][:, wide_ok])) < 2e-2
+    assert not np.array_equal(mixed, full)
+    assert np.array_equal(mixed, la.mcmc(b, k, thin=1, iters=2, verb=False, seed=4, chunk=1))
+    assert abs(mi["accepts"].mean() - fi["accepts"].mean()) < 0.05
