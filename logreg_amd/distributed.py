@@ -103,6 +103,8 @@ def run_sharded(init, run_block, n_chains: int | None = None, dst: int = 0, grou
     init = np.asarray(init)
     C = init.shape[0] if n_chains is None else n_chains
     lo, hi = shard_bounds(C, world, rank)
+    if hi == lo:  # more ranks than chains: the callable's output shape is unknown here (mcmc_sharded handles this case itself)
+        raise ValueError(f"run_sharded: rank {rank} of {world} has no chains ({C} chains in all); use mcmc_sharded or fewer ranks")
     out = run_block(init[lo:hi], lo)
     if not isinstance(out, torch.Tensor):
         out = torch.as_tensor(np.ascontiguousarray(out))
