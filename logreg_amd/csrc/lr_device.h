@@ -343,6 +343,51 @@ __device__ __forceinline__ void draw_group(uint64_t seed, uint64_t chain, uint64
     }
 }
 
+// Draws for SEVERAL consecutive iterations at once.  An iteration needs BPI = ceil(P/4) + 1 Philox blocks (the
+// normal blocks and the accept uniform); the G lanes of a group all execute the generator anyway, so lane gl computes
+// block gl % BPI of iteration base + gl / BPI: NB = G / BPI iterations are covered by ONE Philox + Box-Muller + log per
+// lane, and every iteration then only collects its values from the lanes that hold them (ds_bpermute: a runtime lane
+// index, so the chain loop is not unrolled).  At G = 16, P = 8: 5 iterations per refill (the generator was ~150 of
+// the ~490 instructions of a MALA iteration; now ~45); at one chain per wave (G = 64) 21 iterations per refill.
+// The VALUES are those of draw_normals / draw_log_uniform bit for bit: only who computes them, and when, changes.
+template <typename T, int P, int G> struct DrawBatch {
+    static constexpr int NBn = (P + 3) / 4, BPI = NBn + 1, NB = G / BPI;
+    static constexpr bool kEnabled = NB >= 2;
+    T mine[4];   // this lane's four normals (normal block) -- garbage for the uniform block's lane
+    T lu;        // log(u) of this lane's block word 0 (meaningful in the uniform block's lane)
+    int pos;     // iterations already served from the current refill (NB = refill before use)
+    __device__ __forceinline__ void reset() { pos = NB; }
+    __device__ __forceinline__ void refill(uint64_t seed, uint64_t chain, uint64_t iter_base, int gl) {
+        const int io = gl / BPI, b = gl - io * BPI;
+        const uint64_t it = iter_base + (uint64_t)io;
+        const uint32_t blk = b == NBn ? TAG_UNIFORM : (uint32_t)b;
+        const U4 w = philox4x32_10((uint32_t)chain, (uint32_t)it, (uint32_t)(it >> 32), blk, (uint32_t)seed, (uint32_t)(seed >> 32));
+        box_muller(w.x, w.y, mine[0], mine[1]);
+        box_muller(w.z, w.w, mine[2], mine[3]);
+        if constexpr (sizeof(T) == 4) lu = logf(u01<float>(w.x));
+        else lu = log(u01<double>(w.x));
+        pos = 0;
+    }
+    static __device__ __forceinline__ float fetch(float v, int lane_byte) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(lane_byte, __builtin_bit_cast(int, v)));
+    }
+    static __device__ __forceinline__ double fetch(double v, int lane_byte) {
+        const uint64_t bits = __builtin_bit_cast(uint64_t, v);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(lane_byte, (int)(uint32_t)bits);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(lane_byte, (int)(uint32_t)(bits >> 32));
+        return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+    }
+    // z[0..P) and log(u) of iteration `iter` (iterations must be requested consecutively)
+    __device__ __forceinline__ void next(uint64_t seed, uint64_t chain, uint64_t iter, int gl, T (&z)[P], T& logu) {
+        if (pos >= NB) refill(seed, chain, iter, gl);  // wave-uniform
+        const int base = ((int)(threadIdx.x & 63) - gl + pos * BPI) * 4;  // byte address of lane (group base + pos * BPI)
+#pragma unroll
+        for (int j = 0; j < P; ++j) z[j] = fetch(mine[j & 3], base + 4 * (j >> 2));
+        logu = fetch(lu, base + 4 * NBn);
+        ++pos;
+    }
+};
+
 // ------------------------------------------------------------------------------------------
 // fast scalar math for the hot loop
 // ------------------------------------------------------------------------------------------

@@ -212,12 +212,15 @@ __global__ void __launch_bounds__(256) k_chain(ModelArgs<T, P> m, ChainArgs<T, P
         }
     }
 
+    DrawBatch<T, P, G> draws;  // randomness of several consecutive iterations per generator pass (lr_device.h)
+    draws.reset();
     for (int64_t it = 0; it < a.iters; ++it) {
         for (int64_t jt = 0; jt < a.thin; ++jt) {
             const uint64_t iter = (uint64_t)(a.iter_offset + it * a.thin + jt);
             T z[P];
             T logu_t;
-            draw_group<T, P, G>(a.seed, gchain, iter, gl, z, logu_t);
+            if constexpr (DrawBatch<T, P, G>::kEnabled) draws.next(a.seed, gchain, iter, gl, z, logu_t);
+            else draw_group<T, P, G>(a.seed, gchain, iter, gl, z, logu_t);
 
             if constexpr (KIND == KIND_UL) {
                 // x <- x + 0.5*pre*dt*glp(x) + sqrt(pre*dt)*z            fit-np-ul.py:65-67
