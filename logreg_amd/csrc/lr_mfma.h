@@ -278,16 +278,28 @@ __global__ void __launch_bounds__(256) k_chain_mfma(ModelArgs<float, 8> m, Chain
     for (int64_t it = 0; it < a.iters; ++it) {
         for (int64_t jt = 0; jt < a.thin; ++jt) {
             const uint64_t iter = (uint64_t)(a.iter_offset + it * a.thin + jt);
-            // normals for coordinates k (block 0) and k+4 (block 1): word pair k>>1, element k&1
-            float z[2];
+            // one Philox block per lane instead of three: lane (c, 0) generates normal block 0, (c, 1) block 1, (c, 2) and
+            // (c, 3) the accept-uniform block; every lane then collects the normals of its coordinates k (block 0,
+            // element k) and k + 4 (block 1, element k) and log(u) from those lanes.  Same values, bit for bit.
+            float z[2], logu_f;
+            {
+                const uint32_t blk = k == 0 ? 0u : (k == 1 ? 1u : TAG_UNIFORM);
+                const U4 w4 = philox4x32_10((uint32_t)gchain, (uint32_t)iter, (uint32_t)(iter >> 32), blk, (uint32_t)a.seed,
+                                            (uint32_t)(a.seed >> 32));
+                float nrm[4];
+                box_muller(w4.x, w4.y, nrm[0], nrm[1]);
+                box_muller(w4.z, w4.w, nrm[2], nrm[3]);
+                const float lu = logf(u01<float>(w4.x));
+                auto from = [&](int src_lane, float v) {
+                    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane * 4, __builtin_bit_cast(int, v)));
+                };
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const U4 w4 = philox4x32_10((uint32_t)gchain, (uint32_t)iter, (uint32_t)(iter >> 32), (uint32_t)h,
-                                            (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
-                const uint32_t wa = k < 2 ? w4.x : w4.z, wb = k < 2 ? w4.y : w4.w;
-                float z0, z1;
-                box_muller(wa, wb, z0, z1);
-                z[h] = (k & 1) ? z1 : z0;
+                for (int h = 0; h < 2; ++h) {
+                    const float e0 = from(c + 16 * h, nrm[0]), e1 = from(c + 16 * h, nrm[1]);
+                    const float e2 = from(c + 16 * h, nrm[2]), e3 = from(c + 16 * h, nrm[3]);
+                    z[h] = k < 2 ? (k == 0 ? e0 : e1) : (k == 2 ? e2 : e3);
+                }
+                logu_f = from(c + 32, lu);
             }
             if constexpr (KIND == KIND_UL) {
                 x[0] = fma_t(kb[0], z[0], fma_t(ka[0], g[0], x[0]));
@@ -296,7 +308,7 @@ __global__ void __launch_bounds__(256) k_chain_mfma(ModelArgs<float, 8> m, Chain
                 evaluate(False{}, x, g, d0);
                 ++nacc;
             } else {
-                const double logu = (double)draw_log_uniform<float>(a.seed, gchain, iter);
+                const double logu = (double)logu_f;
                 float xp[2], gp[2];
                 double llp = 0, lprp = 0, logr;
                 if constexpr (KIND == KIND_RWMH) {
