@@ -763,3 +763,29 @@ def test_wide_many_chains_use_the_chain_split_interior_kernel(la):
     assert not np.array_equal(mixed, full)
     assert np.array_equal(mixed, la.mcmc(b, k, thin=1, iters=2, verb=False, seed=4, chunk=1))
     assert abs(mi["accepts"].mean() - fi["accepts"].mean()) < 0.05
+
+
+@pytest.mark.parametrize("n,p", [(900, 128), (3000, 8), (1500, 20)])
+@pytest.mark.parametrize("L", [1, 2, 3, 4])
+def test_short_trajectories_on_the_reduced_precision_interior_kernels(la, n, p, L):
+    """L = 1 has no interior step, L = 2 one (no fused prologue), L = 3 one fused hand-over, L = 4 two (the state and
+    partial buffers of the wide row-split kernel swap twice): every launch sequence of the stepwise HMC loop under the
+    default policy, against the oracle at the reduced-precision tolerance, and reproducible run to run."""
+    from oracle.oracle import OracleModel
+    X, y, _ = la.synthetic_logreg(n, p, seed=n + p, beta_sd=0.4 / np.sqrt(p))
+    ps = np.full(p, 2.0)
+    orc = OracleModel(X, y, ps)
+    m = la.LogReg(X, y, ps)
+    C = 70
+    b = 0.05 * np.random.default_rng(L).standard_normal((C, p))
+    eps = 0.4 / np.sqrt(n)
+    k = la.hmcKernel(m.lpost, m.glp, eps=eps, l=L, dmm=np.ones(p))
+    ref = orc.run("hmc", b, step=eps, l=L, scale=np.ones(p), thin=1, iters=3, seed=9, threads=0)
+    out, info = la.mcmc(b, k, thin=1, iters=3, verb=False, seed=9, mode="stepwise", return_info=True)
+    ok = ref["margin"] > (0.1 if L > 1 else 2e-3 * max(1.0, n / 1000))
+    assert ok.mean() > 0.5
+    assert np.array_equal(info["accepts"][ok], ref["accepts"][ok].astype(np.uint32))
+    assert np.max(np.abs(out[:, ok] - ref["out"][:, ok])) < (3e-2 if L > 1 else 2e-3) / np.sqrt(n) + 1e-5
+    assert np.array_equal(out, la.mcmc(b, k, thin=1, iters=3, verb=False, seed=9, mode="stepwise", chunk=1))
+    if L == 1:  # nothing to approximate: identical to the full-precision run
+        assert np.array_equal(out, la.mcmc(b, k, thin=1, iters=3, verb=False, seed=9, mode="stepwise", precision="full"))
