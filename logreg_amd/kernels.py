@@ -328,9 +328,13 @@ class ChainSet:
 
     def checkpoint(self) -> dict:
         self.sync()
-        return {"state": self.state.to_host(), "ll": self.lp.to_host(), "accepts": self.acc.to_host(),
-                "iter_offset": np.int64(self.iter_offset), "seed": np.uint64(self.seed),
-                "chain_offset": np.int64(self.chain_offset), **self._fingerprint()}
+        ck = {"state": self.state.to_host(), "ll": self.lp.to_host(), "accepts": self.acc.to_host(),
+              "iter_offset": np.int64(self.iter_offset), "seed": np.uint64(self.seed),
+              "chain_offset": np.int64(self.chain_offset), **self._fingerprint()}
+        if self.stats is not None:  # the statistics window travels with the run
+            ck.update(stats=self.stats.to_host(), stats_batch=np.int64(self.stats_batch), stats_kept=np.int64(self.stats_kept),
+                      stats_pivot=np.asarray(self.pivot, dtype=np.float64))
+        return ck
 
     def save(self, path: str) -> str:
         """Write the checkpoint as an .npz archive; returns the path actually written (np.savez appends
@@ -364,6 +368,11 @@ class ChainSet:
                                  f"{val!r} here (a resumed run would silently stop being the continuation)")
         cs.iter_offset = int(ckpt["iter_offset"])
         cs.acc.copy_from(np.asarray(ckpt["accepts"], dtype=np.uint32))
+        if "stats" in ckpt:
+            st = np.asarray(ckpt["stats"], dtype=np.float64)
+            cs.enable_stats(int(ckpt["stats_batch"]), st.shape[0], pivot=ckpt["stats_pivot"])
+            cs.stats.copy_from(st)
+            cs.stats_kept = int(ckpt["stats_kept"])
         return cs
 
 

@@ -127,3 +127,22 @@ def test_statistics_through_host_pointers(la, pima, map_beta):
                             on_device=0, stats=host.ctypes.data, stats_batch=batch, stats_first=first, stats_slots=iters // batch)
         k.launch(opts, st.ctypes.data, None, None, None)
     assert np.array_equal(host, cs.stats.to_host())
+
+
+def test_statistics_window_survives_checkpoint_and_resume(la, pima, map_beta, tmp_path):
+    X, y = pima
+    m = la.LogReg(X, y, PSCALE)
+    k = la.malaKernel(m.lpost, m.glp, dt=1e-5, pre=PRE)
+    q0 = map_beta + 0.01 * np.random.default_rng(6).standard_normal((90, 8))
+    a = la.ChainSet(k, q0, seed=4)
+    a.enable_stats(5, 4)
+    a.advance(20, 3, keep=False)
+    b = la.ChainSet(k, q0, seed=4)
+    b.enable_stats(5, 4)
+    b.advance(8, 3, keep=False)  # stop in the middle of batch 1 ...
+    c = la.ChainSet.resume(k, b.save(str(tmp_path / "ck")))
+    c.advance(12, 3, keep=False)  # ... and continue in another object
+    assert np.array_equal(a.stats.to_host(), c.stats.to_host())
+    sa, sc = a.stats_summary(), c.stats_summary()
+    for key in ("mean", "sd", "rhat", "ess"):
+        assert np.array_equal(sa[key], sc[key])
