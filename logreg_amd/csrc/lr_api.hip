@@ -326,7 +326,8 @@ int setup_tall(lr_model* m, const Plan& pl, hipStream_t st, int64_t C, lr::TallA
     int64_t slice_len_i = 0;
     if (m->P > 32 && m->d_xblk1 && !env_on("LOGREG_WIDE_NO_ROWSPLIT")) {
         const int64_t tiles = (C + 15) / 16;
-        if (tiles <= m->cus) {
+        const char* envt = std::getenv("LOGREG_WIDE_ROWSPLIT_MAX_TILES");  // tuning override
+        if (tiles <= (envt ? std::atoll(envt) : (long long)m->cus)) {
             int64_t want = m->cus / tiles;
             if (want < 1) want = 1;
             const char* envw = std::getenv("LOGREG_WIDE_ROWSPLIT_WAVES");
