@@ -377,6 +377,17 @@ template <typename T, int P, int G> struct DrawBatch {
         const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(lane_byte, (int)(uint32_t)(bits >> 32));
         return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
     }
+    // the two normals of coordinates 2q, 2q + 1 and log(u) only (state distributed over the group: k_chain_rs16)
+    __device__ __forceinline__ void next_pair(uint64_t seed, uint64_t chain, uint64_t iter, int gl, int q, T& zx, T& zy, T& logu) {
+        if (pos >= NB) refill(seed, chain, iter, gl);  // wave-uniform
+        const int base = ((int)(threadIdx.x & 63) - gl + pos * BPI) * 4;
+        const int src = base + 4 * (q >> 1);  // block (2q) / 4 of this iteration
+        const T e0 = fetch(mine[0], src), e1 = fetch(mine[1], src), e2 = fetch(mine[2], src), e3 = fetch(mine[3], src);
+        zx = (q & 1) ? e2 : e0;
+        zy = (q & 1) ? e3 : e1;
+        logu = fetch(lu, base + 4 * NBn);
+        ++pos;
+    }
     // z[0..P) and log(u) of iteration `iter` (iterations must be requested consecutively)
     __device__ __forceinline__ void next(uint64_t seed, uint64_t chain, uint64_t iter, int gl, T (&z)[P], T& logu) {
         if (pos >= NB) refill(seed, chain, iter, gl);  // wave-uniform
@@ -556,6 +567,13 @@ __device__ __forceinline__ void group16_reduce_scatter8(const float (&v)[8], flo
         "s_nop 1\n\t"  // the caller's next instruction may be a DPP read of u1 (the compiler pads nothing after asm)
         : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(s0), "=&v"(s1), "=&v"(u0), "=&v"(u1)
         : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+}
+// sum over the four quads of a 16-lane row of a value that is identical inside each quad; symmetric exchanges
+// (i <-> 7 - i, then i <-> 15 - i), so every lane adds the same two numbers at each level: bit-identical in all 16
+__device__ __forceinline__ float group16_quad_sum(float v) {
+    v += dpp_mov<0x141>(v);  // row_half_mirror: quads 0 <-> 1, 2 <-> 3
+    v += dpp_mov<0x140>(v);  // row_mirror:      quads 0 <-> 3, 1 <-> 2
+    return v;
 }
 // the reverse: every lane of a 16-lane row gets the pair held by quad q (its lane 4q) for q = 0..3: 8 v_mov_b32_dpp row_share
 __device__ __forceinline__ void group16_allgather_pairs(const f32x2& mine, f32x2 (&all)[4]) {

@@ -68,6 +68,15 @@ int launch_eval_v(const LaunchCfg* cfg, int64_t C, const ModelArgs<T, P>& m, con
 template <int G, int MODE, int R>
 int launch_chain_v(const LaunchCfg* cfg, int64_t C, const ModelArgs<T, P>& m, const ChainArgs<T, P>& a) {
     const dim3 grid = grid_for(C, G), block(256);
+#if LR_DTYPE == 0 && LR_P == 8
+    if constexpr (G == 16 && MODE == MODE_REG) {  // state distributed over the 16 lanes of a chain (lr_kernels.h)
+        if (cfg->kind == KIND_RWMH || cfg->kind == KIND_MALA) {
+            if (cfg->kind == KIND_RWMH) hipLaunchKernelGGL((k_chain_rs16<R, KIND_RWMH>), grid, block, 0, cfg->stream, m, a);
+            else hipLaunchKernelGGL((k_chain_rs16<R, KIND_MALA>), grid, block, 0, cfg->stream, m, a);
+            return check(hipGetLastError());
+        }
+    }
+#endif
     switch (cfg->kind) {
     case KIND_RWMH:
         hipLaunchKernelGGL((k_chain<T, P, G, MODE, R, KIND_RWMH>), grid, block, cfg->lds_bytes, cfg->stream, m, a);

@@ -2,6 +2,8 @@
 // for every chain and writes only the thinned states (the whole of the reference's mcmc() double
 // loop, Python/fit-np-hmc.py:89-103, lives inside the kernel).
 #pragma once
+#include <type_traits>
+
 #include "lr_device.h"
 
 namespace lr {
@@ -168,6 +170,128 @@ __device__ __forceinline__ void hmc_interior_rs16(const RegRowPairs<8, R, 16>& r
         xk[2 * j + 1] = bb[j].y;
         pm[2 * j] = pp[j].x;
         pm[2 * j + 1] = pp[j].y;
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// MALA / RWMH for the 16-lanes-per-chain register kernel (float, P = 8) with the chain state DISTRIBUTED over the
+// group for the whole launch (quad q owns coordinates 2q, 2q + 1), as hmc_interior_rs16 does inside a trajectory:
+// proposal, drift terms, proposal-density difference and the accept select act on ONE coordinate pair per lane
+// (12 packed ops instead of 45), the gradient is reduce-scattered (16 DPP adds instead of 32), the proposal is
+// all-gathered for the row pass (8 row_share moves), scalars over the coordinates are summed across the quads with
+// two symmetric DPP adds.  With two waves per SIMD (8192 chains) the saved instructions are saved time.
+// Same Philox stream, same accept rule (fit-np-mala.py:61-78, fit-numpy.py:53-62) as k_chain.
+template <int R, int KIND>
+__global__ void __launch_bounds__(256) k_chain_rs16(ModelArgs<float, 8> m, ChainArgs<float, 8> a) {
+    static_assert(KIND == KIND_MALA || KIND == KIND_RWMH, "threaded-ll kernels");
+    constexpr int P = 8, G = 16;
+    const int gl = threadIdx.x % G;
+    int64_t chain = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const bool live = chain < a.C;
+    if (!live) chain = a.C - 1;
+    const bool writer = live && gl == 0;
+    RegRowPairs<P, R, G> rows;
+    rows.load(m.rows, m.n, gl);
+    const uint64_t gchain = (uint64_t)(a.chain_offset + chain);
+    const int q = (threadIdx.x >> 2) & 3;
+    auto pick = [&](const float (&v)[8]) {
+        const float x01 = q & 1 ? v[2] : v[0], x23 = q & 1 ? v[6] : v[4];
+        const float y01 = q & 1 ? v[3] : v[1], y23 = q & 1 ? v[7] : v[5];
+        return f32x2{q & 2 ? x23 : x01, q & 2 ? y23 : y01};
+    };
+    const f32x2 aq = pick(a.a), bq = pick(a.b), cq = pick(a.c), ivq = pick(m.prior.inv_var);
+    float x8[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) x8[j] = j < a.p ? a.state[chain * a.p + j] : 0.0f;
+    f32x2 xq = pick(x8), gq = {0.0f, 0.0f};
+
+    // ll, lprior (both replicated in the group) and -- GRAD -- the lpost gradient of the lane's pair, at the pair pq
+    auto evaluate = [&](auto want_value, auto want_grad, const f32x2& pq, f32x2& grad_q, double& ll, double& lpr) {
+        constexpr bool VALUE = decltype(want_value)::value, GRAD = decltype(want_grad)::value;
+        f32x2 bb[4];
+        group16_allgather_pairs(pq * f32x2{ExpScale<float>::k, ExpScale<float>::k}, bb);
+        f32x2 gpp[4];
+        float v = 0.0f;
+        row_pairs_eval<P, R, G, VALUE, GRAD>(rows, bb, gpp, v);
+        if constexpr (GRAD) {
+            const float gv[8] = {gpp[0].x, gpp[0].y, gpp[1].x, gpp[1].y, gpp[2].x, gpp[2].y, gpp[3].x, gpp[3].y};
+            float u0, u1;
+            group16_reduce_scatter8(gv, u0, u1);
+            grad_q = __builtin_elementwise_fma(-pq, ivq, f32x2{u0, u1});
+        }
+        if constexpr (VALUE) {
+            ll = group_sum<G>((double)(v + rows.value_fixup()));
+            const f32x2 sq = pq * pq * ivq;
+            lpr = m.prior.lprior_const - 0.5 * (double)group16_quad_sum(sq.x + sq.y);
+        }
+    };
+    using True = std::integral_constant<bool, true>;
+    using False = std::integral_constant<bool, false>;
+
+    double lp = a.lp_state[chain];
+    uint32_t nacc = 0;
+    if constexpr (KIND == KIND_MALA) {
+        double d0, d1;
+        evaluate(False{}, True{}, xq, gq, d0, d1);
+    }
+    DrawBatch<float, P, G> draws;
+    draws.reset();
+    for (int64_t it = 0; it < a.iters; ++it) {
+        for (int64_t jt = 0; jt < a.thin; ++jt) {
+            const uint64_t iter = (uint64_t)(a.iter_offset + it * a.thin + jt);
+            float zx, zy, logu_f;
+            draws.next_pair(a.seed, gchain, iter, gl, q, zx, zy, logu_f);
+            const f32x2 zq = {zx, zy};
+            const double logu = (double)logu_f;
+            f32x2 xp, gp = {0.0f, 0.0f};
+            double llp = 0, lprp = 0, logr;
+            if constexpr (KIND == KIND_RWMH) {
+                xp = __builtin_elementwise_fma(aq, zq, xq);  // prop = x + sd z                      fit-numpy.py:83-84
+                evaluate(True{}, False{}, xp, gp, llp, lprp);
+                logr = (llp + lprp) - lp;
+            } else {
+                const f32x2 advx = __builtin_elementwise_fma(aq, gq, xq);  // advance(x)             fit-np-mala.py:76
+                xp = __builtin_elementwise_fma(bq, zq, advx);
+                evaluate(True{}, True{}, xp, gp, llp, lprp);
+                const f32x2 advp = __builtin_elementwise_fma(aq, gp, xp);
+                const f32x2 d1 = xq - advp, d2 = xp - advx;
+                const f32x2 t = cq * __builtin_elementwise_fma(-d2, d2, d1 * d1);
+                logr = (llp + lprp) - lp - 0.5 * (double)group16_quad_sum(t.x + t.y);
+            }
+            const bool acc = logu < logr;  // NaN -> reject
+            if (acc) {
+                ++nacc;
+                lp = llp + lprp;
+            }
+            xq = acc ? xp : xq;
+            if constexpr (KIND == KIND_MALA) gq = acc ? gp : gq;
+        }
+        if ((a.out || a.stats.buf) && live) {  // group-uniform: the kept sample, gathered back into the writer lane
+            f32x2 all[4];
+            group16_allgather_pairs(xq, all);
+            const float xs[P] = {all[0].x, all[0].y, all[1].x, all[1].y, all[2].x, all[2].y, all[3].x, all[3].y};
+            if (writer) {
+                if (a.out) {
+                    float* o = a.out + (it * a.C + chain) * a.p;
+#pragma unroll
+                    for (int j = 0; j < P; ++j)
+                        if (j < a.p) o[j] = xs[j];
+                }
+                if (a.stats.buf) stats_update<float, P>(a.stats, it, a.C, chain, a.p, xs);
+            }
+        }
+    }
+    {
+        f32x2 all[4];
+        group16_allgather_pairs(xq, all);
+        const float xs[P] = {all[0].x, all[0].y, all[1].x, all[1].y, all[2].x, all[2].y, all[3].x, all[3].y};
+        if (writer) {
+#pragma unroll
+            for (int j = 0; j < P; ++j)
+                if (j < a.p) a.state[chain * a.p + j] = xs[j];
+            if (a.accepts) a.accepts[chain] += nacc;
+            a.lp_state[chain] = lp;
+        }
     }
 }
 

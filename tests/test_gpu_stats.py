@@ -38,7 +38,7 @@ def _check(la, cs, samples, batch):
     return got
 
 
-@pytest.mark.parametrize("kind,mode,group", [("hmc", "auto", 0), ("mala", "reg", 64), ("rwmh", "lds", 8), ("ul", "global", 1),
+@pytest.mark.parametrize("kind,mode,group", [("hmc", "auto", 0), ("mala", "reg", 64), ("mala", "reg", 16), ("rwmh", "reg", 16), ("rwmh", "lds", 8), ("ul", "global", 1),
                                              ("hmc", "mfma", 1), ("hmc", "mfma", 4), ("hmc", "stepwise", 0), ("mala", "stepwise", 0)])
 def test_device_statistics_equal_numpy_on_the_gathered_samples(la, pima, map_beta, kind, mode, group):
     X, y = pima
