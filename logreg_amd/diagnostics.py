@@ -166,7 +166,8 @@ def summary_from_sums(sums, n_chains: int, kept: int, batch: int, pivot) -> dict
     """Posterior summary from chain-pooled sums (rows as in include/logreg_hip.h; sums of several chain shards
     simply add).  Returns mean, sd (ddof = 1 over all draws, as `scipy.stats.describe` in fit-np-hmc.py:113-117),
     rhat (split-R-hat, BDA3: the two halves of every chain), ess (batch means, pooled over chains: what
-    `smfsb::mcmcSummary` reports per chain in Python/analyse.R:17-19), mcse = sd / sqrt(ess)."""
+    `smfsb::mcmcSummary` reports per chain in Python/analyse.R:17-19), mcse = sd / sqrt(ess); mcse_chains / ess_chains
+    (from the spread between the chain means: the estimate to trust when chains are many and short)."""
     S = np.asarray(sums, dtype=np.float64)
     piv = np.asarray(pivot, dtype=np.float64)
     C, n = int(n_chains), int(kept)
@@ -176,6 +177,15 @@ def summary_from_sums(sums, n_chains: int, kept: int, batch: int, pivot) -> dict
     var = (S[2] + S[1] - N * mean_d * mean_d) / max(N - 1, 1)
     res = {"n": N, "chains": C, "mean": piv + mean_d, "sd": np.sqrt(np.maximum(var, 0.0))}
     nan = np.full(S.shape[1], np.nan)
+    # Monte-Carlo error of the pooled mean from the spread BETWEEN the chains' means: with many independent chains
+    # this needs no autocorrelation estimate at all (valid whatever the chains' mixing time, given stationary starts)
+    if C >= 2:
+        var_means = np.maximum(S[1] / n - C * mean_d * mean_d, 0.0) / (C - 1)
+        res["mcse_chains"] = np.sqrt(var_means / C)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            res["ess_chains"] = var / (var_means / C)
+    else:
+        res["mcse_chains"], res["ess_chains"] = nan, nan
     if nb >= 2 and nb % 2 == 0:
         h = nb * batch // 2
         W = S[5] / (2 * C)
