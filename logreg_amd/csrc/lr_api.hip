@@ -128,9 +128,13 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
         //   12288: 2.06e8 | 2.77e8 | 2.45e8     16384: 2.10e8 | 2.79e8 | 3.23e8   65536: 2.19e8 |   --   | 4.12e8
         // S = 4 (rows split over the 4 waves of a workgroup) needs two workgroups per CU to hide its
         // MFMA -> exp -> rcp -> MFMA -> LDS latency chain; S = 1 (16 chains per wave) needs a wave per SIMD.
+        // Mid-size data (256 < n <= 1024; tools/midn_mfma.py, HMC L=20, it/s, reg | mfma S=4): n=400: 1.76e8 | 2.38e8 at
+        // 4096 chains, 1.90e8 | 3.54e8 at 16 384; n=1000: 0.92e8 | 1.33e8 at 4096, 0.98e8 | 1.37e8 at 16 384; below one
+        // workgroup per CU (4096 chains) the register kernels win (n=400, 2048 chains: 1.64e8 | 1.22e8).
         int want_S = 0;
         if (C >= 64LL * m->cus && m->n <= 16 * 13) want_S = 1;
         else if (C >= 24LL * m->cus && m->n <= 16 * 4 * 4) want_S = 4;
+        else if (C >= 16LL * m->cus && m->n > 16 * 4 * 4 && m->n <= 16 * 4 * 16) want_S = 4;
         for (int i = 0; want_S && i < t->nvariants; ++i) {
             const lr::Variant& v = t->variants[i];
             if (v.mode == lr::MODE_MFMA && v.G == want_S && (int64_t)16 * v.G * v.R >= m->n) {

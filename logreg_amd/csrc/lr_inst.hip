@@ -41,9 +41,10 @@ constexpr int P = LR_P;
 #define LR_VARIANTS(X) X(MODE_LDS, 1, 0) X(MODE_LDS, 8, 0) X(MODE_LDS, 64, 0) X(MODE_GLOBAL, 64, 0) X(MODE_GLOBAL, 1, 0)
 #endif
 
-// matrix-core variants (fp32, p = 8): X(row-split ways S, tiles per wave NTW); n <= 16*S*NTW
+// matrix-core variants (fp32, p = 8): X(row-split ways S, tiles per wave NTW), ascending NTW per S; n <= 16*S*NTW
+// (4, 8) and (4, 16): mid-size data, n <= 512 / 1024, for HMC with bf16 interior steps (6 NTW + 4 NTW operand registers)
 #if LR_DTYPE == 0 && LR_P == 8
-#define LR_MFMA_VARIANTS(X) X(1, 13) X(4, 4)
+#define LR_MFMA_VARIANTS(X) X(1, 13) X(4, 4) X(4, 8) X(4, 16)
 #else
 #define LR_MFMA_VARIANTS(X)
 #endif

@@ -310,6 +310,12 @@ def test_planner_engine_choice_by_size(la):
     assert run_plan(hmc, 16384) == {"mode": "mfma", "group": 1, "rows_per_lane": 13}
     assert run_plan(hmc, 16384, precision="full") == {"mode": "reg", "group": 16, "rows_per_lane": 13}
     assert run_plan(mala, 16384) == {"mode": "reg", "group": 16, "rows_per_lane": 13}
+    # mid-size data: rows split over the 4 waves of a workgroup, 8 or 16 tiles per wave, from one workgroup per CU
+    Xm, ym, _ = la.synthetic_logreg(700, 8, seed=700)
+    mm = la.LogReg(Xm, ym, np.ones(8))
+    hm = la.hmcKernel(mm.lpost, mm.glp, eps=0.05, l=10, dmm=np.ones(8))
+    assert run_plan(hm, 4096) == {"mode": "mfma", "group": 4, "rows_per_lane": 16}
+    assert run_plan(hm, 2048)["mode"] == "reg"
 
 
 @pytest.mark.parametrize("engine", ["bf16x3", "fp32"])
@@ -818,3 +824,39 @@ def test_short_trajectories_on_the_reduced_precision_interior_kernels(la, n, p, 
     assert np.array_equal(out, la.mcmc(b, k, thin=1, iters=3, verb=False, seed=9, mode="stepwise", chunk=1))
     if L == 1:  # nothing to approximate: identical to the full-precision run
         assert np.array_equal(out, la.mcmc(b, k, thin=1, iters=3, verb=False, seed=9, mode="stepwise", precision="full"))
+
+
+@pytest.mark.parametrize("n,R", [(400, 8), (1000, 16)])
+def test_matrix_core_kernel_on_mid_size_data(la, n, R):
+    """256 < n <= 1024: mfma S = 4 with 8 / 16 row tiles per wave.  Exact mode step-for-step against the oracle;
+    default mode (bf16 interior steps) close to it, same decisions away from near-ties, bit-exact reruns."""
+    from oracle.oracle import OracleModel
+    X, y, _ = la.synthetic_logreg(n, 8, seed=n)
+    ps = np.array([10.0] + [1.0] * 7)
+    orc = OracleModel(X, y, ps)
+    m = la.LogReg(X, y, ps)
+    assert m.plan(100, 4, "mfma") == {"mode": "mfma", "group": 4, "rows_per_lane": R}
+    C = 100
+    b = 0.1 * np.random.default_rng(n).standard_normal((C, 8))
+    eps, L = 0.6 / np.sqrt(n), 12
+    k = la.hmcKernel(m.lpost, m.glp, eps=eps, l=L, dmm=np.ones(8))
+    ref = orc.run("hmc", b, step=eps, l=L, scale=np.ones(8), thin=1, iters=3, seed=2, threads=0)
+    kw = dict(thin=1, iters=3, verb=False, seed=2, mode="mfma", group=4)
+    full, fi = la.mcmc(b, k, return_info=True, precision="full", **kw)
+    ok = ref["margin"] > 2e-3
+    assert ok.mean() > 0.9
+    assert np.array_equal(fi["accepts"][ok], ref["accepts"][ok].astype(np.uint32))
+    assert np.max(np.abs(full[:, ok] - ref["out"][:, ok])) < 2e-3 / np.sqrt(n)
+    mixed, mi = la.mcmc(b, k, return_info=True, **kw)
+    wide_ok = ref["margin"] > 0.1
+    assert np.array_equal(mi["accepts"][wide_ok], ref["accepts"][wide_ok].astype(np.uint32))
+    assert np.max(np.abs(mixed[:, wide_ok] - ref["out"][:, wide_ok])) < 5e-2 / np.sqrt(n)
+    assert np.array_equal(mixed, la.mcmc(b, k, chunk=1, **kw))
+    for kind, kern, okw in (("mala", la.malaKernel(m.lpost, m.glp, dt=0.05 / n, pre=np.ones(8)), dict(step=0.05 / n, scale=np.ones(8))),
+                            ("rwmh", la.mhKernel(m.lpost, la.rwProposal(np.full(8, 0.3 / np.sqrt(n)))), dict(scale=np.full(8, 0.3 / np.sqrt(n))))):
+        ll0 = orc.lpost(b)
+        r2 = orc.run(kind, b, thin=1, iters=2, seed=3, ll_state=ll0, threads=0, **okw)
+        o2, i2 = la.mcmc(b, kern, thin=1, iters=2, verb=False, seed=3, ll=ll0, mode="mfma", group=4, return_info=True)
+        ok2 = r2["margin"] > 2e-3
+        assert np.array_equal(i2["accepts"][ok2], r2["accepts"][ok2].astype(np.uint32)), kind
+        assert np.max(np.abs(o2[:, ok2] - r2["out"][:, ok2])) < 2e-3 / np.sqrt(n), kind
