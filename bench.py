@@ -202,6 +202,37 @@ def extra_configs(la, L, check, dev, stream):
     return res
 
 
+def default_policy_runs(la, L, check, dev, stream, kern, init, steps):
+    """The headline workload under the library's DEFAULT precision policy (LR_PREC_AUTO): the L-1 interior leapfrog
+    gradients on the bf16 matrix pipe (any deterministic force keeps the leapfrog map reversible and volume-preserving),
+    end points and the MH test in fp32 -- the sampler stays exact, the acceptance rate is the check.  Reported beside
+    `value`, never as it: `value` is the all-fp32 run.  Same timing as the headline (HIP events, `steps` launches of
+    THIN iterations), same data, 4096 chains as the headline and 16 384 / 65 536 chains to show where the kernel goes."""
+    timer = Timer(L, check, dev, stream)
+    rows = []
+    for C in (CHAINS_PER_GPU, 16384, 65536):
+        rng = np.random.Generator(np.random.Philox(SEED + 77))
+        q0 = init + 0.1 * 0.17 * rng.standard_normal((C, N_PAR))
+        row = {"chains": C}
+        for prec in ("auto", "full"):
+            cs = la.ChainSet(kern, q0, seed=SEED, stream=stream, precision=prec)
+            cs.advance(2, THIN, keep=False)
+            cs.sync()
+            a0 = cs.get_accepts().astype(np.int64).sum()
+            timer.start()
+            for _ in range(steps):
+                cs.advance(1, THIN, keep=False)
+            ms = timer.stop_ms()
+            acc = (cs.get_accepts().astype(np.int64).sum() - a0) / (C * steps * THIN)
+            its = C * steps * THIN / (ms * 1e-3)
+            row[prec] = {"kernel_variant": cs.plan(), "chain_iterations_per_s": its, "ms_per_step": ms / steps,
+                         "accept_rate": float(acc),
+                         "algorithmic_TFLOPs": its * LEAP * flops_per_grad_eval(N_ROWS, N_PAR) / 1e12}
+        rows.append(row)
+    return {"note": "same workload, HIP-event timed, not part of `value`: precision='auto' (library default) against "
+                    "precision='full' (what `value` uses)", "runs": rows}
+
+
 def ess_per_draw(la, model, kern, q0, dev):
     """ESS per kept draw (thin 20) from a SEPARATE run of 256 chains x 512 kept draws, Geyer IPS per chain."""
     cs = la.ChainSet(kern, q0[:256], seed=SEED + 7)
@@ -247,6 +278,9 @@ def main():
     ap.add_argument("--chains", type=int, default=CHAINS_PER_GPU, help="chains per GPU")
     ap.add_argument("--group", type=int, default=0, help="lanes per chain (0 = library's choice)")
     ap.add_argument("--mode", default="auto")
+    ap.add_argument("--precision", default="full", choices=["full", "auto", "bf16"],
+                    help="headline run: 'full' = every gradient evaluation in fp32 (the default: `value` is an all-fp32 number); "
+                         "'auto' = the library's default policy (HMC interior gradients on the bf16 matrix pipe)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ess", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the configs 3/4/5 sub-results")
@@ -288,7 +322,7 @@ def main():
     L = _lib.load()
     stream = Ct.c_void_p()
     _lib.check(L.lr_stream_create(dev, Ct.byref(stream)))
-    cs = la.ChainSet(kern, q0, seed=SEED, chain_offset=rank * C, group=a.group, mode=a.mode, stream=stream)
+    cs = la.ChainSet(kern, q0, seed=SEED, chain_offset=rank * C, group=a.group, mode=a.mode, stream=stream, precision=a.precision)
     plan = cs.plan()
     out = la.DeviceArray(dev, (a.steps, C, N_PAR), np.float32)
 
@@ -358,6 +392,10 @@ def main():
             "config": {"workload": "HMC L=50 eps=0.1 unit-mass, n=200 p=8 synthetic logistic regression, "
                                    f"{C} chains/GPU, thin {THIN} (BASELINE.json configs[1])",
                        "chains_per_gpu": C, "thin": THIN, "leapfrog_steps": LEAP,
+                       "precision": {"full": "full: every log-posterior / gradient evaluation in fp32",
+                                     "auto": "auto (library default): L-1 interior leapfrog gradients on the bf16 matrix pipe, "
+                                             "end-point value + gradient and the MH test in fp32",
+                                     "bf16": "bf16 interior gradients forced"}[a.precision],
                        "kernel_variant": plan, "parallelism": f"chains sharded x{world}" + (" + RCCL gather" if world > 1 else "")},
             "grad_evals_per_s": grad_evals / wall,
             "accept_rate": acc / iters_total,
@@ -403,7 +441,8 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(X, y, pscale, init)
         if world == 1 and not a.no_extra:
-            line["extra"] = {"configs": extra_configs(la, L, _lib.check, dev, stream)}
+            line["extra"] = {"configs": extra_configs(la, L, _lib.check, dev, stream),
+                             "default_policy": default_policy_runs(la, L, _lib.check, dev, stream, kern, init, a.steps)}
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

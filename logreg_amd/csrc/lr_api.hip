@@ -123,18 +123,17 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
     if (hmc_bf16 && !for_eval && mode == LR_MODE_AUTO && group == 0 && m->dtype == LR_F32 && m->P == 8 &&
         !env_on("LOGREG_NO_MFMA_INTERIOR")) {
         // register-resident data, many chains: the fused matrix-core kernel with bf16 interior steps (lr_mfma.h).
-        // Measured (bench.py workload, chain-iterations/s, reg 16x13 | mfma S=4 | mfma S=1):
-        //    4096: 1.83e8 | 1.68e8 | 0.82e8      6144: 1.56e8 | 1.84e8 | --        8192: 1.99e8 | 2.44e8 | 1.63e8
-        //   12288: 2.06e8 | 2.77e8 | 2.45e8     16384: 2.10e8 | 2.79e8 | 3.23e8   65536: 2.19e8 |   --   | 4.12e8
-        // S = 4 (rows split over the 4 waves of a workgroup) needs two workgroups per CU to hide its
-        // MFMA -> exp -> rcp -> MFMA -> LDS latency chain; S = 1 (16 chains per wave) needs a wave per SIMD.
-        // Mid-size data (256 < n <= 1024; tools/midn_mfma.py, HMC L=20, it/s, reg | mfma S=4): n=400: 1.76e8 | 2.38e8 at
-        // 4096 chains, 1.90e8 | 3.54e8 at 16 384; n=1000: 0.92e8 | 1.33e8 at 4096, 0.98e8 | 1.37e8 at 16 384; below one
-        // workgroup per CU (4096 chains) the register kernels win (n=400, 2048 chains: 1.64e8 | 1.22e8).
+        // Measured (bench.py workload, chain-iterations/s, reg 16x13 | mfma S=4 | mfma S=1; profiles/r2_mfma_chain_grid.txt):
+        //    4096: 1.88e8 | 2.13e8 | 1.16e8      6144: 1.64e8 | 2.22e8 | 1.74e8      8192: 2.10e8 | 2.93e8 | 2.32e8
+        //   10240: 1.86e8 | 2.61e8 | 2.89e8     16384: 2.25e8 | 3.23e8 | 4.49e8     65536: 2.37e8 | 3.58e8 | 5.18e8
+        // S = 4 (rows split over the 4 waves of a workgroup) pays from one workgroup per CU, S = 1 (16 chains per
+        // wave, no LDS hand-off) from 40 chains per CU.
+        // Mid-size data (256 < n <= 1024; tools/midn_mfma.py, HMC L=20, it/s, reg | mfma S=4): n=400: 1.83e8 | 2.82e8 at
+        // 4096 chains, 1.92e8 | 3.74e8 at 16 384; n=1000: 0.92e8 | 1.69e8 at 4096, 0.98e8 | 1.79e8 at 16 384; below one
+        // workgroup per CU (4096 chains) the register kernels win (n=400, 2048 chains: 1.69e8 | 1.45e8).
         int want_S = 0;
-        if (C >= 64LL * m->cus && m->n <= 16 * 13) want_S = 1;
-        else if (C >= 24LL * m->cus && m->n <= 16 * 4 * 4) want_S = 4;
-        else if (C >= 16LL * m->cus && m->n > 16 * 4 * 4 && m->n <= 16 * 4 * 16) want_S = 4;
+        if (C >= 40LL * m->cus && m->n <= 16 * 13) want_S = 1;
+        else if (C >= 16LL * m->cus && m->n <= 16 * 4 * 16) want_S = 4;
         for (int i = 0; want_S && i < t->nvariants; ++i) {
             const lr::Variant& v = t->variants[i];
             if (v.mode == lr::MODE_MFMA && v.G == want_S && (int64_t)16 * v.G * v.R >= m->n) {

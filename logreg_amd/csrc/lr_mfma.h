@@ -47,14 +47,17 @@ template <int NTW, int S> struct MfmaRows {
     float xg[NTW][4];
     int pad_rows;  // rows >= n among this lane's eta rows (each adds log sigma(0) = -log 2)
     // INTERIOR leapfrog steps on the bf16 matrix pipe (the scheme of lr_tall_mx.h with the rows in registers):
-    //   x = xh + xl, beta = bh + bl (two round-to-nearest bf16 pieces each); lane (c, k) owns coordinates a = k, b = k + 4
-    //   eta tile:  A (lane (row, k)) = [xh_a xl_a xh_b xl_b],  B = [bh_a bh_a bh_b bh_b] then [bl_a bl_a bl_b bl_b]
-    //              (two v_mfma_f32_16x16x16_bf16 into one accumulator: all four piece products of every coordinate)
+    //   xs = x log2 e = xh + xl, beta = bh + bl (two round-to-nearest bf16 pieces each); lane (c, k) owns coordinates a = k, b = k + 4
+    //   eta tile:  ONE v_mfma_f32_16x16x32_bf16 (the K = 32 instruction costs what one K = 16 does: 8 slots per lane)
+    //              A (lane (row, k)) = [xh_a xl_a xh_a xl_a xh_b xl_b xh_b xl_b],  B = [bh_a bh_a bl_a bl_a bh_b bh_b bl_b bl_b]:
+    //              all four piece products of both coordinates.  A one-piece design (half the operand) was tried: on the
+    //              unscaled Pima covariates its 2^-9 rounding raised the sd of the energy error from 0.152 to 0.191 and cost
+    //              1.7 points of acceptance (0.957 -> 0.940), so the second piece stays.
     //   grad tile pair (K = 32 rows):  B = w = sigma(-eta) of the lane's own 2 x 4 accumulator values, one bf16 piece;
     //              A (lane (m', k')) = element m' & 3 of (xh_a xl_a xh_b xl_b) of group m' >> 2, rows of slot group k'
     //              D (lane (c, k), r) = sum_rows w (xh_a, xl_a, xh_b, xl_b)[r]:  g_a = D0 + D1, g_b = D2 + D3
     static constexpr int NPAIR = (NTW + 1) / 2;
-    mf_u32x2 xe[NTW];
+    mf_u32x4 xe[NTW];
     mf_u32x4 xq[NPAIR];
     int ntile_live;  // this wave's tiles that contain at least one real row (all-padding tiles are skipped)
 
@@ -88,8 +91,14 @@ template <int NTW, int S> struct MfmaRows {
         for (int t = 0; t < NTW; ++t) {
             const int64_t base = 16 * ((int64_t)t * S + wave);
             if (base < n) ntile_live = t + 1;
-            xe[t] = mf_u32x2{piece(base + c, k, 0) | (piece(base + c, k, 1) << 16),
-                             piece(base + c, k + 4, 0) | (piece(base + c, k + 4, 1) << 16)};
+            uint32_t hl[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float xs = base + c < n ? rows[(base + c) * 8 + k + 4 * h] * ExpScale<float>::k : 0.0f;
+                const uint32_t hi = mf_pack_rne(xs, xs) & 0xFFFFu;
+                hl[h] = hi | (mf_pack_rne(0.0f, xs - mf_hi_f32(hi)) & 0xFFFF0000u);
+            }
+            xe[t] = mf_u32x4{hl[0], hl[0], hl[1], hl[1]};
         }
         const int grp = c >> 2, el = c & 3;  // gradient A operand: M-row c = 4 grp + el -> element el of group grp
         const int gcoord = grp + 4 * (el >> 1), glo = el & 1;
@@ -106,33 +115,51 @@ template <int NTW, int S> struct MfmaRows {
         }
     }
 
-    // interior-step gradient (likelihood part, this wave's tiles) for the lane's two coordinates
-    __device__ __forceinline__ void eval_bf16(const float (&q2)[2], float (&gl)[2]) const {
-        const float qa = q2[0] * ExpScale<float>::k, qb = q2[1] * ExpScale<float>::k;
-        const uint32_t ha = mf_pack_rne(qa, qa), hb = mf_pack_rne(qb, qb);
-        const float la = qa - mf_hi_f32(ha), lb = qb - mf_hi_f32(hb);
-        const mf_u32x2 bh = {ha, hb}, bl = {mf_pack_rne(la, la), mf_pack_rne(lb, lb)};
+    // interior-step gradient (likelihood part, this wave's tiles) for the lane's two coordinates.  NPL = tile pairs
+    // to run (compile time: a run-time skip of dead tiles inside the step put every tile behind its own branch, each with
+    // the full MFMA -> exp latency exposed).  All-padding tiles inside the NPL pairs have zero operands and add exactly 0.
+    template <int NPL> __device__ __forceinline__ void eval_bf16(const float (&q2)[2], float (&gl)[2]) const {
+        static_assert(NPL >= 1 && NPL <= NPAIR, "pairs");
+        const uint32_t ha = mf_pack_rne(q2[0], q2[0]), hb = mf_pack_rne(q2[1], q2[1]);  // piece | piece << 16
+        const float la = q2[0] - mf_hi_f32(ha), lb = q2[1] - mf_hi_f32(hb);
+        const mf_u32x4 bb = {ha, mf_pack_rne(la, la), hb, mf_pack_rne(lb, lb)};
+        constexpr int NT = 2 * NPL < NTW ? 2 * NPL : NTW;
+        // Issue order.  Measured at one wave per SIMD (HMC L=50, n=200; S=4 at 4096 chains | S=1 at 16 384 chains, ms per
+        // 20 iterations): compiler's order (all eta MFMAs, then the exp / rcp work, gradient MFMAs) 0.390 | 0.786; next
+        // pair's eta MFMAs fenced in front of each pair's exp / rcp work 0.401 | 0.724; MFMAs spread between the VALU
+        // groups with sched_group_barrier 0.420 | 0.739; the same with v_add_f32 for v_pk_add_f32 0.432 | 0.752.  A wave
+        // does not overlap its own MFMAs with its own VALU work to any useful degree here (SQ_ACTIVE_INST_VALU = 76 % of
+        // the wave's cycles for 207 instructions per step, MFMA pipe busy 22 %): the step costs the sum of its issue
+        // slots, so the order only decides how many s_nop states follow the MFMAs.  S = 1 (13 tiles) takes the fenced
+        // order, the short row-split bodies the compiler's.
+        auto eta = [&](int t) {
+            return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mf_bf16x8, xe[t]), __builtin_bit_cast(mf_bf16x8, bb),
+                                                           f32x4{0, 0, 0, 0}, 0, 0, 0);
+        };
+        f32x4 e[2 * NPL];
+        e[0] = eta(0);
+        if constexpr (NT > 1) e[1] = eta(1);
+        if constexpr (S == 1) __builtin_amdgcn_sched_barrier(0);
         f32x4 gacc = {0, 0, 0, 0};
 #pragma unroll
-        for (int pi = 0; pi < NPAIR; ++pi) {
-            if (2 * pi < ntile_live) {  // wave-uniform
-                uint32_t wq[4] = {0u, 0u, 0u, 0u};
+        for (int pi = 0; pi < NPL; ++pi) {
+            uint32_t wq[4] = {0u, 0u, 0u, 0u};
+            if (2 * pi + 2 < NT) e[2 * pi + 2] = eta(2 * pi + 2);
+            if (2 * pi + 3 < NT) e[2 * pi + 3] = eta(2 * pi + 3);
+            if constexpr (S == 1) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int T = 0; T < 2; ++T) {
-                    const int t = 2 * pi + T;
-                    if (t < NTW && t < ntile_live) {
-                        f32x4 e = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(mf_s16x4, xe[t]), __builtin_bit_cast(mf_s16x4, bh),
-                                                                            f32x4{0, 0, 0, 0}, 0, 0, 0);
-                        e = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(mf_s16x4, xe[t]), __builtin_bit_cast(mf_s16x4, bl), e, 0, 0, 0);
-                        const mf_f32x2 d0 = mf_f32x2{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])} + mf_f32x2{1.0f, 1.0f};
-                        const mf_f32x2 d1 = mf_f32x2{__builtin_amdgcn_exp2f(e[2]), __builtin_amdgcn_exp2f(e[3])} + mf_f32x2{1.0f, 1.0f};
-                        wq[2 * T] = mf_pack_rne(fast_rcp(d0.x), fast_rcp(d0.y));
-                        wq[2 * T + 1] = mf_pack_rne(fast_rcp(d1.x), fast_rcp(d1.y));
-                    }
+            for (int T = 0; T < 2; ++T) {
+                const int t = 2 * pi + T;
+                if (t < NT) {
+                    const mf_f32x2 d0 = mf_f32x2{__builtin_amdgcn_exp2f(e[t][0]), __builtin_amdgcn_exp2f(e[t][1])} + mf_f32x2{1.0f, 1.0f};
+                    const mf_f32x2 d1 = mf_f32x2{__builtin_amdgcn_exp2f(e[t][2]), __builtin_amdgcn_exp2f(e[t][3])} + mf_f32x2{1.0f, 1.0f};
+                    wq[2 * T] = mf_pack_rne(fast_rcp(d0.x), fast_rcp(d0.y));
+                    wq[2 * T + 1] = mf_pack_rne(fast_rcp(d1.x), fast_rcp(d1.y));
                 }
-                const mf_u32x4 wv = {wq[0], wq[1], wq[2], wq[3]};
-                gacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mf_bf16x8, xq[pi]), __builtin_bit_cast(mf_bf16x8, wv), gacc, 0, 0, 0);
             }
+            const mf_u32x4 wv = {wq[0], wq[1], wq[2], wq[3]};
+            gacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mf_bf16x8, xq[pi]), __builtin_bit_cast(mf_bf16x8, wv), gacc, 0, 0, 0);
+            if constexpr (S == 1) __builtin_amdgcn_sched_barrier(0);
         }
         gl[0] = gacc[0] + gacc[1];
         gl[1] = gacc[2] + gacc[3];
@@ -169,6 +196,16 @@ template <int NTW, int S> struct MfmaRows {
         if constexpr (VALUE) vsum = v + (float)pad_rows * 0.693147180559945309f;
     }
 };
+
+// f(integral_constant<int, max(n, 1)>) for a run-time 1 <= n <= N
+template <int N, typename F> __device__ __forceinline__ void for_pair_count(int n, F&& f) {
+    if constexpr (N <= 1) {
+        f(std::integral_constant<int, 1>{});
+    } else {
+        if (n >= N) f(std::integral_constant<int, N>{});
+        else for_pair_count<N - 1>(n, f);
+    }
+}
 
 // sum over the 4 parameter groups k (lanes c, c+16, c+32, c+48); identical in all 4 lanes
 template <typename T> __device__ __forceinline__ T ksum(T v) { return swap32_sum(swap16_sum(v)); }
@@ -234,9 +271,9 @@ __global__ void __launch_bounds__(256) k_chain_mfma(ModelArgs<float, 8> m, Chain
         grad[1] = gl[1] - q2[1] * inv_var[1];
     };
     // interior leapfrog step: gradient only, from the bf16 operands (LR_PREC_BF16 / AUTO), else the exact evaluation
-    auto evaluate_interior = [&](const float (&q2)[2], float (&grad)[2]) {
+    auto evaluate_interior = [&](auto npl, const float (&q2)[2], float (&grad)[2]) {
         float gl[2];
-        rows.eval_bf16(q2, gl);
+        rows.template eval_bf16<decltype(npl)::value>(q2, gl);
         if constexpr (S > 1) {
             red[step_parity][wave][lane][0] = gl[0];
             red[step_parity][wave][lane][1] = gl[1];
@@ -348,13 +385,17 @@ __global__ void __launch_bounds__(256) k_chain_mfma(ModelArgs<float, 8> m, Chain
                     pm[0] = fma_t(heps, gp[0], pm[0]);
                     pm[1] = fma_t(heps, gp[1], pm[1]);
                     if (a.interior_bf16) {
-                        for (int i = 0; i < a.l - 1; ++i) {
-                            xp[0] = fma_t(kb[0], pm[0], xp[0]);
-                            xp[1] = fma_t(kb[1], pm[1], xp[1]);
-                            evaluate_interior(xp, gp);
-                            pm[0] = fma_t(a.step, gp[0], pm[0]);
-                            pm[1] = fma_t(a.step, gp[1], pm[1]);
-                        }
+                        // the whole interior loop once per live pair count (wave-uniform; every wave of a row-split
+                        // workgroup still meets the same l - 1 barriers)
+                        for_pair_count<MfmaRows<NTW, S>::NPAIR>((rows.ntile_live + 1) >> 1, [&](auto npl) {
+                            for (int i = 0; i < a.l - 1; ++i) {
+                                xp[0] = fma_t(kb[0], pm[0], xp[0]);
+                                xp[1] = fma_t(kb[1], pm[1], xp[1]);
+                                evaluate_interior(npl, xp, gp);
+                                pm[0] = fma_t(a.step, gp[0], pm[0]);
+                                pm[1] = fma_t(a.step, gp[1], pm[1]);
+                            }
+                        });
                     } else {
                         for (int i = 0; i < a.l - 1; ++i) {
                             xp[0] = fma_t(kb[0], pm[0], xp[0]);

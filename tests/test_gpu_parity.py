@@ -305,7 +305,9 @@ def test_planner_engine_choice_by_size(la):
 
     def run_plan(kernel, C, **kw):
         return la.ChainSet(kernel, np.zeros((C, 8)), seed=0, **kw).plan()
-    assert run_plan(hmc, 4096) == {"mode": "reg", "group": 16, "rows_per_lane": 13}
+    assert run_plan(hmc, 2048)["mode"] == "reg"
+    assert run_plan(hmc, 4096) == {"mode": "mfma", "group": 4, "rows_per_lane": 4}
+    assert run_plan(hmc, 4096, precision="full") == {"mode": "reg", "group": 16, "rows_per_lane": 13}
     assert run_plan(hmc, 8192) == {"mode": "mfma", "group": 4, "rows_per_lane": 4}
     assert run_plan(hmc, 16384) == {"mode": "mfma", "group": 1, "rows_per_lane": 13}
     assert run_plan(hmc, 16384, precision="full") == {"mode": "reg", "group": 16, "rows_per_lane": 13}

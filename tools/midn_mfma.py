@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Mid-size data (256 < n <= 1024, p = 8), HMC L=20: the planner's register variant against the fused matrix-core
+"""Usage: midn_mfma.py [n ...].  Mid-size data (256 < n <= 1024, p = 8), HMC L=20: the planner's register variant against the fused matrix-core
 kernel with the rows split over 4 waves (mode="mfma", group=4) -- chain-iterations/s and acceptance."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, logreg_amd as la
-for n in (400, 512, 700, 1000):
+for n in ([int(a) for a in sys.argv[1:]] or [400, 512, 700, 1000]):
     X, y, _ = la.synthetic_logreg(n, 8, seed=n)
     m = la.LogReg(X, y, np.ones(8))
     bmap, info = la.find_map(m)
