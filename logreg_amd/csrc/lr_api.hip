@@ -480,6 +480,15 @@ int do_stepwise_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs
         K(0, 1);
         a.interior = 0;
     };
+    // wide models: the whole interior of a trajectory in one launch (k_wide_traj_bf16): no slice partials, no update
+    // launches.  One workgroup streams the whole design per step, so it pays once every CU has a tile of its own and
+    // until the 64-chain workgroups of the chain-split kernel amortise the stream better (config 5 design, us per
+    // evaluation of all chains, trajectory kernel | launch per step: 1024 chains 15.7 | 11.5, 2048: 16.1 | 14.4,
+    // 4096: 22.2 | 25.0, 8192: 39.5 | 44.9, 16 384: 73.4 | 72.5).  LOGREG_WIDE_TRAJ=1 forces it on, LOGREG_WIDE_NO_TRAJ=1 off.
+    const int64_t traj_tiles = (C + 15) / 16;
+    const bool traj = P > 32 && bf16_interior && m->d_xblk1 != nullptr && t->launch_tall_traj != nullptr && rs.l > 1 &&
+                      !env_on("LOGREG_WIDE_NO_TRAJ") &&
+                      (env_on("LOGREG_WIDE_TRAJ") || (traj_tiles >= m->cus && traj_tiles < 4LL * m->cus));
     const bool fuse = P > 32 && bf16_interior && a.RS_i > 0 && a.RS_i <= 4 && !env_on("LOGREG_WIDE_NO_FUSE");  // kFuseSlices
     T* qb[2] = {a.q1, const_cast<T*>(a.q1_in)};
     T* pb[2] = {a.pm, const_cast<T*>(a.pm_in)};
@@ -493,7 +502,9 @@ int do_stepwise_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs
     const int64_t total = o->iters * o->thin;
     for (int64_t tt = 0; tt < total && !rc; ++tt) {
         if (kind == lr::KIND_HMC) {
-            if (fuse) {
+            if (traj) {
+                if (!rc) rc = t->launch_tall_traj(st, &a);
+            } else if (fuse) {
                 // row-split interior kernel: every launch but the first finishes the previous leapfrog step in its
                 // own prologue (state and partial buffers ping-pong), so the L - 1 interior steps are L - 1
                 // launches plus ONE update at the end instead of 2 (L - 1) launches

@@ -25,6 +25,8 @@ struct InstTable {
     int (*launch_tall_partial)(hipStream_t, int want_value, int want_grad, const void* tall_args);
     int (*launch_tall_update)(hipStream_t, int kind, int phase, int64_t iter, int64_t out_row, int begin_next,
                               const void* tall_args);
+    // wide models: all L - 1 interior leapfrog steps of an HMC trajectory in one launch (lr_wide_bf16.h); may be null
+    int (*launch_tall_traj)(hipStream_t, const void* tall_args);
 };
 
 }  // namespace lr

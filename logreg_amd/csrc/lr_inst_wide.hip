@@ -55,7 +55,13 @@ int launch_tall_update(hipStream_t st, int kind, int phase, int64_t iter, int64_
     return check(hipGetLastError());
 }
 
-const InstTable kTable = {0, P, 0, nullptr, nullptr, nullptr, &launch_tall_partial, &launch_tall_update};
+int launch_tall_traj(hipStream_t st, const void* tall_args) {
+    const auto& a = *static_cast<const TallArgs<float, P>*>(tall_args);
+    hipLaunchKernelGGL((k_wide_traj_bf16<P>), dim3((unsigned)((a.C + 15) / 16)), dim3(512), 0, st, a);
+    return check(hipGetLastError());
+}
+
+const InstTable kTable = {0, P, 0, nullptr, nullptr, nullptr, &launch_tall_partial, &launch_tall_update, &launch_tall_traj};
 
 }  // namespace
 }  // namespace lr

@@ -586,6 +586,164 @@ __global__ void __launch_bounds__((64 * NW)) k_wide_partial_bf16r(TallArgs<float
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// TRAJECTORY kernel: all L - 1 interior leapfrog steps of one chain tile (16 chains) in ONE launch, no row slicing
+// across workgroups.  Why: inside a launch of the row-split kernel above (config 5, 10 us) a third of the time is the
+// fused prologue re-reading the tile's slice partials and state in each of its 4 slice workgroups (16 MB per step
+// chip-wide), a fifth the reduction + stores, and the 4-block row loop per wave never leaves its start-up transient;
+// swapping the partials between resident workgroups instead (tools/xchg_probe.hip) costs 3.2 us per step on one XCD,
+// 9.5 us across XCDs -- no cheaper than the launch boundary.  So here a tile's gradient never leaves its CU: the 8
+// waves of the workgroup split ALL the rows of the design (each streams its own 32-row block images L2 -> LDS through
+// a private 2-slot DMA ring, exactly the row loop above), the wave partials meet in LDS one 32-coordinate chunk at a
+// time (18 KB: the rings keep 128 KB of the 160), and thread (chain c, coordinate j) -- which owns q[c][j], p[c][j] in
+// registers for the whole trajectory -- finishes the step: g = sum over the waves in wave order - q ivar,
+// p += eps g, q += (eps / m) p, new q to LDS for the next step's beta operand.  The first blocks of the next step
+// are on their way before the reduction starts.  One workgroup streams the whole single-piece image every step
+// (n p 2 bytes from L2: 1 MB for config 5, >= 6.8 us at 64 B/clk/CU), so a step costs the same from 16 to
+// 16 x CUs chains.  Results do not depend on the chain count, the tile position or any slice plan.
+template <int P>
+__global__ void __launch_bounds__(512) k_wide_traj_bf16(TallArgs<float, P> a) {
+    using G = WideBf16Geom<P>;
+    constexpr int NW = 8, BLK_BYTES = G::BUF1 * 2, NBUF = P >= 128 ? 2 : 4, RING_BYTES = NBUF * BLK_BYTES, RW = 36;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NW * RING_BYTES];
+    __shared__ __attribute__((aligned(16))) float red[NW][16][RW];
+    __shared__ __attribute__((aligned(16))) float qnew[16][P];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, kg = lane >> 4;
+    const int64_t chain0 = (int64_t)blockIdx.x * 16;
+    const int nblk = (int)((a.n + 31) / 32);
+    const int per_wave = (nblk + NW - 1) / NW;
+    const int wb0 = wave * per_wave;
+    const int wnb = nblk - wb0 < 0 ? 0 : (nblk - wb0 < per_wave ? nblk - wb0 : per_wave);
+    unsigned char* ring = smem + wave * RING_BYTES;
+    const uint32_t ring_lds = (uint32_t)(uintptr_t)ring;
+
+    auto issue = [&](int b) {  // block b of this wave -> ring slot b % NBUF
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(a.xblk1 + (wb0 + b) * (int64_t)G::BUF1) + lane * 16;
+        const uint32_t dst = ring_lds + (uint32_t)((b & (NBUF - 1)) * BLK_BYTES);
+#pragma unroll
+        for (int ch = 0; ch < BLK_BYTES / 1024; ++ch) {
+            uint32_t keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(src + ch * 1024), "s"(dst + ch * 1024)
+                         : "memory");
+        }
+    };
+
+    // the thread's share of the state: chain oc, coordinates 32 r + oj
+    const int oc = tid >> 5, oj = tid & 31;
+    int64_t ochain = chain0 + oc;
+    const bool olive = ochain < a.C;
+    if (!olive) ochain = a.C - 1;
+    float sq[G::M32], sp[G::M32], sb[G::M32], si[G::M32];
+#pragma unroll
+    for (int r = 0; r < G::M32; ++r) {
+        const int j = 32 * r + oj;
+        sq[r] = a.q1[ochain * P + j];
+        sp[r] = a.pm[ochain * P + j];
+        sb[r] = a.cvec[j];
+        si[r] = a.cvec[P + j];
+    }
+#pragma unroll
+    for (int r = 0; r < G::M32; ++r) qnew[oc][32 * r + oj] = sq[r];
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // nothing but the DMA ring counts on vmcnt from here on
+#pragma unroll
+    for (int b = 0; b < NBUF - 1; ++b)
+        if (b < wnb) issue(b);
+    __syncthreads();
+
+    const int eta_off = G::elem(kg, c, 0) & ~7;
+    const int ri = (lane & 15) >> 2, ci = lane & 3;
+    const int tr_off[2] = {G::elem(ci, 4 * kg + ri, 0), G::elem(ci, 4 * kg + ri, 4)};
+    const int nsteps = a.l - 1;
+    for (int s = 0; s < nsteps; ++s) {
+        // beta = hi + lo (two round-to-nearest bf16 pieces) of the lane's coordinates 32 m + 8 kg + i, times log2(e)
+        u32x4 bq[G::M32][2];
+#pragma unroll
+        for (int m = 0; m < G::M32; ++m) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(&qnew[c][32 * m + 8 * kg]);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(&qnew[c][32 * m + 8 * kg + 4]);
+            const float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            uint32_t hi[4], lo[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float x0 = x[2 * i] * ExpScale<float>::k, x1 = x[2 * i + 1] * ExpScale<float>::k;
+                hi[i] = pack_rne(x0, x1);
+                const float h0 = __builtin_bit_cast(float, hi[i] << 16), h1 = __builtin_bit_cast(float, hi[i] & 0xFFFF0000u);
+                lo[i] = pack_rne(x0 - h0, x1 - h1);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int j = (kg & 1) ? (i ^ 2) : i;  // odd kg: halves swapped, as the eta read delivers them
+                bq[m][0][i] = hi[j];
+                bq[m][1][i] = lo[j];
+            }
+        }
+        f32x4 gacc[G::MBP];
+#pragma unroll
+        for (int mb = 0; mb < G::MBP; ++mb) gacc[mb] = f32x4{0, 0, 0, 0};
+        for (int b = 0; b < wnb; ++b) {
+            if (b + NBUF - 1 < wnb) issue(b + NBUF - 1);
+            const int last = b + NBUF - 1 < wnb ? b + NBUF - 1 : wnb - 1;
+            wait_vm_blocks<BLK_BYTES>(last - b);
+            const uint16_t* base = reinterpret_cast<const uint16_t*>(ring + (b & (NBUF - 1)) * BLK_BYTES);
+            uint32_t wq[4];
+#pragma unroll
+            for (int T = 0; T < 2; ++T) {
+                f32x4 e0 = {0, 0, 0, 0}, e1 = {0, 0, 0, 0};
+#pragma unroll
+                for (int m = 0; m < G::M32; ++m) {
+                    const u32x4 xa = *reinterpret_cast<const u32x4*>(base + G::tile1(T, m) + eta_off);
+                    e0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(xa), as_bf16x8(bq[m][0]), e0, 0, 0, 0);
+                    e1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(xa), as_bf16x8(bq[m][1]), e1, 0, 0, 0);
+                }
+                float w[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) w[r] = fast_rcp(1.0f + __builtin_amdgcn_exp2f(e0[r] + e1[r]));
+                wq[2 * T] = pack_rne(w[0], w[1]);
+                wq[2 * T + 1] = pack_rne(w[2], w[3]);
+            }
+            const u32x4 wv = {wq[0], wq[1], wq[2], wq[3]};
+#pragma unroll
+            for (int mb = 0; mb < G::MBP; ++mb) {
+                const u32x2 t0 = lds_read_tr16(base + G::tile1(0, mb >> 1) + tr_off[mb & 1]);
+                const u32x2 t1 = lds_read_tr16(base + G::tile1(1, mb >> 1) + tr_off[mb & 1]);
+                const u32x4 xg = {t0[0], t0[1], t1[0], t1[1]};
+                gacc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(xg), as_bf16x8(wv), gacc[mb], 0, 0, 0);
+            }
+        }
+        // every ring slot has been read: the next step's first blocks travel while the step is finished
+        if (s + 1 < nsteps) {
+#pragma unroll
+            for (int b = 0; b < NBUF - 1; ++b)
+                if (b < wnb) issue(b);
+        }
+#pragma unroll
+        for (int r = 0; r < G::M32; ++r) {
+            *reinterpret_cast<f32x4*>(&red[wave][c][8 * kg]) = gacc[2 * r];
+            *reinterpret_cast<f32x4*>(&red[wave][c][8 * kg + 4]) = gacc[2 * r + 1];
+            __syncthreads();
+            double gs = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) gs += (double)red[w][oc][oj];  // wave order
+            const float g1 = (float)gs - sq[r] * si[r];
+            sp[r] = fma_t(a.step, g1, sp[r]);
+            sq[r] = fma_t(sb[r], sp[r], sq[r]);
+            qnew[oc][32 * r + oj] = sq[r];
+            __syncthreads();
+        }
+    }
+    if (olive) {
+#pragma unroll
+        for (int r = 0; r < G::M32; ++r) {
+            a.q1[ochain * P + 32 * r + oj] = sq[r];
+            a.pm[ochain * P + 32 * r + oj] = sp[r];
+        }
+    }
+}
+
 // Host side: build the per-32-row-block LDS images (bf16 pieces, swizzled layout) from the signed rows.
 // rows: [n][P] fp32 (host).  out: [ceil(n/32)][BUF] bf16 bit patterns.
 template <int P> inline void wide_bf16_prepare(const float* rows, int64_t n, uint16_t* out) {

@@ -775,12 +775,16 @@ def test_two_chainsets_of_one_model_on_two_streams(la, n, p):
     assert not np.array_equal(seq[0], seq[1])
 
 
-def test_wide_many_chains_use_the_chain_split_interior_kernel(la):
-    """More chain tiles than CUs (C > 16 x 256): the interior steps of wide models run on k_wide_partial_bf16i
-    (workgroups of 4/8 waves x 16 chains sharing staged row blocks, LDS-DMA passes) instead of the row-split kernel.
+@pytest.mark.parametrize("engine", ["trajectory", "chain_split"])
+def test_wide_many_chains_use_the_chain_split_interior_kernel(la, engine, monkeypatch):
+    """More chain tiles than CUs (C > 16 x 256): the interior steps of wide models leave the row-split kernel for
+    k_wide_traj_bf16 (one workgroup per chain tile runs all L - 1 interior steps of the trajectory in one launch;
+    the default from one tile per CU up to four) or k_wide_partial_bf16i (workgroups of 4/8 waves x 16 chains sharing
+    staged row blocks, one launch per step; the default beyond).
     A 64-chain subset against the oracle: decisions away from near-ties, trajectories within the reduced-precision
     tolerance; exact mode at the exact tolerance; reruns bit-identical."""
     from oracle.oracle import OracleModel
+    monkeypatch.setenv("LOGREG_WIDE_NO_TRAJ" if engine == "chain_split" else "LOGREG_WIDE_TRAJ", "1")
     n, p, C = 700, 64, 4200
     X, y, _ = la.synthetic_logreg(n, p, seed=77, beta_sd=0.1)
     ps = np.full(p, 1.5)
@@ -800,6 +804,14 @@ def test_wide_many_chains_use_the_chain_split_interior_kernel(la):
     assert not np.array_equal(mixed, full)
     assert np.array_equal(mixed, la.mcmc(b, k, thin=1, iters=2, verb=False, seed=4, chunk=1))
     assert abs(mi["accepts"].mean() - fi["accepts"].mean()) < 0.05
+    if engine == "trajectory":
+        # a tile's interior steps depend on nothing but its own chains; with the slice count of the end-point kernels
+        # pinned as well, any subset that keeps the chains' global ids reproduces them bit for bit
+        # (80 chains = 5 tiles; 70 = 4 tiles + a ragged one)
+        pinned = la.mcmc(b, k, thin=1, iters=2, verb=False, seed=4, mode="stepwise", group=4)
+        for sub in (80, 70):
+            part = la.mcmc(b[:sub], k, thin=1, iters=2, verb=False, seed=4, mode="stepwise", group=4)
+            assert np.array_equal(part, pinned[:, :sub])
 
 
 @pytest.mark.parametrize("n,p", [(900, 128), (3000, 8), (1500, 20)])
