@@ -91,9 +91,24 @@ def _run(cmd):
 
 
 def build(force: bool = False, jobs: int | None = None, verbose: bool = True) -> str:
+    """Compile and link the library.  Safe to call from several processes at once (one rank per GPU importing the
+    package on a box whose library is stale): an exclusive file lock serialises them, the late-comers find the
+    library current and return; the .so is linked under a temporary name and renamed into place."""
     if not force and not needs_build():
         return LIB
     os.makedirs(OBJDIR, exist_ok=True)
+    import fcntl
+    with open(os.path.join(LIBDIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():  # another process built it while this one waited
+                return LIB
+            return _build_locked(jobs, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(jobs: int | None, verbose: bool) -> str:
     hipcc = _hipcc()
     jobs_list = []
     objs = []
@@ -120,7 +135,9 @@ def build(force: bool = False, jobs: int | None = None, verbose: bool = True) ->
         for warn in ex.map(_run, jobs_list):
             if warn.strip() and verbose:
                 print(warn, file=sys.stderr)
-    _run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB, *objs])
+    tmp = LIB + f".tmp{os.getpid()}"
+    _run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", tmp, *objs])
+    os.replace(tmp, LIB)
     with open(BUILD_ID_FILE, "w") as f:
         f.write(bid + "\n")
     if verbose:
