@@ -120,7 +120,7 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
     const int64_t want_waves = 4LL * m->cus;
     int best = -1;
     long best_score = -1;
-    if (hmc_bf16 && !for_eval && mode == LR_MODE_AUTO && group == 0 && m->dtype == LR_F32 && m->P == 8 &&
+    if (hmc_bf16 && !for_eval && mode == LR_MODE_AUTO && group == 0 && m->dtype == LR_F32 && m->P >= 8 && m->P <= 32 &&
         !env_on("LOGREG_NO_MFMA_INTERIOR")) {
         // register-resident data, many chains: the fused matrix-core kernel with bf16 interior steps (lr_mfma.h).
         // Measured (bench.py workload, chain-iterations/s, reg 16x13 | mfma S=4 | mfma S=1; profiles/r2_mfma_chain_grid.txt):
@@ -131,17 +131,22 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
         // Mid-size data (256 < n <= 1024; tools/midn_mfma.py, HMC L=20, it/s, reg | mfma S=4): n=400: 1.83e8 | 2.82e8 at
         // 4096 chains, 1.92e8 | 3.74e8 at 16 384; n=1000: 0.92e8 | 1.69e8 at 4096, 0.98e8 | 1.79e8 at 16 384; below one
         // workgroup per CU (4096 chains) the register kernels win (n=400, 2048 chains: 1.69e8 | 1.45e8).
-        int want_S = 0;
-        if (C >= 40LL * m->cus && m->n <= 16 * 13) want_S = 1;
-        else if (C >= 16LL * m->cus && m->n <= 16 * 4 * 16) want_S = 4;
-        for (int i = 0; want_S && i < t->nvariants; ++i) {
-            const lr::Variant& v = t->variants[i];
-            if (v.mode == lr::MODE_MFMA && v.G == want_S && (int64_t)16 * v.G * v.R >= m->n) {
-                out->mode = v.mode;
-                out->G = v.G;
-                out->R = v.R;
-                out->lds_bytes = 0;
-                return LR_OK;
+        // Wider models (9 <= p <= 32; profiles/r2_midp_mfma.txt, HMC L=20, algorithmic TF, vector-ALU kernel | mfma S=4):
+        //   n=200 p=12: 13 | 19 at 1024 chains, 33 | 72 at 4096, 34 | 98 (S=1: 138) at 16 384;  n=200 p=32: 25 | 29, 26 | 110, 26 | 118;
+        //   n=500 p=32 (LDS kernel otherwise): 16 | 53, 16 | 199, 37 | 210;  n=1000 p=12: 23 | 39, 23 | 150, 50 | 147;
+        //   n=500 p=16: 43 | 40, 46 | 147, 47 | 160.   p > 8 moves to the matrix pipe from 4 chains per CU.
+        const int64_t s4_from = (m->P > 8 ? 4LL : 16LL) * m->cus;
+        const int try_S[2] = {C >= 40LL * m->cus && m->n <= 16 * 13 ? 1 : 0, C >= s4_from ? 4 : 0};
+        for (int want_S : try_S) {
+            for (int i = 0; want_S && i < t->nvariants; ++i) {
+                const lr::Variant& v = t->variants[i];
+                if (v.mode == lr::MODE_MFMA && v.G == want_S && (int64_t)16 * v.G * v.R >= m->n) {
+                    out->mode = v.mode;
+                    out->G = v.G;
+                    out->R = v.R;
+                    out->lds_bytes = 0;
+                    return LR_OK;
+                }
             }
         }
     }

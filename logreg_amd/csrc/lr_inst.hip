@@ -3,7 +3,7 @@
 #include "lr_inst.h"
 #include "lr_kernels.h"
 #include "lr_tall.h"
-#if LR_DTYPE == 0 && LR_P == 8
+#if LR_DTYPE == 0 && LR_P >= 8
 #include "lr_mfma.h"
 #endif
 #if LR_DTYPE == 0 && LR_P >= 8
@@ -41,10 +41,15 @@ constexpr int P = LR_P;
 #define LR_VARIANTS(X) X(MODE_LDS, 1, 0) X(MODE_LDS, 8, 0) X(MODE_LDS, 64, 0) X(MODE_GLOBAL, 64, 0) X(MODE_GLOBAL, 1, 0)
 #endif
 
-// matrix-core variants (fp32, p = 8): X(row-split ways S, tiles per wave NTW), ascending NTW per S; n <= 16*S*NTW
-// (4, 8) and (4, 16): mid-size data, n <= 512 / 1024, for HMC with bf16 interior steps (6 NTW + 4 NTW operand registers)
+// matrix-core variants (fp32, padded p = 8 / 16 / 32): X(row-split ways S, tiles per wave NTW), ascending NTW per S;
+// n <= 16*S*NTW.  (4, 8) and (4, 16): mid-size data, n <= 512 / 1024, for HMC with bf16 interior steps.  Operand registers
+// per tile: 2.5 p (p/4 + p/4..p/2 fp32 end-point operands, p bf16 interior operands), so p = 32 stops at 8 tiles.
 #if LR_DTYPE == 0 && LR_P == 8
 #define LR_MFMA_VARIANTS(X) X(1, 13) X(4, 4) X(4, 8) X(4, 16)
+#elif LR_DTYPE == 0 && LR_P == 16
+#define LR_MFMA_VARIANTS(X) X(1, 13) X(4, 4) X(4, 8) X(4, 16)
+#elif LR_DTYPE == 0 && LR_P == 32
+#define LR_MFMA_VARIANTS(X) X(4, 4) X(4, 8)
 #else
 #define LR_MFMA_VARIANTS(X)
 #endif
@@ -97,16 +102,16 @@ int launch_chain_v(const LaunchCfg* cfg, int64_t C, const ModelArgs<T, P>& m, co
     return check(hipGetLastError());
 }
 
-#if LR_DTYPE == 0 && LR_P == 8
+#if LR_DTYPE == 0 && LR_P >= 8
 template <int S, int NTW>
 int launch_mfma_v(const LaunchCfg* cfg, int64_t C, const ModelArgs<T, P>& m, const ChainArgs<T, P>& a) {
     const int64_t per_block = S == 1 ? 64 : 16;
     const dim3 grid((unsigned)((C + per_block - 1) / per_block)), block(256);
     switch (cfg->kind) {
-    case KIND_RWMH: hipLaunchKernelGGL((k_chain_mfma<NTW, S, KIND_RWMH>), grid, block, 0, cfg->stream, m, a); break;
-    case KIND_MALA: hipLaunchKernelGGL((k_chain_mfma<NTW, S, KIND_MALA>), grid, block, 0, cfg->stream, m, a); break;
-    case KIND_HMC: hipLaunchKernelGGL((k_chain_mfma<NTW, S, KIND_HMC>), grid, block, 0, cfg->stream, m, a); break;
-    case KIND_UL: hipLaunchKernelGGL((k_chain_mfma<NTW, S, KIND_UL>), grid, block, 0, cfg->stream, m, a); break;
+    case KIND_RWMH: hipLaunchKernelGGL((k_chain_mfma<P, NTW, S, KIND_RWMH>), grid, block, 0, cfg->stream, m, a); break;
+    case KIND_MALA: hipLaunchKernelGGL((k_chain_mfma<P, NTW, S, KIND_MALA>), grid, block, 0, cfg->stream, m, a); break;
+    case KIND_HMC: hipLaunchKernelGGL((k_chain_mfma<P, NTW, S, KIND_HMC>), grid, block, 0, cfg->stream, m, a); break;
+    case KIND_UL: hipLaunchKernelGGL((k_chain_mfma<P, NTW, S, KIND_UL>), grid, block, 0, cfg->stream, m, a); break;
     default: return -1;
     }
     return check(hipGetLastError());

@@ -1,9 +1,11 @@
 // lr_mfma.h -- matrix-core formulation of the fused chain kernel (fp32 in, fp32 accumulate;
-// p = 8; gfx950 v_mfma_f32_16x16x4_f32, which is bit-for-bit a k-ordered fmaf chain).
+// padded p = 8, 16 or 32; gfx950 v_mfma_f32_16x16x4_f32, which is bit-for-bit a k-ordered fmaf chain).
 //
 // One wavefront owns 16 chains.  Lane l = (c, k): c = l & 15 is the chain, k = l >> 4 the
-// parameter group; the lane OWNS parameters k and k+4 of chain c (position, momentum, gradient
-// for those two coordinates live only in this lane).  Data rows are processed in tiles of 16:
+// parameter group; the lane OWNS the NC = p / 4 parameters k + 4h of chain c (position, momentum, gradient
+// for those coordinates live only in this lane).  Written out below for p = 8 (h = 0, 1); wider models repeat
+// the eta MFMAs per h (one accumulator) and the gradient MFMAs per set of four h.
+// Data rows are processed in tiles of 16:
 //
 //   eta tile  E[16 rows x 16 chains] = Xs[16 x 8] . B^T[8 x 16]       2 MFMAs (K = 4 each)
 //       A operand (lane l): Xs[16T + (l&15)][(l>>4) + 4h]       h = 0,1     (registers xa[t][h])
@@ -42,13 +44,18 @@ __device__ __forceinline__ uint32_t mf_pack_rne(float a, float b) {  // two fp32
 }
 __device__ __forceinline__ float mf_hi_f32(uint32_t packed) { return __builtin_bit_cast(float, packed << 16); }
 
-template <int NTW, int S> struct MfmaRows {
-    float xa[NTW][2];
-    float xg[NTW][4];
+template <int P, int NTW, int S> struct MfmaRows {
+    static constexpr int NC = P / 4;             // coordinates per lane: j_h = k + 4 h
+    static constexpr int NU = NC / 2;            // coordinate pairs (h = 2u, 2u + 1): one bf16 MFMA each
+    static constexpr int NG = (NC + 3) / 4;      // fp32 gradient MFMA sets of up to four h
+    static constexpr int HG = NC < 4 ? NC : 4;   // h per set
+    float xa[NTW][NC];
+    float xg[NTW][NG][4];
     int pad_rows;  // rows >= n among this lane's eta rows (each adds log sigma(0) = -log 2)
     // INTERIOR leapfrog steps on the bf16 matrix pipe (the scheme of lr_tall_mx.h with the rows in registers):
-    //   xs = x log2 e = xh + xl, beta = bh + bl (two round-to-nearest bf16 pieces each); lane (c, k) owns coordinates a = k, b = k + 4
-    //   eta tile:  ONE v_mfma_f32_16x16x32_bf16 (the K = 32 instruction costs what one K = 16 does: 8 slots per lane)
+    //   xs = x log2 e = xh + xl, beta = bh + bl (two round-to-nearest bf16 pieces each); per pair u the lane's coordinates
+    //   a = k + 8u, b = a + 4
+    //   eta tile:  ONE v_mfma_f32_16x16x32_bf16 per pair (the K = 32 instruction costs what one K = 16 does: 8 slots per lane)
     //              A (lane (row, k)) = [xh_a xl_a xh_a xl_a xh_b xl_b xh_b xl_b],  B = [bh_a bh_a bl_a bl_a bh_b bh_b bl_b bl_b]:
     //              all four piece products of both coordinates.  A one-piece design (half the operand) was tried: on the
     //              unscaled Pima covariates its 2^-9 rounding raised the sd of the energy error from 0.152 to 0.191 and cost
@@ -57,31 +64,31 @@ template <int NTW, int S> struct MfmaRows {
     //              A (lane (m', k')) = element m' & 3 of (xh_a xl_a xh_b xl_b) of group m' >> 2, rows of slot group k'
     //              D (lane (c, k), r) = sum_rows w (xh_a, xl_a, xh_b, xl_b)[r]:  g_a = D0 + D1, g_b = D2 + D3
     static constexpr int NPAIR = (NTW + 1) / 2;
-    mf_u32x4 xe[NTW];
-    mf_u32x4 xq[NPAIR];
+    mf_u32x4 xe[NTW][NU];
+    mf_u32x4 xq[NPAIR][NU];
     int ntile_live;  // this wave's tiles that contain at least one real row (all-padding tiles are skipped)
 
     __device__ __forceinline__ void load(const float* __restrict__ rows, int64_t n, int wave, int lane) {
         const int c = lane & 15, k = lane >> 4;
-        const int rp = c & 3, kp = c >> 2;           // slot m = c = 4*kp + rp
-        const int gpar = rp < 2 ? kp + 4 * rp : -1;  // parameter of the gradient A operand
+        const int rp = c & 3, kp = c >> 2;  // slot m = c = 4*kp + rp -> parameter kp + 4 rp (+ 16 per set) of the gradient A operand
         pad_rows = 0;
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
             const int64_t base = 16 * ((int64_t)t * S + wave);
             const int64_t ra = base + c;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) xa[t][h] = ra < n ? rows[ra * 8 + k + 4 * h] : 0.0f;
+            for (int h = 0; h < NC; ++h) xa[t][h] = ra < n ? rows[ra * P + k + 4 * h] : 0.0f;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const int64_t rg = base + 4 * k + s;
-                xg[t][s] = (rg < n && gpar >= 0) ? rows[rg * 8 + gpar] : 0.0f;
+#pragma unroll
+                for (int g = 0; g < NG; ++g) xg[t][g][s] = (rg < n && rp < HG) ? rows[rg * P + kp + 4 * rp + 16 * g] : 0.0f;
                 if (rg >= n) ++pad_rows;
             }
         }
         // bf16 operands of the interior steps
         auto piece = [&](int64_t row, int coord, int lo) {  // bf16 bit pattern of the hi / lo piece of X[row][coord]
-            const float x = row < n ? rows[row * 8 + coord] : 0.0f;
+            const float x = row < n ? rows[row * P + coord] : 0.0f;
             const uint32_t h = mf_pack_rne(x, x) & 0xFFFFu;
             if (!lo) return h;
             return mf_pack_rne(x - mf_hi_f32(h), 0.0f) & 0xFFFFu;
@@ -91,40 +98,50 @@ template <int NTW, int S> struct MfmaRows {
         for (int t = 0; t < NTW; ++t) {
             const int64_t base = 16 * ((int64_t)t * S + wave);
             if (base < n) ntile_live = t + 1;
-            uint32_t hl[2];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const float xs = base + c < n ? rows[(base + c) * 8 + k + 4 * h] * ExpScale<float>::k : 0.0f;
-                const uint32_t hi = mf_pack_rne(xs, xs) & 0xFFFFu;
-                hl[h] = hi | (mf_pack_rne(0.0f, xs - mf_hi_f32(hi)) & 0xFFFF0000u);
+            for (int u = 0; u < NU; ++u) {
+                uint32_t hl[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float xs = base + c < n ? rows[(base + c) * P + k + 8 * u + 4 * h] * ExpScale<float>::k : 0.0f;
+                    const uint32_t hi = mf_pack_rne(xs, xs) & 0xFFFFu;
+                    hl[h] = hi | (mf_pack_rne(0.0f, xs - mf_hi_f32(hi)) & 0xFFFF0000u);
+                }
+                xe[t][u] = mf_u32x4{hl[0], hl[0], hl[1], hl[1]};
             }
-            xe[t] = mf_u32x4{hl[0], hl[0], hl[1], hl[1]};
         }
         const int grp = c >> 2, el = c & 3;  // gradient A operand: M-row c = 4 grp + el -> element el of group grp
         const int gcoord = grp + 4 * (el >> 1), glo = el & 1;
 #pragma unroll
         for (int pi = 0; pi < NPAIR; ++pi) {
-            uint32_t v[8];
 #pragma unroll
-            for (int sl = 0; sl < 8; ++sl) {
-                const int t = 2 * pi + (sl >> 2);
-                const int64_t row = 16 * ((int64_t)t * S + wave) + 4 * k + (sl & 3);
-                v[sl] = t < NTW ? piece(row, gcoord, glo) : 0u;
+            for (int u = 0; u < NU; ++u) {
+                uint32_t v[8];
+#pragma unroll
+                for (int sl = 0; sl < 8; ++sl) {
+                    const int t = 2 * pi + (sl >> 2);
+                    const int64_t row = 16 * ((int64_t)t * S + wave) + 4 * k + (sl & 3);
+                    v[sl] = t < NTW ? piece(row, gcoord + 8 * u, glo) : 0u;
+                }
+                xq[pi][u] = mf_u32x4{v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16)};
             }
-            xq[pi] = mf_u32x4{v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16)};
         }
     }
 
-    // interior-step gradient (likelihood part, this wave's tiles) for the lane's two coordinates.  NPL = tile pairs
+    // interior-step gradient (likelihood part, this wave's tiles) for the lane's coordinates.  NPL = tile pairs
     // to run (compile time: a run-time skip of dead tiles inside the step put every tile behind its own branch, each with
     // the full MFMA -> exp latency exposed).  All-padding tiles inside the NPL pairs have zero operands and add exactly 0.
-    template <int NPL> __device__ __forceinline__ void eval_bf16(const float (&q2)[2], float (&gl)[2]) const {
+    template <int NPL> __device__ __forceinline__ void eval_bf16(const float (&q)[NC], float (&gl)[NC]) const {
         static_assert(NPL >= 1 && NPL <= NPAIR, "pairs");
-        const uint32_t ha = mf_pack_rne(q2[0], q2[0]), hb = mf_pack_rne(q2[1], q2[1]);  // piece | piece << 16
-        const float la = q2[0] - mf_hi_f32(ha), lb = q2[1] - mf_hi_f32(hb);
-        const mf_u32x4 bb = {ha, mf_pack_rne(la, la), hb, mf_pack_rne(lb, lb)};
+        mf_u32x4 bb[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const uint32_t ha = mf_pack_rne(q[2 * u], q[2 * u]), hb = mf_pack_rne(q[2 * u + 1], q[2 * u + 1]);  // piece | piece << 16
+            const float la = q[2 * u] - mf_hi_f32(ha), lb = q[2 * u + 1] - mf_hi_f32(hb);
+            bb[u] = mf_u32x4{ha, mf_pack_rne(la, la), hb, mf_pack_rne(lb, lb)};
+        }
         constexpr int NT = 2 * NPL < NTW ? 2 * NPL : NTW;
-        // Issue order.  Measured at one wave per SIMD (HMC L=50, n=200; S=4 at 4096 chains | S=1 at 16 384 chains, ms per
+        // Issue order.  Measured at one wave per SIMD (HMC L=50, n=200, p=8; S=4 at 4096 chains | S=1 at 16 384 chains, ms per
         // 20 iterations): compiler's order (all eta MFMAs, then the exp / rcp work, gradient MFMAs) 0.390 | 0.786; next
         // pair's eta MFMAs fenced in front of each pair's exp / rcp work 0.401 | 0.724; MFMAs spread between the VALU
         // groups with sched_group_barrier 0.420 | 0.739; the same with v_add_f32 for v_pk_add_f32 0.432 | 0.752.  A wave
@@ -133,14 +150,19 @@ template <int NTW, int S> struct MfmaRows {
         // slots, so the order only decides how many s_nop states follow the MFMAs.  S = 1 (13 tiles) takes the fenced
         // order, the short row-split bodies the compiler's.
         auto eta = [&](int t) {
-            return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mf_bf16x8, xe[t]), __builtin_bit_cast(mf_bf16x8, bb),
-                                                           f32x4{0, 0, 0, 0}, 0, 0, 0);
+            f32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+            for (int u = 0; u < NU; ++u)
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mf_bf16x8, xe[t][u]), __builtin_bit_cast(mf_bf16x8, bb[u]), acc, 0, 0, 0);
+            return acc;
         };
         f32x4 e[2 * NPL];
         e[0] = eta(0);
         if constexpr (NT > 1) e[1] = eta(1);
         if constexpr (S == 1) __builtin_amdgcn_sched_barrier(0);
-        f32x4 gacc = {0, 0, 0, 0};
+        f32x4 gacc[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) gacc[u] = f32x4{0, 0, 0, 0};
 #pragma unroll
         for (int pi = 0; pi < NPL; ++pi) {
             uint32_t wq[4] = {0u, 0u, 0u, 0u};
@@ -158,25 +180,34 @@ template <int NTW, int S> struct MfmaRows {
                 }
             }
             const mf_u32x4 wv = {wq[0], wq[1], wq[2], wq[3]};
-            gacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mf_bf16x8, xq[pi]), __builtin_bit_cast(mf_bf16x8, wv), gacc, 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < NU; ++u)
+                gacc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mf_bf16x8, xq[pi][u]), __builtin_bit_cast(mf_bf16x8, wv), gacc[u], 0, 0, 0);
             if constexpr (S == 1) __builtin_amdgcn_sched_barrier(0);
         }
-        gl[0] = gacc[0] + gacc[1];
-        gl[1] = gacc[2] + gacc[3];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            gl[2 * u] = gacc[u][0] + gacc[u][1];
+            gl[2 * u + 1] = gacc[u][2] + gacc[u][3];
+        }
     }
 
-    // likelihood part for the lane's two coordinates over THIS wave's tiles:
+    // likelihood part for the lane's coordinates over THIS wave's tiles:
     //   gl[h] = sum_rows sigma(-t) * xs[row][k+4h],  vsum = sum over the lane's eta rows of log sigma(t)
     template <bool VALUE>
-    __device__ __forceinline__ void eval(const float (&q2)[2], float (&gl)[2], float& vsum) const {
-        const float bs0 = q2[0] * ExpScale<float>::k, bs1 = q2[1] * ExpScale<float>::k;
-        f32x4 ga = {0, 0, 0, 0}, gb = {0, 0, 0, 0};
+    __device__ __forceinline__ void eval(const float (&q)[NC], float (&gl)[NC], float& vsum) const {
+        float bs[NC];
+#pragma unroll
+        for (int h = 0; h < NC; ++h) bs[h] = q[h] * ExpScale<float>::k;
+        f32x4 ga[NG], gb[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) ga[g] = gb[g] = f32x4{0, 0, 0, 0};
         float v = 0.0f;
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
             f32x4 e = {0, 0, 0, 0};
-            e = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[t][0], bs0, e, 0, 0, 0);
-            e = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[t][1], bs1, e, 0, 0, 0);
+#pragma unroll
+            for (int h = 0; h < NC; ++h) e = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[t][h], bs[h], e, 0, 0, 0);
             float w[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -186,13 +217,16 @@ template <int NTW, int S> struct MfmaRows {
                     v += (e[r] < 0.0f ? e[r] * ExpScale<float>::inv : 0.0f) - log1p_unit(__builtin_amdgcn_exp2f(-ats));
                 }
             }
-            ga = __builtin_amdgcn_mfma_f32_16x16x4f32(xg[t][0], w[0], ga, 0, 0, 0);
-            gb = __builtin_amdgcn_mfma_f32_16x16x4f32(xg[t][1], w[1], gb, 0, 0, 0);
-            ga = __builtin_amdgcn_mfma_f32_16x16x4f32(xg[t][2], w[2], ga, 0, 0, 0);
-            gb = __builtin_amdgcn_mfma_f32_16x16x4f32(xg[t][3], w[3], gb, 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                ga[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xg[t][g][0], w[0], ga[g], 0, 0, 0);
+                gb[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xg[t][g][1], w[1], gb[g], 0, 0, 0);
+                ga[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xg[t][g][2], w[2], ga[g], 0, 0, 0);
+                gb[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xg[t][g][3], w[3], gb[g], 0, 0, 0);
+            }
         }
-        gl[0] = ga[0] + gb[0];
-        gl[1] = ga[1] + gb[1];
+#pragma unroll
+        for (int h = 0; h < NC; ++h) gl[h] = ga[h >> 2][h & 3] + gb[h >> 2][h & 3];
         if constexpr (VALUE) vsum = v + (float)pad_rows * 0.693147180559945309f;
     }
 };
@@ -210,10 +244,11 @@ template <int N, typename F> __device__ __forceinline__ void for_pair_count(int 
 // sum over the 4 parameter groups k (lanes c, c+16, c+32, c+48); identical in all 4 lanes
 template <typename T> __device__ __forceinline__ T ksum(T v) { return swap32_sum(swap16_sum(v)); }
 
-template <int NTW, int S, int KIND>
-__global__ void __launch_bounds__(256) k_chain_mfma(ModelArgs<float, 8> m, ChainArgs<float, 8> a) {
-    __shared__ float red[2][4][64][2];   // S = 4: per-step partial gradients, double-buffered
-    __shared__ double redv[4][64];       // S = 4: partial log-likelihood values
+template <int P, int NTW, int S, int KIND>
+__global__ void __launch_bounds__(256) k_chain_mfma(ModelArgs<float, P> m, ChainArgs<float, P> a) {
+    constexpr int NC = P / 4;                 // coordinates per lane
+    __shared__ float red[2][4][64][NC];       // S = 4: per-step partial gradients, double-buffered
+    __shared__ double redv[4][64];            // S = 4: partial log-likelihood values
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, k = lane >> 4;
     const int64_t tile0 = S == 1 ? ((int64_t)blockIdx.x * 4 + wave) * 16 : (int64_t)blockIdx.x * 16;
@@ -223,17 +258,17 @@ __global__ void __launch_bounds__(256) k_chain_mfma(ModelArgs<float, 8> m, Chain
     const bool writer = live && (S == 1 || wave == 0);
     const uint64_t gchain = (uint64_t)(a.chain_offset + chain);
 
-    MfmaRows<NTW, S> rows;
+    MfmaRows<P, NTW, S> rows;
     rows.load(m.rows, m.n, S == 1 ? 0 : wave, lane);
 
-    // the lane's two coordinates: j_h = k + 4h
-    auto pick = [&](const float (&v)[8], int h) {
+    // the lane's coordinates: j_h = k + 4h
+    auto pick = [&](const float (&v)[P], int h) {
         const float lo = k == 0 ? v[4 * h] : v[4 * h + 1], hi = k == 2 ? v[4 * h + 2] : v[4 * h + 3];
         return k < 2 ? lo : hi;
     };
-    float inv_var[2], ka[2], kb[2], kc[2], x[2], g[2];
+    float inv_var[NC], ka[NC], kb[NC], kc[NC], x[NC], g[NC];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NC; ++h) {
         inv_var[h] = pick(m.prior.inv_var, h);
         ka[h] = pick(a.a, h);
         kb[h] = pick(a.b, h);
@@ -243,20 +278,24 @@ __global__ void __launch_bounds__(256) k_chain_mfma(ModelArgs<float, 8> m, Chain
     }
 
     int step_parity = 0;
+    // partial gradients of the 4 waves of a row-split workgroup, summed in a fixed order (identical in all 4 waves)
+    auto combine = [&](float (&gl)[NC]) {
+#pragma unroll
+        for (int h = 0; h < NC; ++h) red[step_parity][wave][lane][h] = gl[h];
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < NC; ++h)
+            gl[h] = (red[step_parity][0][lane][h] + red[step_parity][1][lane][h]) +
+                    (red[step_parity][2][lane][h] + red[step_parity][3][lane][h]);
+    };
     // full gradient (likelihood over all tiles + prior) for own coordinates; VALUE: ll (double, replicated)
-    auto evaluate = [&](auto want_value, const float (&q2)[2], float (&grad)[2], double& ll) {
+    auto evaluate = [&](auto want_value, const float (&q)[NC], float (&grad)[NC], double& ll) {
         constexpr bool VALUE = decltype(want_value)::value;
-        float gl[2], vs = 0.0f;
-        rows.template eval<VALUE>(q2, gl, vs);
+        float gl[NC], vs = 0.0f;
+        rows.template eval<VALUE>(q, gl, vs);
         if constexpr (S > 1) {
-            red[step_parity][wave][lane][0] = gl[0];
-            red[step_parity][wave][lane][1] = gl[1];
             if constexpr (VALUE) redv[wave][lane] = (double)vs;
-            __syncthreads();
-            gl[0] = (red[step_parity][0][lane][0] + red[step_parity][1][lane][0]) +
-                    (red[step_parity][2][lane][0] + red[step_parity][3][lane][0]);
-            gl[1] = (red[step_parity][0][lane][1] + red[step_parity][1][lane][1]) +
-                    (red[step_parity][2][lane][1] + red[step_parity][3][lane][1]);
+            combine(gl);
             double dv = 0;
             if constexpr (VALUE) {
                 dv = (redv[0][lane] + redv[1][lane]) + (redv[2][lane] + redv[3][lane]);
@@ -267,31 +306,27 @@ __global__ void __launch_bounds__(256) k_chain_mfma(ModelArgs<float, 8> m, Chain
         } else {
             if constexpr (VALUE) ll = ksum((double)vs);
         }
-        grad[0] = gl[0] - q2[0] * inv_var[0];
-        grad[1] = gl[1] - q2[1] * inv_var[1];
+#pragma unroll
+        for (int h = 0; h < NC; ++h) grad[h] = gl[h] - q[h] * inv_var[h];
     };
     // interior leapfrog step: gradient only, from the bf16 operands (LR_PREC_BF16 / AUTO), else the exact evaluation
-    auto evaluate_interior = [&](auto npl, const float (&q2)[2], float (&grad)[2]) {
-        float gl[2];
-        rows.template eval_bf16<decltype(npl)::value>(q2, gl);
+    auto evaluate_interior = [&](auto npl, const float (&q)[NC], float (&grad)[NC]) {
+        float gl[NC];
+        rows.template eval_bf16<decltype(npl)::value>(q, gl);
         if constexpr (S > 1) {
-            red[step_parity][wave][lane][0] = gl[0];
-            red[step_parity][wave][lane][1] = gl[1];
-            __syncthreads();
-            gl[0] = (red[step_parity][0][lane][0] + red[step_parity][1][lane][0]) +
-                    (red[step_parity][2][lane][0] + red[step_parity][3][lane][0]);
-            gl[1] = (red[step_parity][0][lane][1] + red[step_parity][1][lane][1]) +
-                    (red[step_parity][2][lane][1] + red[step_parity][3][lane][1]);
+            combine(gl);
             step_parity ^= 1;
         }
-        grad[0] = gl[0] - q2[0] * inv_var[0];
-        grad[1] = gl[1] - q2[1] * inv_var[1];
+#pragma unroll
+        for (int h = 0; h < NC; ++h) grad[h] = gl[h] - q[h] * inv_var[h];
     };
     using True = std::integral_constant<bool, true>;
     using False = std::integral_constant<bool, false>;
-    auto lprior_of = [&](const float (&q2)[2]) {
-        const float quad = ksum(fma_t(q2[0] * q2[0], inv_var[0], q2[1] * q2[1] * inv_var[1]));
-        return m.prior.lprior_const - 0.5 * (double)quad;
+    auto lprior_of = [&](const float (&q)[NC]) {
+        float acc = q[NC - 1] * q[NC - 1] * inv_var[NC - 1];
+#pragma unroll
+        for (int h = NC - 2; h >= 0; --h) acc = fma_t(q[h] * q[h], inv_var[h], acc);
+        return m.prior.lprior_const - 0.5 * (double)ksum(acc);
     };
 
     double lp;
@@ -315,49 +350,61 @@ __global__ void __launch_bounds__(256) k_chain_mfma(ModelArgs<float, 8> m, Chain
     for (int64_t it = 0; it < a.iters; ++it) {
         for (int64_t jt = 0; jt < a.thin; ++jt) {
             const uint64_t iter = (uint64_t)(a.iter_offset + it * a.thin + jt);
-            // one Philox block per lane instead of three: lane (c, 0) generates normal block 0, (c, 1) block 1, (c, 2) and
-            // (c, 3) the accept-uniform block; every lane then collects the normals of its coordinates k (block 0,
-            // element k) and k + 4 (block 1, element k) and log(u) from those lanes.  Same values, bit for bit.
-            float z[2], logu_f;
+            // Philox blocks are dealt over the 4 lanes (c, 0..3) of a chain instead of every lane computing all of them:
+            // in round r lane (c, k) generates normal block 4r + k (coordinates 4b .. 4b + 3 of block b, as everywhere);
+            // p = 8 has two normal blocks, so its lanes k = 2, 3 generate the accept-uniform block in the same round, wider
+            // models generate it in every lane.  Every lane then collects the normal of coordinate k + 4h = element k of
+            // block h from lane (c, h & 3) and log(u).  Same values, bit for bit.
+            float z[NC], logu_f;
             {
-                const uint32_t blk = k == 0 ? 0u : (k == 1 ? 1u : TAG_UNIFORM);
-                const U4 w4 = philox4x32_10((uint32_t)gchain, (uint32_t)iter, (uint32_t)(iter >> 32), blk, (uint32_t)a.seed,
-                                            (uint32_t)(a.seed >> 32));
-                float nrm[4];
-                box_muller(w4.x, w4.y, nrm[0], nrm[1]);
-                box_muller(w4.z, w4.w, nrm[2], nrm[3]);
-                const float lu = logf(u01<float>(w4.x));
+                constexpr int ROUNDS = (NC + 3) / 4;
                 auto from = [&](int src_lane, float v) {
                     return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane * 4, __builtin_bit_cast(int, v)));
                 };
+                auto block = [&](uint32_t blk) {
+                    return philox4x32_10((uint32_t)gchain, (uint32_t)iter, (uint32_t)(iter >> 32), blk, (uint32_t)a.seed,
+                                         (uint32_t)(a.seed >> 32));
+                };
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const float e0 = from(c + 16 * h, nrm[0]), e1 = from(c + 16 * h, nrm[1]);
-                    const float e2 = from(c + 16 * h, nrm[2]), e3 = from(c + 16 * h, nrm[3]);
-                    z[h] = k < 2 ? (k == 0 ? e0 : e1) : (k == 2 ? e2 : e3);
+                for (int r = 0; r < ROUNDS; ++r) {
+                    const uint32_t blk = 4 * r + k < NC ? (uint32_t)(4 * r + k) : TAG_UNIFORM;
+                    const U4 w4 = block(blk);
+                    float nrm[4];
+                    box_muller(w4.x, w4.y, nrm[0], nrm[1]);
+                    box_muller(w4.z, w4.w, nrm[2], nrm[3]);
+                    if constexpr (NC < 4) logu_f = from(c + 32, logf(u01<float>(w4.x)));
+#pragma unroll
+                    for (int hh = 0; hh < 4; ++hh) {
+                        const int h = 4 * r + hh;
+                        if (h < NC) {
+                            const float e0 = from(c + 16 * hh, nrm[0]), e1 = from(c + 16 * hh, nrm[1]);
+                            const float e2 = from(c + 16 * hh, nrm[2]), e3 = from(c + 16 * hh, nrm[3]);
+                            z[h] = k < 2 ? (k == 0 ? e0 : e1) : (k == 2 ? e2 : e3);
+                        }
+                    }
                 }
-                logu_f = from(c + 32, lu);
+                if constexpr (NC >= 4) logu_f = logf(u01<float>(block(TAG_UNIFORM).x));
             }
             if constexpr (KIND == KIND_UL) {
-                x[0] = fma_t(kb[0], z[0], fma_t(ka[0], g[0], x[0]));
-                x[1] = fma_t(kb[1], z[1], fma_t(ka[1], g[1], x[1]));
+#pragma unroll
+                for (int h = 0; h < NC; ++h) x[h] = fma_t(kb[h], z[h], fma_t(ka[h], g[h], x[h]));
                 double d0;
                 evaluate(False{}, x, g, d0);
                 ++nacc;
             } else {
                 const double logu = (double)logu_f;
-                float xp[2], gp[2];
+                float xp[NC], gp[NC];
                 double llp = 0, lprp = 0, logr;
                 if constexpr (KIND == KIND_RWMH) {
-                    xp[0] = fma_t(ka[0], z[0], x[0]);
-                    xp[1] = fma_t(ka[1], z[1], x[1]);
+#pragma unroll
+                    for (int h = 0; h < NC; ++h) xp[h] = fma_t(ka[h], z[h], x[h]);
                     evaluate(True{}, xp, gp, llp);
                     lprp = lprior_of(xp);
                     logr = (llp + lprp) - lp;
                 } else if constexpr (KIND == KIND_MALA) {
-                    float advx[2];
+                    float advx[NC];
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
+                    for (int h = 0; h < NC; ++h) {
                         advx[h] = fma_t(ka[h], g[h], x[h]);
                         xp[h] = fma_t(kb[h], z[h], advx[h]);
                     }
@@ -365,54 +412,54 @@ __global__ void __launch_bounds__(256) k_chain_mfma(ModelArgs<float, 8> m, Chain
                     lprp = lprior_of(xp);
                     float dq = 0.0f;
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
+                    for (int h = 0; h < NC; ++h) {
                         const float advp = fma_t(ka[h], gp[h], xp[h]);
                         const float d1 = x[h] - advp, d2 = xp[h] - advx[h];
                         dq = fma_t(kc[h], d1 * d1 - d2 * d2, dq);
                     }
                     logr = (llp + lprp) - lp - 0.5 * (double)ksum(dq);
                 } else {  // HMC
-                    float pm[2];
+                    float pm[NC];
                     float k0 = 0.0f;
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
+                    for (int h = 0; h < NC; ++h) {
                         pm[h] = z[h] * ka[h];
                         k0 = fma_t(pm[h] * pm[h], kc[h], k0);
                         xp[h] = x[h];
                         gp[h] = g[h];
                     }
                     const float heps = 0.5f * a.step;
-                    pm[0] = fma_t(heps, gp[0], pm[0]);
-                    pm[1] = fma_t(heps, gp[1], pm[1]);
+#pragma unroll
+                    for (int h = 0; h < NC; ++h) pm[h] = fma_t(heps, gp[h], pm[h]);
                     if (a.interior_bf16) {
                         // the whole interior loop once per live pair count (wave-uniform; every wave of a row-split
                         // workgroup still meets the same l - 1 barriers)
-                        for_pair_count<MfmaRows<NTW, S>::NPAIR>((rows.ntile_live + 1) >> 1, [&](auto npl) {
+                        for_pair_count<MfmaRows<P, NTW, S>::NPAIR>((rows.ntile_live + 1) >> 1, [&](auto npl) {
                             for (int i = 0; i < a.l - 1; ++i) {
-                                xp[0] = fma_t(kb[0], pm[0], xp[0]);
-                                xp[1] = fma_t(kb[1], pm[1], xp[1]);
+#pragma unroll
+                                for (int h = 0; h < NC; ++h) xp[h] = fma_t(kb[h], pm[h], xp[h]);
                                 evaluate_interior(npl, xp, gp);
-                                pm[0] = fma_t(a.step, gp[0], pm[0]);
-                                pm[1] = fma_t(a.step, gp[1], pm[1]);
+#pragma unroll
+                                for (int h = 0; h < NC; ++h) pm[h] = fma_t(a.step, gp[h], pm[h]);
                             }
                         });
                     } else {
                         for (int i = 0; i < a.l - 1; ++i) {
-                            xp[0] = fma_t(kb[0], pm[0], xp[0]);
-                            xp[1] = fma_t(kb[1], pm[1], xp[1]);
+#pragma unroll
+                            for (int h = 0; h < NC; ++h) xp[h] = fma_t(kb[h], pm[h], xp[h]);
                             double d0;
                             evaluate(False{}, xp, gp, d0);
-                            pm[0] = fma_t(a.step, gp[0], pm[0]);
-                            pm[1] = fma_t(a.step, gp[1], pm[1]);
+#pragma unroll
+                            for (int h = 0; h < NC; ++h) pm[h] = fma_t(a.step, gp[h], pm[h]);
                         }
                     }
-                    xp[0] = fma_t(kb[0], pm[0], xp[0]);
-                    xp[1] = fma_t(kb[1], pm[1], xp[1]);
+#pragma unroll
+                    for (int h = 0; h < NC; ++h) xp[h] = fma_t(kb[h], pm[h], xp[h]);
                     evaluate(True{}, xp, gp, llp);
                     lprp = lprior_of(xp);
                     float k1 = 0.0f;
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
+                    for (int h = 0; h < NC; ++h) {
                         pm[h] = fma_t(heps, gp[h], pm[h]);
                         k1 = fma_t(pm[h] * pm[h], kc[h], k1);
                     }
@@ -424,7 +471,7 @@ __global__ void __launch_bounds__(256) k_chain_mfma(ModelArgs<float, 8> m, Chain
                     lp = llp + lprp;
                 }
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
+                for (int h = 0; h < NC; ++h) {
                     x[h] = acc ? xp[h] : x[h];
                     if constexpr (KIND != KIND_RWMH) g[h] = acc ? gp[h] : g[h];
                 }
@@ -433,21 +480,21 @@ __global__ void __launch_bounds__(256) k_chain_mfma(ModelArgs<float, 8> m, Chain
         if (a.out && writer) {
             float* o = a.out + (it * a.C + chain) * a.p;
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < NC; ++h)
                 if (k + 4 * h < a.p) o[k + 4 * h] = x[h];
         }
-        if (a.stats.buf && writer) {  // the lane owns coordinates k and k + 4
+        if (a.stats.buf && writer) {  // the lane owns coordinates k + 4h
             const int64_t idx = a.stats.first + it, sb = idx / a.stats.batch, sk = idx - sb * a.stats.batch;
             const double inv = 1.0 / (double)(sk + 1);
             double* s = a.stats.buf + ((sb * a.C + chain) * 2) * a.p;
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < NC; ++h)
                 if (k + 4 * h < a.p) stats_fold(s + k + 4 * h, s + a.p + k + 4 * h, sk, inv, (double)x[h]);
         }
     }
     if (writer) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < NC; ++h)
             if (k + 4 * h < a.p) a.state[chain * a.p + k + 4 * h] = x[h];
         if (k == 0) {
             if (a.accepts) a.accepts[chain] += nacc;

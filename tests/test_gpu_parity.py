@@ -318,6 +318,19 @@ def test_planner_engine_choice_by_size(la):
     hm = la.hmcKernel(mm.lpost, mm.glp, eps=0.05, l=10, dmm=np.ones(8))
     assert run_plan(hm, 4096) == {"mode": "mfma", "group": 4, "rows_per_lane": 16}
     assert run_plan(hm, 2048)["mode"] == "reg"
+    # wider models (9 <= p <= 32): the same kernel family from 4 chains per CU; no variant beyond 8 tiles per wave at p > 16
+    def wide_plan(n, p, C, **kw):
+        Xw, yw, _ = la.synthetic_logreg(n, p, seed=n + p)
+        mw = la.LogReg(Xw, yw, np.ones(p))
+        kw_ = la.hmcKernel(mw.lpost, mw.glp, eps=0.05, l=10, dmm=np.ones(p))
+        return la.ChainSet(kw_, np.zeros((C, p)), seed=0, **kw).plan()
+    assert wide_plan(200, 12, 1024) == {"mode": "mfma", "group": 4, "rows_per_lane": 4}
+    assert wide_plan(200, 12, 16384) == {"mode": "mfma", "group": 1, "rows_per_lane": 13}
+    assert wide_plan(200, 12, 512)["mode"] == "reg"
+    assert wide_plan(200, 12, 4096, precision="full")["mode"] == "reg"
+    assert wide_plan(500, 32, 4096) == {"mode": "mfma", "group": 4, "rows_per_lane": 8}
+    assert wide_plan(900, 16, 4096) == {"mode": "mfma", "group": 4, "rows_per_lane": 16}
+    assert wide_plan(900, 32, 4096)["mode"] != "mfma"
 
 
 @pytest.mark.parametrize("engine", ["bf16x3", "fp32"])
@@ -874,3 +887,83 @@ def test_matrix_core_kernel_on_mid_size_data(la, n, R):
         ok2 = r2["margin"] > 2e-3
         assert np.array_equal(i2["accepts"][ok2], r2["accepts"][ok2].astype(np.uint32)), kind
         assert np.max(np.abs(o2[:, ok2] - r2["out"][:, ok2])) < 2e-3 / np.sqrt(n), kind
+
+
+@pytest.mark.parametrize("n,p,group,R", [(200, 12, 4, 4), (200, 12, 1, 13), (500, 16, 4, 8), (900, 16, 4, 16), (200, 32, 4, 4),
+                                         (450, 24, 4, 8), (180, 9, 1, 13)])
+def test_matrix_core_kernel_for_wider_models(la, n, p, group, R):
+    """Padded p = 16 / 32 (9 <= p <= 32): the lane owns p/4 coordinates, eta takes one bf16 MFMA per coordinate pair,
+    the gradient one per pair and tile pair.  Exact mode step-for-step against the oracle for HMC, MALA and RWMH;
+    default mode (bf16 interior steps) close to it with the same decisions away from near-ties; bit-exact reruns,
+    chunking and chain subsets."""
+    from oracle.oracle import OracleModel
+    X, y, _ = la.synthetic_logreg(n, p, seed=n + p, beta_sd=0.5 / np.sqrt(p))
+    ps = np.linspace(0.5, 2.0, p)
+    orc = OracleModel(X, y, ps)
+    m = la.LogReg(X, y, ps)
+    assert m.plan(100, group, "mfma") == {"mode": "mfma", "group": group, "rows_per_lane": R}
+    C = 100
+    b = 0.1 * np.random.default_rng(n).standard_normal((C, p))
+    dmm = np.linspace(0.8, 1.3, p)
+    eps, L = 0.5 / np.sqrt(n), 9
+    k = la.hmcKernel(m.lpost, m.glp, eps=eps, l=L, dmm=dmm)
+    ref = orc.run("hmc", b, step=eps, l=L, scale=dmm, thin=1, iters=3, seed=2, threads=0)
+    kw = dict(thin=1, iters=3, verb=False, seed=2, mode="mfma", group=group)
+    full, fi = la.mcmc(b, k, return_info=True, precision="full", **kw)
+    ok = ref["margin"] > 2e-3
+    assert ok.mean() > 0.9
+    assert np.array_equal(fi["accepts"][ok], ref["accepts"][ok].astype(np.uint32))
+    assert np.max(np.abs(full[:, ok] - ref["out"][:, ok])) < 2e-3 / np.sqrt(n)
+    mixed, mi = la.mcmc(b, k, return_info=True, **kw)
+    wide_ok = ref["margin"] > 0.1
+    assert np.array_equal(mi["accepts"][wide_ok], ref["accepts"][wide_ok].astype(np.uint32))
+    assert np.max(np.abs(mixed[:, wide_ok] - ref["out"][:, wide_ok])) < 5e-2 / np.sqrt(n)
+    assert not np.array_equal(mixed, full)
+    assert np.array_equal(mixed, la.mcmc(b, k, chunk=1, **kw))
+    assert np.array_equal(mixed[:, :37], la.mcmc(b[:37], k, **kw))
+    pre = np.linspace(0.7, 1.4, p)
+    sd = np.full(p, 0.3 / np.sqrt(n))
+    for kind, kern, okw in (("mala", la.malaKernel(m.lpost, m.glp, dt=0.05 / n, pre=pre), dict(step=0.05 / n, scale=pre)),
+                            ("rwmh", la.mhKernel(m.lpost, la.rwProposal(sd)), dict(scale=sd)),
+                            ("ul", la.ulKernel(m.glp, dt=0.02 / n, pre=pre), dict(step=0.02 / n, scale=pre))):
+        ll0 = orc.lpost(b)
+        r2 = orc.run(kind, b, thin=1, iters=2, seed=3, ll_state=ll0, threads=0, **okw)
+        extra = {} if kind == "ul" else dict(ll=ll0)
+        o2, i2 = la.mcmc(b, kern, thin=1, iters=2, verb=False, seed=3, mode="mfma", group=group, return_info=True, **extra)
+        ok2 = r2["margin"] > 2e-3 if kind != "ul" else np.ones(C, bool)
+        if kind != "ul":
+            assert np.array_equal(i2["accepts"][ok2], r2["accepts"][ok2].astype(np.uint32)), kind
+        assert np.max(np.abs(o2[:, ok2] - r2["out"][:, ok2])) < 2e-3 / np.sqrt(n), kind
+
+
+@pytest.mark.parametrize("n,p", [(300, 12), (400, 28)])
+def test_wider_models_sample_the_same_posterior_on_the_matrix_cores(la, n, p):
+    """The planner's default for 9 <= p <= 32 at >= 1024 chains (matrix-core kernel, bf16 interior steps) against the
+    all-fp32 register / LDS kernels: pooled posterior means and sds agree within the between-chain standard errors,
+    acceptance rates within half a point."""
+    X, y, _ = la.synthetic_logreg(n, p, seed=3 * n + p, beta_sd=0.5 / np.sqrt(p))
+    m = la.LogReg(X, y, np.full(p, 2.0))
+    bmap, info = la.find_map(m)
+    eps = 0.9 / np.sqrt(np.max(np.linalg.eigvalsh(info["hessian"]))) / p ** 0.25
+    k = la.hmcKernel(m.lpost, m.glp, eps=eps, l=12, dmm=np.ones(p))
+    C = 2048
+    res = {}
+    for prec, seed in (("auto", 11), ("full", 12)):
+        q0 = la.overdispersed_init(bmap, info["sd"], C, scale=1.5, seed=seed)
+        cs = la.ChainSet(k, q0, seed=seed, precision=prec)
+        assert (cs.plan()["mode"] == "mfma") == (prec == "auto")
+        cs.advance(1, 60, keep=False)
+        a0 = cs.get_accepts().sum()
+        smp = cs.advance(40, 2).to_host().astype(np.float64)
+        acc = (cs.get_accepts().sum() - a0) / (C * 80)
+        mc = smp.mean(axis=0)                       # per-chain means [C, p]
+        vc = ((smp - smp.mean(axis=(0, 1))) ** 2).mean(axis=0)
+        res[prec] = dict(mean=mc.mean(axis=0), se=mc.std(axis=0, ddof=1) / np.sqrt(C), var=vc.mean(axis=0),
+                         se_var=vc.std(axis=0, ddof=1) / np.sqrt(C), acc=acc)
+    a, f = res["auto"], res["full"]
+    zm = (a["mean"] - f["mean"]) / np.sqrt(a["se"] ** 2 + f["se"] ** 2)
+    zv = (a["var"] - f["var"]) / np.sqrt(a["se_var"] ** 2 + f["se_var"] ** 2)
+    print("z(mean)", np.round(zm, 2), "z(var)", np.round(zv, 2), "accept", a["acc"], f["acc"])
+    assert np.max(np.abs(zm)) < 4.0 and np.max(np.abs(zv)) < 4.0
+    assert np.sqrt(np.mean(zm ** 2)) < 1.6 and np.sqrt(np.mean(zv ** 2)) < 1.6
+    assert abs(a["acc"] - f["acc"]) < 0.005
