@@ -214,7 +214,10 @@ def default_policy_runs(la, L, check, dev, stream, kern, init, steps):
         rng = np.random.Generator(np.random.Philox(SEED + 77))
         q0 = init + 0.1 * 0.17 * rng.standard_normal((C, N_PAR))
         row = {"chains": C}
-        for prec in ("auto", "full"):
+        # "full" only at the headline's own chain count: the same kernel and grid as the timed run, so the per-kernel
+        # averages of a rocprofv3 trace of this command stay those of the headline launch (the all-fp32 kernel at the
+        # larger chain counts is in profiles/r2_mfma_chain_grid.txt)
+        for prec in (("auto", "full") if C == CHAINS_PER_GPU else ("auto",)):
             cs = la.ChainSet(kern, q0, seed=SEED, stream=stream, precision=prec)
             cs.advance(2, THIN, keep=False)
             cs.sync()
