@@ -15,6 +15,7 @@
 #include "lr_inst.h"
 #include "lr_kernels.h"
 #include "lr_hessian.h"
+#include "lr_mfma.h"
 #include "lr_stats.h"
 #include "lr_tall.h"
 #include "lr_tall_mx.h"
@@ -85,6 +86,8 @@ struct lr_model {
     void* d_xblk = nullptr;  // wide models: per-32-row-block bf16-piece images of the rows (lr_wide_bf16.h)
     void* d_xblk1 = nullptr;  // wide models: single-piece round-to-nearest images (interior leapfrog steps)
     void* d_xmx = nullptr;    // float32, P = 8: two-piece bf16 tile images for interior leapfrog steps (lr_tall_mx.h)
+    void* d_xmf = nullptr;    // float32, P = 8 / 16, data beyond the register variants of the matrix-core chain kernel but
+                              // within its LDS variant: fp32 MFMA operand images for the end-point evaluations (lr_mfma.h)
     // stepwise-engine workspaces, one per stream (grow-only, owned by the handle): calls enqueued on ONE stream
     // run in order, so they may share a workspace; calls on different streams overlap on the device and get
     // disjoint ones (two ChainSets of one model on two streams, or an eval on the NULL stream beside a run)
@@ -110,6 +113,15 @@ int wide_engine(const lr_model* m, int64_t C) {
     return m->n / rs2 >= 512 ? 2 : 1;
 }
 int64_t wide_chains_per_block(const lr_model* m, int64_t C) { return wide_engine(m, C) == 2 ? 128 : 64; }
+
+// matrix-core chain kernel with its bf16 operands in LDS (lr_mfma.h MfmaRowsLds): bytes for a row split over S waves
+size_t mfma_lds_bytes(const lr_model* m, int S) {
+    const int64_t tiles = (m->n + 15) / 16, ntw = (tiles + S - 1) / S;
+    const size_t nu = (size_t)m->P / 8;
+    return (size_t)S * ((size_t)ntw * nu * 64 * 8 + (size_t)((ntw + 1) / 2) * nu * 64 * 16);
+}
+// 160 KB less the kernel's static exchange buffers (red: 2 x 4 x 64 x P/4 floats, redv: 4 x 64 doubles)
+size_t mfma_lds_budget(const lr_model* m) { return 160 * 1024 - (size_t)512 * m->P - 2048; }
 
 // Choose the kernel variant.  REG (rows in VGPRs) whenever the data fit (G*R >= n), then LDS,
 // then GLOBAL.  Group size: the smallest available G that still gives every SIMD a wavefront
@@ -140,11 +152,16 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
         for (int want_S : try_S) {
             for (int i = 0; want_S && i < t->nvariants; ++i) {
                 const lr::Variant& v = t->variants[i];
-                if (v.mode == lr::MODE_MFMA && v.G == want_S && (int64_t)16 * v.G * v.R >= m->n) {
+                if (v.mode != lr::MODE_MFMA || v.G != want_S) continue;
+                const bool in_lds = v.R == 0;  // listed after the register variants of the same S
+                // operands in LDS (profiles/r2_midn_lds_mfma.txt, HMC L=20, TF, best other kernel | this one): n=2000 p=8: 34 | 24 at
+                // 1024 chains, 48 | 90 at 4096, 82 | 94 at 16 384; n=1150 p=16: 30 | 32, 33 | 120, 81 | 129: from one workgroup per CU
+                if (in_lds && C < 16LL * m->cus) continue;
+                if (in_lds ? mfma_lds_bytes(m, v.G) <= mfma_lds_budget(m) : (int64_t)16 * v.G * v.R >= m->n) {
                     out->mode = v.mode;
                     out->G = v.G;
                     out->R = v.R;
-                    out->lds_bytes = 0;
+                    out->lds_bytes = in_lds ? mfma_lds_bytes(m, v.G) : 0;
                     return LR_OK;
                 }
             }
@@ -212,11 +229,11 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
             // is faster at every chain count measured (profiles/: 1.93e8 vs 1.65e8 it/s at 16 384
             // chains, 2.00e8 vs 1.86e8 at 65 536).
             if (for_eval) continue;
-            if ((int64_t)16 * v.G * v.R < m->n) continue;
+            if (v.R == 0 ? mfma_lds_bytes(m, v.G) > mfma_lds_budget(m) : (int64_t)16 * v.G * v.R < m->n) continue;
             const bool filled = C >= 16LL * want_waves;
             if (mode == LR_MODE_MFMA) {
                 if (group != 0 && v.G != group) continue;
-                const long score = (filled ? (v.G == 1) : (v.G == 4)) ? 2 : 1;
+                const long score = v.R == 0 ? 0 : ((filled ? (v.G == 1) : (v.G == 4)) ? 2 : 1);  // operands in LDS: only when no register variant fits
                 if (score > best_score) { best_score = score; best = i; }
             }
             continue;
@@ -247,7 +264,8 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
     out->mode = v.mode;
     out->G = v.G;
     out->R = v.R;
-    out->lds_bytes = v.mode == lr::MODE_LDS ? (size_t)m->n * m->P * m->esize() : 0;
+    out->lds_bytes = v.mode == lr::MODE_LDS ? (size_t)m->n * m->P * m->esize()
+                     : (v.mode == lr::MODE_MFMA && v.R == 0 ? mfma_lds_bytes(m, v.G) : 0);
     return LR_OK;
 }
 
@@ -255,6 +273,7 @@ template <typename T, int P> lr::ModelArgs<T, P> model_args(const lr_model* m) {
     lr::ModelArgs<T, P> a;
     a.rows = static_cast<const T*>(m->d_rows);
     a.rows_tw = static_cast<const float*>(m->d_rows_tw);
+    a.rows_mf = static_cast<const float*>(m->d_xmf);
     a.n = m->n;
     for (int j = 0; j < P; ++j) a.prior.inv_var[j] = (T)m->inv_var[j];
     a.prior.lprior_const = m->lprior_const;
@@ -805,6 +824,18 @@ int lr_model_create(const double* X, const double* y, int64_t n, int32_t p, cons
             return fail(LR_ERR_NOMEM, "allocating the bf16 tile images (%zu bytes) failed", img.size() * 2);
         }
     }
+    if ((m->P == 8 || m->P == 16) && dtype == LR_F32 && n > 16 * 4 * 16 && mfma_lds_bytes(m, 4) <= mfma_lds_budget(m)) {
+        // the matrix-core chain kernel would keep its bf16 operands in LDS: fp32 operand images for its end points
+        const float* hrows = reinterpret_cast<const float*>(host.data());
+        const size_t fl = (size_t)((n + 15) / 16) * 64 * (m->P == 8 ? lr::mf_image_floats<8>() : lr::mf_image_floats<16>());
+        std::vector<float> img(fl);
+        if (m->P == 8) lr::mf_image_prepare<8>(hrows, n, img.data());
+        else lr::mf_image_prepare<16>(hrows, n, img.data());
+        if (hipMalloc(&m->d_xmf, fl * 4) != hipSuccess || hipMemcpy(m->d_xmf, img.data(), fl * 4, hipMemcpyHostToDevice) != hipSuccess) {
+            lr_model_destroy(m);
+            return fail(LR_ERR_NOMEM, "allocating the fp32 operand images (%zu bytes) failed", fl * 4);
+        }
+    }
     if (m->P > 32) {  // wide models: bf16-piece block images for the exact-split matrix-core kernel
         const float* hrows = reinterpret_cast<const float*>(host.data());
         const int64_t nblk = (n + 31) / 32;
@@ -841,6 +872,7 @@ void lr_model_destroy(lr_model* m) {
     if (m->d_xblk) (void)hipFree(m->d_xblk);
     if (m->d_xblk1) (void)hipFree(m->d_xblk1);
     if (m->d_xmx) (void)hipFree(m->d_xmx);
+    if (m->d_xmf) (void)hipFree(m->d_xmf);
     delete m;
 }
 

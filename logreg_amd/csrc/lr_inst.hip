@@ -44,10 +44,12 @@ constexpr int P = LR_P;
 // matrix-core variants (fp32, padded p = 8 / 16 / 32): X(row-split ways S, tiles per wave NTW), ascending NTW per S;
 // n <= 16*S*NTW.  (4, 8) and (4, 16): mid-size data, n <= 512 / 1024, for HMC with bf16 interior steps.  Operand registers
 // per tile: 2.5 p (p/4 + p/4..p/2 fp32 end-point operands, p bf16 interior operands), so p = 32 stops at 8 tiles.
+// (4, 0): the bf16 operands in LDS instead (MfmaRowsLds: 64 p/8 bytes per row): n <= 2400 at p = 8, 1200 at p = 16; at p = 32
+// the LDS holds no more rows than the registers do.
 #if LR_DTYPE == 0 && LR_P == 8
-#define LR_MFMA_VARIANTS(X) X(1, 13) X(4, 4) X(4, 8) X(4, 16)
+#define LR_MFMA_VARIANTS(X) X(1, 13) X(4, 4) X(4, 8) X(4, 16) X(4, 0)
 #elif LR_DTYPE == 0 && LR_P == 16
-#define LR_MFMA_VARIANTS(X) X(1, 13) X(4, 4) X(4, 8) X(4, 16)
+#define LR_MFMA_VARIANTS(X) X(1, 13) X(4, 4) X(4, 8) X(4, 16) X(4, 0)
 #elif LR_DTYPE == 0 && LR_P == 32
 #define LR_MFMA_VARIANTS(X) X(4, 4) X(4, 8)
 #else
@@ -108,10 +110,10 @@ int launch_mfma_v(const LaunchCfg* cfg, int64_t C, const ModelArgs<T, P>& m, con
     const int64_t per_block = S == 1 ? 64 : 16;
     const dim3 grid((unsigned)((C + per_block - 1) / per_block)), block(256);
     switch (cfg->kind) {
-    case KIND_RWMH: hipLaunchKernelGGL((k_chain_mfma<P, NTW, S, KIND_RWMH>), grid, block, 0, cfg->stream, m, a); break;
-    case KIND_MALA: hipLaunchKernelGGL((k_chain_mfma<P, NTW, S, KIND_MALA>), grid, block, 0, cfg->stream, m, a); break;
-    case KIND_HMC: hipLaunchKernelGGL((k_chain_mfma<P, NTW, S, KIND_HMC>), grid, block, 0, cfg->stream, m, a); break;
-    case KIND_UL: hipLaunchKernelGGL((k_chain_mfma<P, NTW, S, KIND_UL>), grid, block, 0, cfg->stream, m, a); break;
+    case KIND_RWMH: hipLaunchKernelGGL((k_chain_mfma<P, NTW, S, KIND_RWMH>), grid, block, NTW == 0 ? cfg->lds_bytes : 0, cfg->stream, m, a); break;
+    case KIND_MALA: hipLaunchKernelGGL((k_chain_mfma<P, NTW, S, KIND_MALA>), grid, block, NTW == 0 ? cfg->lds_bytes : 0, cfg->stream, m, a); break;
+    case KIND_HMC: hipLaunchKernelGGL((k_chain_mfma<P, NTW, S, KIND_HMC>), grid, block, NTW == 0 ? cfg->lds_bytes : 0, cfg->stream, m, a); break;
+    case KIND_UL: hipLaunchKernelGGL((k_chain_mfma<P, NTW, S, KIND_UL>), grid, block, NTW == 0 ? cfg->lds_bytes : 0, cfg->stream, m, a); break;
     default: return -1;
     }
     return check(hipGetLastError());

@@ -14,6 +14,8 @@ enum Mode { MODE_REG = 0, MODE_LDS = 1, MODE_GLOBAL = 2, MODE_MFMA = 3, MODE_STE
 template <typename T, int P> struct ModelArgs {
     const T* rows;  // [n][P] signed rows (2y-1)*x, zero-padded to P columns (device)
     const float* rows_tw;  // float32 models, P <= 32: the same rows as twisted row pairs (ScalarRowPairs), else null
+    const float* rows_mf;  // float32 models whose matrix-core operands live in LDS: fp32 MFMA operand images per 16-row tile
+                           // (lr_mfma.h mf_image_floats), else null
     int64_t n;
     Prior<T, P> prior;
 };

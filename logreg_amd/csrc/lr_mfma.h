@@ -44,6 +44,14 @@ __device__ __forceinline__ uint32_t mf_pack_rne(float a, float b) {  // two fp32
 }
 __device__ __forceinline__ float mf_hi_f32(uint32_t packed) { return __builtin_bit_cast(float, packed << 16); }
 
+// rows[row][coord] for row < n, else 0 -- without a branch: a guarded load is a basic block of its own with its own
+// vmcnt(0), and the operand builds below issue hundreds of them per launch (measured on the LDS variant at n = 2000:
+// 190 serial L2 round trips = 25 us per launch of 10 iterations)
+template <int P> __device__ __forceinline__ float mf_row_or_zero(const float* __restrict__ rows, int64_t n, int64_t row, int coord) {
+    const float v = rows[(row < n ? row : n - 1) * P + coord];
+    return row < n ? v : 0.0f;
+}
+
 template <int P, int NTW, int S> struct MfmaRows {
     static constexpr int NC = P / 4;             // coordinates per lane: j_h = k + 4 h
     static constexpr int NU = NC / 2;            // coordinate pairs (h = 2u, 2u + 1): one bf16 MFMA each
@@ -77,18 +85,18 @@ template <int P, int NTW, int S> struct MfmaRows {
             const int64_t base = 16 * ((int64_t)t * S + wave);
             const int64_t ra = base + c;
 #pragma unroll
-            for (int h = 0; h < NC; ++h) xa[t][h] = ra < n ? rows[ra * P + k + 4 * h] : 0.0f;
+            for (int h = 0; h < NC; ++h) xa[t][h] = mf_row_or_zero<P>(rows, n, ra, k + 4 * h);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const int64_t rg = base + 4 * k + s;
 #pragma unroll
-                for (int g = 0; g < NG; ++g) xg[t][g][s] = (rg < n && rp < HG) ? rows[rg * P + kp + 4 * rp + 16 * g] : 0.0f;
+                for (int g = 0; g < NG; ++g) xg[t][g][s] = rp < HG ? mf_row_or_zero<P>(rows, n, rg, kp + 4 * (rp < HG ? rp : 0) + 16 * g) : 0.0f;
                 if (rg >= n) ++pad_rows;
             }
         }
         // bf16 operands of the interior steps
         auto piece = [&](int64_t row, int coord, int lo) {  // bf16 bit pattern of the hi / lo piece of X[row][coord]
-            const float x = row < n ? rows[row * P + coord] : 0.0f;
+            const float x = mf_row_or_zero<P>(rows, n, row, coord);
             const uint32_t h = mf_pack_rne(x, x) & 0xFFFFu;
             if (!lo) return h;
             return mf_pack_rne(x - mf_hi_f32(h), 0.0f) & 0xFFFFu;
@@ -103,7 +111,7 @@ template <int P, int NTW, int S> struct MfmaRows {
                 uint32_t hl[2];
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const float xs = base + c < n ? rows[(base + c) * P + k + 8 * u + 4 * h] * ExpScale<float>::k : 0.0f;
+                    const float xs = mf_row_or_zero<P>(rows, n, base + c, k + 8 * u + 4 * h) * ExpScale<float>::k;
                     const uint32_t hi = mf_pack_rne(xs, xs) & 0xFFFFu;
                     hl[h] = hi | (mf_pack_rne(0.0f, xs - mf_hi_f32(hi)) & 0xFFFF0000u);
                 }
@@ -231,6 +239,241 @@ template <int P, int NTW, int S> struct MfmaRows {
     }
 };
 
+// The same operands kept in LDS instead of registers, for data beyond the register variants (16 S NTW < n): every wave of
+// a row-split workgroup builds the bf16 images of ITS tiles in a private LDS region at kernel start (64 p/8 bytes per
+// row: n <= 2400 at p = 8, 1200 at p = 16) and the interior steps stream them back (ds_read_b64 / b128 per
+// lane and tile, 1.5 KB per tile and wave against ~100 cycles of MFMA + VALU work).  The end-point evaluations (2 of
+// L + 1) take their fp32 operands straight from the row matrix in global memory (L2-resident).
+// fp32 operand image of the end-point evaluations, per GLOBAL 16-row tile T (row-split independent) and lane (c, k):
+//   [T][lane][0 .. NC)            A operand of the eta MFMAs:      rows[16T + c][k + 4h]
+//   [T][lane][NC + 4g + s]        A operand of the gradient MFMAs: rows[16T + 4k + s][c/4 + 4 (c%4) + 16g]  (0 if c%4 >= HG)
+// so that a lane's operands of a tile are (NC + 4 NG) consecutive floats: two or three wide, fully coalesced loads
+// per tile instead of NC + 4 NG scattered dword loads (which kept the TCP / L2 busy for 2000 cycles per tile).
+template <int P> constexpr int mf_image_floats() { return P / 4 + 4 * ((P / 4 + 3) / 4); }
+template <int P> inline void mf_image_prepare(const float* rows, int64_t n, float* out) {
+    constexpr int NC = P / 4, NG = (NC + 3) / 4, HG = NC < 4 ? NC : 4, F = mf_image_floats<P>();
+    const int64_t tiles = (n + 15) / 16;
+    for (int64_t T = 0; T < tiles; ++T)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int c = lane & 15, k = lane >> 4, rp = c & 3, kp = c >> 2;
+            float* o = out + ((size_t)T * 64 + lane) * F;
+            const int64_t ra = 16 * T + c;
+            for (int h = 0; h < NC; ++h) o[h] = ra < n ? rows[ra * P + k + 4 * h] : 0.0f;
+            for (int g = 0; g < NG; ++g)
+                for (int s = 0; s < 4; ++s) {
+                    const int64_t rg = 16 * T + 4 * k + s;
+                    o[NC + 4 * g + s] = (rg < n && rp < HG) ? rows[rg * P + kp + 4 * rp + 16 * g] : 0.0f;
+                }
+        }
+}
+
+extern __shared__ __attribute__((aligned(16))) unsigned char lr_mfma_dyn_smem[];
+template <int P, int S> struct MfmaRowsLds {
+    static constexpr int NC = P / 4, NU = NC / 2, NG = (NC + 3) / 4, HG = NC < 4 ? NC : 4;
+    static constexpr int NPAIR = 1;  // no per-pair-count code versions: the tile loops are run-time loops
+    static __host__ __device__ constexpr size_t bytes_per_wave(int64_t ntw) {  // eta images for an even number of tiles
+        return (size_t)((ntw + 1) / 2) * 2 * NU * 64 * 8 + (size_t)((ntw + 1) / 2) * NU * 64 * 16;
+    }
+    const float* rows;
+    const float* image;  // mf_image_prepare layout, or null (then the operands are gathered from `rows`)
+    int64_t n;
+    int wave, lane, ntw, ntile_live;
+    mf_u32x2* xe;  // [ntw][NU][64]
+    mf_u32x4* xq;  // [(ntw + 1) / 2][NU][64]
+
+    __device__ __forceinline__ void load(const float* __restrict__ rows_, int64_t n_, int wave_, int lane_) {
+        rows = rows_;
+        n = n_;
+        wave = wave_;
+        lane = lane_;
+        const int c = lane & 15, k = lane >> 4;
+        const int64_t tiles = (n + 15) / 16;
+        ntw = (int)((tiles + S - 1) / S);
+        const int npair = (ntw + 1) / 2;
+        unsigned char* base = lr_mfma_dyn_smem + (size_t)wave * bytes_per_wave(ntw);
+        xq = reinterpret_cast<mf_u32x4*>(base);
+        xe = reinterpret_cast<mf_u32x2*>(base + (size_t)npair * NU * 64 * 16);
+        auto piece = [&](int64_t row, int coord, int lo) {
+            const float x = mf_row_or_zero<P>(rows, n, row, coord);
+            const uint32_t h = mf_pack_rne(x, x) & 0xFFFFu;
+            if (!lo) return h;
+            return mf_pack_rne(x - mf_hi_f32(h), 0.0f) & 0xFFFFu;
+        };
+        ntile_live = 0;
+        for (int t = 0; t < 2 * npair; ++t) {  // (an odd tile count: one all-zero image at the end)
+            const int64_t row0 = t < ntw ? 16 * ((int64_t)t * S + wave) : n;
+            if (row0 < n) ntile_live = t + 1;
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                uint32_t hl[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float xs = mf_row_or_zero<P>(rows, n, row0 + c, k + 8 * u + 4 * h) * ExpScale<float>::k;
+                    const uint32_t hi = mf_pack_rne(xs, xs) & 0xFFFFu;
+                    hl[h] = hi | (mf_pack_rne(0.0f, xs - mf_hi_f32(hi)) & 0xFFFF0000u);
+                }
+                xe[(t * NU + u) * 64 + lane] = mf_u32x2{hl[0], hl[1]};
+            }
+        }
+        const int grp = c >> 2, el = c & 3;
+        const int gcoord = grp + 4 * (el >> 1), glo = el & 1;
+        for (int pi = 0; pi < npair; ++pi) {
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                uint32_t v[8];
+#pragma unroll
+                for (int sl = 0; sl < 8; ++sl) {
+                    const int t = 2 * pi + (sl >> 2);
+                    const int64_t row = 16 * ((int64_t)t * S + wave) + 4 * k + (sl & 3);
+                    v[sl] = t < ntw ? piece(row, gcoord + 8 * u, glo) : 0u;
+                }
+                xq[(pi * NU + u) * 64 + lane] = mf_u32x4{v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16)};
+            }
+        }
+    }
+
+    template <int NPL> __device__ __forceinline__ void eval_bf16(const float (&q)[NC], float (&gl)[NC]) const {
+        mf_u32x4 bb[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const uint32_t ha = mf_pack_rne(q[2 * u], q[2 * u]), hb = mf_pack_rne(q[2 * u + 1], q[2 * u + 1]);
+            const float la = q[2 * u] - mf_hi_f32(ha), lb = q[2 * u + 1] - mf_hi_f32(hb);
+            bb[u] = mf_u32x4{ha, mf_pack_rne(la, la), hb, mf_pack_rne(lb, lb)};
+        }
+        f32x4 gacc[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) gacc[u] = f32x4{0, 0, 0, 0};
+        const int npl = (ntile_live + 1) >> 1;
+        auto pair_work = [&](int pi) {
+            mf_u32x2 he[2][NU];
+            mf_u32x4 hq[NU];
+#pragma unroll
+            for (int T = 0; T < 2; ++T)
+#pragma unroll
+                for (int u = 0; u < NU; ++u) he[T][u] = xe[((2 * pi + T) * NU + u) * 64 + lane];
+#pragma unroll
+            for (int u = 0; u < NU; ++u) hq[u] = xq[(pi * NU + u) * 64 + lane];
+            uint32_t wq[4];
+#pragma unroll
+            for (int T = 0; T < 2; ++T) {
+                f32x4 e = {0, 0, 0, 0};
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    const mf_u32x4 av = {he[T][u][0], he[T][u][0], he[T][u][1], he[T][u][1]};
+                    e = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mf_bf16x8, av), __builtin_bit_cast(mf_bf16x8, bb[u]), e, 0, 0, 0);
+                }
+                const mf_f32x2 d0 = mf_f32x2{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])} + mf_f32x2{1.0f, 1.0f};
+                const mf_f32x2 d1 = mf_f32x2{__builtin_amdgcn_exp2f(e[2]), __builtin_amdgcn_exp2f(e[3])} + mf_f32x2{1.0f, 1.0f};
+                wq[2 * T] = mf_pack_rne(fast_rcp(d0.x), fast_rcp(d0.y));
+                wq[2 * T + 1] = mf_pack_rne(fast_rcp(d1.x), fast_rcp(d1.y));
+            }
+            const mf_u32x4 wv = {wq[0], wq[1], wq[2], wq[3]};
+#pragma unroll
+            for (int u = 0; u < NU; ++u)
+                gacc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mf_bf16x8, hq[u]), __builtin_bit_cast(mf_bf16x8, wv), gacc[u], 0, 0, 0);
+        };
+        // two pairs per trip: the scheduler lifts all eight LDS reads of the trip to its top, so the second pair's latency
+        // hides under the first pair's work (one wave per SIMD: nothing else would hide it)
+        int pi = 0;
+        for (; pi + 1 < npl; pi += 2) {
+            pair_work(pi);
+            pair_work(pi + 1);
+        }
+        if (pi < npl) pair_work(pi);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            gl[2 * u] = gacc[u][0] + gacc[u][1];
+            gl[2 * u + 1] = gacc[u][2] + gacc[u][3];
+        }
+    }
+
+    template <bool VALUE>
+    __device__ __forceinline__ void eval(const float (&q)[NC], float (&gl)[NC], float& vsum) const {
+        const int c = lane & 15, k = lane >> 4;
+        const int rp = c & 3, kp = c >> 2;
+        float bs[NC];
+#pragma unroll
+        for (int h = 0; h < NC; ++h) bs[h] = q[h] * ExpScale<float>::k;
+        f32x4 ga[NG], gb[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) ga[g] = gb[g] = f32x4{0, 0, 0, 0};
+        float v = 0.0f;
+        int pad = 0;
+        // the fp32 operands come from global memory (L2): blocks of TB tiles, the next block requested before the current
+        // one is worked on (one tile ahead left 2200 cycles per tile, mostly L2 latency; the operands-in-registers
+        // variant spends 730 on the same arithmetic)
+        constexpr int TB = P <= 8 ? 4 : 2;
+        float ca[TB][NC], cg[TB][NG][4];
+        auto fetch = [&](int t0, float (&fa)[TB][NC], float (&fg)[TB][NG][4]) {
+#pragma unroll
+            for (int i = 0; i < TB; ++i) {
+                const int64_t row0 = 16 * ((int64_t)(t0 + i) * S + wave);  // tiles past the wave's last one: rows >= n, masked to 0
+                if (image) {
+                    const int64_t T = (t0 + i) * S + wave, tiles = (n + 15) / 16;
+                    const float* o = image + ((size_t)(T < tiles ? T : tiles - 1) * 64 + lane) * mf_image_floats<P>();
+#pragma unroll
+                    for (int h = 0; h < NC; ++h) fa[i][h] = T < tiles ? o[h] : 0.0f;
+#pragma unroll
+                    for (int g = 0; g < NG; ++g)
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) fg[i][g][s] = T < tiles ? o[NC + 4 * g + s] : 0.0f;
+                    continue;
+                }
+#pragma unroll
+                for (int h = 0; h < NC; ++h) fa[i][h] = mf_row_or_zero<P>(rows, n, row0 + c, k + 4 * h);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int g = 0; g < NG; ++g)
+                        fg[i][g][s] = rp < HG ? mf_row_or_zero<P>(rows, n, row0 + 4 * k + s, kp + 4 * (rp < HG ? rp : 0) + 16 * g) : 0.0f;
+            }
+        };
+        fetch(0, ca, cg);
+        for (int t0 = 0; t0 < ntile_live; t0 += TB) {
+            float na[TB][NC], ng[TB][NG][4];
+            fetch(t0 + TB, na, ng);
+#pragma unroll
+            for (int i = 0; i < TB; ++i) {
+                if (t0 + i < ntile_live) {
+                    const int64_t row0 = 16 * ((int64_t)(t0 + i) * S + wave);
+                    f32x4 e = {0, 0, 0, 0};
+#pragma unroll
+                    for (int h = 0; h < NC; ++h) e = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[i][h], bs[h], e, 0, 0, 0);
+                    float w[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        w[r] = fast_rcp(1.0f + __builtin_amdgcn_exp2f(e[r]));
+                        if constexpr (VALUE) {
+                            const float ats = e[r] < 0.0f ? -e[r] : e[r];
+                            v += (e[r] < 0.0f ? e[r] * ExpScale<float>::inv : 0.0f) - log1p_unit(__builtin_amdgcn_exp2f(-ats));
+                        }
+                        if (row0 + 4 * k + r >= n) ++pad;
+                    }
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        ga[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(cg[i][g][0], w[0], ga[g], 0, 0, 0);
+                        gb[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(cg[i][g][1], w[1], gb[g], 0, 0, 0);
+                        ga[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(cg[i][g][2], w[2], ga[g], 0, 0, 0);
+                        gb[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(cg[i][g][3], w[3], gb[g], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < TB; ++i) {
+#pragma unroll
+                for (int h = 0; h < NC; ++h) ca[i][h] = na[i][h];
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+#pragma unroll
+                    for (int s2 = 0; s2 < 4; ++s2) cg[i][g][s2] = ng[i][g][s2];
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < NC; ++h) gl[h] = ga[h >> 2][h & 3] + gb[h >> 2][h & 3];
+        if constexpr (VALUE) vsum = v + (float)pad * 0.693147180559945309f;
+    }
+};
+
 // f(integral_constant<int, max(n, 1)>) for a run-time 1 <= n <= N
 template <int N, typename F> __device__ __forceinline__ void for_pair_count(int n, F&& f) {
     if constexpr (N <= 1) {
@@ -258,8 +501,10 @@ __global__ void __launch_bounds__(256) k_chain_mfma(ModelArgs<float, P> m, Chain
     const bool writer = live && (S == 1 || wave == 0);
     const uint64_t gchain = (uint64_t)(a.chain_offset + chain);
 
-    MfmaRows<P, NTW, S> rows;
+    using Rows = std::conditional_t<NTW == 0, MfmaRowsLds<P, S>, MfmaRows<P, (NTW == 0 ? 1 : NTW), S>>;  // NTW = 0: operands in LDS
+    Rows rows;
     rows.load(m.rows, m.n, S == 1 ? 0 : wave, lane);
+    if constexpr (NTW == 0) rows.image = m.rows_mf;
 
     // the lane's coordinates: j_h = k + 4h
     auto pick = [&](const float (&v)[P], int h) {
@@ -434,7 +679,7 @@ __global__ void __launch_bounds__(256) k_chain_mfma(ModelArgs<float, P> m, Chain
                     if (a.interior_bf16) {
                         // the whole interior loop once per live pair count (wave-uniform; every wave of a row-split
                         // workgroup still meets the same l - 1 barriers)
-                        for_pair_count<MfmaRows<P, NTW, S>::NPAIR>((rows.ntile_live + 1) >> 1, [&](auto npl) {
+                        for_pair_count<Rows::NPAIR>((rows.ntile_live + 1) >> 1, [&](auto npl) {
                             for (int i = 0; i < a.l - 1; ++i) {
 #pragma unroll
                                 for (int h = 0; h < NC; ++h) xp[h] = fma_t(kb[h], pm[h], xp[h]);
