@@ -653,14 +653,13 @@ template <typename T, int P, int R, int G> struct RegRows {
         pad_rows = 0;
 #pragma unroll
         for (int k = 0; k < R; ++k) {
-            const int64_t i = gl + (int64_t)k * G;
-            if (i < n) {
+            // branch-free (rows past the end read the last row and are masked): a guarded load is a basic block per element
+            const int64_t i = gl + (int64_t)k * G, ic = i < n ? i : n - 1;
+            if (i >= n) ++pad_rows;
 #pragma unroll
-                for (int j = 0; j < P; ++j) x[k][j] = rows[i * P + j];
-            } else {
-                ++pad_rows;
-#pragma unroll
-                for (int j = 0; j < P; ++j) x[k][j] = T(0);
+            for (int j = 0; j < P; ++j) {
+                const T v = rows[ic * P + j];
+                x[k][j] = i < n ? v : T(0);
             }
         }
     }
@@ -692,9 +691,10 @@ template <int P, int R, int G> struct RegRowPairs {
     int pad_rows;
     __device__ __forceinline__ void load(const float* __restrict__ rows, int64_t n, int gl) {
         pad_rows = 0;
-        auto at = [&](int k, int j) {  // element j of the lane's k-th row (zero beyond n)
+        auto at = [&](int k, int j) {  // element j of the lane's k-th row (zero beyond n); branch-free: clamped load, then mask
             const int64_t i = gl + (int64_t)k * G;
-            return i < n ? rows[i * P + j] : 0.0f;
+            const float v = rows[(i < n ? i : n - 1) * P + j];
+            return i < n ? v : 0.0f;
         };
 #pragma unroll
         for (int k = 0; k < R; ++k)
