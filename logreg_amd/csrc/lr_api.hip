@@ -86,8 +86,9 @@ struct lr_model {
     void* d_xblk = nullptr;  // wide models: per-32-row-block bf16-piece images of the rows (lr_wide_bf16.h)
     void* d_xblk1 = nullptr;  // wide models: single-piece round-to-nearest images (interior leapfrog steps)
     void* d_xmx = nullptr;    // float32, P = 8: two-piece bf16 tile images for interior leapfrog steps (lr_tall_mx.h)
-    void* d_xmf = nullptr;    // float32, P = 8 / 16, data beyond the register variants of the matrix-core chain kernel but
-                              // within its LDS variant: fp32 MFMA operand images for the end-point evaluations (lr_mfma.h)
+    void* d_xmf = nullptr;    // float32, P = 8 / 16, data beyond the register variants of the matrix-core chain kernel:
+                              // fp32 MFMA operand images for the end-point evaluations (lr_mfma.h)
+    void* d_xms = nullptr;    // ... and beyond its LDS variant: the bf16 operand images of the interior steps in device memory
     // stepwise-engine workspaces, one per stream (grow-only, owned by the handle): calls enqueued on ONE stream
     // run in order, so they may share a workspace; calls on different streams overlap on the device and get
     // disjoint ones (two ChainSets of one model on two streams, or an eval on the NULL stream beside a run)
@@ -153,6 +154,18 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
             for (int i = 0; want_S && i < t->nvariants; ++i) {
                 const lr::Variant& v = t->variants[i];
                 if (v.mode != lr::MODE_MFMA || v.G != want_S) continue;
+                if (v.R < 0) {  // operands in device memory: listed last; needs the images built at model creation
+                    // (profiles/r2_midn_lds_mfma.txt, HMC L=20, TF, stepwise | this: n=3000 p=8: 43 | 81 at 4096 chains, 92 | 102 at 16 384;
+                    //  n=5000 p=8: 63 | 85, 111 | 112; n=10 000 p=8: 88 | 90, 131 | 118; n=3000 p=16: 66 | 121, 130 | 146; n=8000 p=16: 109 | 135, 174 | 162)
+                    //  p > 16: n=700 p=30: 31 | 74, 69 | 74; n=2000 p=20: 46 | 74, 85 | 80; n=5000 p=30: 105 | 132, 176 | 135; n=8000 p=24: 108 | 112, 160 | 115)
+                    const int64_t max_rows = C >= 64LL * m->cus ? (m->P == 32 ? 2000 : 4000) : (m->P == 16 ? 8192 : 6000);
+                    if (!m->d_xms || C < 16LL * m->cus || m->n > max_rows) continue;
+                    out->mode = v.mode;
+                    out->G = v.G;
+                    out->R = v.R;
+                    out->lds_bytes = 0;
+                    return LR_OK;
+                }
                 const bool in_lds = v.R == 0;  // listed after the register variants of the same S
                 // operands in LDS (profiles/r2_midn_lds_mfma.txt, HMC L=20, TF, best other kernel | this one): n=2000 p=8: 34 | 24 at
                 // 1024 chains, 48 | 90 at 4096, 82 | 94 at 16 384; n=1150 p=16: 30 | 32, 33 | 120, 81 | 129: from one workgroup per CU
@@ -229,11 +242,13 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
             // is faster at every chain count measured (profiles/: 1.93e8 vs 1.65e8 it/s at 16 384
             // chains, 2.00e8 vs 1.86e8 at 65 536).
             if (for_eval) continue;
-            if (v.R == 0 ? mfma_lds_bytes(m, v.G) > mfma_lds_budget(m) : (int64_t)16 * v.G * v.R < m->n) continue;
+            if (v.R < 0 ? m->d_xms == nullptr
+                        : (v.R == 0 ? mfma_lds_bytes(m, v.G) > mfma_lds_budget(m) : (int64_t)16 * v.G * v.R < m->n)) continue;
             const bool filled = C >= 16LL * want_waves;
             if (mode == LR_MODE_MFMA) {
                 if (group != 0 && v.G != group) continue;
-                const long score = v.R == 0 ? 0 : ((filled ? (v.G == 1) : (v.G == 4)) ? 2 : 1);  // operands in LDS: only when no register variant fits
+                // operands in LDS / device memory: only when no register variant fits
+                const long score = v.R <= 0 ? 0 : ((filled ? (v.G == 1) : (v.G == 4)) ? 2 : 1);
                 if (score > best_score) { best_score = score; best = i; }
             }
             continue;
@@ -274,6 +289,7 @@ template <typename T, int P> lr::ModelArgs<T, P> model_args(const lr_model* m) {
     a.rows = static_cast<const T*>(m->d_rows);
     a.rows_tw = static_cast<const float*>(m->d_rows_tw);
     a.rows_mf = static_cast<const float*>(m->d_xmf);
+    a.ops_mf = static_cast<const unsigned char*>(m->d_xms);
     a.n = m->n;
     for (int j = 0; j < P; ++j) a.prior.inv_var[j] = (T)m->inv_var[j];
     a.prior.lprior_const = m->lprior_const;
@@ -824,16 +840,28 @@ int lr_model_create(const double* X, const double* y, int64_t n, int32_t p, cons
             return fail(LR_ERR_NOMEM, "allocating the bf16 tile images (%zu bytes) failed", img.size() * 2);
         }
     }
-    if ((m->P == 8 || m->P == 16) && dtype == LR_F32 && n > 16 * 4 * 16 && mfma_lds_bytes(m, 4) <= mfma_lds_budget(m)) {
+    // rows the matrix-core chain kernel still takes with its operands streamed from device memory (profiles/r2_midn_lds_mfma.txt)
+    const int64_t kMfmaStreamMaxRows = 8192;
+    if (m->P >= 8 && m->P <= 32 && dtype == LR_F32 && n > (m->P == 32 ? 16 * 4 * 8 : 16 * 4 * 16) && n <= kMfmaStreamMaxRows) {
         // the matrix-core chain kernel would keep its bf16 operands in LDS: fp32 operand images for its end points
         const float* hrows = reinterpret_cast<const float*>(host.data());
-        const size_t fl = (size_t)((n + 15) / 16) * 64 * (m->P == 8 ? lr::mf_image_floats<8>() : lr::mf_image_floats<16>());
+        const size_t fl = (size_t)((n + 15) / 16) * 64 *
+                          (m->P == 8 ? lr::mf_image_floats<8>() : (m->P == 16 ? lr::mf_image_floats<16>() : lr::mf_image_floats<32>()));
         std::vector<float> img(fl);
         if (m->P == 8) lr::mf_image_prepare<8>(hrows, n, img.data());
-        else lr::mf_image_prepare<16>(hrows, n, img.data());
+        else if (m->P == 16) lr::mf_image_prepare<16>(hrows, n, img.data());
+        else lr::mf_image_prepare<32>(hrows, n, img.data());
         if (hipMalloc(&m->d_xmf, fl * 4) != hipSuccess || hipMemcpy(m->d_xmf, img.data(), fl * 4, hipMemcpyHostToDevice) != hipSuccess) {
             lr_model_destroy(m);
             return fail(LR_ERR_NOMEM, "allocating the fp32 operand images (%zu bytes) failed", fl * 4);
+        }
+        if (mfma_lds_bytes(m, 4) > mfma_lds_budget(m) && m->table->mfma_image_bytes && m->table->launch_mfma_image) {
+            const size_t ib = m->table->mfma_image_bytes(n);  // beyond LDS: the interior operands, built on the device once
+            if (hipMalloc(&m->d_xms, ib) != hipSuccess || m->table->launch_mfma_image(nullptr, m->d_rows, n, m->d_xms) != 0 ||
+                hipDeviceSynchronize() != hipSuccess) {
+                lr_model_destroy(m);
+                return fail(LR_ERR_NOMEM, "building the bf16 operand images (%zu bytes) failed", ib);
+            }
         }
     }
     if (m->P > 32) {  // wide models: bf16-piece block images for the exact-split matrix-core kernel
@@ -873,6 +901,7 @@ void lr_model_destroy(lr_model* m) {
     if (m->d_xblk1) (void)hipFree(m->d_xblk1);
     if (m->d_xmx) (void)hipFree(m->d_xmx);
     if (m->d_xmf) (void)hipFree(m->d_xmf);
+    if (m->d_xms) (void)hipFree(m->d_xms);
     delete m;
 }
 

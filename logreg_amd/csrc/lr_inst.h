@@ -27,6 +27,10 @@ struct InstTable {
                               const void* tall_args);
     // wide models: all L - 1 interior leapfrog steps of an HMC trajectory in one launch (lr_wide_bf16.h); may be null
     int (*launch_tall_traj)(hipStream_t, const void* tall_args);
+    // matrix-core chain kernel, operands in device memory: bytes of the bf16 operand images for n rows (0 = not available at
+    // this width) and the one-off build into `store`; may be null
+    size_t (*mfma_image_bytes)(int64_t n);
+    int (*launch_mfma_image)(hipStream_t, const void* rows, int64_t n, void* store);
 };
 
 }  // namespace lr

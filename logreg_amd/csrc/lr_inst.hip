@@ -45,13 +45,13 @@ constexpr int P = LR_P;
 // n <= 16*S*NTW.  (4, 8) and (4, 16): mid-size data, n <= 512 / 1024, for HMC with bf16 interior steps.  Operand registers
 // per tile: 2.5 p (p/4 + p/4..p/2 fp32 end-point operands, p bf16 interior operands), so p = 32 stops at 8 tiles.
 // (4, 0): the bf16 operands in LDS instead (MfmaRowsLds: 64 p/8 bytes per row): n <= 2400 at p = 8, 1200 at p = 16; at p = 32
-// the LDS holds no more rows than the registers do.
+// the LDS holds no more rows than the registers do.  (4, -1): the same images in device memory, built once per model.
 #if LR_DTYPE == 0 && LR_P == 8
-#define LR_MFMA_VARIANTS(X) X(1, 13) X(4, 4) X(4, 8) X(4, 16) X(4, 0)
+#define LR_MFMA_VARIANTS(X) X(1, 13) X(4, 4) X(4, 8) X(4, 16) X(4, 0) X(4, -1)
 #elif LR_DTYPE == 0 && LR_P == 16
-#define LR_MFMA_VARIANTS(X) X(1, 13) X(4, 4) X(4, 8) X(4, 16) X(4, 0)
+#define LR_MFMA_VARIANTS(X) X(1, 13) X(4, 4) X(4, 8) X(4, 16) X(4, 0) X(4, -1)
 #elif LR_DTYPE == 0 && LR_P == 32
-#define LR_MFMA_VARIANTS(X) X(4, 4) X(4, 8)
+#define LR_MFMA_VARIANTS(X) X(4, 4) X(4, 8) X(4, -1)
 #else
 #define LR_MFMA_VARIANTS(X)
 #endif
@@ -120,6 +120,21 @@ int launch_mfma_v(const LaunchCfg* cfg, int64_t C, const ModelArgs<T, P>& m, con
 }
 #endif
 
+#if LR_DTYPE == 0 && LR_P >= 8
+size_t mfma_image_bytes(int64_t n) {
+    const int64_t tiles = (n + 15) / 16, ntw = (tiles + 3) / 4;
+    return 4 * MfmaRowsLds<P, 4, true>::bytes_per_wave(ntw);
+}
+int launch_mfma_image(hipStream_t st, const void* rows, int64_t n, void* store) {
+    hipLaunchKernelGGL((k_mfma_image_build<P, 4>), dim3(1), dim3(256), 0, st, static_cast<const float*>(rows), n,
+                       static_cast<unsigned char*>(store));
+    return check(hipGetLastError());
+}
+#define LR_MFMA_IMAGE_HOOKS &mfma_image_bytes, &launch_mfma_image
+#else
+#define LR_MFMA_IMAGE_HOOKS nullptr, nullptr
+#endif
+
 int launch_eval(const LaunchCfg* cfg, int64_t C, const void* model_args, const void* eval_args) {
     const auto& m = *static_cast<const ModelArgs<T, P>*>(model_args);
     const auto& a = *static_cast<const EvalArgs<T>*>(eval_args);
@@ -172,7 +187,7 @@ int launch_tall_update(hipStream_t st, int kind, int phase, int64_t iter, int64_
 }
 
 const InstTable kTable = {LR_DTYPE, P, (int)(sizeof(kVariants) / sizeof(kVariants[0])), kVariants, &launch_eval,
-                          &launch_chain, &launch_tall_partial, &launch_tall_update, nullptr};
+                          &launch_chain, &launch_tall_partial, &launch_tall_update, nullptr, LR_MFMA_IMAGE_HOOKS};
 
 }  // namespace
 }  // namespace lr

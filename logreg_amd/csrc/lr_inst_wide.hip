@@ -61,7 +61,7 @@ int launch_tall_traj(hipStream_t st, const void* tall_args) {
     return check(hipGetLastError());
 }
 
-const InstTable kTable = {0, P, 0, nullptr, nullptr, nullptr, &launch_tall_partial, &launch_tall_update, &launch_tall_traj};
+const InstTable kTable = {0, P, 0, nullptr, nullptr, nullptr, &launch_tall_partial, &launch_tall_update, &launch_tall_traj, nullptr, nullptr};
 
 }  // namespace
 }  // namespace lr

@@ -16,6 +16,7 @@ template <typename T, int P> struct ModelArgs {
     const float* rows_tw;  // float32 models, P <= 32: the same rows as twisted row pairs (ScalarRowPairs), else null
     const float* rows_mf;  // float32 models whose matrix-core operands live in LDS: fp32 MFMA operand images per 16-row tile
                            // (lr_mfma.h mf_image_floats), else null
+    const unsigned char* ops_mf;  // float32 models beyond that: the bf16 operand images in device memory (MfmaRowsLds<P, 4, true>), else null
     int64_t n;
     Prior<T, P> prior;
 };

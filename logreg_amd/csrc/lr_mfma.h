@@ -268,7 +268,10 @@ template <int P> inline void mf_image_prepare(const float* rows, int64_t n, floa
 }
 
 extern __shared__ __attribute__((aligned(16))) unsigned char lr_mfma_dyn_smem[];
-template <int P, int S> struct MfmaRowsLds {
+// GLOBAL = true: the same images, built once per model by k_mfma_image_build into device memory (one region per wave of the
+// row split, identical for every workgroup) for data beyond LDS; the interior steps then stream them from L2 with the
+// operands of the next two tile pairs requested while the current two are worked on.
+template <int P, int S, bool GLOBAL = false> struct MfmaRowsLds {
     static constexpr int NC = P / 4, NU = NC / 2, NG = (NC + 3) / 4, HG = NC < 4 ? NC : 4;
     static constexpr int NPAIR = 1;  // no per-pair-count code versions: the tile loops are run-time loops
     static __host__ __device__ constexpr size_t bytes_per_wave(int64_t ntw) {  // eta images for an even number of tiles
@@ -281,28 +284,37 @@ template <int P, int S> struct MfmaRowsLds {
     mf_u32x2* xe;  // [ntw][NU][64]
     mf_u32x4* xq;  // [(ntw + 1) / 2][NU][64]
 
-    __device__ __forceinline__ void load(const float* __restrict__ rows_, int64_t n_, int wave_, int lane_) {
+    // point at the wave's image region inside `store` (LDS or device memory); no data is touched
+    __device__ __forceinline__ void attach(const float* __restrict__ rows_, int64_t n_, int wave_, int lane_, unsigned char* store) {
         rows = rows_;
         n = n_;
         wave = wave_;
         lane = lane_;
-        const int c = lane & 15, k = lane >> 4;
         const int64_t tiles = (n + 15) / 16;
         ntw = (int)((tiles + S - 1) / S);
         const int npair = (ntw + 1) / 2;
-        unsigned char* base = lr_mfma_dyn_smem + (size_t)wave * bytes_per_wave(ntw);
+        unsigned char* base = store + (size_t)wave * bytes_per_wave(ntw);
         xq = reinterpret_cast<mf_u32x4*>(base);
         xe = reinterpret_cast<mf_u32x2*>(base + (size_t)npair * NU * 64 * 16);
+        const int64_t live = (tiles - wave + S - 1) / S;  // tiles t with 16 (t S + wave) < n
+        ntile_live = (int)(live < 0 ? 0 : live);
+    }
+    __device__ __forceinline__ void load(const float* __restrict__ rows_, int64_t n_, int wave_, int lane_) {
+        attach(rows_, n_, wave_, lane_, lr_mfma_dyn_smem);
+        build();
+    }
+    // write the wave's images (called by every workgroup for LDS, once per model by k_mfma_image_build for device memory)
+    __device__ __forceinline__ void build() {
+        const int c = lane & 15, k = lane >> 4;
+        const int npair = (ntw + 1) / 2;
         auto piece = [&](int64_t row, int coord, int lo) {
             const float x = mf_row_or_zero<P>(rows, n, row, coord);
             const uint32_t h = mf_pack_rne(x, x) & 0xFFFFu;
             if (!lo) return h;
             return mf_pack_rne(x - mf_hi_f32(h), 0.0f) & 0xFFFFu;
         };
-        ntile_live = 0;
         for (int t = 0; t < 2 * npair; ++t) {  // (an odd tile count: one all-zero image at the end)
             const int64_t row0 = t < ntw ? 16 * ((int64_t)t * S + wave) : n;
-            if (row0 < n) ntile_live = t + 1;
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
                 uint32_t hl[2];
@@ -372,14 +384,66 @@ template <int P, int S> struct MfmaRowsLds {
             for (int u = 0; u < NU; ++u)
                 gacc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mf_bf16x8, hq[u]), __builtin_bit_cast(mf_bf16x8, wv), gacc[u], 0, 0, 0);
         };
-        // two pairs per trip: the scheduler lifts all eight LDS reads of the trip to its top, so the second pair's latency
-        // hides under the first pair's work (one wave per SIMD: nothing else would hide it)
-        int pi = 0;
-        for (; pi + 1 < npl; pi += 2) {
-            pair_work(pi);
-            pair_work(pi + 1);
+        if constexpr (GLOBAL) {
+            // operands from device memory (L2): trips of two pairs, the next trip's operands requested before the current
+            // trip is worked on; two register sets used alternately (no copies).  Pairs past the wave's last one read the
+            // last pair again and are not worked on.
+            struct Trip { mf_u32x2 he[2][2][NU]; mf_u32x4 hq[2][NU]; };
+            auto fetch = [&](int p0, Trip& tr) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int pj = p0 + j < npl ? p0 + j : npl - 1;
+#pragma unroll
+                    for (int T = 0; T < 2; ++T)
+#pragma unroll
+                        for (int u = 0; u < NU; ++u) tr.he[j][T][u] = xe[((2 * pj + T) * NU + u) * 64 + lane];
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) tr.hq[j][u] = xq[(pj * NU + u) * 64 + lane];
+                }
+            };
+            auto work = [&](int p0, const Trip& tr) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (p0 + j < npl) {
+                        uint32_t wq[4];
+#pragma unroll
+                        for (int T = 0; T < 2; ++T) {
+                            f32x4 e = {0, 0, 0, 0};
+#pragma unroll
+                            for (int u = 0; u < NU; ++u) {
+                                const mf_u32x4 av = {tr.he[j][T][u][0], tr.he[j][T][u][0], tr.he[j][T][u][1], tr.he[j][T][u][1]};
+                                e = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mf_bf16x8, av), __builtin_bit_cast(mf_bf16x8, bb[u]), e, 0, 0, 0);
+                            }
+                            const mf_f32x2 d0 = mf_f32x2{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])} + mf_f32x2{1.0f, 1.0f};
+                            const mf_f32x2 d1 = mf_f32x2{__builtin_amdgcn_exp2f(e[2]), __builtin_amdgcn_exp2f(e[3])} + mf_f32x2{1.0f, 1.0f};
+                            wq[2 * T] = mf_pack_rne(fast_rcp(d0.x), fast_rcp(d0.y));
+                            wq[2 * T + 1] = mf_pack_rne(fast_rcp(d1.x), fast_rcp(d1.y));
+                        }
+                        const mf_u32x4 wv = {wq[0], wq[1], wq[2], wq[3]};
+#pragma unroll
+                        for (int u = 0; u < NU; ++u)
+                            gacc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mf_bf16x8, tr.hq[j][u]), __builtin_bit_cast(mf_bf16x8, wv), gacc[u], 0, 0, 0);
+                    }
+                }
+            };
+            Trip ta, tb;
+            if (npl > 0) fetch(0, ta);
+            for (int p0 = 0; p0 < npl; p0 += 4) {
+                fetch(p0 + 2, tb);
+                work(p0, ta);
+                fetch(p0 + 4, ta);
+                work(p0 + 2, tb);
+            }
+        } else {
+            // two pairs per trip: the scheduler lifts all eight LDS reads of the trip to its top, so the second pair's latency
+            // hides under the first pair's work (one wave per SIMD: nothing else would hide it)
+            int pi = 0;
+            for (; pi + 1 < npl; pi += 2) {
+                pair_work(pi);
+                pair_work(pi + 1);
+            }
+            if (pi < npl) pair_work(pi);
         }
-        if (pi < npl) pair_work(pi);
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             gl[2 * u] = gacc[u][0] + gacc[u][1];
@@ -487,6 +551,14 @@ template <int N, typename F> __device__ __forceinline__ void for_pair_count(int 
 // sum over the 4 parameter groups k (lanes c, c+16, c+32, c+48); identical in all 4 lanes
 template <typename T> __device__ __forceinline__ T ksum(T v) { return swap32_sum(swap16_sum(v)); }
 
+// one workgroup of S waves: the bf16 operand images of MfmaRowsLds<P, S, true> into device memory, once per model
+template <int P, int S>
+__global__ void __launch_bounds__(64 * S) k_mfma_image_build(const float* rows, int64_t n, unsigned char* store) {
+    MfmaRowsLds<P, S, true> r;
+    r.attach(rows, n, threadIdx.x >> 6, threadIdx.x & 63, store);
+    r.build();
+}
+
 template <int P, int NTW, int S, int KIND>
 __global__ void __launch_bounds__(256) k_chain_mfma(ModelArgs<float, P> m, ChainArgs<float, P> a) {
     constexpr int NC = P / 4;                 // coordinates per lane
@@ -501,10 +573,13 @@ __global__ void __launch_bounds__(256) k_chain_mfma(ModelArgs<float, P> m, Chain
     const bool writer = live && (S == 1 || wave == 0);
     const uint64_t gchain = (uint64_t)(a.chain_offset + chain);
 
-    using Rows = std::conditional_t<NTW == 0, MfmaRowsLds<P, S>, MfmaRows<P, (NTW == 0 ? 1 : NTW), S>>;  // NTW = 0: operands in LDS
+    // NTW = 0: operands in LDS; NTW = -1: operands in device memory (built once per model)
+    using Rows = std::conditional_t<NTW == 0, MfmaRowsLds<P, S, false>,
+                                    std::conditional_t<NTW < 0, MfmaRowsLds<P, S, true>, MfmaRows<P, (NTW <= 0 ? 1 : NTW), S>>>;
     Rows rows;
-    rows.load(m.rows, m.n, S == 1 ? 0 : wave, lane);
-    if constexpr (NTW == 0) rows.image = m.rows_mf;
+    if constexpr (NTW < 0) rows.attach(m.rows, m.n, wave, lane, const_cast<unsigned char*>(m.ops_mf));
+    else rows.load(m.rows, m.n, S == 1 ? 0 : wave, lane);
+    if constexpr (NTW <= 0) rows.image = m.rows_mf;
 
     // the lane's coordinates: j_h = k + 4h
     auto pick = [&](const float (&v)[P], int h) {

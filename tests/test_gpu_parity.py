@@ -330,12 +330,16 @@ def test_planner_engine_choice_by_size(la):
     assert wide_plan(200, 12, 4096, precision="full")["mode"] == "reg"
     assert wide_plan(500, 32, 4096) == {"mode": "mfma", "group": 4, "rows_per_lane": 8}
     assert wide_plan(900, 16, 4096) == {"mode": "mfma", "group": 4, "rows_per_lane": 16}
-    assert wide_plan(900, 32, 4096)["mode"] != "mfma"
+    assert wide_plan(900, 32, 4096) == {"mode": "mfma", "group": 4, "rows_per_lane": -1}  # p > 16 beyond 8 tiles per wave: operands in device memory
+    assert wide_plan(900, 32, 1024)["mode"] != "mfma"
     # beyond the register variants: the same kernel with its bf16 operands in LDS, from one workgroup per CU
     assert wide_plan(2000, 8, 4096) == {"mode": "mfma", "group": 4, "rows_per_lane": 0}
     assert wide_plan(2000, 8, 2048)["mode"] != "mfma"
     assert wide_plan(1150, 16, 4096) == {"mode": "mfma", "group": 4, "rows_per_lane": 0}
-    assert wide_plan(2600, 8, 4096)["mode"] == "stepwise"
+    assert wide_plan(2600, 8, 4096) == {"mode": "mfma", "group": 4, "rows_per_lane": -1}  # beyond LDS: operand images in device memory
+    assert wide_plan(2600, 8, 2048)["mode"] == "stepwise"
+    assert wide_plan(7000, 8, 4096)["mode"] == "stepwise"
+    assert wide_plan(20000, 8, 4096)["mode"] == "stepwise"
 
 
 @pytest.mark.parametrize("engine", ["bf16x3", "fp32"])
@@ -896,11 +900,13 @@ def test_matrix_core_kernel_on_mid_size_data(la, n, R):
 
 @pytest.mark.parametrize("n,p,group,R", [(200, 12, 4, 4), (200, 12, 1, 13), (500, 16, 4, 8), (900, 16, 4, 16), (200, 32, 4, 4),
                                          (450, 24, 4, 8), (180, 9, 1, 13),
-                                         (1500, 8, 4, 0), (2300, 7, 4, 0), (1100, 12, 4, 0), (1150, 16, 4, 0)])
+                                         (1500, 8, 4, 0), (2300, 7, 4, 0), (1100, 12, 4, 0), (1150, 16, 4, 0),
+                                         (4000, 8, 4, -1), (2500, 6, 4, -1), (3000, 12, 4, -1), (1250, 16, 4, -1), (700, 30, 4, -1), (2000, 20, 4, -1)])
 def test_matrix_core_kernel_for_wider_models(la, n, p, group, R):
     """Padded p = 16 / 32 (9 <= p <= 32): the lane owns p/4 coordinates, eta takes one bf16 MFMA per coordinate pair,
-    the gradient one per pair and tile pair.  rows_per_lane = 0: data beyond the register variants, bf16 operands in LDS
-    (end points read the fp32 rows from global memory).  Exact mode step-for-step against the oracle for HMC, MALA and RWMH;
+    the gradient one per pair and tile pair.  rows_per_lane = 0: data beyond the register variants, bf16 operands in LDS;
+    rows_per_lane = -1: beyond LDS, the same operand images in device memory, built once per model (end points read fp32
+    operand images from global memory in both).  Exact mode step-for-step against the oracle for HMC, MALA and RWMH;
     default mode (bf16 interior steps) close to it with the same decisions away from near-ties; bit-exact reruns,
     chunking and chain subsets."""
     from oracle.oracle import OracleModel
