@@ -219,11 +219,13 @@ template <int P, int NTW, int S> struct MfmaRows {
             float w[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                w[r] = fast_rcp(1.0f + __builtin_amdgcn_exp2f(e[r]));
-                if constexpr (VALUE) {
-                    const float ats = e[r] < 0.0f ? -e[r] : e[r];
-                    v += (e[r] < 0.0f ? e[r] * ExpScale<float>::inv : 0.0f) - log1p_unit(__builtin_amdgcn_exp2f(-ats));
-                }
+                // value: log2 sigma = t - log2(1 + 2^t) from the same 2^t the gradient needs (pair_term's form, lr_device.h:
+                // t clamped at 100 so that 2^t stays finite -- sigma(-t) < 2^-100 there; the cancellation at large t costs
+                // an absolute ulp(t) ~ 1e-6 per row); one v_log per value instead of exp2 + log + 7 VALU
+                const float tr = VALUE ? __builtin_fminf(e[r], 100.0f) : e[r];
+                const float d = 1.0f + __builtin_amdgcn_exp2f(tr);
+                w[r] = fast_rcp(d);
+                if constexpr (VALUE) v += tr - __builtin_amdgcn_logf(d);
             }
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
@@ -235,7 +237,7 @@ template <int P, int NTW, int S> struct MfmaRows {
         }
 #pragma unroll
         for (int h = 0; h < NC; ++h) gl[h] = ga[h >> 2][h & 3] + gb[h >> 2][h & 3];
-        if constexpr (VALUE) vsum = v + (float)pad_rows * 0.693147180559945309f;
+        if constexpr (VALUE) vsum = (v + (float)pad_rows) * ExpScale<float>::inv;  // v in log2 units; a zero row adds log2 sigma(0) = -1
     }
 };
 
@@ -506,11 +508,10 @@ template <int P, int S, bool GLOBAL = false> struct MfmaRowsLds {
                     float w[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        w[r] = fast_rcp(1.0f + __builtin_amdgcn_exp2f(e[r]));
-                        if constexpr (VALUE) {
-                            const float ats = e[r] < 0.0f ? -e[r] : e[r];
-                            v += (e[r] < 0.0f ? e[r] * ExpScale<float>::inv : 0.0f) - log1p_unit(__builtin_amdgcn_exp2f(-ats));
-                        }
+                        const float tr = VALUE ? __builtin_fminf(e[r], 100.0f) : e[r];  // (see MfmaRows::eval)
+                        const float d = 1.0f + __builtin_amdgcn_exp2f(tr);
+                        w[r] = fast_rcp(d);
+                        if constexpr (VALUE) v += tr - __builtin_amdgcn_logf(d);
                         if (row0 + 4 * k + r >= n) ++pad;
                     }
 #pragma unroll
@@ -534,7 +535,7 @@ template <int P, int S, bool GLOBAL = false> struct MfmaRowsLds {
         }
 #pragma unroll
         for (int h = 0; h < NC; ++h) gl[h] = ga[h >> 2][h & 3] + gb[h >> 2][h & 3];
-        if constexpr (VALUE) vsum = v + (float)pad * 0.693147180559945309f;
+        if constexpr (VALUE) vsum = (v + (float)pad) * ExpScale<float>::inv;
     }
 };
 
