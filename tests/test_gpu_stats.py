@@ -80,6 +80,21 @@ def test_statistics_with_a_partial_last_batch_and_wide_models(la):
         cs.advance(3, 1)
 
 
+@pytest.mark.parametrize("n,p,R", [(200, 11, 4), (1100, 14, 0), (1500, 22, -1)])
+def test_statistics_in_the_matrix_core_kernel_for_wider_models(la, n, p, R):
+    """padded p = 16 / 32: the lane owning coordinates k + 4h folds them into the accumulators (operands in registers,
+    in LDS, in device memory)."""
+    X, y, _ = la.synthetic_logreg(n, p, seed=n, beta_sd=0.3 / np.sqrt(p))
+    m = la.LogReg(X, y, np.ones(p))
+    k = la.hmcKernel(m.lpost, m.glp, eps=0.4 / np.sqrt(n), l=6, dmm=np.ones(p))
+    Cn = 90
+    cs = la.ChainSet(k, 0.05 * np.random.default_rng(4).standard_normal((Cn, p)), seed=2, mode="mfma", group=4)
+    assert cs.plan() == {"mode": "mfma", "group": 4, "rows_per_lane": R}
+    cs.enable_stats(5, 4)
+    parts = [cs.advance(kk, 2) for kk in (7, 13)]
+    _check(la, cs, np.concatenate([o.to_host() for o in parts]), 5)
+
+
 def test_summary_only_mcmc_never_builds_the_sample_matrix(la, pima, map_beta):
     """mcmc(summary_only=True) == summarising the samples of the same seeded run; and it agrees with the reference
     posterior (F7) like the sample-keeping path does."""
