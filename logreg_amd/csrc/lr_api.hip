@@ -158,7 +158,8 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
                     // (profiles/r2_midn_lds_mfma.txt, HMC L=20, TF, stepwise | this: n=3000 p=8: 43 | 81 at 4096 chains, 92 | 102 at 16 384;
                     //  n=5000 p=8: 63 | 85, 111 | 112; n=10 000 p=8: 88 | 90, 131 | 118; n=3000 p=16: 66 | 121, 130 | 146; n=8000 p=16: 109 | 135, 174 | 162)
                     //  p > 16: n=700 p=30: 31 | 74, 69 | 74; n=2000 p=20: 46 | 74, 85 | 80; n=5000 p=30: 105 | 132, 176 | 135; n=8000 p=24: 108 | 112, 160 | 115)
-                    const int64_t max_rows = C >= 64LL * m->cus ? (m->P == 32 ? 2000 : 4000) : (m->P == 16 ? 8192 : 6000);
+                    // (after the scalar-loop rework, n=8000: p=8 82 | 103 and 130 | 136; p=16 112 | 148 and 187 | 177; p=24 108 | 118 and 167 | 119)
+                    const int64_t max_rows = C >= 64LL * m->cus ? (m->P == 8 ? 8192 : (m->P == 16 ? 4000 : 2000)) : 8192;
                     if (!m->d_xms || C < 16LL * m->cus || m->n > max_rows) continue;
                     out->mode = v.mode;
                     out->G = v.G;

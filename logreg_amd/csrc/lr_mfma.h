@@ -276,8 +276,11 @@ extern __shared__ __attribute__((aligned(16))) unsigned char lr_mfma_dyn_smem[];
 template <int P, int S, bool GLOBAL = false> struct MfmaRowsLds {
     static constexpr int NC = P / 4, NU = NC / 2, NG = (NC + 3) / 4, HG = NC < 4 ? NC : 4;
     static constexpr int NPAIR = 1;  // no per-pair-count code versions: the tile loops are run-time loops
+    // device memory: PADP all-zero pairs behind the wave's last one, so that the two-trip look-ahead of the interior loop
+    // needs no index clamps
+    static constexpr int PADP = GLOBAL ? 4 : 0;
     static __host__ __device__ constexpr size_t bytes_per_wave(int64_t ntw) {  // eta images for an even number of tiles
-        return (size_t)((ntw + 1) / 2) * 2 * NU * 64 * 8 + (size_t)((ntw + 1) / 2) * NU * 64 * 16;
+        return (size_t)((ntw + 1) / 2 + PADP) * 2 * NU * 64 * 8 + (size_t)((ntw + 1) / 2 + PADP) * NU * 64 * 16;
     }
     const float* rows;
     const float* image;  // mf_image_prepare layout, or null (then the operands are gathered from `rows`)
@@ -294,7 +297,7 @@ template <int P, int S, bool GLOBAL = false> struct MfmaRowsLds {
         lane = lane_;
         const int64_t tiles = (n + 15) / 16;
         ntw = (int)((tiles + S - 1) / S);
-        const int npair = (ntw + 1) / 2;
+        const int npair = (ntw + 1) / 2 + PADP;
         unsigned char* base = store + (size_t)wave * bytes_per_wave(ntw);
         xq = reinterpret_cast<mf_u32x4*>(base);
         xe = reinterpret_cast<mf_u32x2*>(base + (size_t)npair * NU * 64 * 16);
@@ -308,7 +311,7 @@ template <int P, int S, bool GLOBAL = false> struct MfmaRowsLds {
     // write the wave's images (called by every workgroup for LDS, once per model by k_mfma_image_build for device memory)
     __device__ __forceinline__ void build() {
         const int c = lane & 15, k = lane >> 4;
-        const int npair = (ntw + 1) / 2;
+        const int npair = (ntw + 1) / 2 + PADP;
         auto piece = [&](int64_t row, int coord, int lo) {
             const float x = mf_row_or_zero<P>(rows, n, row, coord);
             const uint32_t h = mf_pack_rne(x, x) & 0xFFFFu;
@@ -390,12 +393,12 @@ template <int P, int S, bool GLOBAL = false> struct MfmaRowsLds {
             // operands from device memory (L2): trips of two pairs, the next trip's operands requested before the current
             // trip is worked on; two register sets used alternately (no copies; a third set, i.e. two trips between request and
             // use, was measured: 81 -> 78 TF at n = 3000, so latency is not what limits this path).  Pairs past the wave's last
-            // one read the last pair again and are not worked on.
+            // one are zero images and are not worked on.
             struct Trip { mf_u32x2 he[2][2][NU]; mf_u32x4 hq[2][NU]; };
             auto fetch = [&](int p0, Trip& tr) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const int pj = p0 + j < npl ? p0 + j : npl - 1;
+                    const int pj = p0 + j;  // up to npl + 3: the zero pairs behind the wave's last one
 #pragma unroll
                     for (int T = 0; T < 2; ++T)
 #pragma unroll
@@ -430,7 +433,7 @@ template <int P, int S, bool GLOBAL = false> struct MfmaRowsLds {
                 }
             };
             Trip ta, tb;
-            if (npl > 0) fetch(0, ta);
+            fetch(0, ta);
             for (int p0 = 0; p0 < npl; p0 += 4) {
                 fetch(p0 + 2, tb);
                 work(p0, ta);
@@ -566,7 +569,7 @@ __global__ void __launch_bounds__(256) k_chain_mfma(ModelArgs<float, P> m, Chain
     constexpr int NC = P / 4;                 // coordinates per lane
     __shared__ float red[2][4][64][NC];       // S = 4: per-step partial gradients, double-buffered
     __shared__ double redv[4][64];            // S = 4: partial log-likelihood values
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // (scalar: loop bounds, addresses)
     const int c = lane & 15, k = lane >> 4;
     const int64_t tile0 = S == 1 ? ((int64_t)blockIdx.x * 4 + wave) * 16 : (int64_t)blockIdx.x * 16;
     int64_t chain = tile0 + c;

@@ -338,7 +338,7 @@ def test_planner_engine_choice_by_size(la):
     assert wide_plan(1150, 16, 4096) == {"mode": "mfma", "group": 4, "rows_per_lane": 0}
     assert wide_plan(2600, 8, 4096) == {"mode": "mfma", "group": 4, "rows_per_lane": -1}  # beyond LDS: operand images in device memory
     assert wide_plan(2600, 8, 2048)["mode"] == "stepwise"
-    assert wide_plan(7000, 8, 4096)["mode"] == "stepwise"
+    assert wide_plan(9000, 8, 4096)["mode"] == "stepwise"
     assert wide_plan(20000, 8, 4096)["mode"] == "stepwise"
 
 
