@@ -20,7 +20,7 @@ At N = 1 the line also carries, outside the timed region:
   cpu_baseline   the float64 C oracle (OpenMP over chains) on a bounded sample of the same workload ("port")
   reference_cpu  the reference's own NumPy script, as measured in BASELINE.md (1 core)
   ess            ESS per kept draw from a separate 512-draw run (Geyer), scaled to the timed throughput
-  extra.configs  BASELINE.json configs 3, 4, 5 on this GPU (one GPU's shard where the config is multi-GPU),
+  extra.configs  BASELINE.json configs 1, 3, 4, 5 on this GPU (one GPU's shard where the config is multi-GPU),
                  each with its own roofline block
 
 `--dry-run` exercises the launch plumbing without a GPU (gloo instead of RCCL, no kernels): rank/world parsing,
@@ -130,16 +130,32 @@ def _timed_chainset(la, timer, cs, iters, thin, repeats=3):
 
 
 def extra_configs(la, L, check, dev, stream):
-    """BASELINE.json configs 3, 4, 5 on ONE GPU, timed with HIP events on the launch stream (bounded: a few ms of
+    """BASELINE.json configs 1, 3, 4, 5 on ONE GPU, timed with HIP events on the launch stream (bounded: a few ms of
     GPU time each).  Step sizes: config 3 the reference's; configs 4/5 the tuned ones of
     tests/golden/fullsize_cfg{4,5}.json (acceptance 0.75-0.85: the MH test does real work)."""
     timer = Timer(L, check, dev, stream)
     res = []
-    # ---- config 3: MALA, thin 1000, 8192 chains = one GPU's shard of 65 536 (real Pima data)
     X, y = la.load_pima()
     pre = np.array([100.0, 1, 1, 1, 1, 1, 25, 1])
     bmap = np.array([-9.19131622, 0.09705401, 0.03112265, -0.00564495, -0.00062272, 0.0814371, 1.26032561, 0.03939102])
     m = la.LogReg(X, y, np.array([10.0, 1, 1, 1, 1, 1, 1, 1]), device=dev)
+    # ---- config 1: the reference's fit-numpy.py run as it is -- ONE chain, RWMH, 10 000 kept x thin 1000 on Pima -- bounded
+    # to 1 000 kept samples (10^6 iterations, ~0.3 s; the rate does not depend on the length: one launch, one wave)
+    k1 = la.mhKernel(m.lpost, la.rwProposal(0.02 * np.array([10.0, 1, 1, 1, 1, 1, 5, 1])))
+    cs = la.ChainSet(k1, bmap, seed=1, stream=stream)
+    cs.advance(1, 1000, keep=False)
+    cs.sync()
+    a0 = int(cs.get_accepts().sum())
+    timer.start()
+    s1 = cs.advance(1000, 1000)
+    ms = timer.stop_ms()
+    res.append({"config": 1, "workload": "RWMH prop sd 0.02*[10,1,1,1,1,1,5,1] on Pima n=200 p=8, ONE chain, thin 1000, 1000 of the "
+                "reference's 10 000 kept samples (fit-numpy.py:86)", "kernel_variant": cs.plan(), "chain_iterations_per_s": 1e6 / (ms * 1e-3),
+                "accept_rate": float((int(cs.get_accepts().sum()) - a0) / 1e6), "launch_ms": ms, "reference_cpu_it_per_s": 6486.0,
+                "posterior_mean": np.asarray(s1.to_host(), dtype=np.float64).reshape(-1, 8).mean(axis=0).round(4).tolist(),
+                "note": "a single chain is one 64-lane wave on one SIMD of the chip: a latency figure (0.3 us per iteration), not a "
+                        "throughput one; the many-chain rate of the same kernel family is config 3's"})
+    # ---- config 3: MALA, thin 1000, 8192 chains = one GPU's shard of 65 536 (real Pima data)
     k = la.malaKernel(m.lpost, m.glp, dt=1e-5, pre=pre)
     C3 = 8192
     cs = la.ChainSet(k, np.tile(bmap, (C3, 1)), seed=3, stream=stream)
@@ -287,7 +303,7 @@ def main():
                          "'auto' = the library's default policy (HMC interior gradients on the bf16 matrix pipe)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ess", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the configs 3/4/5 sub-results")
+    ap.add_argument("--no-extra", action="store_true", help="skip the configs 1/3/4/5 sub-results")
     ap.add_argument("--dry-run", action="store_true", help="launch plumbing only (gloo, no GPU work)")
     a = ap.parse_args()
 
