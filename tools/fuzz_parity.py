@@ -33,6 +33,11 @@ for case in range(cases):
                 m.plan(C, g, "reg"); modes.append(("reg", g))
             except la.LogregHipError:
                 pass
+        for g in (1, 4):  # matrix-core chain kernel: operands in registers, LDS or device memory as n grows (twice the weight)
+            try:
+                m.plan(C, g, "mfma"); modes += [("mfma", g)] * 2
+            except la.LogregHipError:
+                pass
     mode, group = modes[int(rng.integers(len(modes)))]
     sc = 1.0 / np.sqrt(max(n, 4))
     q0 = 0.3 * sc * rng.standard_normal((C, p))
