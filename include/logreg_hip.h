@@ -50,8 +50,9 @@ typedef enum lr_status {
 
 enum { LR_F32 = 0, LR_F64 = 1 };
 /* where the data rows live / which pipe does the matvecs: REG/LDS/GLOBAL use the vector ALU with rows in
- * VGPRs / LDS / memory; MFMA uses the fp32 matrix cores with rows in VGPRs (p = 8, small n; there `group`
- * selects the row-split ways S in {1,4} instead of lanes per chain); STEPWISE is the tall-data engine: two
+ * VGPRs / LDS / memory; MFMA is the fused matrix-core chain kernel (5 <= p <= 32; `group` selects the row-split
+ * ways S in {1,4} instead of lanes per chain; its operands live in VGPRs, in LDS or in device memory as n grows --
+ * lr_plan reports tiles of 16 rows per wave, 0 or -1 as rows_out -- up to 8192 rows); STEPWISE is the tall-data engine: two
  * small kernels per log-posterior evaluation, the rows split into slices across the whole chip (`group` = 0
  * lets the library choose the slice count from the chain count, `group` > 0 requests that many slices; lr_plan
  * reports the slice count as group_out and the slice length as rows_out).  Slice partials are summed in slice
@@ -186,7 +187,8 @@ LR_API int lr_stats_reduce(int device, const double* stats, int64_t n_chains, in
 
 /*
  * Which kernel variant the library would launch for (model, n_chains, group, mode):
- * mode_out in LR_MODE_*, group_out lanes per chain, rows_out rows per lane (REG mode, else 0).
+ * mode_out in LR_MODE_*, group_out lanes per chain, rows_out rows per lane (REG mode, else 0; MFMA: 16-row tiles per
+ * wave, 0 = operands in LDS, -1 = operands in device memory; STEPWISE: rows per slice).
  */
 LR_API int lr_plan(const lr_model* m, int64_t n_chains, int32_t group, int32_t mode, int32_t* mode_out,
                    int32_t* group_out, int32_t* rows_out);
