@@ -121,8 +121,8 @@ size_t mfma_lds_bytes(const lr_model* m, int S) {
     const size_t nu = (size_t)m->P / 8;
     return (size_t)S * ((size_t)ntw * nu * 64 * 8 + (size_t)((ntw + 1) / 2) * nu * 64 * 16);
 }
-// 160 KB less the kernel's static exchange buffers (red: 2 x 4 x 64 x P/4 floats, redv: 4 x 64 doubles)
-size_t mfma_lds_budget(const lr_model* m) { return 160 * 1024 - (size_t)512 * m->P - 2048; }
+// 160 KB less the kernel's static exchange buffers (red: 2 x S x 64 x P/4 floats, redv: S x 64 doubles)
+size_t mfma_lds_budget(const lr_model* m, int S = 4) { return 160 * 1024 - (size_t)128 * S * m->P - (size_t)512 * S; }
 
 // Choose the kernel variant.  REG (rows in VGPRs) whenever the data fit (G*R >= n), then LDS,
 // then GLOBAL.  Group size: the smallest available G that still gives every SIMD a wavefront
@@ -171,11 +171,18 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
                 // operands in LDS (profiles/r2_midn_lds_mfma.txt, HMC L=20, TF, best other kernel | this one): n=2000 p=8: 34 | 24 at
                 // 1024 chains, 48 | 90 at 4096, 82 | 94 at 16 384; n=1150 p=16: 30 | 32, 33 | 120, 81 | 129: from one workgroup per CU
                 if (in_lds && C < 16LL * m->cus) continue;
-                if (in_lds ? mfma_lds_bytes(m, v.G) <= mfma_lds_budget(m) : (int64_t)16 * v.G * v.R >= m->n) {
+                if (in_lds ? mfma_lds_bytes(m, v.G) <= mfma_lds_budget(m, v.G) : (int64_t)16 * v.G * v.R >= m->n) {
+                    int G = v.G;
+                    if (in_lds) {  // the 8-wave row split of the LDS variant where it exists and fits (n=2000 p=8: 121 -> 139 TF)
+                        for (int j = 0; j < t->nvariants; ++j)
+                            if (t->variants[j].mode == lr::MODE_MFMA && t->variants[j].G == 8 && t->variants[j].R == 0 &&
+                                mfma_lds_bytes(m, 8) <= mfma_lds_budget(m, 8))
+                                G = 8;
+                    }
                     out->mode = v.mode;
-                    out->G = v.G;
+                    out->G = G;
                     out->R = v.R;
-                    out->lds_bytes = in_lds ? mfma_lds_bytes(m, v.G) : 0;
+                    out->lds_bytes = in_lds ? mfma_lds_bytes(m, G) : 0;
                     return LR_OK;
                 }
             }
@@ -244,7 +251,7 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
             // chains, 2.00e8 vs 1.86e8 at 65 536).
             if (for_eval) continue;
             if (v.R < 0 ? m->d_xms == nullptr
-                        : (v.R == 0 ? mfma_lds_bytes(m, v.G) > mfma_lds_budget(m) : (int64_t)16 * v.G * v.R < m->n)) continue;
+                        : (v.R == 0 ? mfma_lds_bytes(m, v.G) > mfma_lds_budget(m, v.G) : (int64_t)16 * v.G * v.R < m->n)) continue;
             const bool filled = C >= 16LL * want_waves;
             if (mode == LR_MODE_MFMA) {
                 if (group != 0 && v.G != group) continue;

@@ -46,10 +46,12 @@ constexpr int P = LR_P;
 // per tile: 2.5 p (p/4 + p/4..p/2 fp32 end-point operands, p bf16 interior operands), so p = 32 stops at 8 tiles.
 // (4, 0): the bf16 operands in LDS instead (MfmaRowsLds: 64 p/8 bytes per row): n <= 2400 at p = 8, 1200 at p = 16; at p = 32
 // the LDS holds no more rows than the registers do.  (4, -1): the same images in device memory, built once per model.
+// (8, 0): the LDS variant with the rows split over 8 waves (two per SIMD hide each other's LDS and MFMA latencies: +15 %;
+// with the operands in registers the doubled per-wave fixed work costs more than that: n=200 -18 %, n=1000 -3 %).
 #if LR_DTYPE == 0 && LR_P == 8
-#define LR_MFMA_VARIANTS(X) X(1, 13) X(4, 4) X(4, 8) X(4, 16) X(4, 0) X(4, -1)
+#define LR_MFMA_VARIANTS(X) X(1, 13) X(4, 4) X(4, 8) X(4, 16) X(4, 0) X(4, -1) X(8, 0)
 #elif LR_DTYPE == 0 && LR_P == 16
-#define LR_MFMA_VARIANTS(X) X(1, 13) X(4, 4) X(4, 8) X(4, 16) X(4, 0) X(4, -1)
+#define LR_MFMA_VARIANTS(X) X(1, 13) X(4, 4) X(4, 8) X(4, 16) X(4, 0) X(4, -1) X(8, 0)
 #elif LR_DTYPE == 0 && LR_P == 32
 #define LR_MFMA_VARIANTS(X) X(4, 4) X(4, 8) X(4, -1)
 #else
@@ -108,7 +110,7 @@ int launch_chain_v(const LaunchCfg* cfg, int64_t C, const ModelArgs<T, P>& m, co
 template <int S, int NTW>
 int launch_mfma_v(const LaunchCfg* cfg, int64_t C, const ModelArgs<T, P>& m, const ChainArgs<T, P>& a) {
     const int64_t per_block = S == 1 ? 64 : 16;
-    const dim3 grid((unsigned)((C + per_block - 1) / per_block)), block(256);
+    const dim3 grid((unsigned)((C + per_block - 1) / per_block)), block(S == 1 ? 256 : 64 * S);
     switch (cfg->kind) {
     case KIND_RWMH: hipLaunchKernelGGL((k_chain_mfma<P, NTW, S, KIND_RWMH>), grid, block, NTW == 0 ? cfg->lds_bytes : 0, cfg->stream, m, a); break;
     case KIND_MALA: hipLaunchKernelGGL((k_chain_mfma<P, NTW, S, KIND_MALA>), grid, block, NTW == 0 ? cfg->lds_bytes : 0, cfg->stream, m, a); break;

@@ -565,10 +565,11 @@ __global__ void __launch_bounds__(64 * S) k_mfma_image_build(const float* rows, 
 }
 
 template <int P, int NTW, int S, int KIND>
-__global__ void __launch_bounds__(256) k_chain_mfma(ModelArgs<float, P> m, ChainArgs<float, P> a) {
+__global__ void __launch_bounds__((S == 1 ? 256 : 64 * S)) k_chain_mfma(ModelArgs<float, P> m, ChainArgs<float, P> a) {
     constexpr int NC = P / 4;                 // coordinates per lane
-    __shared__ float red[2][4][64][NC];       // S = 4: per-step partial gradients, double-buffered
-    __shared__ double redv[4][64];            // S = 4: partial log-likelihood values
+    constexpr int SW = S == 1 ? 4 : S;        // waves of the workgroup (S = 1: four independent chain tiles)
+    __shared__ float red[2][SW][64][NC];      // row split: per-step partial gradients of the S waves, double-buffered
+    __shared__ double redv[SW][64];           // row split: partial log-likelihood values
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // (scalar: loop bounds, addresses)
     const int c = lane & 15, k = lane >> 4;
     const int64_t tile0 = S == 1 ? ((int64_t)blockIdx.x * 4 + wave) * 16 : (int64_t)blockIdx.x * 16;
@@ -609,9 +610,17 @@ __global__ void __launch_bounds__(256) k_chain_mfma(ModelArgs<float, P> m, Chain
         for (int h = 0; h < NC; ++h) red[step_parity][wave][lane][h] = gl[h];
         __syncthreads();
 #pragma unroll
-        for (int h = 0; h < NC; ++h)
-            gl[h] = (red[step_parity][0][lane][h] + red[step_parity][1][lane][h]) +
-                    (red[step_parity][2][lane][h] + red[step_parity][3][lane][h]);
+        for (int h = 0; h < NC; ++h) {
+            float q4[SW / 4];
+#pragma unroll
+            for (int w = 0; w < SW; w += 4)
+                q4[w / 4] = (red[step_parity][w][lane][h] + red[step_parity][w + 1][lane][h]) +
+                            (red[step_parity][w + 2][lane][h] + red[step_parity][w + 3][lane][h]);
+            float tot = q4[0];
+#pragma unroll
+            for (int w = 1; w < SW / 4; ++w) tot += q4[w];
+            gl[h] = tot;
+        }
     };
     // full gradient (likelihood over all tiles + prior) for own coordinates; VALUE: ll (double, replicated)
     auto evaluate = [&](auto want_value, const float (&q)[NC], float (&grad)[NC], double& ll) {
@@ -623,7 +632,8 @@ __global__ void __launch_bounds__(256) k_chain_mfma(ModelArgs<float, P> m, Chain
             combine(gl);
             double dv = 0;
             if constexpr (VALUE) {
-                dv = (redv[0][lane] + redv[1][lane]) + (redv[2][lane] + redv[3][lane]);
+#pragma unroll
+                for (int w = 0; w < SW; w += 4) dv += (redv[w][lane] + redv[w + 1][lane]) + (redv[w + 2][lane] + redv[w + 3][lane]);
                 __syncthreads();  // redv is single-buffered; value passes are rare
             }
             step_parity ^= 1;

@@ -333,7 +333,7 @@ def test_planner_engine_choice_by_size(la):
     assert wide_plan(900, 32, 4096) == {"mode": "mfma", "group": 4, "rows_per_lane": -1}  # p > 16 beyond 8 tiles per wave: operands in device memory
     assert wide_plan(900, 32, 1024)["mode"] != "mfma"
     # beyond the register variants: the same kernel with its bf16 operands in LDS, from one workgroup per CU
-    assert wide_plan(2000, 8, 4096) == {"mode": "mfma", "group": 4, "rows_per_lane": 0}
+    assert wide_plan(2000, 8, 4096) == {"mode": "mfma", "group": 8, "rows_per_lane": 0}  # (8-wave row split where it fits)
     assert wide_plan(2000, 8, 2048)["mode"] != "mfma"
     assert wide_plan(1150, 16, 4096) == {"mode": "mfma", "group": 4, "rows_per_lane": 0}
     assert wide_plan(2600, 8, 4096) == {"mode": "mfma", "group": 4, "rows_per_lane": -1}  # beyond LDS: operand images in device memory
@@ -900,7 +900,7 @@ def test_matrix_core_kernel_on_mid_size_data(la, n, R):
 
 @pytest.mark.parametrize("n,p,group,R", [(200, 12, 4, 4), (200, 12, 1, 13), (500, 16, 4, 8), (900, 16, 4, 16), (200, 32, 4, 4),
                                          (450, 24, 4, 8), (180, 9, 1, 13),
-                                         (1500, 8, 4, 0), (2300, 7, 4, 0), (1100, 12, 4, 0), (1150, 16, 4, 0),
+                                         (1500, 8, 4, 0), (2300, 7, 4, 0), (1100, 12, 4, 0), (1150, 16, 4, 0), (1500, 8, 8, 0), (2300, 5, 8, 0),
                                          (4000, 8, 4, -1), (2500, 6, 4, -1), (3000, 12, 4, -1), (1250, 16, 4, -1), (700, 30, 4, -1), (2000, 20, 4, -1)])
 def test_matrix_core_kernel_for_wider_models(la, n, p, group, R):
     """Padded p = 16 / 32 (9 <= p <= 32): the lane owns p/4 coordinates, eta takes one bf16 MFMA per coordinate pair,
