@@ -161,8 +161,14 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
                     // (after the scalar-loop rework, n=8000: p=8 82 | 103 and 130 | 136; p=16 112 | 148 and 187 | 177; p=24 108 | 118 and 167 | 119)
                     const int64_t max_rows = C >= 64LL * m->cus ? (m->P == 8 ? 8192 : (m->P == 16 ? 4000 : 2000)) : 8192;
                     if (!m->d_xms || C < 16LL * m->cus || m->n > max_rows) continue;
+                    int G = v.G;
+                    // p = 8 below 64 chains per CU: the 8-wave row split (n=3000: 109 -> 120 TF, n=8000: 118 -> 137 at 4096 chains;
+                    // at 16 384 chains the 4-wave split packs the CUs better: 135 vs 121)
+                    if (m->P == 8 && C < 64LL * m->cus)
+                        for (int j = 0; j < t->nvariants; ++j)
+                            if (t->variants[j].mode == lr::MODE_MFMA && t->variants[j].G == 8 && t->variants[j].R < 0) G = 8;
                     out->mode = v.mode;
-                    out->G = v.G;
+                    out->G = G;
                     out->R = v.R;
                     out->lds_bytes = 0;
                     return LR_OK;

@@ -49,7 +49,7 @@ constexpr int P = LR_P;
 // (8, 0): the LDS variant with the rows split over 8 waves (two per SIMD hide each other's LDS and MFMA latencies: +15 %;
 // with the operands in registers the doubled per-wave fixed work costs more than that: n=200 -18 %, n=1000 -3 %).
 #if LR_DTYPE == 0 && LR_P == 8
-#define LR_MFMA_VARIANTS(X) X(1, 13) X(4, 4) X(4, 8) X(4, 16) X(4, 0) X(4, -1) X(8, 0)
+#define LR_MFMA_VARIANTS(X) X(1, 13) X(4, 4) X(4, 8) X(4, 16) X(4, 0) X(4, -1) X(8, 0) X(8, -1)
 #elif LR_DTYPE == 0 && LR_P == 16
 #define LR_MFMA_VARIANTS(X) X(1, 13) X(4, 4) X(4, 8) X(4, 16) X(4, 0) X(4, -1) X(8, 0)
 #elif LR_DTYPE == 0 && LR_P == 32
@@ -123,13 +123,18 @@ int launch_mfma_v(const LaunchCfg* cfg, int64_t C, const ModelArgs<T, P>& m, con
 #endif
 
 #if LR_DTYPE == 0 && LR_P >= 8
+// two images, one per row split: [S = 4][S = 8 (p = 8 only: at p = 16 the 8-wave split gained nothing)]
+constexpr bool kMfmaImage8 = P == 8;
+size_t mfma_image_bytes4(int64_t n) { return 4 * MfmaRowsLds<P, 4, true>::bytes_per_wave(((n + 15) / 16 + 3) / 4); }
 size_t mfma_image_bytes(int64_t n) {
-    const int64_t tiles = (n + 15) / 16, ntw = (tiles + 3) / 4;
-    return 4 * MfmaRowsLds<P, 4, true>::bytes_per_wave(ntw);
+    return mfma_image_bytes4(n) + (kMfmaImage8 ? 8 * MfmaRowsLds<P, 8, true>::bytes_per_wave(((n + 15) / 16 + 7) / 8) : 0);
 }
 int launch_mfma_image(hipStream_t st, const void* rows, int64_t n, void* store) {
     hipLaunchKernelGGL((k_mfma_image_build<P, 4>), dim3(1), dim3(256), 0, st, static_cast<const float*>(rows), n,
                        static_cast<unsigned char*>(store));
+    if constexpr (kMfmaImage8)
+        hipLaunchKernelGGL((k_mfma_image_build<P, 8>), dim3(1), dim3(512), 0, st, static_cast<const float*>(rows), n,
+                           static_cast<unsigned char*>(store) + mfma_image_bytes4(n));
     return check(hipGetLastError());
 }
 #define LR_MFMA_IMAGE_HOOKS &mfma_image_bytes, &launch_mfma_image

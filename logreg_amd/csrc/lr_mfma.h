@@ -583,7 +583,10 @@ __global__ void __launch_bounds__((S == 1 ? 256 : 64 * S)) k_chain_mfma(ModelArg
     using Rows = std::conditional_t<NTW == 0, MfmaRowsLds<P, S, false>,
                                     std::conditional_t<NTW < 0, MfmaRowsLds<P, S, true>, MfmaRows<P, (NTW <= 0 ? 1 : NTW), S>>>;
     Rows rows;
-    if constexpr (NTW < 0) rows.attach(m.rows, m.n, wave, lane, const_cast<unsigned char*>(m.ops_mf));
+    if constexpr (NTW < 0) {  // device images: the S = 4 one first, the S = 8 one behind it
+        const size_t skip = S == 8 ? 4 * MfmaRowsLds<P, 4, true>::bytes_per_wave((int64_t)(((m.n + 15) / 16 + 3) / 4)) : 0;
+        rows.attach(m.rows, m.n, wave, lane, const_cast<unsigned char*>(m.ops_mf) + skip);
+    }
     else rows.load(m.rows, m.n, S == 1 ? 0 : wave, lane);
     if constexpr (NTW <= 0) rows.image = m.rows_mf;
 

@@ -336,7 +336,8 @@ def test_planner_engine_choice_by_size(la):
     assert wide_plan(2000, 8, 4096) == {"mode": "mfma", "group": 8, "rows_per_lane": 0}  # (8-wave row split where it fits)
     assert wide_plan(2000, 8, 2048)["mode"] != "mfma"
     assert wide_plan(1150, 16, 4096) == {"mode": "mfma", "group": 4, "rows_per_lane": 0}
-    assert wide_plan(2600, 8, 4096) == {"mode": "mfma", "group": 4, "rows_per_lane": -1}  # beyond LDS: operand images in device memory
+    assert wide_plan(2600, 8, 4096) == {"mode": "mfma", "group": 8, "rows_per_lane": -1}  # beyond LDS: operand images in device memory
+    assert wide_plan(2600, 8, 16384) == {"mode": "mfma", "group": 4, "rows_per_lane": -1}
     assert wide_plan(2600, 8, 2048)["mode"] == "stepwise"
     assert wide_plan(9000, 8, 4096)["mode"] == "stepwise"
     assert wide_plan(20000, 8, 4096)["mode"] == "stepwise"
@@ -901,7 +902,7 @@ def test_matrix_core_kernel_on_mid_size_data(la, n, R):
 @pytest.mark.parametrize("n,p,group,R", [(200, 12, 4, 4), (200, 12, 1, 13), (500, 16, 4, 8), (900, 16, 4, 16), (200, 32, 4, 4),
                                          (450, 24, 4, 8), (180, 9, 1, 13),
                                          (1500, 8, 4, 0), (2300, 7, 4, 0), (1100, 12, 4, 0), (1150, 16, 4, 0), (1500, 8, 8, 0), (2300, 5, 8, 0),
-                                         (4000, 8, 4, -1), (2500, 6, 4, -1), (3000, 12, 4, -1), (1250, 16, 4, -1), (700, 30, 4, -1), (2000, 20, 4, -1)])
+                                         (4000, 8, 4, -1), (2500, 6, 4, -1), (3100, 8, 8, -1), (3000, 12, 4, -1), (1250, 16, 4, -1), (700, 30, 4, -1), (2000, 20, 4, -1)])
 def test_matrix_core_kernel_for_wider_models(la, n, p, group, R):
     """Padded p = 16 / 32 (9 <= p <= 32): the lane owns p/4 coordinates, eta takes one bf16 MFMA per coordinate pair,
     the gradient one per pair and tile pair.  rows_per_lane = 0: data beyond the register variants, bf16 operands in LDS;
