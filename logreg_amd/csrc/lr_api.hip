@@ -148,7 +148,7 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
         //   n=200 p=12: 13 | 19 at 1024 chains, 33 | 72 at 4096, 34 | 98 (S=1: 138) at 16 384;  n=200 p=32: 25 | 29, 26 | 110, 26 | 118;
         //   n=500 p=32 (LDS kernel otherwise): 16 | 53, 16 | 199, 37 | 210;  n=1000 p=12: 23 | 39, 23 | 150, 50 | 147;
         //   n=500 p=16: 43 | 40, 46 | 147, 47 | 160.   p > 8 moves to the matrix pipe from 4 chains per CU.
-        const int64_t s4_from = (m->P > 8 ? 4LL : 16LL) * m->cus;
+        const int64_t s4_from = (m->P > 8 ? 4LL : (m->n > 16 * 4 * 16 ? 8LL : 16LL)) * m->cus;  // (p = 8 beyond the registers: see the LDS variant)
         const int try_S[2] = {C >= 40LL * m->cus && m->n <= 16 * 13 ? 1 : 0, C >= s4_from ? 4 : 0};
         for (int want_S : try_S) {
             for (int i = 0; want_S && i < t->nvariants; ++i) {
@@ -176,7 +176,9 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
                 const bool in_lds = v.R == 0;  // listed after the register variants of the same S
                 // operands in LDS (profiles/r2_midn_lds_mfma.txt, HMC L=20, TF, best other kernel | this one): n=2000 p=8: 34 | 24 at
                 // 1024 chains, 48 | 90 at 4096, 82 | 94 at 16 384; n=1150 p=16: 30 | 32, 33 | 120, 81 | 129: from one workgroup per CU
-                if (in_lds && C < 16LL * m->cus) continue;
+                // (8-wave split, n=2000 p=8, HMC L=50: lane-group LDS kernel 56 TF | this 70 at 2048 chains, 43 | 35 at 1024)
+                const bool lds8 = in_lds && m->P == 8 && mfma_lds_bytes(m, 8) <= mfma_lds_budget(m, 8);
+                if (in_lds && C < (lds8 ? 8LL : 16LL) * m->cus) continue;
                 if (in_lds ? mfma_lds_bytes(m, v.G) <= mfma_lds_budget(m, v.G) : (int64_t)16 * v.G * v.R >= m->n) {
                     int G = v.G;
                     if (in_lds) {  // the 8-wave row split of the LDS variant where it exists and fits (n=2000 p=8: 121 -> 139 TF)

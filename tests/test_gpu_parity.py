@@ -334,7 +334,8 @@ def test_planner_engine_choice_by_size(la):
     assert wide_plan(900, 32, 1024)["mode"] != "mfma"
     # beyond the register variants: the same kernel with its bf16 operands in LDS, from one workgroup per CU
     assert wide_plan(2000, 8, 4096) == {"mode": "mfma", "group": 8, "rows_per_lane": 0}  # (8-wave row split where it fits)
-    assert wide_plan(2000, 8, 2048)["mode"] != "mfma"
+    assert wide_plan(2000, 8, 2048) == {"mode": "mfma", "group": 8, "rows_per_lane": 0}
+    assert wide_plan(2000, 8, 1024)["mode"] != "mfma"
     assert wide_plan(1150, 16, 4096) == {"mode": "mfma", "group": 4, "rows_per_lane": 0}
     assert wide_plan(2600, 8, 4096) == {"mode": "mfma", "group": 8, "rows_per_lane": -1}  # beyond LDS: operand images in device memory
     assert wide_plan(2600, 8, 16384) == {"mode": "mfma", "group": 4, "rows_per_lane": -1}
