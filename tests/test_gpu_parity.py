@@ -733,18 +733,18 @@ def test_wide_bf16_split_stays_in_the_fp32_error_class(la, monkeypatch):
 
 
 def test_randomised_parity_fuzz():
-    """tools/fuzz_parity.py: random n (1..9001), p (1..128), chain counts, kernels and engines (every forced
+    """tests/fuzz_parity.py: random n (1..9001), p (1..128), chain counts, kernels and engines (every forced
     variant that accepts the shape) against the oracle -- model values, accept decisions and states."""
     import os
     import subprocess
     import sys
     from conftest import REPO
-    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "fuzz_parity.py"), "80", "7"], capture_output=True,
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tests", "fuzz_parity.py"), "80", "7"], capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " 0 failed" in r.stdout
     # the same generator with the default interior-gradient policy (reduced-precision interior leapfrog steps)
-    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "fuzz_parity.py"), "60", "11", "auto"], capture_output=True,
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tests", "fuzz_parity.py"), "60", "11", "auto"], capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " 0 failed" in r.stdout
