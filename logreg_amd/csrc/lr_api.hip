@@ -148,7 +148,9 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
         //   n=200 p=12: 13 | 19 at 1024 chains, 33 | 72 at 4096, 34 | 98 (S=1: 138) at 16 384;  n=200 p=32: 25 | 29, 26 | 110, 26 | 118;
         //   n=500 p=32 (LDS kernel otherwise): 16 | 53, 16 | 199, 37 | 210;  n=1000 p=12: 23 | 39, 23 | 150, 50 | 147;
         //   n=500 p=16: 43 | 40, 46 | 147, 47 | 160.   p > 8 moves to the matrix pipe from 4 chains per CU.
-        const int64_t s4_from = (m->P > 8 ? 4LL : (m->n > 16 * 4 * 16 ? 8LL : 16LL)) * m->cus;  // (p = 8 beyond the registers: see the LDS variant)
+        // (tools/planner_check.py, sustained clocks, HMC L=50: n=200 p=12..32 wins from 1024 chains (+7..+40 %); n=500 p=16 loses 10 %
+        //  at 1024 chains and wins 1.8x at 2048;  p = 8 beyond the registers: see the LDS variant)
+        const int64_t s4_from = (m->P > 8 ? (m->n <= 256 ? 4LL : 8LL) : (m->n > 16 * 4 * 16 ? 8LL : 16LL)) * m->cus;
         const int try_S[2] = {C >= 40LL * m->cus && m->n <= 16 * 13 ? 1 : 0, C >= s4_from ? 4 : 0};
         for (int want_S : try_S) {
             for (int i = 0; want_S && i < t->nvariants; ++i) {
