@@ -951,17 +951,16 @@ def test_matrix_core_kernel_for_wider_models(la, n, p, group, R):
         assert np.max(np.abs(o2[:, ok2] - r2["out"][:, ok2])) < 2e-3 / np.sqrt(n), kind
 
 
-@pytest.mark.parametrize("n,p", [(300, 12), (400, 28)])
-def test_wider_models_sample_the_same_posterior_on_the_matrix_cores(la, n, p):
-    """The planner's default for 9 <= p <= 32 at >= 1024 chains (matrix-core kernel, bf16 interior steps) against the
-    all-fp32 register / LDS kernels: pooled posterior means and sds agree within the between-chain standard errors,
+@pytest.mark.parametrize("n,p,C", [(300, 12, 2048), (400, 28, 2048), (1500, 7, 4096), (2600, 10, 4096)])
+def test_wider_models_sample_the_same_posterior_on_the_matrix_cores(la, n, p, C):
+    """The planner's default (matrix-core chain kernel, bf16 interior steps; operands in registers, in LDS (n = 1500) and in
+    device memory (n = 2600)) against the all-fp32 register / LDS / stepwise kernels: pooled posterior means and sds agree within the between-chain standard errors,
     acceptance rates within half a point."""
     X, y, _ = la.synthetic_logreg(n, p, seed=3 * n + p, beta_sd=0.5 / np.sqrt(p))
     m = la.LogReg(X, y, np.full(p, 2.0))
     bmap, info = la.find_map(m)
     eps = 0.9 / np.sqrt(np.max(np.linalg.eigvalsh(info["hessian"]))) / p ** 0.25
     k = la.hmcKernel(m.lpost, m.glp, eps=eps, l=12, dmm=np.ones(p))
-    C = 2048
     res = {}
     for prec, seed in (("auto", 11), ("full", 12)):
         q0 = la.overdispersed_init(bmap, info["sd"], C, scale=1.5, seed=seed)
