@@ -408,12 +408,28 @@ int setup_tall(lr_model* m, const Plan& pl, hipStream_t st, int64_t C, lr::TallA
         slice_len_i = ((m->n + want - 1) / want + 31) / 32 * 32;
         if (slice_len_i < 256) slice_len_i = 256;
         RS_i = (int)((m->n + slice_len_i - 1) / slice_len_i);
+        // 16-wave workgroups (one per CU) need a quarter of the slices for the same waves per SIMD: few enough to fold
+        // the update launch into the next launch's prologue (k_tall_partial_mx16).  Only with enough rows per slice to
+        // keep the 4 row groups of a workgroup busy, and when the slice count fits the fused prologue.
+        int64_t want16 = (m->cus + blocks - 1) / blocks;
+        if (want16 < 1) want16 = 1;
+        int64_t len16 = ((m->n + want16 - 1) / want16 + 31) / 32 * 32;
+        if (len16 < 1024) len16 = 1024;
+        const int64_t rs16 = (m->n + len16 - 1) / len16;
+        // (and only when those slices still fill the chip: n=5000 p=30 at 1024 chains would get 5 slices x 16 blocks = 80
+        //  workgroups and ran 13.5 -> 17.9 us per step; n=20 000 p=12: 17.8 -> 13.8, config 4: 29.7 -> 27.5)
+        //  at 4096 chains the steps are long enough that the saved launch no longer shows: -3 .. +5 %, so up to 2048 chains)
+        if (!env_on("LOGREG_TALL_NO_MX16") && rs16 >= 1 && rs16 <= 16 && RS_i > rs16 && 4 * rs16 * blocks >= 3LL * m->cus && blocks <= 32) {
+            RS_i = (int)rs16;
+            slice_len_i = len16;
+            rs_waves = 16;
+        }
     }
     const int RSmax = RS_i > RS ? RS_i : RS;
     const size_t pg = align((size_t)RSmax * C * P * sizeof(T)), cv = align((size_t)2 * P * sizeof(T));
     // (second state pair + second partial buffer + constants: the fused interior steps of the row-split kernel)
     const size_t need = 4 * vec + 2 * dbl + align((size_t)C * 4) + pg + align((size_t)RS * C * sizeof(double)) +
-                        (RS_i > 0 && m->P > 32 ? 2 * vec + pg : 0) + cv;
+                        (RS_i > 0 && (m->P > 32 || rs_waves == 16) ? 2 * vec + pg : 0) + cv;
     lr_model::Ws* slot = nullptr;
     for (auto& e : m->ws)
         if (e.stream == st) slot = &e;
@@ -460,7 +476,7 @@ int setup_tall(lr_model* m, const Plan& pl, hipStream_t st, int64_t C, lr::TallA
     a.rowsplit_waves = rs_waves;
     a.part_v = (double*)carve(align((size_t)RS * C * sizeof(double)));
     a.cvec = (const T*)carve(cv);
-    if (RS_i > 0 && m->P > 32) {  // alternates, parked in the *_in fields until do_stepwise_t starts ping-ponging
+    if (RS_i > 0 && (m->P > 32 || rs_waves == 16)) {  // alternates, parked in the *_in fields until do_stepwise_t starts ping-ponging
         a.q1_in = (const T*)carve(vec);
         a.pm_in = (const T*)carve(vec);
         a.part_in = (const T*)carve(pg);
@@ -547,7 +563,9 @@ int do_stepwise_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs
     const bool traj = P > 32 && bf16_interior && m->d_xblk1 != nullptr && t->launch_tall_traj != nullptr && rs.l > 1 &&
                       !env_on("LOGREG_WIDE_NO_TRAJ") &&
                       (env_on("LOGREG_WIDE_TRAJ") || (traj_tiles >= m->cus && traj_tiles < 4LL * m->cus));
-    const bool fuse = P > 32 && bf16_interior && a.RS_i > 0 && a.RS_i <= 4 && !env_on("LOGREG_WIDE_NO_FUSE");  // kFuseSlices
+    const bool fuse = bf16_interior && a.RS_i > 0 &&
+                      ((P > 32 && a.RS_i <= 4 && !env_on("LOGREG_WIDE_NO_FUSE")) ||         // kFuseSlices (lr_wide_bf16.h)
+                       (P <= 32 && a.rowsplit_waves == 16 && a.RS_i <= 16 && m->d_xmx));   // kMx16FuseSlices (lr_tall_mx.h)
     T* qb[2] = {a.q1, const_cast<T*>(a.q1_in)};
     T* pb[2] = {a.pm, const_cast<T*>(a.pm_in)};
     T* gb[2] = {a.part_g, const_cast<T*>(a.part_in)};

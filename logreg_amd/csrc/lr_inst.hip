@@ -169,7 +169,8 @@ int launch_tall_partial(hipStream_t st, int want_value, int want_grad, const voi
 #if LR_DTYPE == 0 && LR_P >= 8
     if (a.interior && !want_value && a.xmx && a.RS_i > 0) {  // reduced-precision interior leapfrog step on the bf16 matrix pipe
         const dim3 gridm((unsigned)a.RS_i, (unsigned)((a.C + 63) / 64));
-        hipLaunchKernelGGL((k_tall_partial_mx<P, 4>), gridm, dim3(256), 0, st, a);
+        if (a.rowsplit_waves == 16) hipLaunchKernelGGL((k_tall_partial_mx16<P>), gridm, dim3(1024), 0, st, a);
+        else hipLaunchKernelGGL((k_tall_partial_mx<P, 4>), gridm, dim3(256), 0, st, a);
         return check(hipGetLastError());
     }
 #endif

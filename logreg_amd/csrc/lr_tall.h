@@ -87,7 +87,7 @@ template <typename T, int P> struct TallArgs {
     int fuse_mid;
     int RS_i;               // row-split interior kernel (k_wide_partial_bf16r): slices, 0 = not used for this run
     int64_t slice_len_i;    //   and rows per slice (a multiple of 32 * rowsplit_waves: whole 32-row blocks per wave)
-    int rowsplit_waves;     //   4 or 8 waves per workgroup
+    int rowsplit_waves;     //   4 or 8 waves per workgroup (wide); 16: the 16-wave tall kernel k_tall_partial_mx16 is in use
     int p, l;
     T step;
     T a[P], b[P], c[P];

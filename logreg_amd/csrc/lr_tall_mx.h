@@ -168,6 +168,145 @@ __global__ void __launch_bounds__((64 * NW)) k_tall_partial_mx(TallArgs<float, P
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 16-WAVE form (one workgroup per CU: 4 chain groups x 4 row groups): the same tile-pair work, but a workgroup covers
+// 4x the rows of a slice, so the same four waves per SIMD need a quarter of the slices (16 instead of 64 for config 4)
+// -- few enough that every launch but the first can finish the PREVIOUS leapfrog step in its own prologue (kick with
+// the slice partials, drift: k_tall_update's PH_MID, as k_wide_partial_bf16r does for wide models) instead of a
+// launch of its own.  Wave w: chain group cg = w & 3 (chains 16 cg .. 16 cg + 15 of the block's 64), row group
+// rg = w >> 2 (every 4th tile pair of a chunk); the four row groups' gradients meet in LDS in row-group order.
+constexpr int kMx16FuseSlices = 16;  // the host fuses only when RS_i <= this
+template <int P>
+__global__ void __launch_bounds__(1024) k_tall_partial_mx16(TallArgs<float, P> a) {
+    using G = MxGeom<P>;
+    constexpr int NS = G::NS, kMxTileElems = G::TILE, kMxChunkTiles = G::CHUNK_TILES, NW = 16;
+    constexpr int CHUNK_BYTES = kMxChunkBytes;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * CHUNK_BYTES];
+    __shared__ __attribute__((aligned(16))) float qnew[64][P];
+    __shared__ __attribute__((aligned(16))) float red[4][64][P];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cg = wave & 3, rg = wave >> 2;
+    const int c = lane & 15, kg = lane >> 4;
+    const int64_t chain0 = (int64_t)blockIdx.y * 64;
+    const int rs = blockIdx.x;
+    const int64_t s0 = (int64_t)rs * a.slice_len_i, s1 = s0 + a.slice_len_i < a.n ? s0 + a.slice_len_i : a.n;
+    const int64_t tile0 = s0 / 16;
+    const int64_t ntile = s1 > s0 ? ((s1 - s0 + 31) / 32) * 2 : 0;
+    const int64_t nchunk = (ntile + kMxChunkTiles - 1) / kMxChunkTiles;
+    const uint32_t smem_lds = (uint32_t)(uintptr_t)smem;
+
+    auto issue = [&](int64_t g) {  // chunk g -> buffer g & 1; 1 KB per wave-instruction, dealt round-robin to the 16 waves
+        const int64_t t0 = g * kMxChunkTiles;
+        const int nt = (int)(ntile - t0 < kMxChunkTiles ? ntile - t0 : kMxChunkTiles);
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(a.xmx + (tile0 + t0) * (int64_t)kMxTileElems) + lane * 16;
+        const uint32_t dst = smem_lds + (uint32_t)((g & 1) * CHUNK_BYTES);
+        const int nkb = nt * (kMxTileElems * 2) / 1024;
+        for (int ch = wave; ch < nkb; ch += NW) {
+            uint32_t keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(src + ch * 1024), "s"(dst + ch * 1024)
+                         : "memory");
+        }
+    };
+    if (nchunk > 0) issue(0);
+
+    // the position this launch evaluates at: either stored (first interior step) or finished here from the previous step's
+    // slice partials (fuse_mid): g1 = sum over the slices (slice order, fp64) - q ivar;  p += eps g1;  q += (eps / m) p
+    for (int e = tid; e < 64 * P; e += 64 * NW) {
+        const int cc = e / P, j = e % P;
+        int64_t chain = chain0 + cc;
+        const bool live = chain < a.C;
+        if (!live) chain = a.C - 1;
+        const int64_t ix = chain * P + j;
+        float q;
+        if (a.fuse_mid) {
+            float t[kMx16FuseSlices];
+#pragma unroll
+            for (int r = 0; r < kMx16FuseSlices; ++r) t[r] = a.part_in[((int64_t)(r < a.RS_i ? r : a.RS_i - 1) * a.C) * P + ix];
+            const float q0 = a.q1_in[ix], p0 = a.pm_in[ix], bj = a.cvec[j], ivj = a.cvec[P + j];
+            double sum = 0.0;
+#pragma unroll
+            for (int r = 0; r < kMx16FuseSlices; ++r) sum += r < a.RS_i ? (double)t[r] : 0.0;
+            const float g1 = (float)sum - q0 * ivj;
+            const float pn = fma_t(a.step, g1, p0);
+            q = fma_t(bj, pn, q0);
+            if (rs == 0 && live) {
+                a.q1[ix] = q;
+                a.pm[ix] = pn;
+            }
+        } else {
+            q = a.q1[ix];
+        }
+        qnew[cc][j] = q;
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // (the loads above and this wave's share of chunk 0)
+    __syncthreads();
+
+    mx_u32x2 bh[NS], bl[NS];
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+        const float qa = qnew[16 * cg + c][8 * st + kg] * ExpScale<float>::k, qb = qnew[16 * cg + c][8 * st + kg + 4] * ExpScale<float>::k;
+        const uint32_t ha = mx_pack_rne(qa, qa), hb = mx_pack_rne(qb, qb);
+        const float la = qa - __builtin_bit_cast(float, ha << 16), lb = qb - __builtin_bit_cast(float, hb << 16);
+        bh[st] = mx_u32x2{ha, hb};
+        bl[st] = mx_u32x2{mx_pack_rne(la, la), mx_pack_rne(lb, lb)};
+    }
+    const int eta_off = mx_elem(kg, c);
+    const int tr_off = mx_elem(lane & 3, 4 * kg + ((lane & 15) >> 2));
+    mx_f32x4 gacc[NS];
+#pragma unroll
+    for (int st = 0; st < NS; ++st) gacc[st] = mx_f32x4{0, 0, 0, 0};
+
+    for (int64_t g = 0; g < nchunk; ++g) {
+        if (g > 0) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            __syncthreads();
+        }
+        if (g + 1 < nchunk) issue(g + 1);
+        const uint16_t* base = reinterpret_cast<const uint16_t*>(smem + (g & 1) * CHUNK_BYTES);
+        const int nt = (int)(ntile - g * kMxChunkTiles < kMxChunkTiles ? ntile - g * kMxChunkTiles : kMxChunkTiles);
+        for (int t = 2 * rg; t < nt; t += 8) {  // this row group's tile pairs of the chunk
+            const uint16_t* tp = base + t * kMxTileElems;
+            uint32_t wq[4];
+#pragma unroll
+            for (int T = 0; T < 2; ++T) {
+                mx_f32x4 e = {0, 0, 0, 0};
+#pragma unroll
+                for (int st = 0; st < NS; ++st) {
+                    const mx_s16x4 xa = *reinterpret_cast<const mx_s16x4*>(tp + T * kMxTileElems + st * kMxSetElems + eta_off);
+                    e = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(xa, __builtin_bit_cast(mx_s16x4, bh[st]), e, 0, 0, 0);
+                    e = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(xa, __builtin_bit_cast(mx_s16x4, bl[st]), e, 0, 0, 0);
+                }
+                const mx_f32x2 d0 = mx_f32x2{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])} + mx_f32x2{1.0f, 1.0f};
+                const mx_f32x2 d1 = mx_f32x2{__builtin_amdgcn_exp2f(e[2]), __builtin_amdgcn_exp2f(e[3])} + mx_f32x2{1.0f, 1.0f};
+                wq[2 * T] = mx_pack_rne(fast_rcp(d0.x), fast_rcp(d0.y));
+                wq[2 * T + 1] = mx_pack_rne(fast_rcp(d1.x), fast_rcp(d1.y));
+            }
+            const mx_u32x4 wv = {wq[0], wq[1], wq[2], wq[3]};
+#pragma unroll
+            for (int st = 0; st < NS; ++st) {
+                const mx_u32x2 t0 = mx_read_tr16(tp + st * kMxSetElems + tr_off), t1 = mx_read_tr16(tp + kMxTileElems + st * kMxSetElems + tr_off);
+                const mx_u32x4 xg = {t0[0], t0[1], t1[0], t1[1]};
+                gacc[st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mx_bf16x8, xg), __builtin_bit_cast(mx_bf16x8, wv), gacc[st], 0, 0, 0);
+            }
+        }
+    }
+    // the four row groups' gradients of a chain, summed in row-group order, one slice partial per chain and coordinate
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+        red[rg][16 * cg + c][8 * st + kg] = gacc[st][0] + gacc[st][1];
+        red[rg][16 * cg + c][8 * st + kg + 4] = gacc[st][2] + gacc[st][3];
+    }
+    __syncthreads();
+    for (int e = tid; e < 64 * P; e += 64 * NW) {
+        const int cc = e / P, j = e % P;
+        if (chain0 + cc < a.C)
+            a.part_g[((int64_t)rs * a.C + chain0 + cc) * P + j] = (red[0][cc][j] + red[1][cc][j]) + (red[2][cc][j] + red[3][cc][j]);
+    }
+}
+
 // Host side: the tile images.  rows: [n][P] fp32 signed rows.  out: [ceil(n/32) * 2][MxGeom<P>::TILE] bf16 bit patterns.
 inline uint16_t mx_bf16_rne(float x) {
     uint32_t b;
