@@ -179,8 +179,8 @@ constexpr int kMx16FuseSlices = 16;  // the host fuses only when RS_i <= this
 template <int P>
 __global__ void __launch_bounds__(1024) k_tall_partial_mx16(TallArgs<float, P> a) {
     using G = MxGeom<P>;
-    constexpr int NS = G::NS, kMxTileElems = G::TILE, kMxChunkTiles = G::CHUNK_TILES, NW = 16;
-    constexpr int CHUNK_BYTES = kMxChunkBytes;
+    constexpr int CHUNK_BYTES = 2 * kMxChunkBytes;  // 32 KB chunks: half the barriers of the 4-wave kernel (config 4: 30.2 -> 28.9 us per step; 48 KB: 29.5)
+    constexpr int NS = G::NS, kMxTileElems = G::TILE, kMxChunkTiles = CHUNK_BYTES / (G::TILE * 2), NW = 16;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * CHUNK_BYTES];
     __shared__ __attribute__((aligned(16))) float qnew[64][P];
     __shared__ __attribute__((aligned(16))) float red[4][64][P];
