@@ -981,3 +981,36 @@ def test_wider_models_sample_the_same_posterior_on_the_matrix_cores(la, n, p, C)
     assert np.max(np.abs(zm)) < 4.0 and np.max(np.abs(zv)) < 4.0
     assert np.sqrt(np.mean(zm ** 2)) < 1.6 and np.sqrt(np.mean(zv ** 2)) < 1.6
     assert abs(a["acc"] - f["acc"]) < 0.005
+
+
+@pytest.mark.parametrize("n,p", [(20000, 8), (17000, 12), (16500, 24)])
+@pytest.mark.parametrize("L", [2, 3, 5])
+def test_tall_sixteen_wave_interior_kernel_with_the_update_folded_in(la, n, p, L, monkeypatch):
+    """k_tall_partial_mx16 (tall narrow models from ~800 chains: 16-wave workgroups, the previous leapfrog step finished
+    in the next launch's prologue; L = 2: no fused hand-over, L = 3: one, L = 5: the state / partial buffers swap three
+    times): a 64-chain subset against the oracle at the reduced-precision tolerance, the same decisions and close
+    trajectories as the 4-wave form with its separate update launches, reruns and chunking bit-identical, ragged
+    chain count."""
+    from oracle.oracle import OracleModel
+    X, y, _ = la.synthetic_logreg(n, p, seed=n + p, beta_sd=0.4 / np.sqrt(p))
+    ps = np.full(p, 2.0)
+    orc = OracleModel(X, y, ps)
+    m = la.LogReg(X, y, ps)
+    C = 1000  # 16 chain blocks (the last one ragged): 16 slices x 16 blocks fill the chip
+    b = 0.02 * np.random.default_rng(L).standard_normal((C, p))
+    eps = 0.4 / np.sqrt(n)
+    k = la.hmcKernel(m.lpost, m.glp, eps=eps, l=L, dmm=np.ones(p))
+    ref = orc.run("hmc", b[:64], step=eps, l=L, scale=np.ones(p), thin=1, iters=2, seed=9, threads=0)
+    out, info = la.mcmc(b, k, thin=1, iters=2, verb=False, seed=9, return_info=True)
+    assert info["plan"]["mode"] == "stepwise"
+    ok = ref["margin"] > 0.1
+    assert ok.mean() > 0.5
+    assert np.array_equal(info["accepts"][:64][ok], ref["accepts"][ok].astype(np.uint32))
+    assert np.max(np.abs(out[:, :64][:, ok] - ref["out"][:, ok])) < 3e-2 / np.sqrt(n) + 1e-5
+    assert np.array_equal(out, la.mcmc(b, k, thin=1, iters=2, verb=False, seed=9, chunk=1))
+    monkeypatch.setenv("LOGREG_TALL_NO_MX16", "1")
+    old, oi = la.mcmc(b, k, thin=1, iters=2, verb=False, seed=9, return_info=True)
+    assert not np.array_equal(old, out)  # (other slice count, other summation order: the 16-wave kernel did run above)
+    same = oi["accepts"] == info["accepts"]
+    assert same.mean() > 0.99
+    assert np.max(np.abs(old[:, same] - out[:, same])) < 1e-3 / np.sqrt(n)
