@@ -175,6 +175,8 @@ __global__ void __launch_bounds__((64 * NW)) k_tall_partial_mx(TallArgs<float, P
 // the slice partials, drift: k_tall_update's PH_MID, as k_wide_partial_bf16r does for wide models) instead of a
 // launch of its own.  Wave w: chain group cg = w & 3 (chains 16 cg .. 16 cg + 15 of the block's 64), row group
 // rg = w >> 2 (every 4th tile pair of a chunk); the four row groups' gradients meet in LDS in row-group order.
+// (2 chain groups x 8 row groups -- 32 chains per workgroup, two workgroups per CU, eight waves per SIMD -- was measured:
+// config 4 unchanged (29.3 us), p = 12 / 24 / 32 slower (13.5 -> 16.1, 22.9 -> 27.9, 43.3 -> 45.6 us per step).)
 constexpr int kMx16FuseSlices = 16;  // the host fuses only when RS_i <= this
 template <int P>
 __global__ void __launch_bounds__(1024) k_tall_partial_mx16(TallArgs<float, P> a) {
