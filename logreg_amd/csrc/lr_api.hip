@@ -118,8 +118,10 @@ int64_t wide_chains_per_block(const lr_model* m, int64_t C) { return wide_engine
 // matrix-core chain kernel with its bf16 operands in LDS (lr_mfma.h MfmaRowsLds): bytes for a row split over S waves
 size_t mfma_lds_bytes(const lr_model* m, int S) {
     const int64_t tiles = (m->n + 15) / 16, ntw = (tiles + S - 1) / S;
-    const size_t nu = (size_t)m->P / 8;
-    return (size_t)S * ((size_t)ntw * nu * 64 * 8 + (size_t)((ntw + 1) / 2) * nu * 64 * 16);
+    const size_t nu = (size_t)m->P / 8, npair = (size_t)(ntw + 1) / 2;
+    // = S * MfmaRowsLds<P, S, false>::bytes_per_wave(ntw): eta images for an EVEN number of tiles (8 bytes per lane and
+    // coordinate pair), gradient images per tile pair (16 bytes)
+    return (size_t)S * (2 * npair * nu * 64 * 8 + npair * nu * 64 * 16);
 }
 // 160 KB less the kernel's static exchange buffers (red: 2 x S x 64 x P/4 floats, redv: S x 64 doubles)
 size_t mfma_lds_budget(const lr_model* m, int S = 4) { return 160 * 1024 - (size_t)128 * S * m->P - (size_t)512 * S; }
@@ -151,7 +153,9 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
         // (tools/planner_check.py, sustained clocks, HMC L=50: n=200 p=12..32 wins from 1024 chains (+7..+40 %); n=500 p=16 loses 10 %
         //  at 1024 chains and wins 1.8x at 2048;  p = 8 beyond the registers: see the LDS variant)
         const int64_t s4_from = (m->P > 8 ? (m->n <= 256 ? 4LL : 8LL) : (m->n > 16 * 4 * 16 ? 8LL : 16LL)) * m->cus;
-        const int try_S[2] = {C >= 40LL * m->cus && m->n <= 16 * 13 ? 1 : 0, C >= s4_from ? 4 : 0};
+        // (S = 1 beyond 13 tiles per wave, p = 8: the operands in ONE LDS image shared by the workgroup's four waves)
+        const bool s1_lds = m->P == 8 && m->n > 16 * 13 && mfma_lds_bytes(m, 1) <= mfma_lds_budget(m, 4) && !env_on("LOGREG_NO_MFMA_S1_LDS");
+        const int try_S[2] = {C >= 40LL * m->cus && (m->n <= 16 * 13 || s1_lds) ? 1 : 0, C >= s4_from ? 4 : 0};
         for (int want_S : try_S) {
             for (int i = 0; want_S && i < t->nvariants; ++i) {
                 const lr::Variant& v = t->variants[i];
@@ -180,10 +184,10 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
                 // 1024 chains, 48 | 90 at 4096, 82 | 94 at 16 384; n=1150 p=16: 30 | 32, 33 | 120, 81 | 129: from one workgroup per CU
                 // (8-wave split, n=2000 p=8, HMC L=50: lane-group LDS kernel 56 TF | this 70 at 2048 chains, 43 | 35 at 1024)
                 const bool lds8 = in_lds && m->P == 8 && mfma_lds_bytes(m, 8) <= mfma_lds_budget(m, 8);
-                if (in_lds && C < (lds8 ? 8LL : 16LL) * m->cus) continue;
+                if (in_lds && v.G != 1 && C < (lds8 ? 8LL : 16LL) * m->cus) continue;
                 if (in_lds ? mfma_lds_bytes(m, v.G) <= mfma_lds_budget(m, v.G) : (int64_t)16 * v.G * v.R >= m->n) {
                     int G = v.G;
-                    if (in_lds) {  // the 8-wave row split of the LDS variant where it exists and fits (n=2000 p=8: 121 -> 139 TF)
+                    if (in_lds && v.G == 4) {  // the 8-wave row split of the LDS variant where it exists and fits (n=2000 p=8: 121 -> 139 TF)
                         for (int j = 0; j < t->nvariants; ++j)
                             if (t->variants[j].mode == lr::MODE_MFMA && t->variants[j].G == 8 && t->variants[j].R == 0 &&
                                 mfma_lds_bytes(m, 8) <= mfma_lds_budget(m, 8))
@@ -878,7 +882,7 @@ int lr_model_create(const double* X, const double* y, int64_t n, int32_t p, cons
     }
     // rows the matrix-core chain kernel still takes with its operands streamed from device memory (profiles/r2_midn_lds_mfma.txt)
     const int64_t kMfmaStreamMaxRows = 8192;
-    if (m->P >= 8 && m->P <= 32 && dtype == LR_F32 && n > (m->P == 32 ? 16 * 4 * 8 : 16 * 4 * 16) && n <= kMfmaStreamMaxRows) {
+    if (m->P >= 8 && m->P <= 32 && dtype == LR_F32 && n > (m->P == 32 ? 16 * 4 * 8 : (m->P == 8 ? 16 * 13 : 16 * 4 * 16)) && n <= kMfmaStreamMaxRows) {
         // the matrix-core chain kernel would keep its bf16 operands in LDS: fp32 operand images for its end points
         const float* hrows = reinterpret_cast<const float*>(host.data());
         const size_t fl = (size_t)((n + 15) / 16) * 64 *

@@ -46,10 +46,11 @@ constexpr int P = LR_P;
 // per tile: 2.5 p (p/4 + p/4..p/2 fp32 end-point operands, p bf16 interior operands), so p = 32 stops at 8 tiles.
 // (4, 0): the bf16 operands in LDS instead (MfmaRowsLds: 64 p/8 bytes per row): n <= 2400 at p = 8, 1200 at p = 16; at p = 32
 // the LDS holds no more rows than the registers do.  (4, -1): the same images in device memory, built once per model.
+// (1, 0): 16 chains per wave, all rows, the four waves of a workgroup sharing ONE LDS image (many chains, 208 < n <= 2400).
 // (8, 0): the LDS variant with the rows split over 8 waves (two per SIMD hide each other's LDS and MFMA latencies: +15 %;
 // with the operands in registers the doubled per-wave fixed work costs more than that: n=200 -18 %, n=1000 -3 %).
 #if LR_DTYPE == 0 && LR_P == 8
-#define LR_MFMA_VARIANTS(X) X(1, 13) X(4, 4) X(4, 8) X(4, 16) X(4, 0) X(4, -1) X(8, 0) X(8, -1)
+#define LR_MFMA_VARIANTS(X) X(1, 13) X(1, 0) X(4, 4) X(4, 8) X(4, 16) X(4, 0) X(4, -1) X(8, 0) X(8, -1)
 #elif LR_DTYPE == 0 && LR_P == 16
 #define LR_MFMA_VARIANTS(X) X(1, 13) X(4, 4) X(4, 8) X(4, 16) X(4, 0) X(4, -1) X(8, 0)
 #elif LR_DTYPE == 0 && LR_P == 32

@@ -903,10 +903,12 @@ def test_matrix_core_kernel_on_mid_size_data(la, n, R):
 @pytest.mark.parametrize("n,p,group,R", [(200, 12, 4, 4), (200, 12, 1, 13), (500, 16, 4, 8), (900, 16, 4, 16), (200, 32, 4, 4),
                                          (450, 24, 4, 8), (180, 9, 1, 13),
                                          (1500, 8, 4, 0), (2300, 7, 4, 0), (1100, 12, 4, 0), (1150, 16, 4, 0), (1500, 8, 8, 0), (2300, 5, 8, 0),
+                                         (1450, 8, 4, 0), (2100, 8, 8, 0), (1070, 14, 4, 0), (400, 8, 1, 0), (1450, 6, 1, 0),
                                          (4000, 8, 4, -1), (2500, 6, 4, -1), (3100, 8, 8, -1), (3000, 12, 4, -1), (1250, 16, 4, -1), (700, 30, 4, -1), (2000, 20, 4, -1)])
 def test_matrix_core_kernel_for_wider_models(la, n, p, group, R):
     """Padded p = 16 / 32 (9 <= p <= 32): the lane owns p/4 coordinates, eta takes one bf16 MFMA per coordinate pair,
-    the gradient one per pair and tile pair.  rows_per_lane = 0: data beyond the register variants, bf16 operands in LDS;
+    the gradient one per pair and tile pair.  rows_per_lane = 0: data beyond the register variants, bf16 operands in LDS (odd and even tile counts per wave; group 1:
+    one image shared by the four chain tiles of a workgroup);
     rows_per_lane = -1: beyond LDS, the same operand images in device memory, built once per model (end points read fp32
     operand images from global memory in both).  Exact mode step-for-step against the oracle for HMC, MALA and RWMH;
     default mode (bf16 interior steps) close to it with the same decisions away from near-ties; bit-exact reruns,
