@@ -155,7 +155,9 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
         const int64_t s4_from = (m->P > 8 ? (m->n <= 256 ? 4LL : 8LL) : (m->n > 16 * 4 * 16 ? 8LL : 16LL)) * m->cus;
         // (S = 1 beyond 13 tiles per wave, p = 8: the operands in ONE LDS image shared by the workgroup's four waves)
         const bool s1_lds = m->P == 8 && m->n > 16 * 13 && mfma_lds_bytes(m, 1) <= mfma_lds_budget(m, 4) && !env_on("LOGREG_NO_MFMA_S1_LDS");
-        const int try_S[2] = {C >= 40LL * m->cus && (m->n <= 16 * 13 || s1_lds) ? 1 : 0, C >= s4_from ? 4 : 0};
+        // (HMC L=50, sustained clocks, S=4 | S=1 with the LDS image: n=300: 2.24 | 2.30e8 it/s at 16 384 chains, 2.33 | 2.68e8 at 32 768;
+        //  n=700: 1.02 | 1.09, 1.03 | 1.25; n=2000 (S=8): 3.74 | 3.94e7, 3.75 | 3.94: worth it from 96 chains per CU)
+        const int try_S[2] = {(C >= 40LL * m->cus && m->n <= 16 * 13) || (C >= 96LL * m->cus && s1_lds) ? 1 : 0, C >= s4_from ? 4 : 0};
         for (int want_S : try_S) {
             for (int i = 0; want_S && i < t->nvariants; ++i) {
                 const lr::Variant& v = t->variants[i];
