@@ -116,12 +116,18 @@ int wide_engine(const lr_model* m, int64_t C) {
 int64_t wide_chains_per_block(const lr_model* m, int64_t C) { return wide_engine(m, C) == 2 ? 128 : 64; }
 
 // matrix-core chain kernel with its bf16 operands in LDS (lr_mfma.h MfmaRowsLds): bytes for a row split over S waves
+// (the kernel's own layout function, so the two cannot drift apart: an earlier hand-written copy missed the even padding of
+//  the eta images and under-allocated by 512 p/8 bytes per wave for odd tile counts)
+template <int P> size_t mfma_lds_bytes_p(int64_t ntw, int S) {
+    switch (S) {
+    case 1: return 1 * lr::MfmaRowsLds<P, 1, false>::bytes_per_wave(ntw);
+    case 4: return 4 * lr::MfmaRowsLds<P, 4, false>::bytes_per_wave(ntw);
+    default: return 8 * lr::MfmaRowsLds<P, 8, false>::bytes_per_wave(ntw);
+    }
+}
 size_t mfma_lds_bytes(const lr_model* m, int S) {
     const int64_t tiles = (m->n + 15) / 16, ntw = (tiles + S - 1) / S;
-    const size_t nu = (size_t)m->P / 8, npair = (size_t)(ntw + 1) / 2;
-    // = S * MfmaRowsLds<P, S, false>::bytes_per_wave(ntw): eta images for an EVEN number of tiles (8 bytes per lane and
-    // coordinate pair), gradient images per tile pair (16 bytes)
-    return (size_t)S * (2 * npair * nu * 64 * 8 + npair * nu * 64 * 16);
+    return m->P == 8 ? mfma_lds_bytes_p<8>(ntw, S) : (m->P == 16 ? mfma_lds_bytes_p<16>(ntw, S) : mfma_lds_bytes_p<32>(ntw, S));
 }
 // 160 KB less the kernel's static exchange buffers (red: 2 x S x 64 x P/4 floats, redv: S x 64 doubles)
 size_t mfma_lds_budget(const lr_model* m, int S = 4) { return 160 * 1024 - (size_t)128 * S * m->P - (size_t)512 * S; }
