@@ -16,7 +16,8 @@ fails, done, skipped = [], 0, 0
 t0 = time.time()
 for case in range(cases):
     p = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 12, 16, 17, 24, 32, 33, 40, 64, 100, 128]))
-    n = int(rng.choice([1, 2, 3, 7, 16, 33, 64, 100, 199, 200, 201, 255, 256, 257, 400, 513, 1000, 2500, 5001, 9001]))
+    n = int(rng.choice([1, 2, 3, 7, 16, 33, 64, 100, 199, 200, 201, 208, 209, 255, 256, 257, 400, 513, 1000, 1024, 1025, 1450, 2390, 2401, 2500,
+                      5001, 8191, 8193, 9001]))
     if p > 32:
         n = min(n, 1000)
     C = int(rng.choice([1, 2, 15, 16, 17, 63, 64, 65, 130, 300]))
