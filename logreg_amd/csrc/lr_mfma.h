@@ -244,8 +244,10 @@ template <int P, int NTW, int S> struct MfmaRows {
 // The same operands kept in LDS instead of registers, for data beyond the register variants (16 S NTW < n): every wave of
 // a row-split workgroup builds the bf16 images of ITS tiles in a private LDS region at kernel start (64 p/8 bytes per
 // row: n <= 2400 at p = 8, 1200 at p = 16) and the interior steps stream them back (ds_read_b64 / b128 per
-// lane and tile, 1.5 KB per tile and wave against ~100 cycles of MFMA + VALU work).  The end-point evaluations (2 of
-// L + 1) take their fp32 operands straight from the row matrix in global memory (L2-resident).
+// lane and tile, 1.5 KB per tile and wave against ~100 cycles of MFMA + VALU work).  S = 1: the four chain tiles of a
+// workgroup share ONE image (every wave writes the same bytes).  The end-point evaluations take their fp32 MFMA operands
+// from the tile image below (device memory, built on the host at model creation), else gathered from the row matrix.
+//
 // fp32 operand image of the end-point evaluations, per GLOBAL 16-row tile T (row-split independent) and lane (c, k):
 //   [T][lane][0 .. NC)            A operand of the eta MFMAs:      rows[16T + c][k + 4h]
 //   [T][lane][NC + 4g + s]        A operand of the gradient MFMAs: rows[16T + 4k + s][c/4 + 4 (c%4) + 16g]  (0 if c%4 >= HG)
