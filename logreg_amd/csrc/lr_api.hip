@@ -574,7 +574,11 @@ int do_stepwise_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs
     const int64_t traj_tiles = (C + 15) / 16;
     const bool traj = P > 32 && bf16_interior && m->d_xblk1 != nullptr && t->launch_tall_traj != nullptr && rs.l > 1 &&
                       !env_on("LOGREG_WIDE_NO_TRAJ") &&
-                      (env_on("LOGREG_WIDE_TRAJ") || (traj_tiles >= m->cus && traj_tiles < 4LL * m->cus));
+                      (env_on("LOGREG_WIDE_TRAJ") || (traj_tiles >= m->cus && traj_tiles < 4LL * m->cus) ||
+                       // small designs (the one-piece image within 256 KB): the per-step stream is cheap, the launch per step is not
+                       // (us per evaluation, launch per step | trajectory kernel: n=500 p=64: 5.5 | 2.8 at 1024 chains; n=300 p=100:
+                       //  7.0 | 4.7; n=1000 p=128: 7.5 | 6.5; n=2000 p=50: 6.2 | 5.3; n=2000 p=128 (512 KB): 8.4 | 9.3)
+                       (traj_tiles < m->cus && (int64_t)m->n * m->P * 2 <= 256 * 1024));
     const bool fuse = bf16_interior && a.RS_i > 0 &&
                       ((P > 32 && a.RS_i <= 4 && !env_on("LOGREG_WIDE_NO_FUSE")) ||         // kFuseSlices (lr_wide_bf16.h)
                        (P <= 32 && a.rowsplit_waves == 16 && a.RS_i <= 16 && m->d_xmx));   // kMx16FuseSlices (lr_tall_mx.h)
