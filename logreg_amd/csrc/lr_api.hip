@@ -158,7 +158,7 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
         //   n=500 p=16: 43 | 40, 46 | 147, 47 | 160.   p > 8 moves to the matrix pipe from 4 chains per CU.
         // (tools/planner_check.py, sustained clocks, HMC L=50: n=200 p=12..32 wins from 1024 chains (+7..+40 %); n=500 p=16 loses 10 %
         //  at 1024 chains and wins 1.8x at 2048;  p = 8 beyond the registers: see the LDS variant)
-        const int64_t s4_from = (m->P > 8 ? (m->n <= 256 ? 4LL : 8LL) : (m->n > 16 * 4 * 16 ? 8LL : 16LL)) * m->cus;
+        const int64_t s4_from = (m->P > 8 ? (m->n <= 256 || (m->P == 32 && m->n <= 2048) ? 4LL : 8LL) : (m->n > 16 * 4 * 16 ? 8LL : 16LL)) * m->cus;
         // (S = 1 beyond 13 tiles per wave, p = 8: the operands in ONE LDS image shared by the workgroup's four waves)
         const bool s1_lds = m->P == 8 && m->n > 16 * 13 && mfma_lds_bytes(m, 1) <= mfma_lds_budget(m, 4) && !env_on("LOGREG_NO_MFMA_S1_LDS");
         // (HMC L=50, sustained clocks, S=4 | S=1 with the LDS image: n=300: 2.24 | 2.30e8 it/s at 16 384 chains, 2.33 | 2.68e8 at 32 768;
@@ -174,7 +174,9 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
                     //  p > 16: n=700 p=30: 31 | 74, 69 | 74; n=2000 p=20: 46 | 74, 85 | 80; n=5000 p=30: 105 | 132, 176 | 135; n=8000 p=24: 108 | 112, 160 | 115)
                     // (after the scalar-loop rework, n=8000: p=8 82 | 103 and 130 | 136; p=16 112 | 148 and 187 | 177; p=24 108 | 118 and 167 | 119)
                     const int64_t max_rows = C >= 64LL * m->cus ? (m->P == 8 ? 8192 : (m->P == 16 ? 4000 : 2000)) : 8192;
-                    if (!m->d_xms || C < 16LL * m->cus || m->n > max_rows) continue;
+                    // (p > 16, n <= 2048: already from 4 chains per CU -- n=700 p=30 at 1024 chains: 16 -> 19 TF, n=2000 p=20: 16 -> 20)
+                    const int64_t from = (m->P == 32 && m->n <= 2048 ? 4LL : 16LL) * m->cus;
+                    if (!m->d_xms || C < from || m->n > max_rows) continue;
                     int G = v.G;
                     // p = 8 below 64 chains per CU: the 8-wave row split (n=3000: 109 -> 120 TF, n=8000: 118 -> 137 at 4096 chains;
                     // at 16 384 chains the 4-wave split packs the CUs better: 135 vs 121)

@@ -331,7 +331,9 @@ def test_planner_engine_choice_by_size(la):
     assert wide_plan(500, 32, 4096) == {"mode": "mfma", "group": 4, "rows_per_lane": 8}
     assert wide_plan(900, 16, 4096) == {"mode": "mfma", "group": 4, "rows_per_lane": 16}
     assert wide_plan(900, 32, 4096) == {"mode": "mfma", "group": 4, "rows_per_lane": -1}  # p > 16 beyond 8 tiles per wave: operands in device memory
-    assert wide_plan(900, 32, 1024)["mode"] != "mfma"
+    assert wide_plan(900, 32, 1024) == {"mode": "mfma", "group": 4, "rows_per_lane": -1}  # (p > 16, n <= 2048: from 4 chains per CU)
+    assert wide_plan(900, 32, 512)["mode"] != "mfma"
+    assert wide_plan(3000, 32, 1024)["mode"] != "mfma"
     # beyond the register variants: the same kernel with its bf16 operands in LDS, from one workgroup per CU
     assert wide_plan(2000, 8, 4096) == {"mode": "mfma", "group": 8, "rows_per_lane": 0}  # (8-wave row split where it fits)
     assert wide_plan(2000, 8, 2048) == {"mode": "mfma", "group": 8, "rows_per_lane": 0}
