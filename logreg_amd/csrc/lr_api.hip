@@ -158,7 +158,10 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
         //   n=500 p=16: 43 | 40, 46 | 147, 47 | 160.   p > 8 moves to the matrix pipe from 4 chains per CU.
         // (tools/planner_check.py, sustained clocks, HMC L=50: n=200 p=12..32 wins from 1024 chains (+7..+40 %); n=500 p=16 loses 10 %
         //  at 1024 chains and wins 1.8x at 2048;  p = 8 beyond the registers: see the LDS variant)
-        const int64_t s4_from = (m->P > 8 ? (m->n <= 256 || (m->P == 32 && m->n <= 2048) ? 4LL : 8LL) : (m->n > 16 * 4 * 16 ? 8LL : 16LL)) * m->cus;
+        // p > 8: from 4 chains per CU, except where the alternative is still a register-resident vector kernel with more
+        // than 4 tiles per wave here (p <= 16, 256 < n <= 512: n=500 p=16 at 1024 chains 3.17 | 2.87e7 it/s)
+        const bool reg_alternative = m->P == 16 && m->n > 256 && m->n <= 512;
+        const int64_t s4_from = (m->P > 8 ? (reg_alternative || (m->P == 32 && m->n > 2048) ? 8LL : 4LL) : (m->n > 16 * 4 * 16 ? 8LL : 16LL)) * m->cus;
         // (S = 1 beyond 13 tiles per wave, p = 8: the operands in ONE LDS image shared by the workgroup's four waves)
         const bool s1_lds = m->P == 8 && m->n > 16 * 13 && mfma_lds_bytes(m, 1) <= mfma_lds_budget(m, 4) && !env_on("LOGREG_NO_MFMA_S1_LDS");
         // (HMC L=50, sustained clocks, S=4 | S=1 with the LDS image: n=300: 2.24 | 2.30e8 it/s at 16 384 chains, 2.33 | 2.68e8 at 32 768;
