@@ -20,8 +20,10 @@ At N = 1 the line also carries, outside the timed region:
   cpu_baseline   the float64 C oracle (OpenMP over chains) on a bounded sample of the same workload ("port")
   reference_cpu  the reference's own NumPy script, as measured in BASELINE.md (1 core)
   ess            ESS per kept draw from a separate 512-draw run (Geyer), scaled to the timed throughput
-  extra.configs  BASELINE.json configs 1, 3, 4, 5 on this GPU (one GPU's shard where the config is multi-GPU),
-                 each with its own roofline block
+  extra.configs  BASELINE.json configs 1, 3, 4, 5 on this GPU (one GPU's shard where the config is multi-GPU), each with its
+                 own roofline block, and "2_pima": the reference's own HMC run (Pima, eps=1e-3,
+                 dmm=1/pre) at 4096 chains with like-for-like it/s and min-ESS/s
+  extra.f64      the headline workload on the float64 instantiation (the reference computes in float64)
 
 `--dry-run` exercises the launch plumbing without a GPU (gloo instead of RCCL, no kernels): rank/world parsing,
 shard offsets, the gather and the max-over-ranks reduction -- what tests/test_host_logic.py runs on CPU.
@@ -155,6 +157,33 @@ def extra_configs(la, L, check, dev, stream):
                 "posterior_mean": np.asarray(s1.to_host(), dtype=np.float64).reshape(-1, 8).mean(axis=0).round(4).tolist(),
                 "note": "a single chain is one 64-lane wave on one SIMD of the chip: a latency figure (0.3 us per iteration), not a "
                         "throughput one; the many-chain rate of the same kernel family is config 3's"})
+    # ---- config 2 as the REFERENCE runs it: fit-np-hmc.py:105-108 -- HMC eps=1e-3, l=50, dmm=1/pre, thin 20, from the MAP, on
+    # Pima -- at 4096 chains, every evaluation in fp32 (the headline's variant): like-for-like it/s and min-ESS/s beside the
+    # script's own 1 368 it/s and 24.8 ESS/s (same posterior, same tuning, same estimator)
+    C2, KEPT = CHAINS_PER_GPU, 512
+    k2 = la.hmcKernel(m.lpost, m.glp, eps=1e-3, l=LEAP, dmm=1.0 / pre)
+    cs = la.ChainSet(k2, np.tile(bmap, (C2, 1)), seed=2, stream=stream, precision="full")
+    cs.advance(1, 400, keep=False)  # away from the common start (the reference starts at the MAP and keeps everything)
+    cs.sync()
+    a0 = int(cs.get_accepts().astype(np.int64).sum())
+    timer.start()
+    s2 = cs.advance(KEPT, THIN)
+    ms = timer.stop_ms()
+    acc2 = (int(cs.get_accepts().astype(np.int64).sum()) - a0) / (C2 * KEPT * THIN)
+    draws = np.asarray(s2.to_host(), dtype=np.float64)
+    s2.free()
+    ess2 = la.ess_pooled(draws, max_chains=256)  # Geyer per chain on 512 kept draws, 256 of the 4096 chains, scaled
+    its2 = C2 * KEPT * THIN / (ms * 1e-3)
+    res.append({"config": "2_pima", "workload": f"HMC eps=1e-3 L={LEAP} dmm=1/[100,1,1,1,1,1,25,1] thin {THIN} on Pima n=200 p=8 from the MAP "
+                f"(fit-np-hmc.py:105-108), {C2} chains x {KEPT} kept draws", "kernel_variant": cs.plan(), "precision": "full (all fp32)",
+                "chain_iterations_per_s": its2, "grad_evals_per_s": its2 * LEAP, "accept_rate": float(acc2), "launch_ms": ms,
+                "min_ess_per_s": float(ess2.min() / (ms * 1e-3)), "ess_per_kept_draw": (ess2 / (C2 * KEPT)).round(4).tolist(),
+                "ess_estimator": "Geyer initial-positive-sequence per chain (the estimator of BASELINE.md's 24.8 ESS/s), 256 of the "
+                                 f"{C2} chains, scaled; the {KEPT} x {THIN} iterations of the timed launch itself",
+                "posterior_mean": draws.reshape(-1, 8).mean(axis=0).round(4).tolist(),
+                "reference_cpu_it_per_s": REFERENCE_CPU["it_per_s"], "reference_min_ess_per_s": REFERENCE_CPU["min_ess_per_s"],
+                "speedup_it_per_s": its2 / REFERENCE_CPU["it_per_s"],
+                "speedup_min_ess_per_s": float(ess2.min() / (ms * 1e-3)) / REFERENCE_CPU["min_ess_per_s"]})
     # ---- config 3: MALA, thin 1000, 8192 chains = one GPU's shard of 65 536 (real Pima data)
     k = la.malaKernel(m.lpost, m.glp, dt=1e-5, pre=pre)
     C3 = 8192
@@ -253,41 +282,135 @@ def default_policy_runs(la, L, check, dev, stream, kern, init, steps):
                     "precision='full' (what `value` uses)", "runs": rows}
 
 
-def ess_per_draw(la, model, kern, q0, dev):
-    """ESS per kept draw (thin 20) from a SEPARATE run of 256 chains x 512 kept draws, Geyer IPS per chain."""
-    cs = la.ChainSet(kern, q0[:256], seed=SEED + 7)
+PEAK_FP64_TFLOPS = 78.6  # MI355X vector FP64 (cdna_hip_programming.md section 1: the SIMD-16 ceiling of the fp64 pipe)
+
+
+def f64_run(la, L, check, dev, stream, X, y, pscale, q0, steps):
+    """The headline workload on the float64 instantiation of the kernels (the reference's NumPy arithmetic is float64:
+    fit-np-hmc.py:18-19).  The f64 path is the validation-grade one (rows in LDS, no packed math, no matrix pipe): the
+    number says what the dtype choice of `value` buys, not what a tuned fp64 kernel could do."""
+    timer = Timer(L, check, dev, stream)
+    m64 = la.LogReg(X, y, pscale, dtype="float64", device=dev)
+    k64 = la.hmcKernel(m64.lpost, m64.glp, eps=EPS, l=LEAP, dmm=np.ones(N_PAR))
+    cs = la.ChainSet(k64, q0, seed=SEED, stream=stream, precision="full")
+    cs.advance(2, THIN, keep=False)
+    cs.sync()
+    a0 = cs.get_accepts().astype(np.int64).sum()
+    n = max(2, min(steps, 20))
+    timer.start()
+    for _ in range(n):
+        cs.advance(1, THIN, keep=False)
+    ms = timer.stop_ms()
+    C = q0.shape[0]
+    its = C * n * THIN / (ms * 1e-3)
+    tf = its * LEAP * flops_per_grad_eval(N_ROWS, N_PAR) / 1e12
+    return {"dtype": "f64", "kernel_variant": cs.plan(), "chain_iterations_per_s": its, "ms_per_step": ms / n,
+            "accept_rate": float((cs.get_accepts().astype(np.int64).sum() - a0) / (C * n * THIN)),
+            "algorithmic_TFLOPs": tf, "peak": PEAK_FP64_TFLOPS, "frac_of_fp64_vector_peak": tf / PEAK_FP64_TFLOPS,
+            "note": f"same workload, {C} chains, {n} launches of {THIN} iterations, HIP-event timed, not part of `value`"}
+
+
+def ess_per_draw(la, model, kern, q0, dev, plan, precision):
+    """ESS per kept draw (thin 20) from a SEPARATE run of 256 chains x 512 kept draws, Geyer IPS per chain, on the kernel
+    variant and precision policy of the timed run (the plan is pinned: 256 chains alone would be planned otherwise).
+    ESS per draw is a property of (eps, L) and the posterior, not of the variant -- pinning it makes the line say so."""
+    cs = la.ChainSet(kern, q0[:256], seed=SEED + 7, mode=plan["mode"], group=plan["group"], precision=precision)
     cs.advance(1, 200, keep=False)
     s = cs.advance(512, THIN).to_host()
     ess = la.ess_pooled(s, max_chains=None)
-    return ess / (s.shape[0] * s.shape[1]), s.shape
+    return ess / (s.shape[0] * s.shape[1]), s.shape, cs.plan()
 
 
-def dry_run(a, rank, world):
-    """Launch plumbing without a GPU: gloo group, shard offsets, gather to rank 0, max over ranks."""
+class Exchange:
+    """The multi-process side of the bench -- the ONE data-path collective (gather of the thinned samples to rank 0:
+    RCCL over xGMI on GPUs) plus the barrier and the two scalar reductions of the timing contract.  One object for
+    the real run (backend "nccl", CUDA tensors viewing the library's sample buffer in place) and for `--dry-run`
+    (backend "gloo", CPU tensors), so the CPU tests execute the very code the 8-GPU run does.  world = 1 without
+    LOGREG_BENCH_FORCE_DIST: every method is a no-op / identity."""
+
+    def __init__(self, backend, rank, world, local_rank, force=False):
+        self.rank, self.world, self.dist, self.torch, self.dev = rank, world, None, None, "cpu"
+        self.gathered = self.tout = None
+        if world > 1 or force:
+            import torch
+            import torch.distributed as dist
+            self.torch, self.dist = torch, dist
+            if backend == "nccl":
+                os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: the only kind this driver supports
+                torch.cuda.set_device(local_rank)
+                self.dev = f"cuda:{local_rank}"
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(backend)
+
+    @property
+    def active(self):
+        return self.dist is not None
+
+    def attach(self, samples):
+        """`samples`: this rank's [steps, C, p] sample buffer (a DeviceArray viewed in place, or a CPU tensor)."""
+        if not self.active:
+            return
+        self.tout = samples if isinstance(samples, self.torch.Tensor) else self.torch.as_tensor(samples, device=self.dev)
+        self.gathered = [self.torch.empty_like(self.tout) for _ in range(self.world)] if self.rank == 0 else None
+
+    def sync(self):
+        if self.active and self.dev != "cpu":
+            self.torch.cuda.synchronize()
+
+    def barrier(self):
+        """barrier + device synchronize: the bracket of the timed region"""
+        if self.active:
+            self.dist.barrier()
+            self.sync()
+
+    def gather(self) -> float:
+        """Gather every rank's samples to rank 0; returns this rank's wall seconds for it (complete on return)."""
+        if not self.active:
+            return 0.0
+        t = time.perf_counter()
+        self.dist.gather(self.tout, self.gathered, dst=0)
+        self.sync()
+        return time.perf_counter() - t
+
+    def reduce(self, value, op="max"):
+        """max (float) or sum (int) over the ranks"""
+        if not self.active:
+            return value
+        t = self.torch.tensor([value], device=self.dev, dtype=self.torch.float64 if op == "max" else self.torch.int64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX if op == "max" else self.dist.ReduceOp.SUM)
+        return float(t.item()) if op == "max" else int(t.item())
+
+    def close(self):
+        if self.active:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def dry_run(a, rank, world, local_rank):
+    """Launch plumbing without a GPU: the same Exchange object as the real run on the gloo backend -- shard offsets,
+    gather to rank 0, barrier, max/sum over ranks -- with a CPU tensor standing in for the sample buffer."""
     import torch
-    import torch.distributed as dist
-    if world > 1:
-        dist.init_process_group("gloo")
+    ex = Exchange("gloo", rank, world, local_rank)
     C = a.chains
     lo = rank * C  # weak scaling: chain_offset of this rank
-    out = torch.full((a.steps, C, N_PAR), float(rank))
+    ex.attach(torch.full((a.steps, C, N_PAR), float(rank)))
+    ex.gather()  # untimed first use, as in the real run
+    ex.barrier()
     t0 = time.perf_counter()
-    if world > 1:
-        gathered = [torch.empty_like(out) for _ in range(world)] if rank == 0 else None
-        dist.gather(out, gathered, dst=0)
-        dist.barrier()
-    wall = time.perf_counter() - t0
-    tw = torch.tensor([wall], dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+    gather_s = ex.gather()
+    ex.barrier()
+    wall = ex.reduce(time.perf_counter() - t0, "max")
+    gather_s = ex.reduce(gather_s, "max")
+    nacc = ex.reduce(rank + 1, "sum")
     if rank == 0:
-        ok = world == 1 or all(float(g[0, 0, 0]) == r for r, g in enumerate(gathered))
+        ok = world == 1 or ([tuple(g.shape) for g in ex.gathered] == [(a.steps, C, N_PAR)] * world and
+                            all(float(g[0, 0, 0]) == r and float(g[-1, -1, -1]) == r for r, g in enumerate(ex.gathered)))
         print(json.dumps({"dry_run": True, "metric": "MCMC iterations/sec x chains for HMC (L=50) on n=200,p=8", "value": None,
                           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "chain_offsets": [r * C for r in range(world)],
-                          "this_rank_offset": lo, "gather_ok": bool(ok), "scaling": "weak"}), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+                          "this_rank_offset": lo, "gather_ok": bool(ok), "gather_ms": gather_s * 1e3, "wall_ms": wall * 1e3,
+                          "sum_over_ranks_ok": nacc == world * (world + 1) // 2, "scaling": "weak"}), flush=True)
+    ex.close()
 
 
 def main():
@@ -314,14 +437,9 @@ def main():
         if rank == 0:
             print(f"warning: WORLD_SIZE={world} != --gpus {a.gpus}; using WORLD_SIZE", file=sys.stderr)
     if a.dry_run:
-        return dry_run(a, rank, world)
-    dist = None
-    if world > 1 or os.environ.get("LOGREG_BENCH_FORCE_DIST") == "1":  # the env var exercises the RCCL path at N=1
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        return dry_run(a, rank, world, local_rank)
+    # (LOGREG_BENCH_FORCE_DIST=1 runs the RCCL path at N = 1: tests/test_gpu_distributed.py)
+    ex = Exchange("nccl", rank, world, local_rank, force=os.environ.get("LOGREG_BENCH_FORCE_DIST") == "1")
 
     import logreg_amd as la
     from logreg_amd import _lib
@@ -336,7 +454,7 @@ def main():
     rng = np.random.Generator(np.random.Philox(SEED + 1000 * rank))
     q0 = init + 0.1 * 0.17 * rng.standard_normal((C, N_PAR))
 
-    dev = local_rank if dist is not None else 0
+    dev = local_rank if ex.active else 0
     model = la.LogReg(X, y, pscale, dtype="float32", device=dev)
     kern = la.hmcKernel(model.lpost, model.glp, eps=EPS, l=LEAP, dmm=np.ones(N_PAR))
     L = _lib.load()
@@ -363,38 +481,25 @@ def main():
     cs.sync()
 
     timer = Timer(L, _lib.check, dev, stream)
-    gathered = None
-    if dist is not None:
-        import torch
-        tout = torch.as_tensor(out, device=f"cuda:{dev}")
-        gathered = [torch.empty_like(tout) for _ in range(world)] if rank == 0 else None
-        dist.gather(tout, gathered, dst=0)  # untimed warm-up: RCCL sets up its p2p channels on first use
-        dist.barrier()
-        torch.cuda.synchronize()
+    ex.attach(out)
+    ex.gather()  # untimed first use: RCCL sets up its p2p channels
     acc0 = cs.get_accepts().astype(np.int64).sum()
+    ex.barrier()  # barrier + device synchronize on both sides of the timed region
     t0 = time.perf_counter()
     timer.start()
     for i in range(a.steps):
         one_step(i, True)
     _lib.check(L.lr_event_record(dev, timer.e1, stream))
     cs.sync()
-    if dist is not None:
-        dist.gather(tout, gathered, dst=0)  # RCCL gather of the thinned samples to rank 0
-        torch.cuda.synchronize()
-        dist.barrier()
+    gather_s = ex.gather()  # the ONE exchange of the path: RCCL gather of the thinned samples to rank 0
+    ex.barrier()
     t1 = time.perf_counter()
     ms = Ct.c_float()
     _lib.check(L.lr_event_elapsed_ms(dev, timer.e0, timer.e1, Ct.byref(ms)))
     kernel_ms_total = float(ms.value)
-    wall = t1 - t0
-    acc = cs.get_accepts().astype(np.int64).sum() - acc0
-    if dist is not None:
-        tw = torch.tensor([wall], device=f"cuda:{dev}", dtype=torch.float64)
-        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-        wall = float(tw.item())
-        ta = torch.tensor([acc], device=f"cuda:{dev}", dtype=torch.int64)
-        dist.all_reduce(ta)
-        acc = int(ta.item())
+    wall = ex.reduce(t1 - t0, "max")
+    gather_s = ex.reduce(gather_s, "max")
+    acc = ex.reduce(int(cs.get_accepts().astype(np.int64).sum() - acc0), "sum")
 
     if rank == 0:
         iters_total = world * C * a.steps * THIN
@@ -412,6 +517,9 @@ def main():
             "steps": a.steps,
             "warmup": a.warmup,
             "ms_per_step": 1e3 * wall / a.steps,
+            # the exchange's share of the timed region (max over ranks; 0 without a process group): separates compute from
+            # the gather in a 1 -> 8 GPU curve
+            "gather_ms": gather_s * 1e3,
             "prewarm": {"seconds": PREWARM_S, "steps": n_pre, "note": "untimed launches before the W warm-up steps, until the GPU holds its clocks"},
             "higher_is_better": True,
             "scaling": "weak",
@@ -459,7 +567,7 @@ def main():
             except (OSError, KeyError, ValueError):
                 pass
         if not a.no_ess:
-            eff, shape = ess_per_draw(la, model, kern, q0, dev)
+            eff, shape, ess_plan = ess_per_draw(la, model, kern, q0, dev, plan, a.precision)
             draws_per_s = world * C * a.steps / wall
             line["min_ess_per_s"] = float(eff.min() * draws_per_s)
             line["ess"] = {"ess_per_kept_draw_min": float(eff.min()), "ess_per_kept_draw_max": float(eff.max()),
@@ -467,16 +575,18 @@ def main():
                            "estimator": f"Geyer initial-positive-sequence per chain on a separate run of {shape[1]} chains x "
                                         f"{shape[0]} kept draws (thin {THIN}), outside the timed region; min over the {N_PAR} "
                                         "parameters; ESS/s = ESS per kept draw x kept draws/s of the timed run",
-                           "reference_min_ess_per_s": REFERENCE_CPU["min_ess_per_s"]}
+                           "kernel_variant": ess_plan, "precision": a.precision,
+                           "not_comparable_with": "reference_cpu.min_ess_per_s (24.8): that is Pima at eps=1e-3, dmm=1/pre; this is the "
+                                                  "synthetic headline design at eps=0.1, unit mass.  The like-for-like pair is "
+                                                  "extra.configs[config=2_pima]"}
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(X, y, pscale, init)
         if world == 1 and not a.no_extra:
             line["extra"] = {"configs": extra_configs(la, L, _lib.check, dev, stream),
-                             "default_policy": default_policy_runs(la, L, _lib.check, dev, stream, kern, init, a.steps)}
+                             "default_policy": default_policy_runs(la, L, _lib.check, dev, stream, kern, init, a.steps),
+                             "f64": f64_run(la, L, _lib.check, dev, stream, X, y, pscale, q0, a.steps)}
         print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    ex.close()
 
 
 if __name__ == "__main__":

@@ -56,8 +56,9 @@ enum { LR_F32 = 0, LR_F64 = 1 };
  * small kernels per log-posterior evaluation, the rows split into slices across the whole chip (`group` = 0
  * lets the library choose the slice count from the chain count, `group` > 0 requests that many slices; lr_plan
  * reports the slice count as group_out and the slice length as rows_out).  Slice partials are summed in slice
- * order, so launches of different chain counts are bit-identical only under the same slice count: a sharded
- * run that wants bit-exact agreement with the one-GPU run passes the one-GPU plan's group_out explicitly */
+ * order, so launches of different chain counts are bit-identical only under the same slicing: a sharded run
+ * that wants bit-exact agreement with the one-GPU run sets lr_run_opts.plan_chains to the whole run's chain count
+ * (which pins the interior kernels' own slicing as well; an explicit group > 0 pins the end-point slicing only) */
 enum { LR_MODE_AUTO = -1, LR_MODE_REG = 0, LR_MODE_LDS = 1, LR_MODE_GLOBAL = 2, LR_MODE_MFMA = 3, LR_MODE_STEPWISE = 4 };
 
 typedef struct lr_model lr_model;
@@ -69,7 +70,8 @@ typedef struct lr_run_opts {
     int64_t iters;        /* kept samples in this call       (mcmc(iters=...)) */
     int64_t iter_offset;  /* global index of this call's first iteration (chunked runs) */
     uint64_t seed;
-    int32_t group;        /* lanes per chain: 1,2,4,...,64; 0 = choose automatically */
+    int32_t group;        /* 0 = choose automatically; else per mode: lanes per chain 1,2,4,...,64 (REG / LDS / GLOBAL), row-split
+                           * ways 1, 4 or 8 (MFMA), slice count >= 1 (STEPWISE and every model with p > 32) */
     int32_t mode;         /* LR_MODE_*: where the data rows live during the launch */
     int32_t on_device;    /* see conventions */
     void* stream;         /* hipStream_t when on_device = 1 */
@@ -79,7 +81,10 @@ typedef struct lr_run_opts {
     int64_t stats_first;  /* index, within the statistics window, of this call's first kept sample */
     int64_t stats_slots;  /* slots in the buffer: stats_first + iters <= stats_slots * stats_batch */
     int32_t precision;    /* LR_PREC_*: arithmetic of HMC's INTERIOR leapfrog gradients (see below) */
-    int32_t reserved;     /* must be 0 */
+    int32_t plan_chains;  /* 0, or the chain count to PLAN for instead of n_chains: a shard of a larger run passes the whole
+                           * run's chain count, so that every choice that depends on the chain count (kernel variant, row
+                           * slicing of the stepwise engine and of its interior kernels, trajectory kernels) is the one-GPU
+                           * run's and the shard's output is bit-identical to the same chains of that run */
 } lr_run_opts;
 
 /*
@@ -88,9 +93,17 @@ typedef struct lr_run_opts {
  * Metropolis test uses the log-posterior at the two END points, which is always evaluated in the model's full
  * precision (as are the end-point half-kicks).  So the interior evaluations may be cheaper without biasing the
  * sampler; the only possible cost is acceptance rate.
- *   LR_PREC_AUTO   library's choice: LR_PREC_BF16 where a reduced-precision kernel exists (wide models,
- *                  32 < p <= 128: rows in one bf16 piece, beta in two, on the bf16 matrix pipe), else full
- *   LR_PREC_FULL   every evaluation in the model's dtype (bit-comparable with the float64 oracle step by step)
+ *   LR_PREC_AUTO   (= 0: what a zeroed lr_run_opts asks for, and the default of the Python face's mcmc()) the library's
+ *                  choice: reduced-precision interior gradients wherever such a kernel exists for a float32 model --
+ *                    narrow models, 8 <= padded p <= 32, n <= 8192: the fused matrix-core chain kernel (LR_MODE_MFMA; rows
+ *                      and beta in two bf16 pieces each, w = sigma(-eta) in one), planned from about 4 chains per CU
+ *                      (p > 8) / 16 per CU (p <= 8) upward, i.e. 1024 - 4096 chains on MI355X;
+ *                    tall models on the stepwise engine (the same scheme with the rows streamed: lr_tall_mx.h);
+ *                    wide models, 32 < p <= 128 (rows in one bf16 piece, beta in two: lr_wide_bf16.h);
+ *                  elsewhere (float64 models, p < 5, few chains on register/LDS-resident data) it is LR_PREC_FULL.
+ *                  A default HMC run is therefore NOT step-for-step comparable with a float64 reference run (the
+ *                  posterior is the same; acceptance rates measured within 0.001 - 0.01 of the exact-gradient run);
+ *   LR_PREC_FULL   every evaluation in the model's dtype (comparable with the float64 oracle step by step)
  *   LR_PREC_BF16   request the reduced-precision interior kernels (ignored where none exists)
  * RWMH, MALA and UL ignore the field (every evaluation of theirs enters an accept ratio or is the sample itself).
  */

@@ -29,7 +29,7 @@ class RunOpts(C.Structure):
                 ("iter_offset", C.c_int64), ("seed", C.c_uint64), ("group", C.c_int32), ("mode", C.c_int32),
                 ("on_device", C.c_int32), ("stream", C.c_void_p),
                 ("stats", C.c_void_p), ("stats_batch", C.c_int64), ("stats_first", C.c_int64), ("stats_slots", C.c_int64),
-                ("precision", C.c_int32), ("reserved", C.c_int32)]
+                ("precision", C.c_int32), ("plan_chains", C.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/logreg_hip.h declares

@@ -37,7 +37,11 @@ ARCH = "gfx950"
 # 256 registers, so the accumulator file buys nothing.
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-fno-slp-vectorize", "-falign-loops=64", "-mllvm", "-amdgpu-sched-strategy=max-ilp",
           "-mllvm", "-amdgpu-mfma-vgpr-form", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall",
-          "-Wno-unused-function", "-I", CSRC, "-I", INCLUDE] + os.environ.get("LOGREG_HIPCC_FLAGS", "").split()
+          "-Wno-unused-function", "-I", CSRC, "-I", INCLUDE]
+# development flags (e.g. -DLR_STAMPS) come from the environment of the BUILDING process only: they are recorded next to
+# the library, and every other process judges staleness against the recorded value, so ranks whose environments differ
+# do not rebuild the library back and forth
+EXTRA_ENV = "LOGREG_HIPCC_FLAGS"
 
 INSTANCES = [(dt, dtype_id, ctype, p) for dt, dtype_id, ctype in (("f32", 0, "float"), ("f64", 1, "double"))
              for p in (4, 8, 16, 32)]
@@ -57,30 +61,46 @@ def _sources():
 BUILD_ID_FILE = os.path.join(LIBDIR, "build_id.txt")
 
 
-def source_hash() -> str:
+def built_extra() -> str:
+    """The development flags the library on disk was built with (second line of build_id.txt; empty if none)."""
+    try:
+        with open(BUILD_ID_FILE) as f:
+            lines = f.read().split("\n")
+        return lines[1].strip() if len(lines) > 1 else ""
+    except OSError:
+        return ""
+
+
+def source_hash(extra: str | None = None) -> str:
     """Content hash of every kernel source, the ABI header and the compile flags: the library carries it
     (`lr_build_id()`), so a stale .so is recognised whatever the file times say (the library is git-ignored and
-    travels to the GPU box inside a snapshot whose mtimes mean nothing)."""
+    travels to the GPU box inside a snapshot whose mtimes mean nothing).  `extra`: development flags; None = the ones
+    recorded for the library on disk."""
     import hashlib
     h = hashlib.sha256()
     for path in _sources():
         h.update(os.path.basename(path).encode())
         with open(path, "rb") as f:
             h.update(f.read())
-    h.update(" ".join(f for f in COMMON if not os.path.isabs(f)).encode())  # flags without the -I paths
+    flags = [f for f in COMMON if not os.path.isabs(f)] + (built_extra() if extra is None else extra).split()
+    h.update(" ".join(flags).encode())  # flags without the -I paths
     return h.hexdigest()[:16]
 
 
 def built_id() -> str | None:
     try:
         with open(BUILD_ID_FILE) as f:
-            return f.read().strip()
+            return f.read().split("\n")[0].strip()
     except OSError:
         return None
 
 
 def needs_build() -> bool:
-    return not os.path.exists(LIB) or built_id() != source_hash()
+    """Missing, built from other sources, or built with development flags other than the ones this process asks for
+    explicitly (an UNSET variable asks for nothing: such a process takes the library as it is)."""
+    if not os.path.exists(LIB) or built_id() != source_hash():
+        return True
+    return EXTRA_ENV in os.environ and os.environ[EXTRA_ENV].split() != built_extra().split()
 
 
 def _run(cmd):
@@ -110,6 +130,8 @@ def build(force: bool = False, jobs: int | None = None, verbose: bool = True) ->
 
 def _build_locked(jobs: int | None, verbose: bool) -> str:
     hipcc = _hipcc()
+    extra = os.environ.get(EXTRA_ENV, "")
+    COMMON = globals()["COMMON"] + extra.split()
     jobs_list = []
     objs = []
     for dt, dtype_id, ctype, p in INSTANCES:
@@ -126,7 +148,7 @@ def _build_locked(jobs: int | None, verbose: bool) -> str:
                           os.path.join(CSRC, "lr_inst_wide.hip"), "-o", obj])
     api_obj = os.path.join(OBJDIR, "lr_api.o")
     objs.append(api_obj)
-    bid = source_hash()
+    bid = source_hash(extra)
     jobs_list.append([hipcc, *COMMON, f'-DLR_BUILD_ID="{bid}"', "-c", os.path.join(CSRC, "lr_api.hip"), "-o", api_obj])
     jobs = jobs or min(len(jobs_list), max(1, (os.cpu_count() or 2)))
     if verbose:
@@ -139,7 +161,7 @@ def _build_locked(jobs: int | None, verbose: bool) -> str:
     _run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", tmp, *objs])
     os.replace(tmp, LIB)
     with open(BUILD_ID_FILE, "w") as f:
-        f.write(bid + "\n")
+        f.write(bid + "\n" + extra + "\n")
     if verbose:
         print(f"[logreg_amd.build] wrote {LIB}", flush=True)
     return LIB

@@ -69,6 +69,18 @@ bool env_on(const char* name) {
 constexpr int kMaxP = 128;
 constexpr size_t kLdsBudget = 160 * 1024;
 
+#ifdef LR_STAMPS  // development builds only: time stamps of the first kStampSlots interior-step launches (tools/stamps.py)
+constexpr int kStampSlots = 64, kStampWgs = 512;
+int g_stamp_slot = 0;
+unsigned long long* g_stamp_buf = nullptr;
+constexpr size_t kStampBytes = (size_t)kStampSlots * kStampWgs * 16 * 16 * sizeof(unsigned long long);
+unsigned long long* stamp_buffer() {
+    if (!g_stamp_buf && (hipMalloc(&g_stamp_buf, kStampBytes) != hipSuccess || hipMemset(g_stamp_buf, 0, kStampBytes) != hipSuccess))
+        g_stamp_buf = nullptr;
+    return g_stamp_buf;
+}
+#endif
+
 }  // namespace
 
 struct lr_model {
@@ -331,6 +343,9 @@ template <typename T, int P> lr::ModelArgs<T, P> model_args(const lr_model* m) {
     return a;
 }
 
+// the chain count every chain-count-dependent choice is made for (lr_run_opts.plan_chains: a shard plans as the whole run)
+int64_t plan_count(const lr_run_opts* o) { return o->plan_chains > 0 ? (int64_t)o->plan_chains : o->n_chains; }
+
 struct RunSpec {
     int kind;
     double step;
@@ -393,7 +408,8 @@ int do_chain_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs, c
 }
 
 template <typename T, int P>
-int setup_tall(lr_model* m, const Plan& pl, hipStream_t st, int64_t C, lr::TallArgs<T, P>* pa) {
+int setup_tall(lr_model* m, const Plan& pl, hipStream_t st, int64_t C, int64_t Cp, lr::TallArgs<T, P>* pa) {
+    // C: chains of this call (sizes the workspace and the grids);  Cp: chains the slicing decisions are made for
     lr::TallArgs<T, P>& a = *pa;
     const int RS = pl.G;
     auto align = [](size_t b) { return (b + 255) & ~(size_t)255; };
@@ -403,7 +419,7 @@ int setup_tall(lr_model* m, const Plan& pl, hipStream_t st, int64_t C, lr::TallA
     int RS_i = 0, rs_waves = 4;
     int64_t slice_len_i = 0;
     if (m->P > 32 && m->d_xblk1 && !env_on("LOGREG_WIDE_NO_ROWSPLIT")) {
-        const int64_t tiles = (C + 15) / 16;
+        const int64_t tiles = (Cp + 15) / 16;
         const char* envt = std::getenv("LOGREG_WIDE_ROWSPLIT_MAX_TILES");  // tuning override
         if (tiles <= (envt ? std::atoll(envt) : (long long)m->cus)) {
             int64_t want = m->cus / tiles;
@@ -419,7 +435,7 @@ int setup_tall(lr_model* m, const Plan& pl, hipStream_t st, int64_t C, lr::TallA
     if (m->P <= 32 && m->d_xmx) {
         // narrow models, interior leapfrog steps on the matrix pipe (lr_tall_mx.h): 4-wave workgroups of 64 chains;
         // slices fine enough for ~4 waves per SIMD, each at least 256 rows, whole tile pairs
-        const int64_t blocks = (C + 63) / 64;
+        const int64_t blocks = (Cp + 63) / 64;
         int64_t want = (4LL * 4 * m->cus + 4 * blocks - 1) / (4 * blocks);
         if (want < 1) want = 1;
         slice_len_i = ((m->n + want - 1) / want + 31) / 32 * 32;
@@ -503,7 +519,7 @@ int setup_tall(lr_model* m, const Plan& pl, hipStream_t st, int64_t C, lr::TallA
     {
         // wide models: the exact-split bf16 matrix-core kernel (lr_wide_bf16.h) is the default -- same fp32
         // tolerances, 1.5x the fp32-MFMA kernel; LOGREG_WIDE_BF16=0 selects the fp32-MFMA kernel (lr_wide.h)
-        a.wide_bf16 = (m->P > 32 && m->d_xblk) ? wide_engine(m, C) : 0;
+        a.wide_bf16 = (m->P > 32 && m->d_xblk) ? wide_engine(m, Cp) : 0;
         a.xblk = static_cast<const uint16_t*>(m->d_xblk);
         a.xblk1 = static_cast<const uint16_t*>(m->d_xblk1);
         a.xmx = static_cast<const uint16_t*>(m->d_xmx);
@@ -515,8 +531,9 @@ int setup_tall(lr_model* m, const Plan& pl, hipStream_t st, int64_t C, lr::TallA
 template <typename T, int P>
 int do_eval_stepwise_t(lr_model* m, const Plan& pl, hipStream_t st, int64_t C, const void* beta, void* ll, void* lprior,
                        void* lpost, void* grad) {
+    if ((C + 63) / 64 > 65535) return fail(LR_ERR_UNSUPPORTED, "the stepwise engine takes at most %lld chains per call (got %lld)", 65535LL * 64, (long long)C);
     lr::TallArgs<T, P> a;
-    int rc = setup_tall<T, P>(m, pl, st, C, &a);
+    int rc = setup_tall<T, P>(m, pl, st, C, C, &a);
     if (rc) return rc;
     a.state = static_cast<T*>(const_cast<void*>(beta));
     a.ev_ll = static_cast<T*>(ll);
@@ -534,9 +551,11 @@ int do_eval_stepwise_t(lr_model* m, const Plan& pl, hipStream_t st, int64_t C, c
 template <typename T, int P>
 int do_stepwise_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs, const lr_run_opts* o, void* state,
                   double* lp_state, void* out, uint32_t* accepts) {
-    const int64_t C = o->n_chains;
+    const int64_t C = o->n_chains, Cp = plan_count(o);
+    // (chain blocks of 16 .. 128 chains are the grid's y / x dimension of the partial kernels: y is a 16-bit quantity)
+    if ((C + 63) / 64 > 65535) return fail(LR_ERR_UNSUPPORTED, "the stepwise engine takes at most %lld chains per call (got %lld): split the run into shards (chain_offset)", 65535LL * 64, (long long)C);
     lr::TallArgs<T, P> a;
-    int rc = setup_tall<T, P>(m, pl, st, C, &a);
+    int rc = setup_tall<T, P>(m, pl, st, C, Cp, &a);
     if (rc) return rc;
     a.state = static_cast<T*>(state);
     a.lp_state = lp_state;
@@ -568,7 +587,14 @@ int do_stepwise_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs
     if (!bf16_interior) a.RS_i = 0;
     auto KI = [&]() {
         a.interior = bf16_interior ? 1 : 0;
+#ifdef LR_STAMPS
+        a.stamps = g_stamp_slot < kStampSlots ? stamp_buffer() : nullptr;
+        a.stamp_slot = g_stamp_slot++;
+#endif
         K(0, 1);
+#ifdef LR_STAMPS
+        a.stamps = nullptr;
+#endif
         a.interior = 0;
     };
     // wide models: the whole interior of a trajectory in one launch (k_wide_traj_bf16): no slice partials, no update
@@ -576,7 +602,7 @@ int do_stepwise_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs
     // until the 64-chain workgroups of the chain-split kernel amortise the stream better (config 5 design, us per
     // evaluation of all chains, trajectory kernel | launch per step: 1024 chains 15.7 | 11.5, 2048: 16.1 | 14.4,
     // 4096: 22.2 | 25.0, 8192: 39.5 | 44.9, 16 384: 73.4 | 72.5).  LOGREG_WIDE_TRAJ=1 forces it on, LOGREG_WIDE_NO_TRAJ=1 off.
-    const int64_t traj_tiles = (C + 15) / 16;
+    const int64_t traj_tiles = (Cp + 15) / 16;
     const bool traj = P > 32 && bf16_interior && m->d_xblk1 != nullptr && t->launch_tall_traj != nullptr && rs.l > 1 &&
                       !env_on("LOGREG_WIDE_NO_TRAJ") &&
                       (env_on("LOGREG_WIDE_TRAJ") || (traj_tiles >= m->cus && traj_tiles < 4LL * m->cus) ||
@@ -701,19 +727,39 @@ int do_chain(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs, con
     LR_DISPATCH_TP(m, do_chain_t, m, pl, st, rs, o, state, lp_state, out, accepts);
 }
 
+// `group` means different things per mode (include/logreg_hip.h): lanes per chain (REG / LDS / GLOBAL / AUTO on narrow models:
+// a power of two <= 64), row-split ways of the matrix-core chain kernel (MFMA: 1, 4, 8), or the slice count of the stepwise
+// engine (STEPWISE, and every mode of a wide model: any positive count up to one slice per 32-row block -- ceil(n / slice_len)
+// is arbitrary, e.g. 63 for n = 20 000 at 1024 chains, and lr_plan's group_out must round-trip)
+int check_group(const lr_model* m, int group, int mode) {
+    if (group == 0) return LR_OK;
+    if (group < 0) return fail(LR_ERR_INVALID, "group must be >= 0 (got %d)", group);
+    if (mode == LR_MODE_STEPWISE || m->P > 32) {
+        const int64_t max_slices = (m->n + 31) / 32;
+        if (group > max_slices) return fail(LR_ERR_INVALID, "stepwise slice count %d exceeds the %lld 32-row blocks of the data", group, (long long)max_slices);
+        return LR_OK;
+    }
+    if (mode == LR_MODE_MFMA) {
+        if (group != 1 && group != 4 && group != 8) return fail(LR_ERR_INVALID, "matrix-core mode: group (row-split ways) must be 0, 1, 4 or 8 (got %d)", group);
+        return LR_OK;
+    }
+    if (group > 64 || (group & (group - 1))) return fail(LR_ERR_INVALID, "group (lanes per chain) must be 0 or a power of two <= 64 (got %d)", group);
+    return LR_OK;
+}
+
 int check_opts(const lr_model* m, const lr_run_opts* o, bool run) {
     if (!m) return fail(LR_ERR_INVALID, "model is NULL");
     if (!o) return fail(LR_ERR_INVALID, "opts is NULL");
     if (o->n_chains <= 0) return fail(LR_ERR_INVALID, "n_chains must be positive (got %lld)", (long long)o->n_chains);
-    if (o->group < 0 || o->group > 64 || (o->group & (o->group - 1)))
-        return fail(LR_ERR_INVALID, "group must be 0 or a power of two <= 64 (got %d)", o->group);
+    if (o->plan_chains < 0) return fail(LR_ERR_INVALID, "plan_chains must be 0 (= n_chains) or positive (got %d)", o->plan_chains);
+    if (const int rcg = check_group(m, o->group, o->mode)) return rcg;
     if (run) {
         if (o->thin <= 0 || o->iters < 0) return fail(LR_ERR_INVALID, "thin must be > 0 and iters >= 0");
         if (o->chain_offset < 0 || o->iter_offset < 0) return fail(LR_ERR_INVALID, "offsets must be >= 0");
         if ((uint64_t)(o->chain_offset + o->n_chains) > 0xFFFFFFFFull)
             return fail(LR_ERR_INVALID, "global chain ids must fit 32 bits");
-        if (o->precision < LR_PREC_AUTO || o->precision > LR_PREC_BF16 || o->reserved != 0)
-            return fail(LR_ERR_INVALID, "precision must be LR_PREC_AUTO/FULL/BF16 and reserved 0");
+        if (o->precision < LR_PREC_AUTO || o->precision > LR_PREC_BF16)
+            return fail(LR_ERR_INVALID, "precision must be LR_PREC_AUTO/FULL/BF16");
         if (o->stats) {
             if (o->stats_batch < 1 || o->stats_first < 0 || o->stats_slots < 1)
                 return fail(LR_ERR_INVALID, "stats needs stats_batch >= 1, stats_first >= 0, stats_slots >= 1");
@@ -745,7 +791,7 @@ int run_common(lr_model* m, const RunSpec& rs, const lr_run_opts* o, void* state
     if (threaded && !lp_state) return fail(LR_ERR_INVALID, "lp_state is required for RWMH/MALA");
     LR_HIP(hipSetDevice(m->device));
     Plan pl;
-    rc = make_plan(m, o->n_chains, o->group, o->mode, &pl, false, rs.kind == lr::KIND_HMC && o->precision != LR_PREC_FULL);
+    rc = make_plan(m, plan_count(o), o->group, o->mode, &pl, false, rs.kind == lr::KIND_HMC && o->precision != LR_PREC_FULL);
     if (rc) return rc;
     if (o->iters == 0) return LR_OK;
     if (o->on_device) return do_chain(m, pl, (hipStream_t)o->stream, rs, o, state, threaded ? lp_state : nullptr, out, accepts);
@@ -798,6 +844,20 @@ const char* lr_last_error(void) { return g_err; }
 #endif
 const char* lr_build_id(void) { return LR_BUILD_ID; }
 int lr_sizeof_run_opts(void) { return (int)sizeof(lr_run_opts); }
+
+#ifdef LR_STAMPS
+// development builds only: copy the stamp buffer [slots][512 workgroups][16 waves][16] to the host, restart the slot counter
+LR_API int lr_debug_read_stamps(unsigned long long* out, int* slots, int* wgs) {
+    if (slots) *slots = kStampSlots;
+    if (wgs) *wgs = kStampWgs;
+    if (!g_stamp_buf || !out) return LR_OK;
+    LR_HIP(hipDeviceSynchronize());
+    LR_HIP(hipMemcpy(out, g_stamp_buf, kStampBytes, hipMemcpyDeviceToHost));
+    LR_HIP(hipMemset(g_stamp_buf, 0, kStampBytes));
+    g_stamp_slot = 0;
+    return LR_OK;
+}
+#endif
 
 int lr_device_count(void) {
     int n = 0;
@@ -884,7 +944,10 @@ int lr_model_create(const double* X, const double* y, int64_t n, int32_t p, cons
             return fail(LR_ERR_NOMEM, "allocating the row-pair image (%zu bytes) failed", tw.size() * 4);
         }
     }
-    if (m->P >= 8 && m->P <= 32 && dtype == LR_F32) {  // narrow models: two-piece bf16 tile images (interior HMC steps on the matrix pipe)
+    // narrow models the planner would ever send to the stepwise engine by itself (rows beyond 64 KB): two-piece bf16 tile images
+    // for the interior HMC steps on the matrix pipe.  Smaller models run the engine only when forced (mode = STEPWISE), then in
+    // fp32 throughout, and carry no image.
+    if (m->P >= 8 && m->P <= 32 && dtype == LR_F32 && (size_t)n * m->P * 4 > 64 * 1024) {
         const float* hrows = reinterpret_cast<const float*>(host.data());
         const int64_t ntile = (n + 31) / 32 * 2;
         std::vector<uint16_t> img((size_t)ntile * (m->P / 8) * lr::kMxSetElems);
@@ -976,8 +1039,7 @@ int lr_plan(const lr_model* m, int64_t n_chains, int32_t group, int32_t mode, in
             int32_t* rows_out) {
     if (!m) return fail(LR_ERR_INVALID, "model is NULL");
     if (n_chains <= 0) return fail(LR_ERR_INVALID, "n_chains must be positive (got %lld)", (long long)n_chains);
-    if (group < 0 || group > 64 || (group & (group - 1)))
-        return fail(LR_ERR_INVALID, "group must be 0 or a power of two <= 64 (got %d)", group);
+    if (const int rcg = check_group(m, group, mode)) return rcg;
     Plan pl;
     const int rc = make_plan(m, n_chains, group, mode, &pl);
     if (rc) return rc;
@@ -992,7 +1054,7 @@ int lr_plan_run(const lr_model* m, int32_t kind, const lr_run_opts* o, int32_t* 
     if (rc) return rc;
     if (kind < LR_KIND_RWMH || kind > LR_KIND_UL) return fail(LR_ERR_INVALID, "kind must be one of LR_KIND_*");
     Plan pl;
-    rc = make_plan(m, o->n_chains, o->group, o->mode, &pl, false, kind == LR_KIND_HMC && o->precision != LR_PREC_FULL);
+    rc = make_plan(m, plan_count(o), o->group, o->mode, &pl, false, kind == LR_KIND_HMC && o->precision != LR_PREC_FULL);
     if (rc) return rc;
     if (mode_out) *mode_out = pl.mode;
     if (group_out) *group_out = pl.G;

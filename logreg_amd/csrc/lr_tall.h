@@ -92,7 +92,23 @@ template <typename T, int P> struct TallArgs {
     T step;
     T a[P], b[P], c[P];
     StatsArgs stats;  // streaming statistics of the kept samples (lr_device.h); buf = null: off
+#ifdef LR_STAMPS  // development builds only (LOGREG_HIPCC_FLAGS=-DLR_STAMPS): per-wave time stamps of the partial kernels
+    unsigned long long* stamps;  // [launch slot][workgroup][16 waves][16]
+    int stamp_slot;
+#endif
 };
+
+// LR_STAMP(a, k): lane 0 of every wave records the 100 MHz wall clock at point k < 8 of the kernel; LR_STAMP_CLK(a, k),
+// 8 <= k < 16: the shader clock (development builds only)
+#ifdef LR_STAMPS
+#define LR_STAMP_AT(a, k)                                                                                                    \
+    (a).stamps[((((size_t)(a).stamp_slot * (gridDim.x * gridDim.y) + blockIdx.y * gridDim.x + blockIdx.x) * 16) + (threadIdx.x >> 6)) * 16 + (k)]
+#define LR_STAMP(a, k) do { if ((a).stamps && (threadIdx.x & 63) == 0) LR_STAMP_AT(a, k) = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define LR_STAMP_CLK(a, k) do { if ((a).stamps && (threadIdx.x & 63) == 0) LR_STAMP_AT(a, k) = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define LR_STAMP(a, k) do { } while (0)
+#define LR_STAMP_CLK(a, k) do { } while (0)
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // Workgroup = NW waves x 64 chains: wave w of the group takes the w-th sub-slice of the group's

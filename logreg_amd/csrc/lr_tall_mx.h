@@ -14,10 +14,14 @@
 //   x = xh + xl, beta = bh + bl (two round-to-nearest bf16 pieces each: 16 significand bits), and
 //   eta = sum_j (xh_j + xl_j)(bh_j + bl_j) takes all four piece products of every coordinate from 2 x 16 K-slots.
 // Lane l = (c, kg) of a wave (c = l & 15: chain, kg = l >> 4) OWNS coordinates a = kg and b = kg + 4.
-//   eta tile (16 rows x 16 chains), two K = 16 MFMAs (v_mfma_f32_16x16x16_bf16) into one accumulator:
-//                                    A (lane (row, kg)) = [xh_a xl_a xh_b xl_b]          (K-slots 4 kg .. 4 kg + 3)
-//                                    B (lane (c,   kg)) = [bh_a bh_a bh_b bh_b], then [bl_a bl_a bl_b bl_b]
+//   eta tile (16 rows x 16 chains), ONE K = 32 MFMA (v_mfma_f32_16x16x32_bf16) per coordinate set:
+//                                    A (lane (row, kg)) = [xh_a xl_a xh_b xl_b | xh_a xl_a xh_b xl_b]   (K-slots 8 kg .. 8 kg + 7): the lane's
+//                                                         8 image bytes TWICE, by one ds_read2_b64 with equal offsets (mx_read_dup)
+//                                    B (lane (c,   kg)) = [bh_a bh_a bh_b bh_b | bl_a bl_a bl_b bl_b]
 //                                    D (lane (c, kg), r) = eta[row 4 kg + r][chain c]
+//   (round 2 used two K = 16 MFMAs per tile and set; measured in isolation, tools/mx_loop_probe.hip, ns per tile pair and SIMD at
+//    4 waves per SIMD: 117.6 -> 105.3 with the K = 32 form, -> 91.8 with two pairs per trip so that one pair's MFMAs issue among the
+//    other's exp / rcp; the vector ALU alone -- 16 transcendentals, 4 packed adds, 4 packs -- takes 79.6, the MFMAs + LDS alone 45.7)
 //   w = sigma(-eta) on the accumulator registers of two tiles, rounded to ONE bf16 piece = B of the gradient MFMA
 //       (K-slot 8 kg + i <-> i < 4: tile 0 row 4 kg + i; i >= 4: tile 1 row 4 kg + i - 4: the lane's own outputs)
 //   grad tile (K = 32 rows):  A (lane (m', kg)) = the 8 rows of slot group kg, element m' & 3 of coordinate group
@@ -33,6 +37,7 @@
 // four workgroups per CU), one barrier per chunk.
 #pragma once
 #include <cstring>
+#include <utility>
 
 #include "lr_tall.h"
 
@@ -56,6 +61,7 @@ template <int P> struct MxGeom {
     static constexpr int NS = P / 8;
     static constexpr int TILE = NS * kMxSetElems;              // bf16 elements per tile image
     static constexpr int CHUNK_TILES = kMxChunkBytes / (TILE * 2);
+    static constexpr int PAIRS_PER_TRIP = NS <= 2 ? 2 : 1;     // tile pairs per call of mx_pairs (register budget: 4 waves per SIMD)
 };
 
 __host__ __device__ constexpr int mx_elem(int kg, int row) { return kg * 64 + ((row + 8 * (kg >> 1)) & 15) * 4; }
@@ -65,6 +71,91 @@ __device__ __forceinline__ uint32_t mx_pack_rne(float a, float b) {
 }
 __device__ __forceinline__ mx_u32x2 mx_read_tr16(const uint16_t* p) {
     return __builtin_bit_cast(mx_u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) mx_s16x4*)(p)));
+}
+
+// The eta operand: the lane's 8 bytes [xh_a xl_a xh_b xl_b] of a (set, tile) image, duplicated into 4 registers by ONE
+// ds_read2_b64 whose two offsets are equal -- the duplicate comes out of the LDS unit, which has the slack, not out of v_mov
+// on the vector ALU, which has none.  Inline asm (told about the two identical halves the compiler reads once and copies);
+// the compiler does not count this read: mx_wait_dup names the destinations behind an lgkmcnt(0) before their first use.
+// OFF8: byte offset / 8 from `lds_addr`; the instruction's offsets are 8-bit (units of 8 bytes): what exceeds them is added to the
+// address (one v_add per 2 KB window, shared by the reads of the window).
+// the transposing read by LDS byte address (constant offsets fold into the instruction)
+__device__ __forceinline__ mx_u32x2 mx_read_tr16_at(uint32_t lds_addr) {
+    return __builtin_bit_cast(mx_u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) mx_s16x4*)(uintptr_t)lds_addr));
+}
+template <int OFF8> __device__ __forceinline__ void mx_read_dup(uint32_t lds_addr, mx_u32x4& a) {
+    asm volatile("ds_read2_b64 %0, %1 offset0:%2 offset1:%2" : "=&v"(a) : "v"(lds_addr + 8u * (OFF8 & ~255)), "i"(OFF8 & 255) : "memory");
+}
+
+// every (tile t, set st) of a trip, I = t NS + st (a fold: the offsets are immediates)
+template <int P, int NT, int... I>
+__device__ __forceinline__ void mx_read_dup_all(uint32_t eta_lds, mx_u32x4 (&xa)[NT][MxGeom<P>::NS], std::integer_sequence<int, I...>) {
+    constexpr int NS = MxGeom<P>::NS, TILE = MxGeom<P>::TILE;
+    (mx_read_dup<((I / NS) * TILE + (I % NS) * kMxSetElems) * 2 / 8>(eta_lds, xa[I / NS][I % NS]), ...);
+}
+
+// NPAIR (1 or 2) adjacent tile pairs of one wave's 16 chains: eta of every tile (K = 32 MFMA per coordinate set), w = sigma(-eta)
+// rounded to one bf16 piece, gradient MFMA per pair and set.  Two pairs per call leave the compiler one pair's MFMAs to place
+// among the other pair's exp / rcp (tools/mx_loop_probe.hip: 105 -> 92 ns per pair and SIMD).
+//   eta_lds / tr_lds   LDS byte address of the first tile image + the lane's offset for the eta read / the transposing read
+//   b32[st]            B operand of the eta MFMA of coordinate set st
+template <int P, int NPAIR>
+__device__ __forceinline__ void mx_pairs(uint32_t eta_lds, uint32_t tr_lds, const mx_u32x4 (&b32)[MxGeom<P>::NS], mx_f32x4 (&gacc)[MxGeom<P>::NS]) {
+    using G = MxGeom<P>;
+    constexpr int NS = G::NS, TILE = G::TILE, NT = 2 * NPAIR;
+    mx_u32x4 xa[NT][NS];
+    mx_read_dup_all<P, NT>(eta_lds, xa, std::make_integer_sequence<int, NT * NS>{});
+    mx_u32x2 xt[NT][NS];  // the gradient operands (transposing reads of the same images)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int st = 0; st < NS; ++st) xt[t][st] = mx_read_tr16_at(tr_lds + (uint32_t)(t * TILE + st * kMxSetElems) * 2);
+    // (every read above has returned: the asm reads are not counted by the compiler, and the counter is in order)
+    if constexpr (NT == 2 && NS == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xa[0][0]), "+v"(xa[1][0])::"memory");
+    else if constexpr (NT == 4 && NS == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xa[0][0]), "+v"(xa[1][0]), "+v"(xa[2][0]), "+v"(xa[3][0])::"memory");
+    else if constexpr (NT == 2 && NS == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xa[0][0]), "+v"(xa[0][1]), "+v"(xa[1][0]), "+v"(xa[1][1])::"memory");
+    else if constexpr (NT == 4 && NS == 2)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xa[0][0]), "+v"(xa[0][1]), "+v"(xa[1][0]), "+v"(xa[1][1]), "+v"(xa[2][0]), "+v"(xa[2][1]), "+v"(xa[3][0]), "+v"(xa[3][1])::"memory");
+    else if constexpr (NT == 2 && NS == 4)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xa[0][0]), "+v"(xa[0][1]), "+v"(xa[0][2]), "+v"(xa[0][3]), "+v"(xa[1][0]), "+v"(xa[1][1]), "+v"(xa[1][2]), "+v"(xa[1][3])::"memory");
+    else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xa[0][0]), "+v"(xa[0][1]), "+v"(xa[0][2]), "+v"(xa[0][3]), "+v"(xa[1][0]), "+v"(xa[1][1]), "+v"(xa[1][2]), "+v"(xa[1][3]),
+                     "+v"(xa[2][0]), "+v"(xa[2][1]), "+v"(xa[2][2]), "+v"(xa[2][3]), "+v"(xa[3][0]), "+v"(xa[3][1]), "+v"(xa[3][2]), "+v"(xa[3][3])::"memory");
+    mx_f32x4 e[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        e[t] = mx_f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int st = 0; st < NS; ++st)
+            e[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mx_bf16x8, xa[t][st]), __builtin_bit_cast(mx_bf16x8, b32[st]), e[t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int pr = 0; pr < NPAIR; ++pr) {
+        uint32_t wq[4];
+#pragma unroll
+        for (int T = 0; T < 2; ++T) {
+            const mx_f32x4& et = e[2 * pr + T];
+            const mx_f32x2 d0 = mx_f32x2{__builtin_amdgcn_exp2f(et[0]), __builtin_amdgcn_exp2f(et[1])} + mx_f32x2{1.0f, 1.0f};
+            const mx_f32x2 d1 = mx_f32x2{__builtin_amdgcn_exp2f(et[2]), __builtin_amdgcn_exp2f(et[3])} + mx_f32x2{1.0f, 1.0f};
+            wq[2 * T] = mx_pack_rne(fast_rcp(d0.x), fast_rcp(d0.y));
+            wq[2 * T + 1] = mx_pack_rne(fast_rcp(d1.x), fast_rcp(d1.y));
+        }
+        const mx_u32x4 wv = {wq[0], wq[1], wq[2], wq[3]};
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+            const mx_u32x4 xg = {xt[2 * pr][st][0], xt[2 * pr][st][1], xt[2 * pr + 1][st][0], xt[2 * pr + 1][st][1]};
+            gacc[st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mx_bf16x8, xg), __builtin_bit_cast(mx_bf16x8, wv), gacc[st], 0, 0, 0);
+        }
+    }
+}
+
+// B operands of the eta MFMAs from a chain's position: [bh_a bh_a bh_b bh_b | bl_a bl_a bl_b bl_b] of the lane's coordinates
+// a = 8 st + kg, b = 8 st + kg + 4, times log2(e), in two round-to-nearest bf16 pieces
+__device__ __forceinline__ mx_u32x4 mx_beta_operand(float qa_, float qb_) {
+    const float qa = qa_ * ExpScale<float>::k, qb = qb_ * ExpScale<float>::k;
+    const uint32_t ha = mx_pack_rne(qa, qa), hb = mx_pack_rne(qb, qb);
+    const float la = qa - __builtin_bit_cast(float, ha << 16), lb = qb - __builtin_bit_cast(float, hb << 16);
+    return mx_u32x4{ha, hb, mx_pack_rne(la, la), mx_pack_rne(lb, lb)};
 }
 
 template <int P, int NW>
@@ -107,18 +198,9 @@ __global__ void __launch_bounds__((64 * NW)) k_tall_partial_mx(TallArgs<float, P
     };
     if (nchunk > 0) issue(0);
 
-    // beta pieces of the lane's coordinates a = 8 s + kg, b = 8 s + kg + 4, times log2(e): B operands of the K = 16 eta MFMAs
-    // (K-slots 4 kg .. 4 kg + 3 of lane (c, kg):  [bh_a bh_a bh_b bh_b]  and  [bl_a bl_a bl_b bl_b]  against
-    //  A = [xh_a xl_a xh_b xl_b], the 8 bytes the image holds per (set, row, kg): no register shuffling per tile)
-    mx_u32x2 bh[NS], bl[NS];
+    mx_u32x4 b32[NS];
 #pragma unroll
-    for (int st = 0; st < NS; ++st) {
-        const float qa = a.q1[chain * P + 8 * st + kg] * ExpScale<float>::k, qb = a.q1[chain * P + 8 * st + kg + 4] * ExpScale<float>::k;
-        const uint32_t ha = mx_pack_rne(qa, qa), hb = mx_pack_rne(qb, qb);
-        const float la = qa - __builtin_bit_cast(float, ha << 16), lb = qb - __builtin_bit_cast(float, hb << 16);
-        bh[st] = mx_u32x2{ha, hb};
-        bl[st] = mx_u32x2{mx_pack_rne(la, la), mx_pack_rne(lb, lb)};
-    }
+    for (int st = 0; st < NS; ++st) b32[st] = mx_beta_operand(a.q1[chain * P + 8 * st + kg], a.q1[chain * P + 8 * st + kg + 4]);
 
     const int eta_off = mx_elem(kg, c);                                            // lane (row c, kg): its 4 elements
     const int tr_off = mx_elem(lane & 3, 4 * kg + ((lane & 15) >> 2));             // lane (kg, ri, ci): chunk ci, row 4 kg + ri
@@ -130,33 +212,15 @@ __global__ void __launch_bounds__((64 * NW)) k_tall_partial_mx(TallArgs<float, P
         __builtin_amdgcn_s_waitcnt(0x0F70);  // own share of chunk g has landed ...
         __syncthreads();                     // ... everybody's has, and nobody still reads the other buffer
         if (g + 1 < nchunk) issue(g + 1);
-        const uint16_t* base = reinterpret_cast<const uint16_t*>(smem + (g & 1) * CHUNK_BYTES);
         const int nt = (int)(ntile - g * kMxChunkTiles < kMxChunkTiles ? ntile - g * kMxChunkTiles : kMxChunkTiles);
-        for (int t = 0; t < nt; t += 2) {
-            const uint16_t* tp = base + t * kMxTileElems;
-            uint32_t wq[4];
-#pragma unroll
-            for (int T = 0; T < 2; ++T) {
-                mx_f32x4 e = {0, 0, 0, 0};
-#pragma unroll
-                for (int st = 0; st < NS; ++st) {
-                    const mx_s16x4 xa = *reinterpret_cast<const mx_s16x4*>(tp + T * kMxTileElems + st * kMxSetElems + eta_off);
-                    e = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(xa, __builtin_bit_cast(mx_s16x4, bh[st]), e, 0, 0, 0);
-                    e = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(xa, __builtin_bit_cast(mx_s16x4, bl[st]), e, 0, 0, 0);
-                }
-                const mx_f32x2 d0 = mx_f32x2{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])} + mx_f32x2{1.0f, 1.0f};
-                const mx_f32x2 d1 = mx_f32x2{__builtin_amdgcn_exp2f(e[2]), __builtin_amdgcn_exp2f(e[3])} + mx_f32x2{1.0f, 1.0f};
-                wq[2 * T] = mx_pack_rne(fast_rcp(d0.x), fast_rcp(d0.y));
-                wq[2 * T + 1] = mx_pack_rne(fast_rcp(d1.x), fast_rcp(d1.y));
-            }
-            const mx_u32x4 wv = {wq[0], wq[1], wq[2], wq[3]};
-#pragma unroll
-            for (int st = 0; st < NS; ++st) {
-                const mx_u32x2 t0 = mx_read_tr16(tp + st * kMxSetElems + tr_off), t1 = mx_read_tr16(tp + kMxTileElems + st * kMxSetElems + tr_off);
-                const mx_u32x4 xg = {t0[0], t0[1], t1[0], t1[1]};
-                gacc[st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mx_bf16x8, xg), __builtin_bit_cast(mx_bf16x8, wv), gacc[st], 0, 0, 0);
-            }
-        }
+        // running LDS addresses of the eta and the transposing reads (opaque to the optimiser: left to it, it keeps the chunk offset
+        // apart and adds it back on every trip -- 4 address adds per trip instead of 2)
+        uint32_t eta_lds = smem_lds + (uint32_t)((g & 1) * CHUNK_BYTES) + 2u * eta_off, tr_lds = smem_lds + (uint32_t)((g & 1) * CHUNK_BYTES) + 2u * tr_off;
+        asm volatile("" : "+v"(eta_lds), "+v"(tr_lds));
+        constexpr uint32_t kTrip = 2 * G::PAIRS_PER_TRIP * kMxTileElems * 2;
+        int t = 0;
+        for (; t + 2 * G::PAIRS_PER_TRIP <= nt; t += 2 * G::PAIRS_PER_TRIP, eta_lds += kTrip, tr_lds += kTrip) mx_pairs<P, G::PAIRS_PER_TRIP>(eta_lds, tr_lds, b32, gacc);
+        for (; t < nt; t += 2, eta_lds += 2 * kMxTileElems * 2, tr_lds += 2 * kMxTileElems * 2) mx_pairs<P, 1>(eta_lds, tr_lds, b32, gacc);
     }
     if (live) {
         float* dst = a.part_g + ((int64_t)rs * a.C + chain) * P;
@@ -197,6 +261,7 @@ __global__ void __launch_bounds__(1024) k_tall_partial_mx16(TallArgs<float, P> a
     const int64_t ntile = s1 > s0 ? ((s1 - s0 + 31) / 32) * 2 : 0;
     const int64_t nchunk = (ntile + kMxChunkTiles - 1) / kMxChunkTiles;
     const uint32_t smem_lds = (uint32_t)(uintptr_t)smem;
+    LR_STAMP(a, 0);
 
     auto issue = [&](int64_t g) {  // chunk g -> buffer g & 1; 1 KB per wave-instruction, dealt round-robin to the 16 waves
         const int64_t t0 = g * kMxChunkTiles;
@@ -243,58 +308,51 @@ __global__ void __launch_bounds__(1024) k_tall_partial_mx16(TallArgs<float, P> a
         }
         qnew[cc][j] = q;
     }
+    LR_STAMP(a, 1);
     __builtin_amdgcn_s_waitcnt(0x0F70);  // (the loads above and this wave's share of chunk 0)
     __syncthreads();
+    LR_STAMP(a, 2);
 
-    mx_u32x2 bh[NS], bl[NS];
+    mx_u32x4 b32[NS];
 #pragma unroll
-    for (int st = 0; st < NS; ++st) {
-        const float qa = qnew[16 * cg + c][8 * st + kg] * ExpScale<float>::k, qb = qnew[16 * cg + c][8 * st + kg + 4] * ExpScale<float>::k;
-        const uint32_t ha = mx_pack_rne(qa, qa), hb = mx_pack_rne(qb, qb);
-        const float la = qa - __builtin_bit_cast(float, ha << 16), lb = qb - __builtin_bit_cast(float, hb << 16);
-        bh[st] = mx_u32x2{ha, hb};
-        bl[st] = mx_u32x2{mx_pack_rne(la, la), mx_pack_rne(lb, lb)};
-    }
+    for (int st = 0; st < NS; ++st) b32[st] = mx_beta_operand(qnew[16 * cg + c][8 * st + kg], qnew[16 * cg + c][8 * st + kg + 4]);
     const int eta_off = mx_elem(kg, c);
     const int tr_off = mx_elem(lane & 3, 4 * kg + ((lane & 15) >> 2));
     mx_f32x4 gacc[NS];
 #pragma unroll
     for (int st = 0; st < NS; ++st) gacc[st] = mx_f32x4{0, 0, 0, 0};
 
+    LR_STAMP(a, 3);
+    LR_STAMP_CLK(a, 8);
     for (int64_t g = 0; g < nchunk; ++g) {
         if (g > 0) {
             __builtin_amdgcn_s_waitcnt(0x0F70);
             __syncthreads();
         }
         if (g + 1 < nchunk) issue(g + 1);
-        const uint16_t* base = reinterpret_cast<const uint16_t*>(smem + (g & 1) * CHUNK_BYTES);
         const int nt = (int)(ntile - g * kMxChunkTiles < kMxChunkTiles ? ntile - g * kMxChunkTiles : kMxChunkTiles);
-        for (int t = 2 * rg; t < nt; t += 8) {  // this row group's tile pairs of the chunk
-            const uint16_t* tp = base + t * kMxTileElems;
-            uint32_t wq[4];
-#pragma unroll
-            for (int T = 0; T < 2; ++T) {
-                mx_f32x4 e = {0, 0, 0, 0};
-#pragma unroll
-                for (int st = 0; st < NS; ++st) {
-                    const mx_s16x4 xa = *reinterpret_cast<const mx_s16x4*>(tp + T * kMxTileElems + st * kMxSetElems + eta_off);
-                    e = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(xa, __builtin_bit_cast(mx_s16x4, bh[st]), e, 0, 0, 0);
-                    e = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(xa, __builtin_bit_cast(mx_s16x4, bl[st]), e, 0, 0, 0);
-                }
-                const mx_f32x2 d0 = mx_f32x2{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])} + mx_f32x2{1.0f, 1.0f};
-                const mx_f32x2 d1 = mx_f32x2{__builtin_amdgcn_exp2f(e[2]), __builtin_amdgcn_exp2f(e[3])} + mx_f32x2{1.0f, 1.0f};
-                wq[2 * T] = mx_pack_rne(fast_rcp(d0.x), fast_rcp(d0.y));
-                wq[2 * T + 1] = mx_pack_rne(fast_rcp(d1.x), fast_rcp(d1.y));
-            }
-            const mx_u32x4 wv = {wq[0], wq[1], wq[2], wq[3]};
-#pragma unroll
-            for (int st = 0; st < NS; ++st) {
-                const mx_u32x2 t0 = mx_read_tr16(tp + st * kMxSetElems + tr_off), t1 = mx_read_tr16(tp + kMxTileElems + st * kMxSetElems + tr_off);
-                const mx_u32x4 xg = {t0[0], t0[1], t1[0], t1[1]};
-                gacc[st] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mx_bf16x8, xg), __builtin_bit_cast(mx_bf16x8, wv), gacc[st], 0, 0, 0);
+        // this row group's tile pairs of the chunk: two ADJACENT pairs (tiles 16 k + 4 rg .. 16 k + 4 rg + 3) per round of 16 tiles,
+        // so that one trip's images sit within the immediate offsets of one base address
+        // running LDS addresses of the eta and the transposing reads: the row group's first tile of the chunk, 16 tiles further per
+        // round (opaque to the optimiser: left to it, it keeps the chunk offset apart and adds it back on every trip)
+        constexpr uint32_t kRound = 16 * kMxTileElems * 2;
+        const uint32_t first = smem_lds + (uint32_t)((g & 1) * CHUNK_BYTES) + (uint32_t)(4 * rg) * (kMxTileElems * 2);
+        uint32_t eta_lds = first + 2u * eta_off, tr_lds = first + 2u * tr_off;
+        asm volatile("" : "+v"(eta_lds), "+v"(tr_lds));
+        int t = 4 * rg;
+        for (; t + 4 <= nt; t += 16, eta_lds += kRound, tr_lds += kRound) {
+            if constexpr (G::PAIRS_PER_TRIP == 2) {
+                mx_pairs<P, 2>(eta_lds, tr_lds, b32, gacc);
+            } else {
+                mx_pairs<P, 1>(eta_lds, tr_lds, b32, gacc);
+                mx_pairs<P, 1>(eta_lds + 2 * kMxTileElems * 2, tr_lds + 2 * kMxTileElems * 2, b32, gacc);
             }
         }
+        if (t < nt)  // the slice's last round may end after the first pair of a row group's two (tile counts are even)
+            mx_pairs<P, 1>(eta_lds, tr_lds, b32, gacc);
     }
+    LR_STAMP_CLK(a, 9);
+    LR_STAMP(a, 4);
     // the four row groups' gradients of a chain, summed in row-group order, one slice partial per chain and coordinate
 #pragma unroll
     for (int st = 0; st < NS; ++st) {
@@ -302,11 +360,13 @@ __global__ void __launch_bounds__(1024) k_tall_partial_mx16(TallArgs<float, P> a
         red[rg][16 * cg + c][8 * st + kg + 4] = gacc[st][2] + gacc[st][3];
     }
     __syncthreads();
+    LR_STAMP(a, 5);
     for (int e = tid; e < 64 * P; e += 64 * NW) {
         const int cc = e / P, j = e % P;
         if (chain0 + cc < a.C)
             a.part_g[((int64_t)rs * a.C + chain0 + cc) * P + j] = (red[0][cc][j] + red[1][cc][j]) + (red[2][cc][j] + red[3][cc][j]);
     }
+    LR_STAMP(a, 6);
 }
 
 // Host side: the tile images.  rows: [n][P] fp32 signed rows.  out: [ceil(n/32) * 2][MxGeom<P>::TILE] bf16 bit patterns.

@@ -428,6 +428,7 @@ __global__ void __launch_bounds__((64 * NW)) k_wide_partial_bf16r(TallArgs<float
     const int64_t blk0 = s0 / 32 + wb0;
     unsigned char* ring = smem + wave * RING_BYTES;
     const uint32_t ring_lds = (uint32_t)(uintptr_t)ring;  // LDS byte address (generic -> local keeps the low 32 bits)
+    LR_STAMP(a, 0);
 
     auto issue = [&](int b) {  // block b of this wave -> ring slot b % NBUF
         const unsigned char* src = reinterpret_cast<const unsigned char*>(a.xblk1 + (blk0 + b) * (int64_t)G::BUF1) + lane * 16;
@@ -441,9 +442,8 @@ __global__ void __launch_bounds__((64 * NW)) k_wide_partial_bf16r(TallArgs<float
                          : "memory");
         }
     };
-#pragma unroll
-    for (int b = 0; b < NBUF - 1; ++b)
-        if (b < wnb) issue(b);
+    // (the first blocks are requested below, BEHIND the prologue's own loads: issuing the DMA first put its 60-185 cycles per
+    //  1 KB piece in front of the one memory round trip the prologue waits for)
 
     // fused previous step (k_tall_update's PH_MID done here):  g1 = sum of the slice partials (slice order, fp64)
     // - q ivar;  p += eps g1;  q += (eps / m) p.  The four waves hold the SAME 16 chains, so the work is dealt out:
@@ -451,7 +451,10 @@ __global__ void __launch_bounds__((64 * NW)) k_wide_partial_bf16r(TallArgs<float
     // leaves the new position in LDS for the others and -- slice 0 only -- in the state buffers for the next launch.
     // Identical arithmetic in the RS_i workgroups of a tile.
     constexpr int kFuseSlices = 4;  // the host fuses only when RS_i <= kFuseSlices
-    __shared__ __attribute__((aligned(16))) float qnew[16][P];
+    // the new position, laid out for the b128 accesses of lanes (c, kg): coordinate j of chain c at [j / 8][(j / 4) & 1][c][j & 3] -- the
+    // 16 lanes of a service group (8 of one kg, 8 of the next: 512 bytes apart) then cover 16 distinct 16-byte bank slots.  As
+    // [16][P] (round 2) the chains were 512 bytes = 0 banks apart: every access a 16-way conflict, 41 % of the kernel's LDS cycles.
+    __shared__ __attribute__((aligned(16))) float qnew[P / 8][2][16][4];
     if (a.fuse_mid) {
         if (wave < G::M32) {
             const int m = wave;
@@ -467,6 +470,9 @@ __global__ void __launch_bounds__((64 * NW)) k_wide_partial_bf16r(TallArgs<float
                 vb[h] = *reinterpret_cast<const f32x4*>(a.cvec + 32 * m + 8 * kg + 4 * h);
                 vi[h] = *reinterpret_cast<const f32x4*>(a.cvec + P + 32 * m + 8 * kg + 4 * h);
             }
+#pragma unroll
+            for (int b = 0; b < NBUF - 1; ++b)
+                if (b < wnb) issue(b);
             f32x4 xn[2], pn[2];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -479,17 +485,27 @@ __global__ void __launch_bounds__((64 * NW)) k_wide_partial_bf16r(TallArgs<float
                 pn[e >> 2][e & 3] = pmn;
                 xn[e >> 2][e & 3] = fma_t(vb[e >> 2][e & 3], pmn, vq[e >> 2][e & 3]);
             }
-            *reinterpret_cast<f32x4*>(&qnew[c][32 * m + 8 * kg]) = xn[0];
-            *reinterpret_cast<f32x4*>(&qnew[c][32 * m + 8 * kg + 4]) = xn[1];
+            *reinterpret_cast<f32x4*>(&qnew[4 * m + kg][0][c][0]) = xn[0];
+            *reinterpret_cast<f32x4*>(&qnew[4 * m + kg][1][c][0]) = xn[1];
             if (rs == 0 && chain0 + c < a.C) {
                 *reinterpret_cast<f32x4*>(a.q1 + at) = xn[0];
                 *reinterpret_cast<f32x4*>(a.q1 + at + 4) = xn[1];
                 *reinterpret_cast<f32x4*>(a.pm + at) = pn[0];
                 *reinterpret_cast<f32x4*>(a.pm + at + 4) = pn[1];
             }
+        } else {
+#pragma unroll
+            for (int b = 0; b < NBUF - 1; ++b)
+                if (b < wnb) issue(b);
         }
+        LR_STAMP(a, 1);
         __syncthreads();
+    } else {
+#pragma unroll
+        for (int b = 0; b < NBUF - 1; ++b)
+            if (b < wnb) issue(b);
     }
+    LR_STAMP(a, 2);
     // beta = hi + lo (two round-to-nearest bf16 pieces) of the lane's coordinates 32 m + 8 kg + i, times log2(e)
     u32x4 bq[G::M32][2];
 #pragma unroll
@@ -497,8 +513,8 @@ __global__ void __launch_bounds__((64 * NW)) k_wide_partial_bf16r(TallArgs<float
         const int64_t at = chain * P + 32 * m + 8 * kg;
         float x[8];
         if (a.fuse_mid) {
-            const f32x4 v0 = *reinterpret_cast<const f32x4*>(&qnew[c][32 * m + 8 * kg]);
-            const f32x4 v1 = *reinterpret_cast<const f32x4*>(&qnew[c][32 * m + 8 * kg + 4]);
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(&qnew[4 * m + kg][0][c][0]);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(&qnew[4 * m + kg][1][c][0]);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 x[e] = v0[e];
@@ -535,6 +551,8 @@ __global__ void __launch_bounds__((64 * NW)) k_wide_partial_bf16r(TallArgs<float
 #pragma unroll
     for (int mb = 0; mb < G::MBP; ++mb) gacc[mb] = f32x4{0, 0, 0, 0};
 
+    LR_STAMP(a, 3);
+    LR_STAMP_CLK(a, 8);
     for (int b = 0; b < wnb; ++b) {
         // slot (b - 1) % NBUF was read during the previous trip and those reads have returned (their MFMAs
         // issued): refill it with block b + NBUF - 1, then wait for block b with the younger ones still in flight
@@ -567,12 +585,15 @@ __global__ void __launch_bounds__((64 * NW)) k_wide_partial_bf16r(TallArgs<float
             gacc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(xg), as_bf16x8(wv), gacc[mb], 0, 0, 0);
         }
     }
+    LR_STAMP_CLK(a, 9);
+    LR_STAMP(a, 4);
     // the four waves' gradients of the tile, summed in wave order (deterministic) and written once
     float* otile = reinterpret_cast<float*>(ring);
 #pragma unroll
     for (int mb = 0; mb < G::MBP; ++mb)
         *reinterpret_cast<f32x4*>(otile + c * OT + 32 * (mb >> 1) + 8 * kg + 4 * (mb & 1)) = gacc[mb];
     __syncthreads();
+    LR_STAMP(a, 5);
     {
         const int64_t nlive = a.C - chain0 < 16 ? a.C - chain0 : 16;
         f32x4* dst = reinterpret_cast<f32x4*>(a.part_g + ((int64_t)rs * a.C + chain0) * P);
@@ -581,9 +602,14 @@ __global__ void __launch_bounds__((64 * NW)) k_wide_partial_bf16r(TallArgs<float
             f32x4 acc = *reinterpret_cast<const f32x4*>(smem + off * 4);
 #pragma unroll
             for (int w = 1; w < NW; ++w) acc += *reinterpret_cast<const f32x4*>(smem + w * RING_BYTES + off * 4);  // wave order
+#ifdef LR_WIDE_NT_PARTIALS
             __builtin_nontemporal_store(acc, &dst[i]);
+#else
+            dst[i] = acc;  // plain: the 4 slice workgroups of the tile that read it back next launch sit on this XCD
+#endif
         }
     }
+    LR_STAMP(a, 6);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

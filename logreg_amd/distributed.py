@@ -135,9 +135,11 @@ def mcmc_sharded(init, make_kernel, thin=10, iters=10000, seed=0, dst=0, group=N
     `summary_only=True`, on EVERY rank the posterior summary dict of all chains from one all-reduce of the
     on-device statistics (`reduce_stats`); no samples are stored or moved.
 
-    `plan="global"` pins the kernel variant to the one a single GPU would pick for all C chains, which makes the
-    output bit-identical to the one-GPU run (summation order depends on the variant); the default "local" lets
-    every rank plan for its own shard size (statistically identical, fastest).
+    `plan="global"` makes every rank plan for all C chains (`lr_run_opts.plan_chains = C`): the kernel variant, the
+    row slicing of the stepwise engine and of its reduced-precision interior kernels and the trajectory-kernel choice
+    are then the ones a single GPU running all C chains would make -- for this kernel family and this `precision` --
+    so the output is bit-identical to the one-GPU run (summation order is a property of those choices); the default
+    "local" lets every rank plan for its own shard size (statistically identical, fastest).
     `chainset_factory(kernel, block, seed, chain_offset=..., **kw)` defaults to `ChainSet` (tests inject a CPU one).
     """
     import os
@@ -153,10 +155,9 @@ def mcmc_sharded(init, make_kernel, thin=10, iters=10000, seed=0, dst=0, group=N
     C, p = init.shape
     lo, hi = shard_bounds(C, world, rank)
     kernel = make_kernel(local_device)
-    if plan == "global" and "mode" not in kw and hasattr(kernel, "model"):
-        pl = kernel.model.plan(C)
-        kw = dict(kw, mode=pl["mode"], group=pl["group"])
-    elif plan not in ("local", "global"):
+    if plan == "global":
+        kw = dict(kw, plan_chains=C)
+    elif plan != "local":
         raise ValueError("plan must be 'local' or 'global'")
     cs = factory(kernel, init[lo:hi], seed, chain_offset=lo, **kw) if hi > lo else None
     if chunk is None:

@@ -211,7 +211,7 @@ class ChainSet:
     """
 
     def __init__(self, kernel: FusedKernel, init, seed: int, chain_offset: int = 0, ll=None, group: int = 0,
-                 mode: str = "auto", stream=None, precision: str = "auto"):
+                 mode: str = "auto", stream=None, precision: str = "auto", plan_chains: int = 0):
         self.kernel = kernel
         self.model = kernel.model
         m = self.model
@@ -226,6 +226,9 @@ class ChainSet:
         self.mode = _lib.MODE_BY_NAME[mode]
         # arithmetic of HMC's interior leapfrog gradients (include/logreg_hip.h LR_PREC_*): "auto" | "full" | "bf16"
         self.precision = _lib.PREC_BY_NAME[precision]
+        # chain count every chain-count-dependent choice is made for (0 = this set's own): a shard of a larger run passes the
+        # whole run's count and reproduces the one-GPU run bit for bit (lr_run_opts.plan_chains)
+        self.plan_chains = int(plan_chains)
         self.stream = stream
         self.state = DeviceArray.from_host(m.device, st)
         lp0 = np.full(self.C, -np.inf) if ll is None else np.broadcast_to(np.asarray(ll, dtype=np.float64), (self.C,))
@@ -241,7 +244,7 @@ class ChainSet:
 
     def plan(self):
         """The kernel variant `advance` launches for this chain set (family- and precision-aware: `lr_plan_run`)."""
-        opts = RunOpts(n_chains=self.C, group=self.group, mode=self.mode, precision=self.precision)
+        opts = RunOpts(n_chains=self.C, group=self.group, mode=self.mode, precision=self.precision, plan_chains=self.plan_chains)
         m, g, r = C.c_int32(), C.c_int32(), C.c_int32()
         check(_lib.load().lr_plan_run(self.model.handle, _lib.KIND_BY_NAME[self.kernel.kind], C.byref(opts), C.byref(m),
                                       C.byref(g), C.byref(r)))
@@ -269,7 +272,7 @@ class ChainSet:
             out = DeviceArray(m.device, (iters, self.C, m.p), m.np_dtype)
         opts = RunOpts(n_chains=self.C, chain_offset=self.chain_offset, thin=int(thin), iters=int(iters),
                        iter_offset=self.iter_offset, seed=self.seed, group=self.group, mode=self.mode, on_device=1,
-                       stream=self.stream, precision=self.precision)
+                       stream=self.stream, precision=self.precision, plan_chains=self.plan_chains)
         use_stats = self.stats is not None if stats is None else bool(stats)
         if use_stats:
             if self.stats is None:
@@ -386,7 +389,7 @@ def _auto_chunk(kernel: FusedKernel, C: int, thin: int, iters: int) -> int:
 
 
 def mcmc(init, kernel, thin=10, iters=10000, verb=True, *, seed=None, chunk=None, chain_offset=0, ll=None,
-         group=0, mode="auto", return_info=False, summary_only=False, max_batches=16, precision="auto"):
+         group=0, mode="auto", return_info=False, summary_only=False, max_batches=16, precision="auto", plan_chains=0):
     """Run a chain (or C chains): `mat[i]` = state after (i+1)*thin iterations (fit-np-hmc.py:89-103).
 
     Fused kernels run on the device; `init` of shape [p] returns a float64 `[iters, p]` matrix
@@ -398,6 +401,12 @@ def mcmc(init, kernel, thin=10, iters=10000, verb=True, *, seed=None, chunk=None
     `summary_only=True` (fused kernels): no sample matrix at all -- the kept samples are folded into on-device
     running statistics and the call returns a dict (mean, sd, rhat, ess, mcse, accept_rate, ...): what the
     reference computes from the full matrix afterwards (fit-np-hmc.py:113-117, analyse.R:17-19).
+
+    `precision` (HMC): "auto" (DEFAULT) lets the L - 1 interior leapfrog gradients of a trajectory run on the bf16 matrix
+    pipe where such a kernel exists (the end-point value + gradient and the Metropolis test stay in the model's dtype, so
+    the sampler stays exact; the acceptance rate is the only thing that can move); "full" keeps every evaluation in the
+    model's dtype (step-for-step comparable with the float64 reference); see include/logreg_hip.h LR_PREC_*.
+    `plan_chains`: chain count to plan the kernel variant for (a shard of a larger run: the whole run's count).
     """
     if not isinstance(kernel, FusedKernel):
         return _mcmc_generic(init, kernel, thin, iters, verb)
@@ -405,7 +414,8 @@ def mcmc(init, kernel, thin=10, iters=10000, verb=True, *, seed=None, chunk=None
     single = init.ndim == 1
     if seed is None:
         seed = int(np.random.randint(0, 2**31 - 1))
-    cs = ChainSet(kernel, init, seed, chain_offset=chain_offset, ll=ll, group=group, mode=mode, precision=precision)
+    cs = ChainSet(kernel, init, seed, chain_offset=chain_offset, ll=ll, group=group, mode=mode, precision=precision,
+                  plan_chains=plan_chains)
     m = kernel.model
     if chunk is None:
         chunk = _auto_chunk(kernel, cs.C, thin, iters)

@@ -85,6 +85,7 @@ class _OracleChainSet:
         self.acc = np.zeros(self.state.shape[0], dtype=np.uint64)
         self.kept, self.batch, self.pivot = None, 0, None
         self.launches = 0
+        self.kw = kw
 
     def enable_stats(self, batch, slots, pivot=None):
         self.kept, self.batch, self.pivot = [], batch, np.asarray(pivot)
@@ -135,6 +136,12 @@ def _worker_mcmc_sharded(rank, world, port, C, tmp):
         return made[-1]
     out = mcmc_sharded(init, make_kernel, thin=2, iters=8, seed=31, chunk=3, chainset_factory=factory)
     assert (made[0].launches == 3) if made else (C < world and rank >= C)  # 8 kept samples in chunks of 3, 3, 2
+    assert all("plan_chains" not in cs.kw for cs in made)  # plan="local" (the default): every rank plans for its own shard
+    n0 = len(made)
+    again = mcmc_sharded(init, make_kernel, thin=2, iters=8, seed=31, chunk=3, chainset_factory=factory, plan="global", precision="auto")
+    # plan="global": every shard plans for ALL C chains (lr_run_opts.plan_chains), whatever else the caller passed on
+    assert all(cs.kw == {"plan_chains": C, "precision": "auto"} for cs in made[n0:])
+    assert (again is None) == (rank != 0) and (rank != 0 or np.array_equal(again.numpy(), out.numpy()))
     summ = mcmc_sharded(init, make_kernel, thin=2, iters=8, seed=31, summary_only=True, max_batches=4, chainset_factory=factory)
     if rank == 0:
         np.save(os.path.join(tmp, "gathered.npy"), out.numpy())

@@ -111,6 +111,32 @@ def _fullsize(la, cfg, expect_slices, margin, state_tol_sd, burn, keep, precisio
     return res
 
 
+@pytest.mark.parametrize("name", ["cfg4", "cfg5", "mid"])
+def test_model_closures_match_the_reference_at_other_shapes(la, name):
+    """ll / lprior / lpost / glp through the C ABI against numbers the REFERENCE's closures produced on these designs
+    (tests/golden/shape_*.json, made by make_shape_fixtures.py with the script's globals X, y, pscale replaced):
+    BASELINE configs 4 and 5 at full size and a mid shape (n = 1000, p = 20) -- no oracle in between.  The leapfrog
+    vector of the same fixtures pins the oracle (tests/test_oracle.py), which _fullsize() replays on the device stream."""
+    g = load_golden(f"shape_{name}.json")
+    X, y, _ = la.synthetic_logreg(g["n"], g["p"], seed=g["data_seed"], beta_sd=g["beta_sd"])
+    beta = np.array(g["beta"])
+    colsum = np.abs(X).sum(axis=0)
+    for dtype, tol in (("float32", 2e-6), ("float64", 1e-11)):
+        if dtype == "float64" and g["p"] > 32:
+            continue  # wide models are float32 only (bf16 matrix pipe with exact three-piece splits)
+        m = la.LogReg(X, y, np.array(g["pscale"]), dtype=dtype)
+        r = m.eval(beta)
+        for nm in ("ll", "lprior", "lpost"):
+            ref = np.array(g[nm])
+            assert np.max(np.abs(r[nm] - ref) / np.abs(ref)) < tol, (name, dtype, nm)
+        gerr = np.max(np.abs(r["glp"] - np.array(g["glp"])) / colsum)
+        print(f"{name} {dtype}: plan {m.plan(len(beta))}, glp err / colsum {gerr:.2e}")
+        assert gerr < tol, (name, dtype)
+        # the scalar closures, one beta at a time, as the reference calls them
+        assert m.lpost(beta[2]) == pytest.approx(g["lpost"][2], rel=tol)
+        assert np.max(np.abs(m.glp(beta[2]) - np.array(g["glp"][2])) / colsum) < tol
+
+
 def test_config4_tall_data_full_size(la):
     """n = 100 000, p = 8, 1024 chains: 16 row slices x 16 waves x ~390 rows, twisted-pair SMEM streaming with
     fp64 block flushes -- the slice/block counts and summation lengths the config actually runs with."""

@@ -168,10 +168,12 @@ def test_split_rhat_and_overdispersed_init():
     np.testing.assert_array_equal(init, la.overdispersed_init(np.zeros(3), np.array([1.0, 2.0, 3.0]), 5000, 2.0, 1))
 
 
-def test_bench_launch_plumbing_under_torchrun_gloo():
-    """bench.py as the driver launches it for N > 1 (`python -m torch.distributed.run --nproc-per-node 2 ... bench.py
-    --gpus 2 ...`), up to the first GPU call: `--dry-run` swaps RCCL for gloo and skips the kernels, so rank/world
-    parsing, weak-scaling chain offsets, the gather to rank 0 and the max-over-ranks reduction run here on CPU."""
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_launch_plumbing_under_torchrun_gloo(world):
+    """bench.py as the driver launches it for N > 1 (`python -m torch.distributed.run --nproc-per-node N ... bench.py
+    --gpus N ...`), N = 2 and the full node's 8: `--dry-run` runs bench.py's own Exchange object -- the one the GPU run
+    uses -- on the gloo backend with a CPU tensor for the sample buffer, so rank/world parsing, weak-scaling chain offsets
+    (0 ... 7 x 4096), the gather to rank 0 (shapes and contents), the barrier and the max / sum reductions run here."""
     import json
     import socket
     import subprocess
@@ -180,11 +182,12 @@ def test_bench_launch_plumbing_under_torchrun_gloo():
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
                         "--master-addr", "127.0.0.1", "--master-port", str(port), __import__("os").path.join(REPO, "bench.py"),
-                        "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"], capture_output=True, text=True, timeout=300)
+                        "--gpus", str(world), "--steps", "3", "--warmup", "1", "--dry-run"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1  # rank 0 only
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["chain_offsets"] == [0, 4096] and d["gather_ok"] and d["scaling"] == "weak"
+    assert d["n_gpus"] == world and d["chain_offsets"] == [4096 * r for r in range(world)] and d["scaling"] == "weak"
+    assert d["gather_ok"] and d["sum_over_ranks_ok"] and d["gather_ms"] > 0 and d["wall_ms"] >= d["gather_ms"]

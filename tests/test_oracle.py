@@ -173,3 +173,28 @@ def test_oracle_acceptance_rates_match_reference(oracle_model, map_beta):  # F8b
                          seed=5, keep=False, threads=0)
     rate = r["accepts"].sum() / (C * 3000)
     assert abs(rate - g["rwmh"]["rate"]) < 0.01
+
+
+# ---- shapes other than Pima's: vectors the reference's own closures produced on synthetic designs put in place of
+# ---- its globals X, y, pscale (tests/golden/make_shape_fixtures.py): BASELINE configs 4 and 5 at full size, one mid shape
+@pytest.mark.parametrize("name", ["cfg4", "cfg5", "mid"])
+def test_oracle_matches_reference_at_other_shapes(name):
+    from logreg_amd.data import synthetic_logreg
+    g = load_golden(f"shape_{name}.json")
+    X, y, _ = synthetic_logreg(g["n"], g["p"], seed=g["data_seed"], beta_sd=g["beta_sd"])
+    m = orc.OracleModel(X, y, np.array(g["pscale"]))
+    beta = np.array(g["beta"])
+    for nm in ("ll", "lprior", "lpost"):
+        np.testing.assert_allclose(getattr(m, nm)(beta), np.array(g[nm]), rtol=1e-11, atol=0)
+    ref = np.array(g["glp"])
+    # a gradient coordinate is a sum of n terms that largely cancel: tolerance relative to the sum of the terms'
+    # magnitudes (<= sum_i |x_ij|), as everywhere (1e-4 of the term sum for fp32; here float64, 1e-11 would do)
+    scale = np.abs(X).sum(axis=0)
+    assert np.max(np.abs(m.glp(beta) - ref) / scale) < 1e-13
+    lf = g["leap"]
+    dmm = np.array(lf["dmm"])
+    q, p = m.leapfrog(lf["q0"], lf["p0"], lf["eps"], lf["l"], dmm)
+    np.testing.assert_allclose(q, lf["q1"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(p, lf["p1_negated"], rtol=1e-9, atol=1e-10)
+    assert m.alpi(lf["q0"], lf["p0"], dmm) == pytest.approx(lf["alpi0"], rel=1e-12)
+    assert m.alpi(q, p, dmm) == pytest.approx(lf["alpi1"], rel=1e-11)
