@@ -724,9 +724,9 @@ template <int P, int R, int G> struct is_row_pairs<RegRowPairs<P, R, G>> { stati
 //   Cancellation at large ts costs an absolute ulp(ts) ~ 1e-6 per row, the size of the fp32 summation
 //   error of the value itself.
 // The row data may sit in VGPRs (RegRowPairs) or in SGPRs (ScalarRowPairs: scalar operands of the v_pk ops).
-template <int P, bool VALUE, bool GRAD>
+template <int P, bool VALUE, bool GRAD, bool PROD = false>
 __device__ __forceinline__ void pair_term(const f32x2 (&q)[P], const f32x2 (&bb)[P / 2], f32x2 (&gp)[P / 2],
-                                          f32x2 (&hp)[P / 2], f32x2& vacc) {
+                                          f32x2 (&hp)[P / 2], f32x2& vacc, f32x2* pacc = nullptr) {
     typedef f32x2 f2;
     f2 ts = q[0] * bb[0];
     ts = __builtin_elementwise_fma(q[1], __builtin_shufflevector(bb[0], bb[0], 1, 0), ts);
@@ -745,10 +745,21 @@ __device__ __forceinline__ void pair_term(const f32x2 (&q)[P], const f32x2 (&bb)
             hp[j / 2] = __builtin_elementwise_fma(q[j + 1], w, hp[j / 2]);
         }
     }
-    if constexpr (VALUE) vacc += ts - f2{__builtin_amdgcn_logf(d.x), __builtin_amdgcn_logf(d.y)};
+    if constexpr (VALUE && PROD) {  // sum of the ts, PRODUCT of the 1 + 2^ts: one v_log per lane instead of one per row (row_pairs_eval)
+        vacc += ts;
+        *pacc *= d;
+    } else if constexpr (VALUE) {
+        vacc += ts - f2{__builtin_amdgcn_logf(d.x), __builtin_amdgcn_logf(d.y)};
+    }
 }
 
 // all rows of a RegRowPairs lane: gradient partial sums into gp[P/2] = (g_j, g_{j+1}) pairs, value into v.
+// The value of a lane's rows is sum_i (ts_i - log2(1 + 2^ts_i)) = sum_i ts_i - log2(prod_i (1 + 2^ts_i)): the rows sit in registers, so
+// the product of the lane's <= 16 factors replaces all but two of its quarter-rate v_log by full-rate multiplies (MALA at 13 rows
+// per lane: 39 -> 28 transcendentals per lane and iteration).  Every factor is >= 1 and <= 1 + 2^100 (ts is clamped), so the
+// product can only fail by OVERFLOW (positive logits summing beyond ~127 in one lane); a lane whose product overflowed takes the
+// per-row form instead -- a per-LANE select, so a chain's value never depends on which chains share its wave; the per-row pass
+// itself runs (wave-uniformly) only when some lane needs it.  Same cancellation class as the per-row form: ulp(sum ts) per lane.
 template <int P, int R, int G, bool VALUE, bool GRAD>
 __device__ __forceinline__ void row_pairs_eval(const RegRowPairs<P, R, G>& rows, const f32x2 (&bb)[P / 2],
                                                f32x2 (&gp)[P / 2], float& v) {
@@ -756,10 +767,14 @@ __device__ __forceinline__ void row_pairs_eval(const RegRowPairs<P, R, G>& rows,
     f2 hp[P / 2];
 #pragma unroll
     for (int j = 0; j < P / 2; ++j) gp[j] = hp[j] = f2{0.0f, 0.0f};
-    f2 vacc = {0.0f, 0.0f};
+    // (from 8 rows per lane: with 4 -- one chain per wave, a latency-bound launch -- the two logs saved do not pay for the
+    //  overflow check: config 1 ran 6 % slower in the product form, MALA at 13 rows per lane 3 % faster)
+    constexpr bool PROD = VALUE && R >= 8;
+    f2 vacc = {0.0f, 0.0f}, pacc = {1.0f, 1.0f};
     float vs = 0.0f;
 #pragma unroll
-    for (int k = 0; k < RegRowPairs<P, R, G>::RP; ++k) pair_term<P, VALUE, GRAD>(rows.q[k], bb, gp, hp, vacc);
+    for (int k = 0; k < RegRowPairs<P, R, G>::RP; ++k) pair_term<P, VALUE, GRAD, PROD>(rows.q[k], bb, gp, hp, vacc, &pacc);
+    float ts_odd = 0.0f;
     if constexpr (RegRowPairs<P, R, G>::ODD) {
         f2 acc = rows.s[0] * bb[0];
 #pragma unroll
@@ -772,9 +787,29 @@ __device__ __forceinline__ void row_pairs_eval(const RegRowPairs<P, R, G>& rows,
 #pragma unroll
             for (int j = 0; j < P / 2; ++j) gp[j] = __builtin_elementwise_fma(f2{w, w}, rows.s[j], gp[j]);
         }
-        if constexpr (VALUE) vs = ts - __builtin_amdgcn_logf(d);
+        if constexpr (PROD) {
+            vs = ts;
+            pacc.y *= d;
+            ts_odd = ts;
+        } else if constexpr (VALUE) {
+            vs = ts - __builtin_amdgcn_logf(d);
+        }
     }
-    if constexpr (VALUE) v += ((vacc.x + vacc.y) + vs) * ExpScale<float>::inv;
+    if constexpr (VALUE && !PROD) v += ((vacc.x + vacc.y) + vs) * ExpScale<float>::inv;
+    if constexpr (PROD) {
+        float val = ((vacc.x + vacc.y) + vs) - (__builtin_amdgcn_logf(pacc.x) + __builtin_amdgcn_logf(pacc.y));
+        const bool bad = !(val > -3.0e38f);  // a product overflowed (-inf), or NaN input
+        if (__builtin_amdgcn_ballot_w64(bad) != 0) {  // rare: per-row logs, selected per lane
+            f2 va = {0.0f, 0.0f}, g0[P / 2], h0[P / 2];
+#pragma unroll
+            for (int k = 0; k < RegRowPairs<P, R, G>::RP; ++k) pair_term<P, true, false, false>(rows.q[k], bb, g0, h0, va);
+            float vo = 0.0f;
+            if constexpr (RegRowPairs<P, R, G>::ODD) vo = ts_odd - __builtin_amdgcn_logf(1.0f + ExpScale<float>::exp_scaled(ts_odd));
+            const float safe = (va.x + va.y) + vo;
+            val = bad ? safe : val;
+        }
+        v += val * ExpScale<float>::inv;
+    }
     if constexpr (GRAD) {
 #pragma unroll
         for (int j = 0; j < P / 2; ++j) gp[j] += __builtin_shufflevector(hp[j], hp[j], 1, 0);

@@ -76,6 +76,22 @@ def test_model_closures_match_golden(models, pima, dtype):  # F1 through the C A
     assert m.lprior(b) == pytest.approx(-11.193243358631427, rel=2e-5)
 
 
+@pytest.mark.parametrize("group", [16, 32])
+def test_value_by_lane_product_and_its_overflow_fallback(models, group):
+    """Register-resident rows, >= 8 rows per lane: the value is sum ts - log2(prod (1 + 2^ts)) per lane (two v_log instead of
+    one per row) with a per-lane fall-back to the per-row form where the product overflows.  F1 holds both regimes: posterior
+    draws (products of ~1e0 .. 1e6) and the +-(50, 1, ..., 1) points, where every clamped factor is 2^100 and every lane
+    overflows -- and one batch mixes them, so lanes of one wave take different branches."""
+    g = load_golden("model_eval.json")
+    beta = np.array(g["beta"])
+    m = models["float32"]
+    r = m.eval(beta, mode="reg", group=group)
+    assert m.plan(len(beta), group, "reg")["rows_per_lane"] >= 7
+    for nm in ("ll", "lpost"):
+        np.testing.assert_allclose(r[nm], np.array(g[nm]), rtol=2e-5)
+    assert np.abs(np.array(g["ll"])).max() > 1e4  # the extreme points are in the batch
+
+
 @pytest.mark.parametrize("mode,group", VARIANTS)
 def test_every_kernel_variant_evaluates_the_same_model(models, oracle_model, mode, group):
     rng = np.random.default_rng(3)
