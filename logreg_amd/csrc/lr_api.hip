@@ -104,6 +104,9 @@ struct lr_model {
     // stepwise-engine workspaces, one per stream (grow-only, owned by the handle): calls enqueued on ONE stream
     // run in order, so they may share a workspace; calls on different streams overlap on the device and get
     // disjoint ones (two ChainSets of one model on two streams, or an eval on the NULL stream beside a run)
+    // time-out word of the persistent trajectory kernel (lr_wide_persist.h): host memory the device writes and every API entry reads
+    uint32_t* h_xerr = nullptr;
+    uint32_t* d_xerr = nullptr;  // the same word as the device addresses it
     struct Ws { hipStream_t stream; void* p; size_t bytes; };
     std::vector<Ws> ws;
     size_t esize() const { return dtype == LR_F32 ? 4 : 8; }
@@ -407,6 +410,31 @@ int do_chain_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs, c
     return LR_OK;
 }
 
+// Persistent row-split trajectory kernel for wide models (lr_wide_persist.h): slices S per group of 32 chains and 32-row blocks
+// per slice for Cp chains, or S = 0 when it does not apply: every (group, slice) workgroup must be resident at once (one per
+// CU), the slice's block images + 32 KB have to fit the LDS, and the grid should fill at least half the chip.
+struct PersistPlan { int S, nbs; };
+PersistPlan persist_plan(const lr_model* m, int64_t Cp) {
+    PersistPlan none{0, 0};
+    // OPT-IN (LOGREG_WIDE_PERSIST=1): built, measured and, at config 5, slower than a launch per step -- 12.8 vs 10.3 us per
+    // evaluation (tools/stamps_persist.py, us per step: row loop 3.5, the 8 waves' gradients through LDS 2.5 [128 KB of ds_write at
+    // ~79 B/clk], publish 0.9, poll 1.2, gather of the 8 slices' partials 3.1 [128 KB per workgroup through the ~15 B/clk a CU gets
+    // from beyond its L2], operand build 0.5).  Kept with its tests as the measured answer to "why not a persistent kernel".
+    if (m->P <= 32 || !m->d_xblk1 || !m->table->launch_tall_traj_rs || !m->h_xerr || !env_on("LOGREG_WIDE_PERSIST")) return none;
+    const int64_t groups = (Cp + 31) / 32;
+    if (groups > m->cus) return none;
+    const int nblk = (int)((m->n + 31) / 32);
+    int S = (int)(m->cus / groups);
+    if (S > 16) S = 16;
+    if (const char* e = std::getenv("LOGREG_WIDE_PERSIST_SLICES")) S = std::atoi(e);  // tuning override
+    if (S < 1 || S > 64 || groups * S > m->cus) return none;
+    if (S > nblk) S = nblk;
+    const int nbs = (nblk + S - 1) / S;
+    if (m->table->traj_rs_lds_bytes(nbs) > kLdsBudget) return none;
+    if (groups * S * 2 < m->cus) return none;
+    return PersistPlan{S, nbs};
+}
+
 template <typename T, int P>
 int setup_tall(lr_model* m, const Plan& pl, hipStream_t st, int64_t C, int64_t Cp, lr::TallArgs<T, P>* pa) {
     // C: chains of this call (sizes the workspace and the grids);  Cp: chains the slicing decisions are made for
@@ -461,8 +489,12 @@ int setup_tall(lr_model* m, const Plan& pl, hipStream_t st, int64_t C, int64_t C
     const int RSmax = RS_i > RS ? RS_i : RS;
     const size_t pg = align((size_t)RSmax * C * P * sizeof(T)), cv = align((size_t)2 * P * sizeof(T));
     // (second state pair + second partial buffer + constants: the fused interior steps of the row-split kernel)
+    const PersistPlan pp = persist_plan(m, Cp);
+    const size_t xgroups = (size_t)((C + 31) / 32);
+    const size_t xch_bytes = pp.S ? align(2 * xgroups * pp.S * 32 * P * sizeof(float)) : 0, xfl_bytes = pp.S ? align(xgroups * pp.S * 4) : 0;
+    if (xch_bytes > 0xFFFFFFFFull) return fail(LR_ERR_UNSUPPORTED, "exchange buffer of the persistent trajectory kernel exceeds 4 GB");
     const size_t need = 4 * vec + 2 * dbl + align((size_t)C * 4) + pg + align((size_t)RS * C * sizeof(double)) +
-                        (RS_i > 0 && (m->P > 32 || rs_waves == 16) ? 2 * vec + pg : 0) + cv;
+                        (RS_i > 0 && (m->P > 32 || rs_waves == 16) ? 2 * vec + pg : 0) + cv + xch_bytes + xfl_bytes;
     lr_model::Ws* slot = nullptr;
     for (auto& e : m->ws)
         if (e.stream == st) slot = &e;
@@ -513,6 +545,15 @@ int setup_tall(lr_model* m, const Plan& pl, hipStream_t st, int64_t C, int64_t C
         a.q1_in = (const T*)carve(vec);
         a.pm_in = (const T*)carve(vec);
         a.part_in = (const T*)carve(pg);
+    }
+    a.traj_S = pp.S;
+    a.traj_nbs = pp.nbs;
+    a.traj_scatter = env_on("LOGREG_WIDE_PERSIST_SCATTER");
+    if (pp.S) {
+        a.xch = (float*)carve(xch_bytes);
+        a.xch_bytes = (uint32_t)xch_bytes;
+        a.xflags = (uint32_t*)carve(xfl_bytes);
+        a.xerr = m->d_xerr;
     }
     a.C = C;
     a.p = m->p;
@@ -610,6 +651,9 @@ int do_stepwise_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs
                        // (us per evaluation, launch per step | trajectory kernel: n=500 p=64: 5.5 | 2.8 at 1024 chains; n=300 p=100:
                        //  7.0 | 4.7; n=1000 p=128: 7.5 | 6.5; n=2000 p=50: 6.2 | 5.3; n=2000 p=128 (512 KB): 8.4 | 9.3)
                        (traj_tiles < m->cus && (int64_t)m->n * m->P * 2 <= 256 * 1024));
+    // wide models, few chains: the persistent row-split trajectory kernel (lr_wide_persist.h) -- the slices resident in LDS, one
+    // hand-off between the resident workgroups per step; opt-in, see persist_plan
+    const bool persist = P > 32 && bf16_interior && rs.l > 1 && a.traj_S > 0 && !traj;
     const bool fuse = bf16_interior && a.RS_i > 0 &&
                       ((P > 32 && a.RS_i <= 4 && !env_on("LOGREG_WIDE_NO_FUSE")) ||         // kFuseSlices (lr_wide_bf16.h)
                        (P <= 32 && a.rowsplit_waves == 16 && a.RS_i <= 16 && m->d_xmx));   // kMx16FuseSlices (lr_tall_mx.h)
@@ -625,7 +669,16 @@ int do_stepwise_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs
     const int64_t total = o->iters * o->thin;
     for (int64_t tt = 0; tt < total && !rc; ++tt) {
         if (kind == lr::KIND_HMC) {
-            if (traj) {
+            if (persist) {
+#ifdef LR_STAMPS
+                a.stamps = stamp_buffer();  // (one slot: the phase sums of the latest trajectory)
+                a.stamp_slot = 0;
+#endif
+                if (!rc) rc = t->launch_tall_traj_rs(st, &a);
+#ifdef LR_STAMPS
+                a.stamps = nullptr;
+#endif
+            } else if (traj) {
                 if (!rc) rc = t->launch_tall_traj(st, &a);
             } else if (fuse) {
                 // row-split interior kernel: every launch but the first finishes the previous leapfrog step in its
@@ -750,6 +803,9 @@ int check_group(const lr_model* m, int group, int mode) {
 int check_opts(const lr_model* m, const lr_run_opts* o, bool run) {
     if (!m) return fail(LR_ERR_INVALID, "model is NULL");
     if (!o) return fail(LR_ERR_INVALID, "opts is NULL");
+    if (m->h_xerr && *(volatile uint32_t*)m->h_xerr)  // sticky: the samples since then are poisoned with NaN
+        return fail(LR_ERR_HIP, "an earlier HMC run on this model timed out inside the persistent trajectory kernel (its workgroups "
+                                "were not all resident: is the GPU shared?); recreate the model and set LOGREG_WIDE_NO_PERSIST=1");
     if (o->n_chains <= 0) return fail(LR_ERR_INVALID, "n_chains must be positive (got %lld)", (long long)o->n_chains);
     if (o->plan_chains < 0) return fail(LR_ERR_INVALID, "plan_chains must be 0 (= n_chains) or positive (got %d)", o->plan_chains);
     if (const int rcg = check_group(m, o->group, o->mode)) return rcg;
@@ -984,6 +1040,17 @@ int lr_model_create(const double* X, const double* y, int64_t n, int32_t p, cons
             }
         }
     }
+    if (m->P > 32) {  // wide models: the time-out word of the persistent trajectory kernel (host memory, mapped for the device)
+        void* hp = nullptr;
+        void* dp = nullptr;
+        if (hipHostMalloc(&hp, sizeof(uint32_t), hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
+            m->h_xerr = static_cast<uint32_t*>(hp);
+            m->d_xerr = static_cast<uint32_t*>(dp);
+            *m->h_xerr = 0;
+        } else if (hp) {
+            (void)hipHostFree(hp);  // (without the word the kernel is simply not used)
+        }
+    }
     if (m->P > 32) {  // wide models: bf16-piece block images for the exact-split matrix-core kernel
         const float* hrows = reinterpret_cast<const float*>(host.data());
         const int64_t nblk = (n + 31) / 32;
@@ -1022,6 +1089,7 @@ void lr_model_destroy(lr_model* m) {
     if (m->d_xmx) (void)hipFree(m->d_xmx);
     if (m->d_xmf) (void)hipFree(m->d_xmf);
     if (m->d_xms) (void)hipFree(m->d_xms);
+    if (m->h_xerr) (void)hipHostFree(m->h_xerr);
     delete m;
 }
 

@@ -4,6 +4,7 @@
 #include "lr_inst.h"
 #include "lr_wide.h"
 #include "lr_wide_bf16.h"
+#include "lr_wide_persist.h"
 
 namespace lr {
 namespace {
@@ -61,7 +62,25 @@ int launch_tall_traj(hipStream_t st, const void* tall_args) {
     return check(hipGetLastError());
 }
 
-const InstTable kTable = {0, P, 0, nullptr, nullptr, nullptr, &launch_tall_partial, &launch_tall_update, &launch_tall_traj, nullptr, nullptr};
+// persistent row-split trajectory kernel (lr_wide_persist.h): a.traj_S slices per group of 32 chains, one workgroup per
+// (group, slice); the step flags are zeroed before every launch (cdna_hip_programming.md Guideline 16: re-initialise every call)
+int launch_tall_traj_rs(hipStream_t st, const void* tall_args) {
+    const auto& a = *static_cast<const TallArgs<float, P>*>(tall_args);
+    const int ngroups = (int)((a.C + kPersistChains - 1) / kPersistChains);
+    const size_t lds = persist_lds_bytes<P>(a.traj_nbs);
+    static size_t lds_set = 0;
+    if (lds > lds_set) {  // dynamic LDS beyond 64 KB has to be asked for
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wide_traj_rs<P>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
+        lds_set = lds;
+    }
+    if (hipMemsetAsync(a.xflags, 0, (size_t)ngroups * a.traj_S * sizeof(uint32_t), st) != hipSuccess) return -2;
+    hipLaunchKernelGGL((k_wide_traj_rs<P>), dim3((unsigned)(ngroups * a.traj_S)), dim3(64 * kPersistWaves), lds, st, a);
+    return check(hipGetLastError());
+}
+size_t traj_rs_lds_bytes(int blocks_per_slice) { return persist_lds_bytes<P>(blocks_per_slice); }
+
+const InstTable kTable = {0, P, 0, nullptr, nullptr, nullptr, &launch_tall_partial, &launch_tall_update, &launch_tall_traj, nullptr, nullptr,
+                          &launch_tall_traj_rs, &traj_rs_lds_bytes};
 
 }  // namespace
 }  // namespace lr

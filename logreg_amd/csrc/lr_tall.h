@@ -88,6 +88,14 @@ template <typename T, int P> struct TallArgs {
     int RS_i;               // row-split interior kernel (k_wide_partial_bf16r): slices, 0 = not used for this run
     int64_t slice_len_i;    //   and rows per slice (a multiple of 32 * rowsplit_waves: whole 32-row blocks per wave)
     int rowsplit_waves;     //   4 or 8 waves per workgroup (wide); 16: the 16-wave tall kernel k_tall_partial_mx16 is in use
+    // persistent row-split trajectory kernel (lr_wide_persist.h): slices per chain group, 32-row blocks per slice, the exchange
+    // buffer [2][groups][S][32][P] with its size, the step flags [groups][S] (zeroed before every launch), the time-out word
+    int traj_S, traj_nbs;
+    int traj_scatter;  // test switch: lay a group's slices out across the XCDs instead of within one (results must not change)
+    float* xch;
+    uint32_t xch_bytes;
+    uint32_t* xflags;
+    uint32_t* xerr;
     int p, l;
     T step;
     T a[P], b[P], c[P];

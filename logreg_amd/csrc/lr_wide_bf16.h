@@ -460,6 +460,10 @@ __global__ void __launch_bounds__((64 * NW)) k_wide_partial_bf16r(TallArgs<float
             const int m = wave;
             const int64_t at = chain * P + 32 * m + 8 * kg;
             f32x4 pg[kFuseSlices][2], vq[2], vp[2], vb[2], vi[2];
+#ifdef LR_STAMPS
+            if (a.stamps && lane == 0) LR_STAMP_AT(a, 10) = __builtin_amdgcn_s_memrealtime();
+            asm volatile("" ::: "memory");
+#endif
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -470,9 +474,17 @@ __global__ void __launch_bounds__((64 * NW)) k_wide_partial_bf16r(TallArgs<float
                 vb[h] = *reinterpret_cast<const f32x4*>(a.cvec + 32 * m + 8 * kg + 4 * h);
                 vi[h] = *reinterpret_cast<const f32x4*>(a.cvec + P + 32 * m + 8 * kg + 4 * h);
             }
+#ifdef LR_STAMPS
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (a.stamps && lane == 0) LR_STAMP_AT(a, 11) = __builtin_amdgcn_s_memrealtime();
+            asm volatile("" ::: "memory");
+#endif
 #pragma unroll
             for (int b = 0; b < NBUF - 1; ++b)
                 if (b < wnb) issue(b);
+#ifdef LR_STAMPS
+            if (a.stamps && lane == 0) LR_STAMP_AT(a, 12) = __builtin_amdgcn_s_memrealtime();
+#endif
             f32x4 xn[2], pn[2];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {

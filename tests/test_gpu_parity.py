@@ -1051,3 +1051,43 @@ def test_tall_sixteen_wave_interior_kernel_with_the_update_folded_in(la, n, p, L
     same = oi["accepts"] == info["accepts"]
     assert same.mean() > 0.99
     assert np.max(np.abs(old[:, same] - out[:, same])) < 1e-3 / np.sqrt(n)
+
+
+@pytest.mark.parametrize("n,p,C,L", [(2048, 128, 1024, 5), (1500, 100, 1000, 4), (4100, 50, 1024, 3), (4096, 128, 1024, 6)])
+def test_wide_persistent_row_split_trajectory_kernel(la, n, p, C, L, monkeypatch):
+    """k_wide_traj_rs (lr_wide_persist.h; opt-in with LOGREG_WIDE_PERSIST=1 -- it lost to the launch-per-step path at config 5,
+    12.8 vs 10.3 us per evaluation, and is kept as that measurement; wide models from half a chip of chain groups): the L - 1 interior steps
+    of a trajectory in ONE launch, row slices resident in LDS, the slices' partial gradients handed between the resident
+    workgroups through device memory once per step.  Against the float64 oracle at the reduced-precision tolerance (64-chain
+    subset, decisions away from near-ties), against the launch-per-step path (same posterior arithmetic class, other
+    summation order), bit-exact reruns / chunking / shards planned for the whole run, ragged last chain group (C = 1000),
+    p padded to 128 and to 64, and -- the hand-off protocol may not depend on placement -- identical results when the
+    chain groups are laid out ACROSS the XCDs instead of within one."""
+    from oracle.oracle import OracleModel
+    X, y, _ = la.synthetic_logreg(n, p, seed=n + p, beta_sd=0.4 / np.sqrt(p))
+    ps = np.full(p, 2.0)
+    orc = OracleModel(X, y, ps)
+    m = la.LogReg(X, y, ps)
+    b = 0.02 * np.random.default_rng(L).standard_normal((C, p))
+    eps = 0.4 / np.sqrt(n)
+    k = la.hmcKernel(m.lpost, m.glp, eps=eps, l=L, dmm=np.ones(p))
+    ref = orc.run("hmc", b[:64], step=eps, l=L, scale=np.ones(p), thin=1, iters=2, seed=9, threads=0)
+    monkeypatch.setenv("LOGREG_WIDE_PERSIST", "1")
+    out, info = la.mcmc(b, k, thin=1, iters=2, verb=False, seed=9, return_info=True)
+    assert info["plan"]["mode"] == "stepwise" and np.all(np.isfinite(out))
+    ok = ref["margin"] > 0.1
+    assert ok.mean() > 0.5
+    assert np.array_equal(info["accepts"][:64][ok], ref["accepts"][ok].astype(np.uint32))
+    assert np.max(np.abs(out[:, :64][:, ok] - ref["out"][:, ok])) < 3e-2 / np.sqrt(n) + 1e-5
+    assert np.array_equal(out, la.mcmc(b, k, thin=1, iters=2, verb=False, seed=9, chunk=1))
+    lo, hi = 96, 192
+    assert np.array_equal(out[:, lo:hi], la.mcmc(b[lo:hi], k, thin=1, iters=2, verb=False, seed=9, chain_offset=lo, plan_chains=C))
+    monkeypatch.setenv("LOGREG_WIDE_PERSIST_SCATTER", "1")  # groups across XCDs: a speed matter only
+    assert np.array_equal(out, la.mcmc(b, k, thin=1, iters=2, verb=False, seed=9))
+    monkeypatch.delenv("LOGREG_WIDE_PERSIST_SCATTER")
+    monkeypatch.delenv("LOGREG_WIDE_PERSIST")
+    old, oi = la.mcmc(b, k, thin=1, iters=2, verb=False, seed=9, return_info=True)
+    assert not np.array_equal(old, out)  # (the persistent kernel did run above)
+    same = oi["accepts"] == info["accepts"]
+    assert same.mean() > 0.99
+    assert np.max(np.abs(old[:, same] - out[:, same])) < 1e-3 / np.sqrt(n)

@@ -52,6 +52,11 @@ for cfg in [int(x) for x in sys.argv[1:]] or [4, 5]:
         for k_ in range(6):
             d = (x[:, :, k_ + 1] - x[:, :, k_]) * tick
             print(f"    {names[k_]:32s} median {np.median(d):6.2f}  p10 {np.percentile(d, 10):6.2f}  p90 {np.percentile(d, 90):6.2f}  max {d.max():6.2f} us")
+        if (x[:, 0, 10] != 0).all():  # finer prologue stamps (wide row-split kernel, waves that do the fused update)
+            w = x[:, :, 10] != 0
+            for nm, a_, b_ in (("  entry -> address setup done", 0, 10), ("  loads issued -> all returned", 10, 11), ("  first DMA blocks issued", 11, 12), ("  update arithmetic + LDS + stores", 12, 1)):
+                d = ((x[:, :, b_] - x[:, :, a_]) * tick)[w]
+                print(f"    {nm:32s} median {np.median(d):6.2f}  p10 {np.percentile(d, 10):6.2f}  p90 {np.percentile(d, 90):6.2f}  max {d.max():6.2f} us")
         clk = (x[:, :, 9] - x[:, :, 8]) / np.maximum((x[:, :, 4] - x[:, :, 3]) * tick, 1e-9)
         print(f"    shader clock inside the row loop: median {np.median(clk) / 1e3:.2f} GHz; loop cycles median {np.median(x[:, :, 9] - x[:, :, 8])}")
         wg_span = (x[:, :, 6].max(axis=1) - x[:, :, 0].min(axis=1)) * tick
