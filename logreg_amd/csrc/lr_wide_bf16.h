@@ -405,7 +405,7 @@ template <int BYTES> __device__ __forceinline__ void wait_vm_blocks(int younger)
 }
 
 template <int P, int NW>
-__global__ void __launch_bounds__((64 * NW)) k_wide_partial_bf16r(TallArgs<float, P> a) {
+__global__ void __launch_bounds__((64 * NW)) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4))) k_wide_partial_bf16r(TallArgs<float, P> a) {
     using G = WideBf16Geom<P>;
     // NW = 4: one wave per SIMD, ring of 4 block images per wave; NW = 8: two waves per SIMD (each hides the other's
     // LDS -> MFMA latency, which is what a block costs at one wave per SIMD), ring of 2
@@ -431,16 +431,27 @@ __global__ void __launch_bounds__((64 * NW)) k_wide_partial_bf16r(TallArgs<float
     LR_STAMP(a, 0);
 
     auto issue = [&](int b) {  // block b of this wave -> ring slot b % NBUF
-        const unsigned char* src = reinterpret_cast<const unsigned char*>(a.xblk1 + (blk0 + b) * (int64_t)G::BUF1) + lane * 16;
-        const uint32_t dst = ring_lds + (uint32_t)((b & (NBUF - 1)) * BLK_BYTES);
-#pragma unroll
-        for (int ch = 0; ch < BLK_BYTES / 1024; ++ch) {
-            uint32_t keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep)
-                         : "v"(src + ch * 1024), "s"(dst + ch * 1024)
-                         : "memory");
-        }
+        // ONE M0 set-up per block: the instruction offset (13-bit signed) is added to the global AND to the LDS address, so the
+        // block's 1 KB pieces are the offsets -4096 ... +3072 around its middle.  (A set-up per piece -- 4 scalar instructions
+        // each -- made the 8 pieces of a block cost ~230 cycles of the wave's issue: 1.2 of the loop's 4.6 us at config 5.)
+        static_assert(BLK_BYTES == 8192 || BLK_BYTES == 4096, "pieces addressed around the middle of the block");
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(a.xblk1 + (blk0 + b) * (int64_t)G::BUF1) + lane * 16 + BLK_BYTES / 2;
+        const uint32_t dst = ring_lds + (uint32_t)((b & (NBUF - 1)) * BLK_BYTES) + BLK_BYTES / 2;
+        uint32_t keep;
+        if constexpr (BLK_BYTES == 8192)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                         "global_load_lds_dwordx4 %1, off offset:-4096\n\tglobal_load_lds_dwordx4 %1, off offset:-3072\n\t"
+                         "global_load_lds_dwordx4 %1, off offset:-2048\n\tglobal_load_lds_dwordx4 %1, off offset:-1024\n\t"
+                         "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
+                         "global_load_lds_dwordx4 %1, off offset:2048\n\tglobal_load_lds_dwordx4 %1, off offset:3072\n\t"
+                         "s_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+        else
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                         "global_load_lds_dwordx4 %1, off offset:-2048\n\tglobal_load_lds_dwordx4 %1, off offset:-1024\n\t"
+                         "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
+                         "s_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
     };
     // (the first blocks are requested below, BEHIND the prologue's own loads: issuing the DMA first put its 60-185 cycles per
     //  1 KB piece in front of the one memory round trip the prologue waits for)
@@ -572,15 +583,29 @@ __global__ void __launch_bounds__((64 * NW)) k_wide_partial_bf16r(TallArgs<float
         const int last = b + NBUF - 1 < wnb ? b + NBUF - 1 : wnb - 1;
         wait_vm_blocks<BLK_BYTES>(last - b);
         const uint16_t* base = reinterpret_cast<const uint16_t*>(ring + (b & (NBUF - 1)) * BLK_BYTES);
+        // every operand of the block is requested before the first MFMA (16 + 16 registers of eta operands, 32 of transposed
+        // ones): left to a 128-register budget the compiler re-used one register quad for the eta reads and each MFMA pair
+        // waited for its own LDS round trip
+        u32x4 xa[2][G::M32];
+#pragma unroll
+        for (int T = 0; T < 2; ++T)
+#pragma unroll
+            for (int m = 0; m < G::M32; ++m) xa[T][m] = *reinterpret_cast<const u32x4*>(base + G::tile1(T, m) + eta_off);
+        u32x2 xt[G::MBP][2];
+#pragma unroll
+        for (int mb = 0; mb < G::MBP; ++mb) {
+            xt[mb][0] = lds_read_tr16(base + G::tile1(0, mb >> 1) + tr_off[mb & 1]);
+            xt[mb][1] = lds_read_tr16(base + G::tile1(1, mb >> 1) + tr_off[mb & 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise sinks every read back to its use)
         uint32_t wq[4];
 #pragma unroll
         for (int T = 0; T < 2; ++T) {
             f32x4 e0 = {0, 0, 0, 0}, e1 = {0, 0, 0, 0};
 #pragma unroll
             for (int m = 0; m < G::M32; ++m) {
-                const u32x4 xa = *reinterpret_cast<const u32x4*>(base + G::tile1(T, m) + eta_off);
-                e0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(xa), as_bf16x8(bq[m][0]), e0, 0, 0, 0);
-                e1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(xa), as_bf16x8(bq[m][1]), e1, 0, 0, 0);
+                e0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(xa[T][m]), as_bf16x8(bq[m][0]), e0, 0, 0, 0);
+                e1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(xa[T][m]), as_bf16x8(bq[m][1]), e1, 0, 0, 0);
             }
             float w[4];
 #pragma unroll
@@ -591,9 +616,7 @@ __global__ void __launch_bounds__((64 * NW)) k_wide_partial_bf16r(TallArgs<float
         const u32x4 wv = {wq[0], wq[1], wq[2], wq[3]};
 #pragma unroll
         for (int mb = 0; mb < G::MBP; ++mb) {
-            const u32x2 t0 = lds_read_tr16(base + G::tile1(0, mb >> 1) + tr_off[mb & 1]);
-            const u32x2 t1 = lds_read_tr16(base + G::tile1(1, mb >> 1) + tr_off[mb & 1]);
-            const u32x4 xg = {t0[0], t0[1], t1[0], t1[1]};
+            const u32x4 xg = {xt[mb][0][0], xt[mb][0][1], xt[mb][1][0], xt[mb][1][1]};
             gacc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(xg), as_bf16x8(wv), gacc[mb], 0, 0, 0);
         }
     }
@@ -657,17 +680,25 @@ __global__ void __launch_bounds__(512) k_wide_traj_bf16(TallArgs<float, P> a) {
     unsigned char* ring = smem + wave * RING_BYTES;
     const uint32_t ring_lds = (uint32_t)(uintptr_t)ring;
 
-    auto issue = [&](int b) {  // block b of this wave -> ring slot b % NBUF
-        const unsigned char* src = reinterpret_cast<const unsigned char*>(a.xblk1 + (wb0 + b) * (int64_t)G::BUF1) + lane * 16;
-        const uint32_t dst = ring_lds + (uint32_t)((b & (NBUF - 1)) * BLK_BYTES);
-#pragma unroll
-        for (int ch = 0; ch < BLK_BYTES / 1024; ++ch) {
-            uint32_t keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep)
-                         : "v"(src + ch * 1024), "s"(dst + ch * 1024)
-                         : "memory");
-        }
+    auto issue = [&](int b) {  // block b of this wave -> ring slot b % NBUF; one M0 set-up per block (see k_wide_partial_bf16r)
+        static_assert(BLK_BYTES == 8192 || BLK_BYTES == 4096, "pieces addressed around the middle of the block");
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(a.xblk1 + (wb0 + b) * (int64_t)G::BUF1) + lane * 16 + BLK_BYTES / 2;
+        const uint32_t dst = ring_lds + (uint32_t)((b & (NBUF - 1)) * BLK_BYTES) + BLK_BYTES / 2;
+        uint32_t keep;
+        if constexpr (BLK_BYTES == 8192)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                         "global_load_lds_dwordx4 %1, off offset:-4096\n\tglobal_load_lds_dwordx4 %1, off offset:-3072\n\t"
+                         "global_load_lds_dwordx4 %1, off offset:-2048\n\tglobal_load_lds_dwordx4 %1, off offset:-1024\n\t"
+                         "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
+                         "global_load_lds_dwordx4 %1, off offset:2048\n\tglobal_load_lds_dwordx4 %1, off offset:3072\n\t"
+                         "s_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+        else
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                         "global_load_lds_dwordx4 %1, off offset:-2048\n\tglobal_load_lds_dwordx4 %1, off offset:-1024\n\t"
+                         "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
+                         "s_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
     };
 
     // the thread's share of the state: chain oc, coordinates 32 r + oj
