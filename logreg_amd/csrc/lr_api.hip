@@ -112,227 +112,9 @@ struct lr_model {
     size_t esize() const { return dtype == LR_F32 ? 4 : 8; }
 };
 
+#include "lr_plan.h"
+
 namespace {
-
-struct Plan { int mode, G, R; size_t lds_bytes; };
-
-// wide models: 0 = fp32-MFMA kernel (LOGREG_WIDE_BF16=0), 1 = bf16x3 with 4 waves (64 chains) per workgroup,
-// 2 = bf16x3 with 8 waves (128 chains) per workgroup.  Measured (tools/wide_nsweep.py, wide_sweep.py): the
-// 128-chain workgroup halves the staging per chain but needs twice the row slices to fill the chip, so it wins only
-// when there are >= 4096 chains AND its slices still hold >= 512 rows (4096 chains: n = 2048 35.6 vs 36.6 us per
-// step for 4 vs 8 waves, n = 4096 equal, n = 8192 102 vs 85; n = 512: 18.9 vs 25.9)
-int wide_engine(const lr_model* m, int64_t C) {
-    const char* env = std::getenv("LOGREG_WIDE_BF16");
-    if (env) return std::atoi(env);
-    if (C < 4096) return 1;
-    const int64_t blocks2 = (C + 127) / 128, rs2 = (m->cus + blocks2 - 1) / blocks2;
-    return m->n / rs2 >= 512 ? 2 : 1;
-}
-int64_t wide_chains_per_block(const lr_model* m, int64_t C) { return wide_engine(m, C) == 2 ? 128 : 64; }
-
-// matrix-core chain kernel with its bf16 operands in LDS (lr_mfma.h MfmaRowsLds): bytes for a row split over S waves
-// (the kernel's own layout function, so the two cannot drift apart: an earlier hand-written copy missed the even padding of
-//  the eta images and under-allocated by 512 p/8 bytes per wave for odd tile counts)
-template <int P> size_t mfma_lds_bytes_p(int64_t ntw, int S) {
-    switch (S) {
-    case 1: return 1 * lr::MfmaRowsLds<P, 1, false>::bytes_per_wave(ntw);
-    case 4: return 4 * lr::MfmaRowsLds<P, 4, false>::bytes_per_wave(ntw);
-    default: return 8 * lr::MfmaRowsLds<P, 8, false>::bytes_per_wave(ntw);
-    }
-}
-size_t mfma_lds_bytes(const lr_model* m, int S) {
-    const int64_t tiles = (m->n + 15) / 16, ntw = (tiles + S - 1) / S;
-    return m->P == 8 ? mfma_lds_bytes_p<8>(ntw, S) : (m->P == 16 ? mfma_lds_bytes_p<16>(ntw, S) : mfma_lds_bytes_p<32>(ntw, S));
-}
-// 160 KB less the kernel's static exchange buffers (red: 2 x S x 64 x P/4 floats, redv: S x 64 doubles)
-size_t mfma_lds_budget(const lr_model* m, int S = 4) { return 160 * 1024 - (size_t)128 * S * m->P - (size_t)512 * S; }
-
-// Choose the kernel variant.  REG (rows in VGPRs) whenever the data fit (G*R >= n), then LDS,
-// then GLOBAL.  Group size: the smallest available G that still gives every SIMD a wavefront
-// (C*G/64 >= 4*CUs), else the largest; an explicit `group` request is honoured exactly.
-// `hmc_bf16`: the run is HMC and its interior leapfrog gradients may use the bf16 matrix pipe (LR_PREC_AUTO / BF16)
-int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool for_eval = false, bool hmc_bf16 = false) {
-    const lr::InstTable* t = m->table;
-    const int64_t want_waves = 4LL * m->cus;
-    int best = -1;
-    long best_score = -1;
-    if (hmc_bf16 && !for_eval && mode == LR_MODE_AUTO && group == 0 && m->dtype == LR_F32 && m->P >= 8 && m->P <= 32 &&
-        !env_on("LOGREG_NO_MFMA_INTERIOR")) {
-        // register-resident data, many chains: the fused matrix-core kernel with bf16 interior steps (lr_mfma.h).
-        // Measured (bench.py workload, chain-iterations/s, reg 16x13 | mfma S=4 | mfma S=1; profiles/r2_mfma_chain_grid.txt):
-        //    4096: 1.88e8 | 2.13e8 | 1.16e8      6144: 1.64e8 | 2.22e8 | 1.74e8      8192: 2.10e8 | 2.93e8 | 2.32e8
-        //   10240: 1.86e8 | 2.61e8 | 2.89e8     16384: 2.25e8 | 3.23e8 | 4.49e8     65536: 2.37e8 | 3.58e8 | 5.18e8
-        // S = 4 (rows split over the 4 waves of a workgroup) pays from one workgroup per CU, S = 1 (16 chains per
-        // wave, no LDS hand-off) from 40 chains per CU.
-        // Mid-size data (256 < n <= 1024; tools/midn_mfma.py, HMC L=20, it/s, reg | mfma S=4): n=400: 1.83e8 | 2.82e8 at
-        // 4096 chains, 1.92e8 | 3.74e8 at 16 384; n=1000: 0.92e8 | 1.69e8 at 4096, 0.98e8 | 1.79e8 at 16 384; below one
-        // workgroup per CU (4096 chains) the register kernels win (n=400, 2048 chains: 1.69e8 | 1.45e8).
-        // Wider models (9 <= p <= 32; profiles/r2_midp_mfma.txt, HMC L=20, algorithmic TF, vector-ALU kernel | mfma S=4):
-        //   n=200 p=12: 13 | 19 at 1024 chains, 33 | 72 at 4096, 34 | 98 (S=1: 138) at 16 384;  n=200 p=32: 25 | 29, 26 | 110, 26 | 118;
-        //   n=500 p=32 (LDS kernel otherwise): 16 | 53, 16 | 199, 37 | 210;  n=1000 p=12: 23 | 39, 23 | 150, 50 | 147;
-        //   n=500 p=16: 43 | 40, 46 | 147, 47 | 160.   p > 8 moves to the matrix pipe from 4 chains per CU.
-        // (tools/planner_check.py, sustained clocks, HMC L=50: n=200 p=12..32 wins from 1024 chains (+7..+40 %); n=500 p=16 loses 10 %
-        //  at 1024 chains and wins 1.8x at 2048;  p = 8 beyond the registers: see the LDS variant)
-        // p > 8: from 4 chains per CU, except where the alternative is still a register-resident vector kernel with more
-        // than 4 tiles per wave here (p <= 16, 256 < n <= 512: n=500 p=16 at 1024 chains 3.17 | 2.87e7 it/s)
-        const bool reg_alternative = m->P == 16 && m->n > 256 && m->n <= 512;
-        const int64_t s4_from = (m->P > 8 ? (reg_alternative || (m->P == 32 && m->n > 2048) ? 8LL : 4LL) : (m->n > 16 * 4 * 16 ? 8LL : 16LL)) * m->cus;
-        // (S = 1 beyond 13 tiles per wave, p = 8: the operands in ONE LDS image shared by the workgroup's four waves)
-        const bool s1_lds = m->P == 8 && m->n > 16 * 13 && mfma_lds_bytes(m, 1) <= mfma_lds_budget(m, 4) && !env_on("LOGREG_NO_MFMA_S1_LDS");
-        // (HMC L=50, sustained clocks, S=4 | S=1 with the LDS image: n=300: 2.24 | 2.30e8 it/s at 16 384 chains, 2.33 | 2.68e8 at 32 768;
-        //  n=700: 1.02 | 1.09, 1.03 | 1.25; n=2000 (S=8): 3.74 | 3.94e7, 3.75 | 3.94: worth it from 96 chains per CU)
-        const int try_S[2] = {(C >= 40LL * m->cus && m->n <= 16 * 13) || (C >= 96LL * m->cus && s1_lds) ? 1 : 0, C >= s4_from ? 4 : 0};
-        for (int want_S : try_S) {
-            for (int i = 0; want_S && i < t->nvariants; ++i) {
-                const lr::Variant& v = t->variants[i];
-                if (v.mode != lr::MODE_MFMA || v.G != want_S) continue;
-                if (v.R < 0) {  // operands in device memory: listed last; needs the images built at model creation
-                    // (profiles/r2_midn_lds_mfma.txt, HMC L=20, TF, stepwise | this: n=3000 p=8: 43 | 81 at 4096 chains, 92 | 102 at 16 384;
-                    //  n=5000 p=8: 63 | 85, 111 | 112; n=10 000 p=8: 88 | 90, 131 | 118; n=3000 p=16: 66 | 121, 130 | 146; n=8000 p=16: 109 | 135, 174 | 162)
-                    //  p > 16: n=700 p=30: 31 | 74, 69 | 74; n=2000 p=20: 46 | 74, 85 | 80; n=5000 p=30: 105 | 132, 176 | 135; n=8000 p=24: 108 | 112, 160 | 115)
-                    // (after the scalar-loop rework, n=8000: p=8 82 | 103 and 130 | 136; p=16 112 | 148 and 187 | 177; p=24 108 | 118 and 167 | 119)
-                    const int64_t max_rows = C >= 64LL * m->cus ? (m->P == 8 ? 8192 : (m->P == 16 ? 4000 : 2000)) : 8192;
-                    // (p > 16, n <= 2048: already from 4 chains per CU -- n=700 p=30 at 1024 chains: 16 -> 19 TF, n=2000 p=20: 16 -> 20)
-                    const int64_t from = (m->P == 32 && m->n <= 2048 ? 4LL : 16LL) * m->cus;
-                    if (!m->d_xms || C < from || m->n > max_rows) continue;
-                    int G = v.G;
-                    // p = 8 below 64 chains per CU: the 8-wave row split (n=3000: 109 -> 120 TF, n=8000: 118 -> 137 at 4096 chains;
-                    // at 16 384 chains the 4-wave split packs the CUs better: 135 vs 121)
-                    if (m->P == 8 && C < 64LL * m->cus)
-                        for (int j = 0; j < t->nvariants; ++j)
-                            if (t->variants[j].mode == lr::MODE_MFMA && t->variants[j].G == 8 && t->variants[j].R < 0) G = 8;
-                    out->mode = v.mode;
-                    out->G = G;
-                    out->R = v.R;
-                    out->lds_bytes = 0;
-                    return LR_OK;
-                }
-                const bool in_lds = v.R == 0;  // listed after the register variants of the same S
-                // operands in LDS (profiles/r2_midn_lds_mfma.txt, HMC L=20, TF, best other kernel | this one): n=2000 p=8: 34 | 24 at
-                // 1024 chains, 48 | 90 at 4096, 82 | 94 at 16 384; n=1150 p=16: 30 | 32, 33 | 120, 81 | 129: from one workgroup per CU
-                // (8-wave split, n=2000 p=8, HMC L=50: lane-group LDS kernel 56 TF | this 70 at 2048 chains, 43 | 35 at 1024)
-                const bool lds8 = in_lds && m->P == 8 && mfma_lds_bytes(m, 8) <= mfma_lds_budget(m, 8);
-                if (in_lds && v.G != 1 && C < (lds8 ? 8LL : 16LL) * m->cus) continue;
-                if (in_lds ? mfma_lds_bytes(m, v.G) <= mfma_lds_budget(m, v.G) : (int64_t)16 * v.G * v.R >= m->n) {
-                    int G = v.G;
-                    if (in_lds && v.G == 4) {  // the 8-wave row split of the LDS variant where it exists and fits (n=2000 p=8: 121 -> 139 TF)
-                        for (int j = 0; j < t->nvariants; ++j)
-                            if (t->variants[j].mode == lr::MODE_MFMA && t->variants[j].G == 8 && t->variants[j].R == 0 &&
-                                mfma_lds_bytes(m, 8) <= mfma_lds_budget(m, 8))
-                                G = 8;
-                    }
-                    out->mode = v.mode;
-                    out->G = G;
-                    out->R = v.R;
-                    out->lds_bytes = in_lds ? mfma_lds_bytes(m, G) : 0;
-                    return LR_OK;
-                }
-            }
-        }
-    }
-    if (m->P > 32) {
-        // wide models (32 < p <= 128): only the stepwise engine exists; its partial kernel is an MFMA
-        // GEMM over blocks of 64 chains x row slices (lr_wide.h).  ~2 workgroups per CU.
-        if (mode != LR_MODE_AUTO && mode != LR_MODE_STEPWISE)
-            return fail(LR_ERR_UNSUPPORTED, "p=%d > 32 runs on the stepwise engine only (mode=%d requested)", m->p, mode);
-        const int64_t cpb = wide_chains_per_block(m, C);
-        const int64_t blocks = (C + cpb - 1) / cpb;
-        // measured (tools/wide_sweep.py): 2 workgroups per CU pay off only when each still gets >= 32
-        // row tiles (8192 chains: 96 vs 77 TFLOP/s); with less work 1 per CU wins (1024 chains: 51 vs 44)
-        const char* env = std::getenv("LOGREG_WIDE_WG_PER_CU");  // tuning override
-        const int64_t tiles_at_2 = (m->n / 16) * blocks / (2LL * m->cus);
-        // bf16 kernels (48-64 KB of LDS: 2-3 workgroups per CU would fit): one per CU -- the fewest row
-        // slices -- measured fastest (8192 chains: 188 / 170 / 155 TFLOP/s at 1 / 2 / 3 per CU)
-        const int64_t per_cu = env && std::atoi(env) > 0 ? std::atoi(env)
-                               : (wide_engine(m, C) != 0 ? 1 : (tiles_at_2 >= 32 ? 2 : 1));
-        int64_t RS = (per_cu * m->cus + blocks - 1) / blocks;
-        if (group > 0) RS = group;  // explicit slice count: pins the summation order whatever the chain count
-        int64_t slice_len = (m->n + RS - 1) / RS;
-        slice_len = (slice_len + 31) / 32 * 32;  // whole 32-row blocks (the bf16 kernel's K = 32)
-        RS = (m->n + slice_len - 1) / slice_len;
-        out->mode = lr::MODE_STEPWISE;
-        out->G = (int)RS;
-        out->R = (int)slice_len;
-        out->lds_bytes = 0;
-        return LR_OK;
-    }
-    if (for_eval && (mode == LR_MODE_MFMA || mode == LR_MODE_STEPWISE)) { mode = LR_MODE_AUTO; group = 0; }
-    // tall data: neither VGPRs nor LDS can hold the rows -> stepwise engine (lr_tall.h): split the rows into
-    // RS slices so that every evaluation occupies the whole chip with ~4 waves per SIMD
-    // measured (tools/midn_sweep.py, HMC, p = 8, chain-rows/s): rows streamed from L2 by every group never beat
-    // the stepwise engine (n = 6000-8000: 0.4-1.0e12 vs 0.6-2.0e12), and LDS-resident rows lose to it once they
-    // take more than 64 KB (one workgroup per CU) and there are >= 2048 chains (n = 4000: 0.8e12 vs 1.1-1.8e12)
-    const size_t row_bytes = (size_t)m->n * m->P * m->esize();
-    const bool fits_lds = row_bytes <= kLdsBudget;
-    const bool prefer_stepwise = !fits_lds || (row_bytes > 64 * 1024 && C >= 2048);  // (never register-sized)
-    if (!for_eval && (mode == LR_MODE_STEPWISE || (mode == LR_MODE_AUTO && group == 0 && prefer_stepwise))) {
-        // a workgroup = NW waves x 64 chains working on one slice (NW as lr::TallGeom: LDS-limited)
-        const int raw = 2048 / (m->P * (int)m->esize());
-        const int64_t NW = raw >= 16 ? 16 : (raw >= 8 ? 8 : 4);
-        const int64_t waves_per_slice = NW * ((C + 63) / 64);
-        int64_t RS = (4 * want_waves + waves_per_slice - 1) / waves_per_slice;
-        if (mode == LR_MODE_STEPWISE && group > 0) RS = group;  // explicit slice count (see the wide branch)
-        int64_t slice_len = (m->n + RS - 1) / RS;
-        if (slice_len < 16 * NW) slice_len = 16 * NW;  // at least 16 rows per wave
-        slice_len = (slice_len + 1) & ~(int64_t)1;      // even: the float32 kernel walks row pairs
-        if (m->d_xmx) slice_len = (slice_len + 31) / 32 * 32;  // whole tile pairs: the matrix-pipe interior kernel
-        RS = (m->n + slice_len - 1) / slice_len;
-        out->mode = lr::MODE_STEPWISE;
-        out->G = (int)RS;
-        out->R = (int)slice_len;
-        out->lds_bytes = 0;
-        return LR_OK;
-    }
-    for (int i = 0; i < t->nvariants; ++i) {
-        const lr::Variant& v = t->variants[i];
-        if (v.mode == lr::MODE_MFMA) {
-            // fp32 matrix-core variants; G = row-split ways S, R = tiles per wave.  Opt-in only
-            // (mode = LR_MODE_MFMA): fp32 MFMA shares the fp32 multipliers with the vector ALU, and
-            // since the vector kernels went fully packed (v_pk_fma_f32 + fused v_add_f32_dpp) reg 16x13
-            // is faster at every chain count measured (profiles/: 1.93e8 vs 1.65e8 it/s at 16 384
-            // chains, 2.00e8 vs 1.86e8 at 65 536).
-            if (for_eval) continue;
-            if (v.R < 0 ? m->d_xms == nullptr
-                        : (v.R == 0 ? mfma_lds_bytes(m, v.G) > mfma_lds_budget(m, v.G) : (int64_t)16 * v.G * v.R < m->n)) continue;
-            const bool filled = C >= 16LL * want_waves;
-            if (mode == LR_MODE_MFMA) {
-                if (group != 0 && v.G != group) continue;
-                // operands in LDS / device memory: only when no register variant fits
-                const long score = v.R <= 0 ? 0 : ((filled ? (v.G == 1) : (v.G == 4)) ? 2 : 1);
-                if (score > best_score) { best_score = score; best = i; }
-            }
-            continue;
-        }
-        if (mode != LR_MODE_AUTO && v.mode != mode) continue;
-        if (group != 0 && v.G != group) continue;
-        if (v.mode == lr::MODE_REG && (int64_t)v.G * v.R < m->n) continue;
-        if (v.mode == lr::MODE_LDS && (size_t)m->n * m->P * m->esize() > kLdsBudget) continue;
-        // score: residency tier first (REG > LDS > GLOBAL), then group fitness, then fewer padded rows
-        const int64_t waves = (C * v.G + 63) / 64;
-        long score = (2 - v.mode) * 1000000L;
-        if (waves >= want_waves) score += 100000L - 1000L * v.G;  // filled: prefer small groups
-        else score += 10L * v.G;                                   // not filled: prefer large groups
-        if (v.mode == lr::MODE_REG) score -= v.R;                  // exact-fit R before padded R
-        // lane-per-chain with rows broadcast from the scalar unit has no replicated work and no
-        // reductions: measured fastest once there are >= 3 waves per SIMD to hide the SMEM latency (HMC,
-        // n=200, p=8: 2.20 / 2.46 / 2.64e8 it/s at 2 / 4 / 8 waves per SIMD against 2.21e8 for rows in
-        // registers), provided the rows fit the 16 KB scalar cache
-        if (mode == LR_MODE_AUTO && group == 0 && v.mode == lr::MODE_GLOBAL && v.G == 1 && waves >= 3 * want_waves &&
-            (size_t)m->n * m->P * m->esize() <= 16 * 1024)
-            score = 4000000L;
-        if (score > best_score) { best_score = score; best = i; }
-    }
-    if (best < 0)
-        return fail(LR_ERR_UNSUPPORTED, "no kernel variant for dtype=%d p=%d (padded %d) n=%lld group=%d mode=%d",
-                    m->dtype, m->p, m->P, (long long)m->n, group, mode);
-    const lr::Variant& v = t->variants[best];
-    out->mode = v.mode;
-    out->G = v.G;
-    out->R = v.R;
-    out->lds_bytes = v.mode == lr::MODE_LDS ? (size_t)m->n * m->P * m->esize()
-                     : (v.mode == lr::MODE_MFMA && v.R == 0 ? mfma_lds_bytes(m, v.G) : 0);
-    return LR_OK;
-}
 
 template <typename T, int P> lr::ModelArgs<T, P> model_args(const lr_model* m) {
     lr::ModelArgs<T, P> a;
@@ -408,31 +190,6 @@ int do_chain_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs, c
     if (rc != 0) return fail(rc == -3 ? LR_ERR_UNSUPPORTED : LR_ERR_HIP, "chain launch failed (%d): %s", rc,
                              hipGetErrorString(hipGetLastError()));
     return LR_OK;
-}
-
-// Persistent row-split trajectory kernel for wide models (lr_wide_persist.h): slices S per group of 32 chains and 32-row blocks
-// per slice for Cp chains, or S = 0 when it does not apply: every (group, slice) workgroup must be resident at once (one per
-// CU), the slice's block images + 32 KB have to fit the LDS, and the grid should fill at least half the chip.
-struct PersistPlan { int S, nbs; };
-PersistPlan persist_plan(const lr_model* m, int64_t Cp) {
-    PersistPlan none{0, 0};
-    // OPT-IN (LOGREG_WIDE_PERSIST=1): built, measured and, at config 5, slower than a launch per step -- 12.8 vs 10.3 us per
-    // evaluation (tools/stamps_persist.py, us per step: row loop 3.5, the 8 waves' gradients through LDS 2.5 [128 KB of ds_write at
-    // ~79 B/clk], publish 0.9, poll 1.2, gather of the 8 slices' partials 3.1 [128 KB per workgroup through the ~15 B/clk a CU gets
-    // from beyond its L2], operand build 0.5).  Kept with its tests as the measured answer to "why not a persistent kernel".
-    if (m->P <= 32 || !m->d_xblk1 || !m->table->launch_tall_traj_rs || !m->h_xerr || !env_on("LOGREG_WIDE_PERSIST")) return none;
-    const int64_t groups = (Cp + 31) / 32;
-    if (groups > m->cus) return none;
-    const int nblk = (int)((m->n + 31) / 32);
-    int S = (int)(m->cus / groups);
-    if (S > 16) S = 16;
-    if (const char* e = std::getenv("LOGREG_WIDE_PERSIST_SLICES")) S = std::atoi(e);  // tuning override
-    if (S < 1 || S > 64 || groups * S > m->cus) return none;
-    if (S > nblk) S = nblk;
-    const int nbs = (nblk + S - 1) / S;
-    if (m->table->traj_rs_lds_bytes(nbs) > kLdsBudget) return none;
-    if (groups * S * 2 < m->cus) return none;
-    return PersistPlan{S, nbs};
 }
 
 template <typename T, int P>

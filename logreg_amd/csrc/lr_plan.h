@@ -1,0 +1,288 @@
+// lr_plan.h -- which kernel variant runs a request: the planner of the C ABI (lr_plan, lr_plan_run, every lr_run_*).
+// Part of lr_api.hip's translation unit (included behind `struct lr_model`); host code only.
+//
+// The measured crossovers live in DATA: kMfmaRules (when HMC with reduced-precision interior steps moves to the fused
+// matrix-core chain kernel, by padded width, row count and chains per CU) and kPlanConst (the stepwise / scalar-row /
+// wide-engine thresholds), each row with the measurement it came from (profiles/).  make_plan() applies them and checks what
+// a table cannot know: which variants this build instantiates and whether a variant's operands fit its store (registers,
+// LDS, the device-memory images the model carries).  tests/test_gpu_planner.py times AUTO against every forced alternative
+// at shapes on both sides of the table's boundaries and fails when AUTO is more than 10 % off the best.
+#pragma once
+
+namespace {
+
+struct Plan { int mode, G, R; size_t lds_bytes; };
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// thresholds outside the matrix-core table
+struct PlanConst {
+    // tall data: LDS-resident rows lose to the stepwise engine once they take more than this many bytes (one workgroup per CU)
+    // and there are this many chains (tools/midn_sweep.py, n = 4000 p = 8: 0.8e12 vs 1.1-1.8e12 chain-rows/s)
+    // (round 3, tools/planner_bench.py, lds 64 lanes per chain | stepwise, chain-iterations/s: MALA n=4000 p=8: 2.32e8 | 1.48e8 at 2048
+    //  chains, 2.33 | 2.43 at 4096, 2.33 | 3.23 at 8192; HMC all-fp32 n=4000: 1.64e7 | 1.00e7 at 2048, 1.64 | 1.54 at 4096: from 4096 chains)
+    size_t lds_rows_prefer_stepwise_bytes = 64 * 1024;
+    int64_t lds_rows_prefer_stepwise_chains = 4096;
+    // register-resident rows, lanes per chain G: time of a launch ~ (R + reg_fixed_rows) f(w), R = rows per lane of the variant,
+    // w = waves per SIMD (rounded up: the fullest SIMD sets the time), f(w) = 1 + reg_corun (w - 1).  Fitted to HMC n=200 p=8
+    // (tools/planner_bench.py): exactly-filled launches give 8.88 / 6.69 / 5.2 us per iteration for G = 16 / 32 / 64 (R = 13 / 7 /
+    // 4): fixed work (generator, reductions, update) worth 11 rows; two co-resident waves take 1.88x one.  Replaces "the
+    // smallest G that still gives every SIMD a wave", which put 2560 chains on G = 32 (2.16e8 it/s) when G = 16 runs 2.88e8,
+    // and MALA at 3072 chains on G = 32 (2.72e9) against 3.30e9.
+    double reg_fixed_rows = 11.0;
+    double reg_corun = 0.88;
+    // lane-per-chain with rows from the scalar unit: from this many waves per SIMD (HMC n=200 p=8: 2.20 / 2.46 / 2.64e8 it/s at
+    // 2 / 4 / 8 waves per SIMD against 2.21e8 for rows in registers), rows within the 16 KB scalar cache
+    int scalar_rows_waves_per_simd = 3;
+    size_t scalar_rows_max_bytes = 16 * 1024;
+    // wide models: the 8-wave (128-chain) exact kernel from this many chains, while its slices still hold this many rows
+    // (tools/wide_nsweep.py: 4096 chains, n = 2048 35.6 vs 36.6 us per step for 4 vs 8 waves, n = 8192 102 vs 85; n = 512 18.9 vs 25.9)
+    int64_t wide_8wave_chains = 4096;
+    int64_t wide_8wave_min_slice_rows = 512;
+    // wide models, fp32-MFMA engine only (LOGREG_WIDE_BF16=0): two workgroups per CU once each still gets this many 16-row tiles
+    int64_t wide_fp32_two_per_cu_tiles = 32;
+};
+constexpr PlanConst kPlanConst{};
+
+// wide models: 0 = fp32-MFMA kernel (LOGREG_WIDE_BF16=0), 1 = bf16x3 with 4 waves (64 chains) per workgroup,
+// 2 = bf16x3 with 8 waves (128 chains) per workgroup: the 128-chain workgroup halves the staging per chain but needs twice the
+// row slices to fill the chip
+int wide_engine(const lr_model* m, int64_t C) {
+    const char* env = std::getenv("LOGREG_WIDE_BF16");
+    if (env) return std::atoi(env);
+    if (C < kPlanConst.wide_8wave_chains) return 1;
+    const int64_t blocks2 = (C + 127) / 128, rs2 = (m->cus + blocks2 - 1) / blocks2;
+    return m->n / rs2 >= kPlanConst.wide_8wave_min_slice_rows ? 2 : 1;
+}
+int64_t wide_chains_per_block(const lr_model* m, int64_t C) { return wide_engine(m, C) == 2 ? 128 : 64; }
+
+// matrix-core chain kernel with its bf16 operands in LDS (lr_mfma.h MfmaRowsLds): bytes for a row split over S waves
+// (the kernel's own layout function, so the two cannot drift apart: an earlier hand-written copy missed the even padding of
+//  the eta images and under-allocated by 512 p/8 bytes per wave for odd tile counts)
+template <int P> size_t mfma_lds_bytes_p(int64_t ntw, int S) {
+    switch (S) {
+    case 1: return 1 * lr::MfmaRowsLds<P, 1, false>::bytes_per_wave(ntw);
+    case 4: return 4 * lr::MfmaRowsLds<P, 4, false>::bytes_per_wave(ntw);
+    default: return 8 * lr::MfmaRowsLds<P, 8, false>::bytes_per_wave(ntw);
+    }
+}
+size_t mfma_lds_bytes(const lr_model* m, int S) {
+    const int64_t tiles = (m->n + 15) / 16, ntw = (tiles + S - 1) / S;
+    return m->P == 8 ? mfma_lds_bytes_p<8>(ntw, S) : (m->P == 16 ? mfma_lds_bytes_p<16>(ntw, S) : mfma_lds_bytes_p<32>(ntw, S));
+}
+// 160 KB less the kernel's static exchange buffers (red: 2 x S x 64 x P/4 floats, redv: S x 64 doubles)
+size_t mfma_lds_budget(const lr_model* m, int S = 4) { return 160 * 1024 - (size_t)128 * S * m->P - (size_t)512 * S; }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// HMC whose interior leapfrog gradients may use the bf16 matrix pipe (LR_PREC_AUTO / LR_PREC_BF16), float32, padded p = 8 / 16 /
+// 32: when the fused matrix-core chain kernel (lr_mfma.h, LR_MODE_MFMA) takes over from the vector-ALU kernels and the stepwise
+// engine.  Rows are tried top to bottom; the first whose (row-split ways S, operand store) variant exists and whose operands fit
+// wins.  cpc = chains per CU (chains / CUs: the thresholds scale with the chip).  Operand stores: registers (n <= 16 S R for
+// the instantiated tile counts R), LDS (lr_mfma.h MfmaRowsLds within mfma_lds_budget), device memory (images built at model
+// creation for 208 / 1024 / 512 < n <= 8192).  "S = 8 where it exists" = the 8-wave row split of the LDS / device variants.
+enum Store { ST_REG, ST_LDS, ST_DEV };
+struct MfmaRule {
+    int P;                    // padded width
+    Store store;
+    int S;                    // row-split ways requested (LDS / device rows: upgraded to 8 where `s8` says so)
+    int64_t n_lo, n_hi;       // n_lo < n <= n_hi
+    int cpc_lo, cpc_hi;       // cpc_lo <= chains per CU < cpc_hi (0 = no upper bound)
+    bool s8;                  // take the 8-wave split when that variant exists and fits
+    const char* why;
+};
+constexpr int64_t kAnyN = INT64_MAX;
+constexpr MfmaRule kMfmaRules[] = {
+    // ---- p <= 8.  Bench workload (n = 200), chain-iterations/s, reg 16x13 | mfma S=4 | mfma S=1 (profiles/r2_mfma_chain_grid.txt):
+    //      4096: 1.88e8 | 2.13e8 | 1.16e8    8192: 2.10e8 | 2.93e8 | 2.32e8    10240: 1.86e8 | 2.61e8 | 2.89e8    16384: 2.25e8 | 3.23e8 | 4.49e8
+    {8, ST_REG, 1, 0, 208, 40, 0, false, "16 chains per wave, no LDS hand-off: from 40 chains per CU (10 240 chains: 2.89e8 vs 2.61e8 for S=4)"},
+    {8, ST_LDS, 1, 208, kAnyN, 96, 0, false, "one LDS image shared by the workgroup's four chain tiles: n=300 2.24 | 2.30e8 at 16 384 chains, 2.33 | 2.68e8 at 32 768 (S=4 | this)"},
+    {8, ST_REG, 4, 0, 1024, 16, 0, false, "rows in registers, split over 4 waves: from one workgroup per CU (4096 chains: 2.13e8 vs 1.88e8 reg 16x13; n=400: 2.82e8 vs 1.83e8); below, the register kernels win (n=400, 2048 chains: 1.45e8 vs 1.69e8)"},
+    {8, ST_LDS, 4, 1024, kAnyN, 8, 0, true, "operands in LDS, 8-wave split: n=2000 HMC L=50 lane-group LDS kernel 56 TF | this 70 at 2048 chains (43 | 35 at 1024); 121 -> 139 TF over the 4-wave split"},
+    {8, ST_LDS, 4, 1024, kAnyN, 16, 0, false, "operands in LDS, 4-wave split where the 8-wave one does not fit: n=2000 48 | 90 TF at 4096 chains (best other | this)"},
+    {8, ST_DEV, 4, 1024, 6000, 8, 64, true, "operands streamed from device memory, 8-wave split below 64 chains per CU (n=3000 109 -> 120 TF at 4096 chains); from 8 chains per CU up to n = 6000 (round 3, 2048 chains, it/s, lds 64 | stepwise | this: n=3000 2.12 | 1.16 | 2.42e7, n=5000 1.35 | 1.08 | 1.57e7, n=6000 - | 1.33 | 1.33e7; at 1024 chains the lane-group LDS kernel wins, 2.11 | 0.65 | 1.21e7)"},
+    {8, ST_DEV, 4, 6000, 8192, 16, 64, true, "... beyond n = 6000 from 16 chains per CU: n=8000 at 2048 chains stepwise 1.27e7 | this 1.04e7, at 4096 chains 118 -> 137 TF over the 4-wave split"},
+    {8, ST_DEV, 4, 1024, 8192, 64, 0, false, "... 4-wave split from 64 chains per CU (16 384 chains: 135 vs 121 TF); n=8000: stepwise 130 | this 136"},
+    // ---- 8 < p <= 16 (profiles/r2_midp_mfma.txt, HMC L=20, algorithmic TF, vector-ALU kernel | this): n=200 p=12: 13 | 19 at 1024 chains,
+    //      33 | 72 at 4096, 34 | 138 (S=1) at 16 384; n=1000 p=12: 23 | 39, 23 | 150, 50 | 147
+    {16, ST_REG, 1, 0, 208, 40, 0, false, "n=200 p=12: 98 (S=4) -> 138 TF at 16 384 chains"},
+    {16, ST_REG, 4, 0, 256, 4, 0, false, "p > 8 moves to the matrix pipe from 4 chains per CU: n=200 p=12..16 +7..+40 % at 1024 chains (tools/planner_check.py)"},
+    {16, ST_REG, 4, 256, 512, 8, 0, false, "the alternative is still a register-resident vector kernel (reg 64x8): n=500 p=16 at 1024 chains 3.17e7 | 2.87e7, at 2048 1.8x"},
+    {16, ST_REG, 4, 512, 1024, 4, 0, false, "n=1000 p=12: 23 | 39 TF at 1024 chains"},
+    {16, ST_LDS, 4, 1024, kAnyN, 16, 0, true, "operands in LDS: n=1150 p=16 30 | 32 TF at 1024 chains, 33 | 120 at 4096, 81 | 129 at 16 384: from one workgroup per CU"},
+    {16, ST_DEV, 4, 1024, 4000, 4, 0, false, "device-memory operands: n=3000 p=16 stepwise | this 5.5 | 8.1e6 it/s at 1024 chains, 0.98 | 1.62e7 at 2048 (round 3), 66 | 121 TF at 4096, 130 | 146 at 16 384"},
+    {16, ST_DEV, 4, 4000, 8192, 16, 64, false, "... beyond n = 4000 from 16 and below 64 chains per CU: n=8000 p=16 112 | 148 TF at 4096 chains but 187 | 177 at 16 384, and stepwise 4.9 | 3.3e6 it/s at 1024 chains, 9.6 | 6.7e6 at 2048; n=5000: 5.1 | 5.1e6 at 1024"},
+    // ---- 16 < p <= 32 (8 tiles per wave at most: n <= 512 in registers; no LDS variant -- the LDS holds no more rows than the registers)
+    {32, ST_REG, 4, 0, 512, 4, 0, false, "n=200 p=32: 25 | 29 TF at 1024 chains, 26 | 110 at 4096; n=500 p=32 (LDS kernel otherwise): 16 | 53, 16 | 199"},
+    {32, ST_DEV, 4, 512, 2000, 4, 0, false, "n=700 p=30 at 1024 chains 16 -> 19 TF, n=2000 p=20 16 -> 20; at 4096 chains 31 | 74, 46 | 74"},
+    {32, ST_DEV, 4, 2000, 2048, 4, 64, false, "(the 64-chains-per-CU row limit of 2000 below)"},
+    {32, ST_DEV, 4, 2048, 8192, 16, 64, false, "n=5000 p=30: 105 | 132 TF at 4096 chains, 176 | 135 at 16 384: below 64 chains per CU only"},
+};
+
+// does the (S, store) variant exist in this build and do the model's operands fit it?  Fills the plan.
+bool mfma_variant_fits(const lr_model* m, int S, Store st, Plan* out) {
+    const lr::InstTable* t = m->table;
+    for (int i = 0; i < t->nvariants; ++i) {
+        const lr::Variant& v = t->variants[i];
+        if (v.mode != lr::MODE_MFMA || v.G != S) continue;
+        if (st == ST_REG && v.R > 0 && (int64_t)16 * v.G * v.R >= m->n) {  // (ascending R per S: the smallest that holds the rows)
+            *out = Plan{v.mode, v.G, v.R, 0};
+            return true;
+        }
+        // (S = 1 shares one image among the four chain tiles of a 4-wave workgroup: its statics are those of the 4-wave split)
+        if (st == ST_LDS && v.R == 0 && mfma_lds_bytes(m, S) <= mfma_lds_budget(m, S == 1 ? 4 : S)) {
+            *out = Plan{v.mode, v.G, 0, mfma_lds_bytes(m, S)};
+            return true;
+        }
+        if (st == ST_DEV && v.R < 0 && m->d_xms != nullptr) {
+            *out = Plan{v.mode, v.G, v.R, 0};
+            return true;
+        }
+    }
+    return false;
+}
+
+bool plan_mfma_hmc(const lr_model* m, int64_t C, Plan* out) {
+    if (m->dtype != LR_F32 || m->P < 8 || m->P > 32 || env_on("LOGREG_NO_MFMA_INTERIOR")) return false;
+    for (const MfmaRule& r : kMfmaRules) {
+        if (r.P != m->P || m->n <= r.n_lo || m->n > r.n_hi) continue;
+        if (C < (int64_t)r.cpc_lo * m->cus || (r.cpc_hi && C >= (int64_t)r.cpc_hi * m->cus)) continue;
+        if (r.store == ST_LDS && r.S == 1 && env_on("LOGREG_NO_MFMA_S1_LDS")) continue;
+        if (r.s8 && mfma_variant_fits(m, 8, r.store, out)) return true;
+        if (r.s8 && r.store == ST_LDS && r.cpc_lo < 16 && m->P == 8) continue;  // (the 8-chains-per-CU row is the 8-wave split's own)
+        if (mfma_variant_fits(m, r.S, r.store, out)) return true;
+    }
+    return false;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Choose the kernel variant.  REG (rows in VGPRs) whenever the data fit (G*R >= n), then LDS, then GLOBAL.  Group size: the
+// smallest available G that still gives every SIMD a wavefront (C*G/64 >= 4*CUs), else the largest; an explicit `group`
+// request is honoured exactly.
+// `hmc_bf16`: the run is HMC and its interior leapfrog gradients may use the bf16 matrix pipe (LR_PREC_AUTO / BF16)
+int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool for_eval = false, bool hmc_bf16 = false) {
+    const lr::InstTable* t = m->table;
+    const int64_t want_waves = 4LL * m->cus;
+    int best = -1;
+    long best_score = -1;
+    if (hmc_bf16 && !for_eval && mode == LR_MODE_AUTO && group == 0 && plan_mfma_hmc(m, C, out)) return LR_OK;
+    if (m->P > 32) {
+        // wide models (32 < p <= 128): only the stepwise engine exists; its partial kernel is an MFMA
+        // GEMM over blocks of 64 chains x row slices (lr_wide.h).
+        if (mode != LR_MODE_AUTO && mode != LR_MODE_STEPWISE)
+            return fail(LR_ERR_UNSUPPORTED, "p=%d > 32 runs on the stepwise engine only (mode=%d requested)", m->p, mode);
+        const int64_t cpb = wide_chains_per_block(m, C);
+        const int64_t blocks = (C + cpb - 1) / cpb;
+        const char* env = std::getenv("LOGREG_WIDE_WG_PER_CU");  // tuning override
+        const int64_t tiles_at_2 = (m->n / 16) * blocks / (2LL * m->cus);
+        // bf16 kernels (48-64 KB of LDS: 2-3 workgroups per CU would fit): one per CU -- the fewest row
+        // slices -- measured fastest (8192 chains: 188 / 170 / 155 TFLOP/s at 1 / 2 / 3 per CU)
+        const int64_t per_cu = env && std::atoi(env) > 0 ? std::atoi(env)
+                               : (wide_engine(m, C) != 0 ? 1 : (tiles_at_2 >= kPlanConst.wide_fp32_two_per_cu_tiles ? 2 : 1));
+        int64_t RS = (per_cu * m->cus + blocks - 1) / blocks;
+        if (group > 0) RS = group;  // explicit slice count: pins the summation order whatever the chain count
+        int64_t slice_len = (m->n + RS - 1) / RS;
+        slice_len = (slice_len + 31) / 32 * 32;  // whole 32-row blocks (the bf16 kernel's K = 32)
+        RS = (m->n + slice_len - 1) / slice_len;
+        *out = Plan{lr::MODE_STEPWISE, (int)RS, (int)slice_len, 0};
+        return LR_OK;
+    }
+    if (for_eval && (mode == LR_MODE_MFMA || mode == LR_MODE_STEPWISE)) { mode = LR_MODE_AUTO; group = 0; }
+    // tall data: neither VGPRs nor LDS can hold the rows -> stepwise engine (lr_tall.h): split the rows into
+    // RS slices so that every evaluation occupies the whole chip with ~4 waves per SIMD
+    // measured (tools/midn_sweep.py, HMC, p = 8, chain-rows/s): rows streamed from L2 by every group never beat
+    // the stepwise engine (n = 6000-8000: 0.4-1.0e12 vs 0.6-2.0e12)
+    const size_t row_bytes = (size_t)m->n * m->P * m->esize();
+    const bool fits_lds = row_bytes <= kLdsBudget;
+    const bool prefer_stepwise = !fits_lds || (row_bytes > kPlanConst.lds_rows_prefer_stepwise_bytes && C >= kPlanConst.lds_rows_prefer_stepwise_chains);
+    if (!for_eval && (mode == LR_MODE_STEPWISE || (mode == LR_MODE_AUTO && group == 0 && prefer_stepwise))) {
+        // a workgroup = NW waves x 64 chains working on one slice (NW as lr::TallGeom: LDS-limited)
+        const int raw = 2048 / (m->P * (int)m->esize());
+        const int64_t NW = raw >= 16 ? 16 : (raw >= 8 ? 8 : 4);
+        const int64_t waves_per_slice = NW * ((C + 63) / 64);
+        int64_t RS = (4 * want_waves + waves_per_slice - 1) / waves_per_slice;
+        if (mode == LR_MODE_STEPWISE && group > 0) RS = group;  // explicit slice count (see the wide branch)
+        int64_t slice_len = (m->n + RS - 1) / RS;
+        if (slice_len < 16 * NW) slice_len = 16 * NW;  // at least 16 rows per wave
+        slice_len = (slice_len + 1) & ~(int64_t)1;      // even: the float32 kernel walks row pairs
+        if (m->d_xmx) slice_len = (slice_len + 31) / 32 * 32;  // whole tile pairs: the matrix-pipe interior kernel
+        RS = (m->n + slice_len - 1) / slice_len;
+        *out = Plan{lr::MODE_STEPWISE, (int)RS, (int)slice_len, 0};
+        return LR_OK;
+    }
+    for (int i = 0; i < t->nvariants; ++i) {
+        const lr::Variant& v = t->variants[i];
+        if (v.mode == lr::MODE_MFMA) {
+            // fp32 matrix-core variants; G = row-split ways S, R = tiles per wave.  In all-fp32 arithmetic opt-in only
+            // (mode = LR_MODE_MFMA): fp32 MFMA shares the fp32 multipliers with the vector ALU, and since the vector kernels
+            // went fully packed (v_pk_fma_f32 + fused v_add_f32_dpp) reg 16x13 is faster at every chain count measured
+            // (1.93e8 vs 1.65e8 it/s at 16 384 chains, 2.00e8 vs 1.86e8 at 65 536).
+            if (for_eval) continue;
+            if (v.R < 0 ? m->d_xms == nullptr
+                        : (v.R == 0 ? mfma_lds_bytes(m, v.G) > mfma_lds_budget(m, v.G) : (int64_t)16 * v.G * v.R < m->n)) continue;
+            const bool filled = C >= 16LL * want_waves;
+            if (mode == LR_MODE_MFMA) {
+                if (group != 0 && v.G != group) continue;
+                // operands in LDS / device memory: only when no register variant fits
+                const long score = v.R <= 0 ? 0 : ((filled ? (v.G == 1) : (v.G == 4)) ? 2 : 1);
+                if (score > best_score) { best_score = score; best = i; }
+            }
+            continue;
+        }
+        if (mode != LR_MODE_AUTO && v.mode != mode) continue;
+        if (group != 0 && v.G != group) continue;
+        if (v.mode == lr::MODE_REG && (int64_t)v.G * v.R < m->n) continue;
+        if (v.mode == lr::MODE_LDS && (size_t)m->n * m->P * m->esize() > kLdsBudget) continue;
+        // score: residency tier first (REG > LDS > GLOBAL), then group fitness, then fewer padded rows
+        const int64_t waves = (C * v.G + 63) / 64;
+        long score = (2 - v.mode) * 1000000L;
+        if (waves >= want_waves) score += 100000L - 1000L * v.G;  // filled: prefer small groups
+        else score += 10L * v.G;                                   // not filled: prefer large groups
+        if (v.mode == lr::MODE_REG && group == 0) {
+            // the register family by the launch-time model of kPlanConst (the lowest predicted time wins; ties: fewer padded rows)
+            const int64_t wps = (waves + want_waves - 1) / want_waves;
+            const double cost = ((double)v.R + kPlanConst.reg_fixed_rows) * (1.0 + kPlanConst.reg_corun * (double)(wps - 1));
+            score = 2900000L - (long)(cost * 1000.0) - v.R;
+        } else if (v.mode == lr::MODE_REG) {
+            score -= v.R;  // exact-fit R before padded R
+        }
+        // lane-per-chain with rows broadcast from the scalar unit has no replicated work and no reductions
+        if (mode == LR_MODE_AUTO && group == 0 && v.mode == lr::MODE_GLOBAL && v.G == 1 &&
+            waves >= kPlanConst.scalar_rows_waves_per_simd * want_waves && (size_t)m->n * m->P * m->esize() <= kPlanConst.scalar_rows_max_bytes)
+            score = 4000000L;
+        if (score > best_score) { best_score = score; best = i; }
+    }
+    if (best < 0)
+        return fail(LR_ERR_UNSUPPORTED, "no kernel variant for dtype=%d p=%d (padded %d) n=%lld group=%d mode=%d",
+                    m->dtype, m->p, m->P, (long long)m->n, group, mode);
+    const lr::Variant& v = t->variants[best];
+    *out = Plan{v.mode, v.G, v.R, v.mode == lr::MODE_LDS ? (size_t)m->n * m->P * m->esize()
+                                  : (v.mode == lr::MODE_MFMA && v.R == 0 ? mfma_lds_bytes(m, v.G) : 0)};
+    return LR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Persistent row-split trajectory kernel for wide models (lr_wide_persist.h): slices S per group of 32 chains and 32-row blocks
+// per slice for Cp chains, or S = 0 when it does not apply: every (group, slice) workgroup must be resident at once (one per
+// CU), the slice's block images + 32 KB have to fit the LDS, and the grid should fill at least half the chip.
+struct PersistPlan { int S, nbs; };
+PersistPlan persist_plan(const lr_model* m, int64_t Cp) {
+    PersistPlan none{0, 0};
+    // OPT-IN (LOGREG_WIDE_PERSIST=1): built, measured and, at config 5, slower than a launch per step -- 12.8 vs 10.3 us per
+    // evaluation (tools/stamps_persist.py, us per step: row loop 3.5, the 8 waves' gradients through LDS 2.5 [128 KB of ds_write at
+    // ~79 B/clk], publish 0.9, poll 1.2, gather of the 8 slices' partials 3.1 [128 KB per workgroup through the ~15 B/clk a CU gets
+    // from beyond its L2], operand build 0.5).  Kept with its tests as the measured answer to "why not a persistent kernel".
+    if (m->P <= 32 || !m->d_xblk1 || !m->table->launch_tall_traj_rs || !m->h_xerr || !env_on("LOGREG_WIDE_PERSIST")) return none;
+    const int64_t groups = (Cp + 31) / 32;
+    if (groups > m->cus) return none;
+    const int nblk = (int)((m->n + 31) / 32);
+    int S = (int)(m->cus / groups);
+    if (S > 16) S = 16;
+    if (const char* e = std::getenv("LOGREG_WIDE_PERSIST_SLICES")) S = std::atoi(e);  // tuning override
+    if (S < 1 || S > 64 || groups * S > m->cus) return none;
+    if (S > nblk) S = nblk;
+    const int nbs = (nblk + S - 1) / S;
+    if (m->table->traj_rs_lds_bytes(nbs) > kLdsBudget) return none;
+    if (groups * S * 2 < m->cus) return none;
+    return PersistPlan{S, nbs};
+}
+
+}  // namespace

@@ -301,6 +301,12 @@ def test_planner_engine_choice_by_size(la):
         X, y, _ = la.synthetic_logreg(n, p, seed=n)
         return la.LogReg(X, y, np.ones(p)).plan(C)
     assert plan(200, 4096) == {"mode": "reg", "group": 16, "rows_per_lane": 13}
+    # lanes per chain by the launch-time model (lr_plan.h kPlanConst): between the exactly-filled chain counts a wave alone on
+    # its SIMD beats two narrower ones sharing it
+    assert plan(200, 1024) == {"mode": "reg", "group": 64, "rows_per_lane": 4}
+    assert plan(200, 2048) == {"mode": "reg", "group": 32, "rows_per_lane": 7}
+    assert plan(200, 2560) == {"mode": "reg", "group": 16, "rows_per_lane": 13}
+    assert plan(200, 5120) == {"mode": "reg", "group": 16, "rows_per_lane": 13}
     assert plan(200, 64)["group"] == 64
     assert plan(200, 1 << 18)["mode"] == "global" and plan(200, 1 << 18)["group"] == 1
     assert plan(300, 4096) == {"mode": "reg", "group": 32, "rows_per_lane": 16}
@@ -308,6 +314,7 @@ def test_planner_engine_choice_by_size(la):
     assert plan(1000, 4096) == {"mode": "reg", "group": 64, "rows_per_lane": 16}
     assert plan(1500, 4096)["mode"] == "lds"
     assert plan(4000, 1024)["mode"] == "lds"        # 128 KB of rows, few chains
+    assert plan(4000, 2048)["mode"] == "lds"        # (round 3: 64 lanes per chain still 1.6x the stepwise engine here)
     assert plan(4000, 4096)["mode"] == "stepwise"   # same rows, enough chains to fill the chip per slice
     assert plan(6000, 64)["mode"] == "stepwise"     # beyond LDS
     assert plan(300, 64, p=100)["mode"] == "stepwise"
@@ -357,7 +364,11 @@ def test_planner_engine_choice_by_size(la):
     assert wide_plan(1150, 16, 4096) == {"mode": "mfma", "group": 4, "rows_per_lane": 0}
     assert wide_plan(2600, 8, 4096) == {"mode": "mfma", "group": 8, "rows_per_lane": -1}  # beyond LDS: operand images in device memory
     assert wide_plan(2600, 8, 16384) == {"mode": "mfma", "group": 4, "rows_per_lane": -1}
-    assert wide_plan(2600, 8, 2048)["mode"] == "stepwise"
+    assert wide_plan(2600, 8, 2048) == {"mode": "mfma", "group": 8, "rows_per_lane": -1}  # (from 8 chains per CU up to n = 6000)
+    assert wide_plan(2600, 8, 1024)["mode"] == "lds"
+    assert wide_plan(7000, 8, 2048)["mode"] == "stepwise"
+    assert wide_plan(3000, 16, 1024) == {"mode": "mfma", "group": 4, "rows_per_lane": -1}
+    assert wide_plan(5000, 16, 1024)["mode"] == "stepwise"
     assert wide_plan(9000, 8, 4096)["mode"] == "stepwise"
     assert wide_plan(20000, 8, 4096)["mode"] == "stepwise"
 

@@ -1,0 +1,39 @@
+"""The planner (logreg_amd/csrc/lr_plan.h) against measurement: at shapes on both sides of its table's boundaries AUTO must be
+within 10 % of the best forced alternative.  The timing harness is tools/planner_bench.py (every (mode, group) the library
+accepts for the shape, sustained clocks, best of 3); a kernel change that moves a crossover, or a chip with another CU count,
+fails here instead of silently running the slower variant."""
+import os
+import sys
+
+import pytest
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.join(REPO, "tools"))
+
+# (n, p, chains, kernel family, precision policy, leapfrog steps)
+SHAPES = [
+    # the register family's lanes per chain by the launch-time model (chain counts between the exactly-filled ones included)
+    (200, 8, 2048, "hmc", "auto", 20), (200, 8, 2560, "hmc", "full", 20), (200, 8, 4096, "hmc", "full", 20), (200, 8, 5120, "hmc", "full", 20),
+    (200, 8, 3072, "mala", "auto", 0), (200, 8, 8192, "mala", "auto", 0),
+    # matrix-core chain kernel: registers (S = 4 from 16 chains per CU, S = 1 from 40), LDS, device memory
+    (200, 8, 4096, "hmc", "auto", 50), (200, 8, 8192, "hmc", "auto", 20), (200, 8, 10240, "hmc", "auto", 20), (400, 8, 4096, "hmc", "auto", 20),
+    (2000, 8, 1024, "hmc", "auto", 20), (2000, 8, 2048, "hmc", "auto", 20), (3000, 8, 2048, "hmc", "auto", 20), (6000, 8, 4096, "hmc", "auto", 20),
+    (500, 16, 1024, "hmc", "auto", 20), (500, 16, 2048, "hmc", "auto", 20), (3000, 16, 1024, "hmc", "auto", 20), (8000, 16, 2048, "hmc", "auto", 20),
+    (200, 24, 1024, "hmc", "auto", 20),
+    # LDS-resident rows against the stepwise engine (all-fp32 families)
+    (4000, 8, 2048, "mala", "auto", 0), (4000, 8, 8192, "mala", "auto", 0), (4000, 8, 2048, "hmc", "full", 20),
+]
+
+
+@pytest.mark.parametrize("n,p,C,kind,precision,L", SHAPES)
+def test_auto_is_within_ten_percent_of_the_best_alternative(n, p, C, kind, precision, L):
+    import planner_bench as pb
+    res = pb.candidates(n, p, C, kind, precision, L=L or 20)
+    auto, best = res[0], max(res, key=lambda r: r[2])
+    print(f"n={n} p={p} C={C} {kind} {precision}: AUTO {pb.fmt(auto[1])} {auto[2]:.3e}, best {pb.fmt(best[1])} {best[2]:.3e}; "
+          + " | ".join(f"{pb.fmt(pl)} {r:.2e}" for _, pl, r in res[1:]))
+    assert len(res) >= 3  # alternatives were actually timed
+    assert auto[2] >= 0.9 * best[2], (pb.fmt(auto[1]), pb.fmt(best[1]))
