@@ -429,6 +429,9 @@ __global__ void __launch_bounds__((64 * NW)) __attribute__((amdgpu_waves_per_eu(
     unsigned char* ring = smem + wave * RING_BYTES;
     const uint32_t ring_lds = (uint32_t)(uintptr_t)ring;  // LDS byte address (generic -> local keeps the low 32 bits)
     LR_STAMP(a, 0);
+#ifdef LR_STAMPS
+    if (a.stamps && lane == 0) LR_STAMP_AT(a, 13) = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 15;  // HW_REG_XCC_ID, bits 3:0
+#endif
 
     auto issue = [&](int b) {  // block b of this wave -> ring slot b % NBUF
         // ONE M0 set-up per block: the instruction offset (13-bit signed) is added to the global AND to the LDS address, so the

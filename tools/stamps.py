@@ -57,6 +57,10 @@ for cfg in [int(x) for x in sys.argv[1:]] or [4, 5]:
             for nm, a_, b_ in (("  entry -> address setup done", 0, 10), ("  loads issued -> all returned", 10, 11), ("  first DMA blocks issued", 11, 12), ("  update arithmetic + LDS + stores", 12, 1)):
                 d = ((x[:, :, b_] - x[:, :, a_]) * tick)[w]
                 print(f"    {nm:32s} median {np.median(d):6.2f}  p10 {np.percentile(d, 10):6.2f}  p90 {np.percentile(d, 90):6.2f}  max {d.max():6.2f} us")
+        if x[:, 0, 13].max() > 0:  # XCC id per workgroup (wide kernel): which XCD do the row slices of one chain tile run on?
+            live_idx = np.nonzero(live)[0]
+            xcc = {int(w): int(x[i, 0, 13]) for i, w in enumerate(live_idx)}
+            print("    XCC id of workgroups 0..15 (linear id x + 64 y):", [xcc.get(w) for w in range(16)], " slices y = 0..3 of tile 5:", [xcc.get(5 + 64 * y_) for y_ in range(4)])
         clk = (x[:, :, 9] - x[:, :, 8]) / np.maximum((x[:, :, 4] - x[:, :, 3]) * tick, 1e-9)
         print(f"    shader clock inside the row loop: median {np.median(clk) / 1e3:.2f} GHz; loop cycles median {np.median(x[:, :, 9] - x[:, :, 8])}")
         wg_span = (x[:, :, 6].max(axis=1) - x[:, :, 0].min(axis=1)) * tick
