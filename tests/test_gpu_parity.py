@@ -646,6 +646,13 @@ def test_errors_are_loud(la, models, map_beta):
         la.LogReg(np.ones((4, 2)), np.array([0, 1, 2, 0.0]), 1.0)
     with pytest.raises(ValueError):
         m.lpost(np.zeros(5))
+    k = la.hmcKernel(m.lpost, m.glp, eps=1e-3, l=5, dmm=1)
+    with pytest.raises(la.LogregHipError, match="plan_chains"):
+        la.mcmc(map_beta, k, iters=1, verb=False, plan_chains=-3)
+    with pytest.raises(la.LogregHipError, match="group"):
+        la.mcmc(map_beta, k, iters=1, verb=False, group=24)  # lanes per chain: a power of two
+    with pytest.raises(la.LogregHipError, match="row-split"):
+        la.mcmc(map_beta, k, iters=1, verb=False, mode="mfma", group=16)
 
 
 def test_other_parameter_counts_use_padded_kernels(la, oracle_model):
