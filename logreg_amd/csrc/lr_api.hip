@@ -21,53 +21,9 @@
 #include "lr_tall_mx.h"
 #include "lr_wide_bf16.h"
 
-LR_DECLARE_INST(f32_p4)
-LR_DECLARE_INST(f32_p8)
-LR_DECLARE_INST(f32_p16)
-LR_DECLARE_INST(f32_p32)
-LR_DECLARE_INST(f64_p4)
-LR_DECLARE_INST(f64_p8)
-LR_DECLARE_INST(f64_p16)
-LR_DECLARE_INST(f64_p32)
-LR_DECLARE_INST(f32_p64)   // wide models: stepwise engine with the MFMA partial kernel only
-LR_DECLARE_INST(f32_p128)
+#include "lr_model.h"
 
 namespace {
-
-thread_local char g_err[512] = "";
-
-int fail(int code, const char* fmt, ...) {
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_err, sizeof(g_err), fmt, ap);
-    va_end(ap);
-    return code;
-}
-
-#define LR_HIP(call)                                                                                    \
-    do {                                                                                                \
-        hipError_t e_ = (call);                                                                         \
-        if (e_ != hipSuccess) return fail(LR_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));   \
-    } while (0)
-
-const lr::InstTable* find_table(int dtype, int P) {
-    const lr::InstTable* all[] = {lr_inst_table_f32_p4(),  lr_inst_table_f32_p8(), lr_inst_table_f32_p16(),
-                                  lr_inst_table_f32_p32(), lr_inst_table_f64_p4(), lr_inst_table_f64_p8(),
-                                  lr_inst_table_f64_p16(), lr_inst_table_f64_p32(), lr_inst_table_f32_p64(),
-                                  lr_inst_table_f32_p128()};
-    for (const lr::InstTable* t : all)
-        if (t->dtype == dtype && t->P == P) return t;
-    return nullptr;
-}
-
-// tuning / A-B switches: set to a non-zero number to turn the named feature off
-bool env_on(const char* name) {
-    const char* v = std::getenv(name);
-    return v && std::atoi(v) != 0;
-}
-
-constexpr int kMaxP = 128;
-constexpr size_t kLdsBudget = 160 * 1024;
 
 #ifdef LR_STAMPS  // development builds only: time stamps of the first kStampSlots interior-step launches (tools/stamps.py)
 constexpr int kStampSlots = 64, kStampWgs = 512;
@@ -82,35 +38,6 @@ unsigned long long* stamp_buffer() {
 #endif
 
 }  // namespace
-
-struct lr_model {
-    int device = 0;
-    int dtype = LR_F32;
-    int64_t n = 0;
-    int p = 0;   // real parameter count
-    int P = 0;   // padded width (4, 8, 16, 32)
-    int cus = 256;
-    void* d_rows = nullptr;  // [n][P] signed rows, dtype
-    void* d_rows_tw = nullptr;  // float32, P <= 32: [ceil(n/2)][P][2] twisted row pairs (lr::ScalarRowPairs)
-    double inv_var[kMaxP];
-    double lprior_const = 0;
-    const lr::InstTable* table = nullptr;
-    void* d_xblk = nullptr;  // wide models: per-32-row-block bf16-piece images of the rows (lr_wide_bf16.h)
-    void* d_xblk1 = nullptr;  // wide models: single-piece round-to-nearest images (interior leapfrog steps)
-    void* d_xmx = nullptr;    // float32, P = 8: two-piece bf16 tile images for interior leapfrog steps (lr_tall_mx.h)
-    void* d_xmf = nullptr;    // float32, P = 8 / 16, data beyond the register variants of the matrix-core chain kernel:
-                              // fp32 MFMA operand images for the end-point evaluations (lr_mfma.h)
-    void* d_xms = nullptr;    // ... and beyond its LDS variant: the bf16 operand images of the interior steps in device memory
-    // stepwise-engine workspaces, one per stream (grow-only, owned by the handle): calls enqueued on ONE stream
-    // run in order, so they may share a workspace; calls on different streams overlap on the device and get
-    // disjoint ones (two ChainSets of one model on two streams, or an eval on the NULL stream beside a run)
-    // time-out word of the persistent trajectory kernel (lr_wide_persist.h): host memory the device writes and every API entry reads
-    uint32_t* h_xerr = nullptr;
-    uint32_t* d_xerr = nullptr;  // the same word as the device addresses it
-    struct Ws { hipStream_t stream; void* p; size_t bytes; };
-    std::vector<Ws> ws;
-    size_t esize() const { return dtype == LR_F32 ? 4 : 8; }
-};
 
 #include "lr_plan.h"
 
@@ -537,26 +464,6 @@ int do_chain(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs, con
     LR_DISPATCH_TP(m, do_chain_t, m, pl, st, rs, o, state, lp_state, out, accepts);
 }
 
-// `group` means different things per mode (include/logreg_hip.h): lanes per chain (REG / LDS / GLOBAL / AUTO on narrow models:
-// a power of two <= 64), row-split ways of the matrix-core chain kernel (MFMA: 1, 4, 8), or the slice count of the stepwise
-// engine (STEPWISE, and every mode of a wide model: any positive count up to one slice per 32-row block -- ceil(n / slice_len)
-// is arbitrary, e.g. 63 for n = 20 000 at 1024 chains, and lr_plan's group_out must round-trip)
-int check_group(const lr_model* m, int group, int mode) {
-    if (group == 0) return LR_OK;
-    if (group < 0) return fail(LR_ERR_INVALID, "group must be >= 0 (got %d)", group);
-    if (mode == LR_MODE_STEPWISE || m->P > 32) {
-        const int64_t max_slices = (m->n + 31) / 32;
-        if (group > max_slices) return fail(LR_ERR_INVALID, "stepwise slice count %d exceeds the %lld 32-row blocks of the data", group, (long long)max_slices);
-        return LR_OK;
-    }
-    if (mode == LR_MODE_MFMA) {
-        if (group != 1 && group != 4 && group != 8) return fail(LR_ERR_INVALID, "matrix-core mode: group (row-split ways) must be 0, 1, 4 or 8 (got %d)", group);
-        return LR_OK;
-    }
-    if (group > 64 || (group & (group - 1))) return fail(LR_ERR_INVALID, "group (lanes per chain) must be 0 or a power of two <= 64 (got %d)", group);
-    return LR_OK;
-}
-
 int check_opts(const lr_model* m, const lr_run_opts* o, bool run) {
     if (!m) return fail(LR_ERR_INVALID, "model is NULL");
     if (!o) return fail(LR_ERR_INVALID, "opts is NULL");
@@ -565,7 +472,7 @@ int check_opts(const lr_model* m, const lr_run_opts* o, bool run) {
                                 "were not all resident: is the GPU shared?); recreate the model and set LOGREG_WIDE_NO_PERSIST=1");
     if (o->n_chains <= 0) return fail(LR_ERR_INVALID, "n_chains must be positive (got %lld)", (long long)o->n_chains);
     if (o->plan_chains < 0) return fail(LR_ERR_INVALID, "plan_chains must be 0 (= n_chains) or positive (got %d)", o->plan_chains);
-    if (const int rcg = check_group(m, o->group, o->mode)) return rcg;
+    if (const int rcg = check_group_for(m, o->group, o->mode)) return rcg;
     if (run) {
         if (o->thin <= 0 || o->iters < 0) return fail(LR_ERR_INVALID, "thin must be > 0 and iters >= 0");
         if (o->chain_offset < 0 || o->iter_offset < 0) return fail(LR_ERR_INVALID, "offsets must be >= 0");
@@ -705,7 +612,8 @@ int lr_model_create(const double* X, const double* y, int64_t n, int32_t p, cons
     m->dtype = dtype;
     m->n = n;
     m->p = p;
-    m->P = p <= 4 ? 4 : p <= 8 ? 8 : p <= 16 ? 16 : p <= 32 ? 32 : p <= 64 ? 64 : 128;
+    m->P = padded_width(p);
+    const ModelImages images = model_images(n, m->P, dtype);
     m->table = find_table(dtype, m->P);
     if (!m->table) { delete m; return fail(LR_ERR_UNSUPPORTED, "no kernels for dtype=%d padded p=%d", dtype, m->P); }
     hipDeviceProp_t prop;
@@ -760,7 +668,7 @@ int lr_model_create(const double* X, const double* y, int64_t n, int32_t p, cons
     // narrow models the planner would ever send to the stepwise engine by itself (rows beyond 64 KB): two-piece bf16 tile images
     // for the interior HMC steps on the matrix pipe.  Smaller models run the engine only when forced (mode = STEPWISE), then in
     // fp32 throughout, and carry no image.
-    if (m->P >= 8 && m->P <= 32 && dtype == LR_F32 && (size_t)n * m->P * 4 > 64 * 1024) {
+    if (images.tall_mx) {
         const float* hrows = reinterpret_cast<const float*>(host.data());
         const int64_t ntile = (n + 31) / 32 * 2;
         std::vector<uint16_t> img((size_t)ntile * (m->P / 8) * lr::kMxSetElems);
@@ -773,9 +681,7 @@ int lr_model_create(const double* X, const double* y, int64_t n, int32_t p, cons
             return fail(LR_ERR_NOMEM, "allocating the bf16 tile images (%zu bytes) failed", img.size() * 2);
         }
     }
-    // rows the matrix-core chain kernel still takes with its operands streamed from device memory (profiles/r2_midn_lds_mfma.txt)
-    const int64_t kMfmaStreamMaxRows = 8192;
-    if (m->P >= 8 && m->P <= 32 && dtype == LR_F32 && n > (m->P == 32 ? 16 * 4 * 8 : (m->P == 8 ? 16 * 13 : 16 * 4 * 16)) && n <= kMfmaStreamMaxRows) {
+    if (images.mf_end) {  // (up to 8192 rows: profiles/r2_midn_lds_mfma.txt)
         // the matrix-core chain kernel would keep its bf16 operands in LDS: fp32 operand images for its end points
         const float* hrows = reinterpret_cast<const float*>(host.data());
         const size_t fl = (size_t)((n + 15) / 16) * 64 *
@@ -788,7 +694,7 @@ int lr_model_create(const double* X, const double* y, int64_t n, int32_t p, cons
             lr_model_destroy(m);
             return fail(LR_ERR_NOMEM, "allocating the fp32 operand images (%zu bytes) failed", fl * 4);
         }
-        if (mfma_lds_bytes(m, 4) > mfma_lds_budget(m) && m->table->mfma_image_bytes && m->table->launch_mfma_image) {
+        if (model_wants_xms(m) && m->table->mfma_image_bytes && m->table->launch_mfma_image) {
             const size_t ib = m->table->mfma_image_bytes(n);  // beyond LDS: the interior operands, built on the device once
             if (hipMalloc(&m->d_xms, ib) != hipSuccess || m->table->launch_mfma_image(nullptr, m->d_rows, n, m->d_xms) != 0 ||
                 hipDeviceSynchronize() != hipSuccess) {
@@ -864,7 +770,7 @@ int lr_plan(const lr_model* m, int64_t n_chains, int32_t group, int32_t mode, in
             int32_t* rows_out) {
     if (!m) return fail(LR_ERR_INVALID, "model is NULL");
     if (n_chains <= 0) return fail(LR_ERR_INVALID, "n_chains must be positive (got %lld)", (long long)n_chains);
-    if (const int rcg = check_group(m, group, mode)) return rcg;
+    if (const int rcg = check_group_for(m, group, mode)) return rcg;
     Plan pl;
     const int rc = make_plan(m, n_chains, group, mode, &pl);
     if (rc) return rc;

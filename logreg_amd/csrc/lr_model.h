@@ -1,0 +1,118 @@
+// lr_model.h -- the model handle of the C ABI and the small host helpers around it (error text, tuning switches, kernel tables),
+// shared by lr_api.hip and by tests/host/plan_harness.hip, which runs the planner (lr_plan.h) in the GPU-less build container.
+// Host code only; included once per translation unit.
+#pragma once
+#include "../../include/logreg_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "lr_inst.h"
+
+LR_DECLARE_INST(f32_p4)
+LR_DECLARE_INST(f32_p8)
+LR_DECLARE_INST(f32_p16)
+LR_DECLARE_INST(f32_p32)
+LR_DECLARE_INST(f64_p4)
+LR_DECLARE_INST(f64_p8)
+LR_DECLARE_INST(f64_p16)
+LR_DECLARE_INST(f64_p32)
+LR_DECLARE_INST(f32_p64)   // wide models: stepwise engine with the MFMA partial kernel only
+LR_DECLARE_INST(f32_p128)
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define LR_HIP(call)                                                                                    \
+    do {                                                                                                \
+        hipError_t e_ = (call);                                                                         \
+        if (e_ != hipSuccess) return fail(LR_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));   \
+    } while (0)
+
+const lr::InstTable* find_table(int dtype, int P) {
+    const lr::InstTable* all[] = {lr_inst_table_f32_p4(),  lr_inst_table_f32_p8(), lr_inst_table_f32_p16(),
+                                  lr_inst_table_f32_p32(), lr_inst_table_f64_p4(), lr_inst_table_f64_p8(),
+                                  lr_inst_table_f64_p16(), lr_inst_table_f64_p32(), lr_inst_table_f32_p64(),
+                                  lr_inst_table_f32_p128()};
+    for (const lr::InstTable* t : all)
+        if (t->dtype == dtype && t->P == P) return t;
+    return nullptr;
+}
+
+// tuning / A-B switches: set to a non-zero number to turn the named feature off
+bool env_on(const char* name) {
+    const char* v = std::getenv(name);
+    return v && std::atoi(v) != 0;
+}
+
+constexpr int kMaxP = 128;
+constexpr size_t kLdsBudget = 160 * 1024;
+
+}  // namespace
+
+struct lr_model {
+    int device = 0;
+    int dtype = LR_F32;
+    int64_t n = 0;
+    int p = 0;   // real parameter count
+    int P = 0;   // padded width (4, 8, 16, 32)
+    int cus = 256;
+    void* d_rows = nullptr;  // [n][P] signed rows, dtype
+    void* d_rows_tw = nullptr;  // float32, P <= 32: [ceil(n/2)][P][2] twisted row pairs (lr::ScalarRowPairs)
+    double inv_var[kMaxP];
+    double lprior_const = 0;
+    const lr::InstTable* table = nullptr;
+    void* d_xblk = nullptr;  // wide models: per-32-row-block bf16-piece images of the rows (lr_wide_bf16.h)
+    void* d_xblk1 = nullptr;  // wide models: single-piece round-to-nearest images (interior leapfrog steps)
+    void* d_xmx = nullptr;    // float32, P = 8: two-piece bf16 tile images for interior leapfrog steps (lr_tall_mx.h)
+    void* d_xmf = nullptr;    // float32, P = 8 / 16, data beyond the register variants of the matrix-core chain kernel:
+                              // fp32 MFMA operand images for the end-point evaluations (lr_mfma.h)
+    void* d_xms = nullptr;    // ... and beyond its LDS variant: the bf16 operand images of the interior steps in device memory
+    // stepwise-engine workspaces, one per stream (grow-only, owned by the handle): calls enqueued on ONE stream
+    // run in order, so they may share a workspace; calls on different streams overlap on the device and get
+    // disjoint ones (two ChainSets of one model on two streams, or an eval on the NULL stream beside a run)
+    // time-out word of the persistent trajectory kernel (lr_wide_persist.h): host memory the device writes and every API entry reads
+    uint32_t* h_xerr = nullptr;
+    uint32_t* d_xerr = nullptr;  // the same word as the device addresses it
+    struct Ws { hipStream_t stream; void* p; size_t bytes; };
+    std::vector<Ws> ws;
+    size_t esize() const { return dtype == LR_F32 ? 4 : 8; }
+};
+
+
+namespace {
+
+// Which operand images a model of this shape carries besides its rows (one rule for lr_model_create, which builds them, and for
+// the CPU planner harness, which only needs to know they would exist):
+//   tall_mx   two-piece bf16 tile images for the interior steps of the stepwise engine (narrow float32 models the planner would
+//             ever send there by itself: rows beyond 64 KB)
+//   mf_end    fp32 MFMA operand images for the end points of the matrix-core chain kernel, beyond its register variants
+//   wide      three-piece and one-piece bf16 block images (32 < p <= 128)
+// (the device-memory operand images of the matrix-core chain kernel, d_xms, additionally need "beyond the LDS variant", which
+//  only lr_plan.h's mfma_lds_bytes can say: see model_wants_xms there)
+struct ModelImages { bool tall_mx, mf_end, wide; };
+inline ModelImages model_images(int64_t n, int P, int dtype) {
+    constexpr int64_t kMfmaStreamMaxRows = 8192;  // rows the matrix-core chain kernel still takes with its operands streamed from device memory
+    ModelImages im{};
+    im.tall_mx = P >= 8 && P <= 32 && dtype == LR_F32 && (size_t)n * P * 4 > 64 * 1024;
+    im.mf_end = P >= 8 && P <= 32 && dtype == LR_F32 && n > (P == 32 ? 16 * 4 * 8 : (P == 8 ? 16 * 13 : 16 * 4 * 16)) && n <= kMfmaStreamMaxRows;
+    im.wide = P > 32;
+    return im;
+}
+inline int padded_width(int p) { return p <= 4 ? 4 : p <= 8 ? 8 : p <= 16 ? 16 : p <= 32 ? 32 : p <= 64 ? 64 : 128; }
+
+}  // namespace

@@ -71,6 +71,8 @@ size_t mfma_lds_bytes(const lr_model* m, int S) {
 }
 // 160 KB less the kernel's static exchange buffers (red: 2 x S x 64 x P/4 floats, redv: S x 64 doubles)
 size_t mfma_lds_budget(const lr_model* m, int S = 4) { return 160 * 1024 - (size_t)128 * S * m->P - (size_t)512 * S; }
+// beyond the LDS variant of the matrix-core chain kernel: the model also carries the bf16 operand images in device memory (d_xms)
+bool model_wants_xms(const lr_model* m) { return model_images(m->n, m->P, m->dtype).mf_end && mfma_lds_bytes(m, 4) > mfma_lds_budget(m); }
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // HMC whose interior leapfrog gradients may use the bf16 matrix pipe (LR_PREC_AUTO / LR_PREC_BF16), float32, padded p = 8 / 16 /
@@ -256,6 +258,26 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
     const lr::Variant& v = t->variants[best];
     *out = Plan{v.mode, v.G, v.R, v.mode == lr::MODE_LDS ? (size_t)m->n * m->P * m->esize()
                                   : (v.mode == lr::MODE_MFMA && v.R == 0 ? mfma_lds_bytes(m, v.G) : 0)};
+    return LR_OK;
+}
+
+// `group` means different things per mode (include/logreg_hip.h): lanes per chain (REG / LDS / GLOBAL / AUTO on narrow models:
+// a power of two <= 64), row-split ways of the matrix-core chain kernel (MFMA: 1, 4, 8), or the slice count of the stepwise
+// engine (STEPWISE, and every mode of a wide model: any positive count up to one slice per 32-row block -- ceil(n / slice_len)
+// is arbitrary, e.g. 63 for n = 20 000 at 1024 chains, and lr_plan's group_out must round-trip)
+int check_group_for(const lr_model* m, int group, int mode) {
+    if (group == 0) return LR_OK;
+    if (group < 0) return fail(LR_ERR_INVALID, "group must be >= 0 (got %d)", group);
+    if (mode == LR_MODE_STEPWISE || m->P > 32) {
+        const int64_t max_slices = (m->n + 31) / 32;
+        if (group > max_slices) return fail(LR_ERR_INVALID, "stepwise slice count %d exceeds the %lld 32-row blocks of the data", group, (long long)max_slices);
+        return LR_OK;
+    }
+    if (mode == LR_MODE_MFMA) {
+        if (group != 1 && group != 4 && group != 8) return fail(LR_ERR_INVALID, "matrix-core mode: group (row-split ways) must be 0, 1, 4 or 8 (got %d)", group);
+        return LR_OK;
+    }
+    if (group > 64 || (group & (group - 1))) return fail(LR_ERR_INVALID, "group (lanes per chain) must be 0 or a power of two <= 64 (got %d)", group);
     return LR_OK;
 }
 

@@ -1,0 +1,44 @@
+// plan_harness.hip -- the planner of the C ABI (logreg_amd/csrc/lr_plan.h) as a host program: no GPU, no HIP call.
+// Test infrastructure (tests/test_planner_cpu.py builds it with hipcc against the library's own instantiation objects, so the
+// variant tables are the real ones): the host-side logic that picks kernels and sizes their LDS can then be exercised in the
+// GPU-less build container instead of with metered GPU minutes.
+//   stdin:  one request per line   dtype(0|1) p n chains kind(0 rwmh,1 mala,2 hmc,3 ul) precision(0 auto,1 full,2 bf16) group mode cus
+//   stdout: one line per request   "<mode> <group> <rows_per_lane> <lds_bytes>"   or   "ERR <status> <message>"
+#include "lr_model.h"
+
+#include "lr_kernels.h"
+#include "lr_mfma.h"
+#include "lr_tall.h"
+
+#include "lr_plan.h"
+
+int main() {
+    int dtype, p, kind, prec, group, mode, cus;
+    long long n, chains;
+    while (std::scanf("%d %d %lld %lld %d %d %d %d %d", &dtype, &p, &n, &chains, &kind, &prec, &group, &mode, &cus) == 9) {
+        lr_model m;
+        m.dtype = dtype;
+        m.n = n;
+        m.p = p;
+        m.P = padded_width(p);
+        m.cus = cus;
+        m.table = find_table(dtype, m.P);
+        if (!m.table || (m.P > 32 && dtype != LR_F32)) {
+            std::printf("ERR %d no kernels for dtype=%d padded p=%d\n", LR_ERR_UNSUPPORTED, dtype, m.P);
+            continue;
+        }
+        // the images lr_model_create would have built for this shape (same rule: lr_model.h model_images / lr_plan.h model_wants_xms)
+        void* const yes = reinterpret_cast<void*>(1);
+        const ModelImages im = model_images(n, m.P, dtype);
+        m.d_xmx = im.tall_mx ? yes : nullptr;
+        m.d_xmf = im.mf_end ? yes : nullptr;
+        m.d_xms = im.mf_end && model_wants_xms(&m) && m.table->mfma_image_bytes ? yes : nullptr;
+        m.d_xblk = m.d_xblk1 = im.wide ? yes : nullptr;
+        Plan pl{};
+        int rc = check_group_for(&m, group, mode);
+        if (rc == LR_OK) rc = make_plan(&m, chains, group, mode, &pl, false, kind == LR_KIND_HMC && prec != LR_PREC_FULL);
+        if (rc != LR_OK) std::printf("ERR %d %s\n", rc, g_err);
+        else std::printf("%d %d %d %zu\n", pl.mode, pl.G, pl.R, pl.lds_bytes);
+    }
+    return 0;
+}

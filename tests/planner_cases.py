@@ -1,0 +1,64 @@
+"""What the planner (logreg_amd/csrc/lr_plan.h) must choose at 256 CUs -- shared by the GPU test (through the C ABI:
+tests/test_gpu_parity.py::test_planner_engine_choice_by_size) and the CPU test (tests/test_planner_cpu.py: the same planner code
+as a host program, tests/host/plan_harness.hip).  One line per case:
+    (n, p, chains, kernel family, precision policy, expectation)
+expectation: a full plan {"mode", "group", "rows_per_lane"}, or {"mode": m}, or {"mode": m, "group": g}, or {"not_mode": m};
+an optional "dtype": "float64" selects the float64 model."""
+
+
+def REG(g, r):
+    return {"mode": "reg", "group": g, "rows_per_lane": r}
+
+
+def MFMA(s, r):
+    return {"mode": "mfma", "group": s, "rows_per_lane": r}
+
+
+CASES = [
+    # ---- kernel-family-blind planning (MALA stands for "not HMC with reduced-precision interior steps")
+    (200, 8, 4096, "mala", "auto", REG(16, 13)),
+    # lanes per chain by the launch-time model: between the exactly-filled chain counts a wave alone on its SIMD beats two
+    # narrower ones sharing it
+    (200, 8, 1024, "mala", "auto", REG(64, 4)), (200, 8, 2048, "mala", "auto", REG(32, 7)), (200, 8, 2560, "mala", "auto", REG(16, 13)),
+    (200, 8, 5120, "mala", "auto", REG(16, 13)), (200, 8, 64, "mala", "auto", {"mode": "reg", "group": 64}),
+    (200, 8, 1 << 18, "mala", "auto", {"mode": "global", "group": 1}),
+    (300, 8, 4096, "mala", "auto", REG(32, 16)), (600, 8, 4096, "mala", "auto", REG(64, 12)), (1000, 8, 4096, "mala", "auto", REG(64, 16)),
+    (1500, 8, 4096, "mala", "auto", {"mode": "lds"}),
+    (4000, 8, 1024, "mala", "auto", {"mode": "lds"}),        # 128 KB of rows, few chains
+    (4000, 8, 2048, "mala", "auto", {"mode": "lds"}),        # (round 3: 64 lanes per chain still 1.6x the stepwise engine here)
+    (4000, 8, 4096, "mala", "auto", {"mode": "stepwise"}),   # same rows, enough chains to fill the chip per slice
+    (6000, 8, 64, "mala", "auto", {"mode": "stepwise"}),     # beyond LDS
+    (300, 100, 64, "mala", "auto", {"mode": "stepwise"}),
+    (200, 12, 4096, "mala", "auto", REG(32, 7)),
+    # ---- HMC whose interior gradients may use the bf16 matrix pipe moves to the fused matrix-core kernels once there are enough
+    # ---- chains; "full" precision never does
+    (200, 8, 2048, "hmc", "auto", {"mode": "reg"}), (200, 8, 4096, "hmc", "auto", MFMA(4, 4)), (200, 8, 4096, "hmc", "full", REG(16, 13)),
+    (200, 8, 8192, "hmc", "auto", MFMA(4, 4)), (200, 8, 16384, "hmc", "auto", MFMA(1, 13)), (200, 8, 16384, "hmc", "full", REG(16, 13)),
+    (200, 8, 16384, "mala", "auto", REG(16, 13)),
+    # mid-size data: rows split over the 4 waves of a workgroup, 8 or 16 tiles per wave, from one workgroup per CU
+    (700, 8, 4096, "hmc", "auto", MFMA(4, 16)), (700, 8, 2048, "hmc", "auto", {"mode": "reg"}),
+    # wider models (9 <= p <= 32): the same kernel family from 4 chains per CU; no variant beyond 8 tiles per wave at p > 16
+    (200, 12, 1024, "hmc", "auto", MFMA(4, 4)), (200, 12, 16384, "hmc", "auto", MFMA(1, 13)), (200, 12, 512, "hmc", "auto", {"mode": "reg"}),
+    (200, 12, 4096, "hmc", "full", {"mode": "reg"}), (500, 32, 4096, "hmc", "auto", MFMA(4, 8)), (900, 16, 4096, "hmc", "auto", MFMA(4, 16)),
+    (900, 32, 4096, "hmc", "auto", MFMA(4, -1)),   # p > 16 beyond 8 tiles per wave: operands in device memory
+    (900, 32, 1024, "hmc", "auto", MFMA(4, -1)),   # (p > 16, n <= 2048: from 4 chains per CU)
+    (900, 32, 512, "hmc", "auto", {"not_mode": "mfma"}), (3000, 32, 1024, "hmc", "auto", {"not_mode": "mfma"}),
+    # beyond the register variants: the same kernel with its bf16 operands in LDS, from one workgroup per CU
+    (2000, 8, 4096, "hmc", "auto", MFMA(8, 0)), (2000, 8, 2048, "hmc", "auto", MFMA(8, 0)), (2000, 8, 1024, "hmc", "auto", {"not_mode": "mfma"}),
+    (1150, 16, 4096, "hmc", "auto", {"mode": "mfma", "rows_per_lane": 0}),
+    # beyond LDS: operand images in device memory
+    (2600, 8, 4096, "hmc", "auto", MFMA(8, -1)), (2600, 8, 16384, "hmc", "auto", MFMA(4, -1)),
+    (2600, 8, 2048, "hmc", "auto", MFMA(8, -1)),   # (round 3: from 8 chains per CU up to n = 6000)
+    (2600, 8, 1024, "hmc", "auto", {"mode": "lds"}), (7000, 8, 2048, "hmc", "auto", {"mode": "stepwise"}),
+    (3000, 16, 1024, "hmc", "auto", MFMA(4, -1)), (5000, 16, 1024, "hmc", "auto", {"mode": "stepwise"}),
+    (9000, 8, 4096, "hmc", "auto", {"mode": "stepwise"}), (20000, 8, 4096, "hmc", "auto", {"mode": "stepwise"}),
+    # float64 (p <= 8: rows in registers as well; wider: LDS / global only)
+    (200, 8, 4096, "hmc", "full", {"dtype": "float64", "mode": "reg", "group": 32, "rows_per_lane": 7}),
+    (200, 12, 4096, "hmc", "full", {"dtype": "float64", "mode": "lds"}),
+]
+
+
+def matches(plan: dict, expect: dict) -> bool:
+    if "not_mode" in expect:
+        return plan["mode"] != expect["not_mode"]
+    return all(plan[k] == v for k, v in expect.items() if k != "dtype")

@@ -294,83 +294,25 @@ def test_tall_data_uses_stepwise_engine_and_matches_oracle(la):
 
 
 def test_planner_engine_choice_by_size(la):
-    """lr_plan's measured rules (tools/midn_sweep.py): registers while the rows fit them (n <= 1024 at p = 8), LDS up to 64 KB of
-    rows (or up to the LDS size with few chains), the stepwise engine beyond; lane-per-chain scalar rows from
-    three waves per SIMD."""
-    def plan(n, C, p=8):
-        X, y, _ = la.synthetic_logreg(n, p, seed=n)
-        return la.LogReg(X, y, np.ones(p)).plan(C)
-    assert plan(200, 4096) == {"mode": "reg", "group": 16, "rows_per_lane": 13}
-    # lanes per chain by the launch-time model (lr_plan.h kPlanConst): between the exactly-filled chain counts a wave alone on
-    # its SIMD beats two narrower ones sharing it
-    assert plan(200, 1024) == {"mode": "reg", "group": 64, "rows_per_lane": 4}
-    assert plan(200, 2048) == {"mode": "reg", "group": 32, "rows_per_lane": 7}
-    assert plan(200, 2560) == {"mode": "reg", "group": 16, "rows_per_lane": 13}
-    assert plan(200, 5120) == {"mode": "reg", "group": 16, "rows_per_lane": 13}
-    assert plan(200, 64)["group"] == 64
-    assert plan(200, 1 << 18)["mode"] == "global" and plan(200, 1 << 18)["group"] == 1
-    assert plan(300, 4096) == {"mode": "reg", "group": 32, "rows_per_lane": 16}
-    assert plan(600, 4096) == {"mode": "reg", "group": 64, "rows_per_lane": 12}
-    assert plan(1000, 4096) == {"mode": "reg", "group": 64, "rows_per_lane": 16}
-    assert plan(1500, 4096)["mode"] == "lds"
-    assert plan(4000, 1024)["mode"] == "lds"        # 128 KB of rows, few chains
-    assert plan(4000, 2048)["mode"] == "lds"        # (round 3: 64 lanes per chain still 1.6x the stepwise engine here)
-    assert plan(4000, 4096)["mode"] == "stepwise"   # same rows, enough chains to fill the chip per slice
-    assert plan(6000, 64)["mode"] == "stepwise"     # beyond LDS
-    assert plan(300, 64, p=100)["mode"] == "stepwise"
-    assert plan(200, 4096, p=12) == {"mode": "reg", "group": 32, "rows_per_lane": 7}
-    # family-aware planning (lr_plan_run): HMC whose interior gradients may use the bf16 matrix pipe moves to the
-    # fused matrix-core kernels once there are enough chains to hide their latency chain; "full" precision never does
-    X, y, _ = la.synthetic_logreg(200, 8, seed=200)
-    m = la.LogReg(X, y, np.ones(8))
-    hmc = la.hmcKernel(m.lpost, m.glp, eps=0.1, l=10, dmm=np.ones(8))
-    mala = la.malaKernel(m.lpost, m.glp, dt=1e-3, pre=np.ones(8))
-
-    def run_plan(kernel, C, **kw):
-        return la.ChainSet(kernel, np.zeros((C, 8)), seed=0, **kw).plan()
-    assert run_plan(hmc, 2048)["mode"] == "reg"
-    assert run_plan(hmc, 4096) == {"mode": "mfma", "group": 4, "rows_per_lane": 4}
-    assert run_plan(hmc, 4096, precision="full") == {"mode": "reg", "group": 16, "rows_per_lane": 13}
-    assert run_plan(hmc, 8192) == {"mode": "mfma", "group": 4, "rows_per_lane": 4}
-    assert run_plan(hmc, 16384) == {"mode": "mfma", "group": 1, "rows_per_lane": 13}
-    assert run_plan(hmc, 16384, precision="full") == {"mode": "reg", "group": 16, "rows_per_lane": 13}
-    assert run_plan(mala, 16384) == {"mode": "reg", "group": 16, "rows_per_lane": 13}
-    # mid-size data: rows split over the 4 waves of a workgroup, 8 or 16 tiles per wave, from one workgroup per CU
-    Xm, ym, _ = la.synthetic_logreg(700, 8, seed=700)
-    mm = la.LogReg(Xm, ym, np.ones(8))
-    hm = la.hmcKernel(mm.lpost, mm.glp, eps=0.05, l=10, dmm=np.ones(8))
-    assert run_plan(hm, 4096) == {"mode": "mfma", "group": 4, "rows_per_lane": 16}
-    assert run_plan(hm, 2048)["mode"] == "reg"
-    # wider models (9 <= p <= 32): the same kernel family from 4 chains per CU; no variant beyond 8 tiles per wave at p > 16
-    def wide_plan(n, p, C, **kw):
-        Xw, yw, _ = la.synthetic_logreg(n, p, seed=n + p)
-        mw = la.LogReg(Xw, yw, np.ones(p))
-        kw_ = la.hmcKernel(mw.lpost, mw.glp, eps=0.05, l=10, dmm=np.ones(p))
-        return la.ChainSet(kw_, np.zeros((C, p)), seed=0, **kw).plan()
-    assert wide_plan(200, 12, 1024) == {"mode": "mfma", "group": 4, "rows_per_lane": 4}
-    assert wide_plan(200, 12, 16384) == {"mode": "mfma", "group": 1, "rows_per_lane": 13}
-    assert wide_plan(200, 12, 512)["mode"] == "reg"
-    assert wide_plan(200, 12, 4096, precision="full")["mode"] == "reg"
-    assert wide_plan(500, 32, 4096) == {"mode": "mfma", "group": 4, "rows_per_lane": 8}
-    assert wide_plan(900, 16, 4096) == {"mode": "mfma", "group": 4, "rows_per_lane": 16}
-    assert wide_plan(900, 32, 4096) == {"mode": "mfma", "group": 4, "rows_per_lane": -1}  # p > 16 beyond 8 tiles per wave: operands in device memory
-    assert wide_plan(900, 32, 1024) == {"mode": "mfma", "group": 4, "rows_per_lane": -1}  # (p > 16, n <= 2048: from 4 chains per CU)
-    assert wide_plan(900, 32, 512)["mode"] != "mfma"
-    assert wide_plan(3000, 32, 1024)["mode"] != "mfma"
-    # beyond the register variants: the same kernel with its bf16 operands in LDS, from one workgroup per CU
-    assert wide_plan(2000, 8, 4096) == {"mode": "mfma", "group": 8, "rows_per_lane": 0}  # (8-wave row split where it fits)
-    assert wide_plan(2000, 8, 2048) == {"mode": "mfma", "group": 8, "rows_per_lane": 0}
-    assert wide_plan(2000, 8, 1024)["mode"] != "mfma"
-    assert wide_plan(1150, 16, 4096) == {"mode": "mfma", "group": 4, "rows_per_lane": 0}
-    assert wide_plan(2600, 8, 4096) == {"mode": "mfma", "group": 8, "rows_per_lane": -1}  # beyond LDS: operand images in device memory
-    assert wide_plan(2600, 8, 16384) == {"mode": "mfma", "group": 4, "rows_per_lane": -1}
-    assert wide_plan(2600, 8, 2048) == {"mode": "mfma", "group": 8, "rows_per_lane": -1}  # (from 8 chains per CU up to n = 6000)
-    assert wide_plan(2600, 8, 1024)["mode"] == "lds"
-    assert wide_plan(7000, 8, 2048)["mode"] == "stepwise"
-    assert wide_plan(3000, 16, 1024) == {"mode": "mfma", "group": 4, "rows_per_lane": -1}
-    assert wide_plan(5000, 16, 1024)["mode"] == "stepwise"
-    assert wide_plan(9000, 8, 4096)["mode"] == "stepwise"
-    assert wide_plan(20000, 8, 4096)["mode"] == "stepwise"
+    """What AUTO plans, through the C ABI (lr_plan_run), for the cases of tests/planner_cases.py -- the same list the CPU test
+    runs against the planner code compiled as a host program (tests/test_planner_cpu.py), so the two cannot drift apart:
+    register-resident rows with the lanes per chain of the launch-time model, LDS, stepwise; HMC under the default precision
+    policy on the fused matrix-core kernel (operands in registers / LDS / device memory) by chains per CU; float64."""
+    from planner_cases import CASES, matches
+    models = {}
+    for n, p, C, kind, prec, expect in CASES:
+        dtype = expect.get("dtype", "float32")
+        if (n, p, dtype) not in models:
+            X, y, _ = la.synthetic_logreg(n, p, seed=n + p)
+            models[(n, p, dtype)] = la.LogReg(X, y, np.ones(p), dtype=dtype)
+        m = models[(n, p, dtype)]
+        k = (la.hmcKernel(m.lpost, m.glp, eps=0.05, l=10, dmm=np.ones(p)) if kind == "hmc"
+             else la.malaKernel(m.lpost, m.glp, dt=1e-3, pre=np.ones(p)))
+        plan = la.ChainSet(k, np.zeros((C, p)), seed=0, precision=prec).plan()
+        assert matches(plan, expect), (n, p, C, kind, prec, plan, expect)
+        if kind == "mala":  # the family-blind entry point (lr_plan) agrees
+            assert m.plan(C) == plan
+    assert la.device_count() >= 1
 
 
 @pytest.mark.parametrize("engine", ["bf16x3", "fp32"])

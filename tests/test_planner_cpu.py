@@ -1,0 +1,71 @@
+"""The planner of the C ABI (logreg_amd/csrc/lr_plan.h) in the GPU-less build container: tests/host/plan_harness.hip compiles the
+very planning code of the library as a host program (no HIP call; linked against the library's own instantiation objects, so the
+variant tables are the real ones) and answers plan requests on stdin.  The expectations are the ones the GPU test checks through
+the C ABI (tests/planner_cases.py): host-side planning defects -- a threshold, an LDS-size formula, a variant that does not fit --
+show here, not in metered GPU minutes."""
+import os
+import subprocess
+
+import pytest
+
+from conftest import REPO
+from planner_cases import CASES, matches
+
+MODES = {0: "reg", 1: "lds", 2: "global", 3: "mfma", 4: "stepwise"}
+KIND = {"rwmh": 0, "mala": 1, "hmc": 2, "ul": 3}
+PREC = {"auto": 0, "full": 1, "bf16": 2}
+
+
+@pytest.fixture(scope="module")
+def harness(tmp_path_factory):
+    from logreg_amd import build as b
+    b.build(verbose=False)  # the instantiation objects the harness links against
+    out = tmp_path_factory.mktemp("plan_harness")
+    obj, exe = str(out / "plan_harness.o"), str(out / "plan_harness")
+    hipcc = b._hipcc()
+    inc = ["-I", os.path.join(REPO, "logreg_amd", "csrc"), "-I", os.path.join(REPO, "include")]
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O1", "-std=c++17", *inc, "-c", os.path.join(REPO, "tests", "host", "plan_harness.hip"),
+                    "-o", obj], check=True, capture_output=True)
+    objs = sorted(os.path.join(b.OBJDIR, f) for f in os.listdir(b.OBJDIR) if f.startswith("lr_inst_") and f.endswith(".o"))
+    assert len(objs) == 10
+    subprocess.run([hipcc, "--offload-arch=gfx950", obj, *objs, "-o", exe], check=True, capture_output=True)
+
+    def ask(requests, cus=256):
+        """requests: (dtype, p, n, chains, kind, precision, group, mode) -> plan dicts or ("ERR", text)"""
+        text = "".join(f"{d} {p} {n} {c} {KIND[k]} {PREC[pr]} {g} {m} {cus}\n" for d, p, n, c, k, pr, g, m in requests)
+        r = subprocess.run([exe], input=text, capture_output=True, text=True, check=True)
+        res = []
+        for line in r.stdout.strip().split("\n"):
+            f = line.split()
+            res.append(("ERR", line) if f[0] == "ERR" else {"mode": MODES[int(f[0])], "group": int(f[1]), "rows_per_lane": int(f[2]), "lds_bytes": int(f[3])})
+        return res
+    return ask
+
+
+def test_planner_choices_on_the_cpu(harness):
+    reqs = [(1 if e.get("dtype") == "float64" else 0, p, n, C, kind, prec, 0, -1) for n, p, C, kind, prec, e in CASES]
+    plans = harness(reqs)
+    bad = [(c, pl) for c, pl in zip(CASES, plans) if isinstance(pl, tuple) or not matches(pl, c[5])]
+    assert not bad, bad
+
+
+def test_planner_scales_with_the_cu_count_and_sizes_lds_within_the_chip(harness):
+    # thresholds are in chains per CU: a chip of 128 CUs moves HMC to the matrix-core kernel at half the chain counts
+    a, b, c = harness([(0, 8, 200, 2048, "hmc", "auto", 0, -1), (0, 8, 200, 1024, "hmc", "auto", 0, -1), (0, 8, 200, 5120, "hmc", "auto", 0, -1)], cus=128)
+    assert a["mode"] == "mfma" and a["group"] == 4 and b["mode"] == "reg" and c == {"mode": "mfma", "group": 1, "rows_per_lane": 13, "lds_bytes": 0}
+    # every LDS-resident plan fits the 160 KB of a CU, for every row count up to what the variant accepts (odd tile counts per
+    # wave included: round 2 found its LDS-size defect on the GPU)
+    reqs = [(0, p, n, C, "hmc", "auto", 0, -1) for p in (8, 12) for n in range(1040, 2600, 37) for C in (2048, 4096, 32768)]
+    for rq, pl in zip(reqs, harness(reqs)):
+        assert not isinstance(pl, tuple), (rq, pl)
+        assert pl["lds_bytes"] <= 160 * 1024 - 4096, (rq, pl)
+        if pl["mode"] == "mfma" and pl["rows_per_lane"] == 0:
+            assert pl["lds_bytes"] > 0 and pl["group"] in (1, 4, 8)
+
+
+def test_group_is_validated_per_mode_on_the_cpu(harness):
+    res = harness([(0, 8, 200, 100, "mala", "auto", 48, -1), (0, 8, 200, 100, "hmc", "auto", 2, 3), (0, 8, 20000, 1024, "hmc", "auto", 63, 4),
+                   (0, 8, 20000, 1024, "hmc", "auto", 10 ** 6, 4), (0, 100, 300, 64, "hmc", "auto", 5, -1)])
+    assert res[0][0] == "ERR" and res[1][0] == "ERR" and res[3][0] == "ERR"
+    assert res[2]["mode"] == "stepwise" and res[2]["group"] == 63  # any slice count up to one per 32-row block
+    assert res[4]["mode"] == "stepwise" and res[4]["group"] == 5
