@@ -315,6 +315,10 @@ int do_stepwise_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs
 #ifdef LR_STAMPS
         a.stamps = g_stamp_slot < kStampSlots ? stamp_buffer() : nullptr;
         a.stamp_slot = g_stamp_slot++;
+        {
+            const char* e = getenv("LOGREG_DEBUG_EXP");
+            a.dbg = e ? atoi(e) : 0;
+        }
 #endif
         K(0, 1);
 #ifdef LR_STAMPS

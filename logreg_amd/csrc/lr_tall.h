@@ -103,6 +103,7 @@ template <typename T, int P> struct TallArgs {
 #ifdef LR_STAMPS  // development builds only (LOGREG_HIPCC_FLAGS=-DLR_STAMPS): per-wave time stamps of the partial kernels
     unsigned long long* stamps;  // [launch slot][workgroup][16 waves][16]
     int stamp_slot;
+    int dbg;  // experiment switches (LOGREG_DEBUG_EXP): timing experiments that knowingly break the results
 #endif
 };
 
@@ -113,7 +114,9 @@ template <typename T, int P> struct TallArgs {
     (a).stamps[((((size_t)(a).stamp_slot * (gridDim.x * gridDim.y) + blockIdx.y * gridDim.x + blockIdx.x) * 16) + (threadIdx.x >> 6)) * 16 + (k)]
 #define LR_STAMP(a, k) do { if ((a).stamps && (threadIdx.x & 63) == 0) LR_STAMP_AT(a, k) = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define LR_STAMP_CLK(a, k) do { if ((a).stamps && (threadIdx.x & 63) == 0) LR_STAMP_AT(a, k) = __builtin_amdgcn_s_memtime(); } while (0)
+#define LR_DBG(a, bit) (((a).dbg >> (bit)) & 1)
 #else
+#define LR_DBG(a, bit) 0
 #define LR_STAMP(a, k) do { } while (0)
 #define LR_STAMP_CLK(a, k) do { } while (0)
 #endif

@@ -324,12 +324,25 @@ __global__ void __launch_bounds__(1024) k_tall_partial_mx16(TallArgs<float, P> a
 
     LR_STAMP(a, 3);
     LR_STAMP_CLK(a, 8);
+#ifdef LR_STAMPS
+    unsigned long long bar_cyc = 0, dma_cyc = 0;  // shader cycles this wave spent in the chunk barriers / issuing the chunk loads
+#endif
     for (int64_t g = 0; g < nchunk; ++g) {
-        if (g > 0) {
+#ifdef LR_STAMPS
+        const unsigned long long tb0 = __builtin_amdgcn_s_memtime();
+#endif
+        if (g > 0 && !LR_DBG(a, 0)) {  // (dbg bit 0: no chunk barriers; bit 1: no chunk loads -- timing experiments)
             __builtin_amdgcn_s_waitcnt(0x0F70);
             __syncthreads();
         }
-        if (g + 1 < nchunk) issue(g + 1);
+#ifdef LR_STAMPS
+        const unsigned long long tb1 = __builtin_amdgcn_s_memtime();
+#endif
+        if (g + 1 < nchunk && !LR_DBG(a, 1)) issue(g + 1);
+#ifdef LR_STAMPS
+        bar_cyc += tb1 - tb0;
+        dma_cyc += __builtin_amdgcn_s_memtime() - tb1;
+#endif
         const int nt = (int)(ntile - g * kMxChunkTiles < kMxChunkTiles ? ntile - g * kMxChunkTiles : kMxChunkTiles);
         // this row group's tile pairs of the chunk: two ADJACENT pairs (tiles 16 k + 4 rg .. 16 k + 4 rg + 3) per round of 16 tiles,
         // so that one trip's images sit within the immediate offsets of one base address
@@ -353,6 +366,12 @@ __global__ void __launch_bounds__(1024) k_tall_partial_mx16(TallArgs<float, P> a
     }
     LR_STAMP_CLK(a, 9);
     LR_STAMP(a, 4);
+#ifdef LR_STAMPS
+    if (a.stamps && lane == 0) {
+        LR_STAMP_AT(a, 14) = bar_cyc;
+        LR_STAMP_AT(a, 15) = dma_cyc;
+    }
+#endif
     // the four row groups' gradients of a chain, summed in row-group order, one slice partial per chain and coordinate
 #pragma unroll
     for (int st = 0; st < NS; ++st) {

@@ -52,6 +52,11 @@ for cfg in [int(x) for x in sys.argv[1:]] or [4, 5]:
         for k_ in range(6):
             d = (x[:, :, k_ + 1] - x[:, :, k_]) * tick
             print(f"    {names[k_]:32s} median {np.median(d):6.2f}  p10 {np.percentile(d, 10):6.2f}  p90 {np.percentile(d, 90):6.2f}  max {d.max():6.2f} us")
+        if x[:, :, 14].max() > 0:  # 16-wave tall kernel: shader cycles of a wave inside the chunk barriers / issuing the chunk loads
+            loop = (x[:, :, 9] - x[:, :, 8]).astype(float)
+            for nm, k_ in (("  of it in chunk barriers", 14), ("  of it issuing chunk loads", 15)):
+                d = x[:, :, k_] / loop * 100
+                print(f"    {nm:32s} median {np.median(d):6.1f}  p10 {np.percentile(d, 10):6.1f}  p90 {np.percentile(d, 90):6.1f}  max {d.max():6.1f} % of the loop cycles")
         if (x[:, 0, 10] != 0).all():  # finer prologue stamps (wide row-split kernel, waves that do the fused update)
             w = x[:, :, 10] != 0
             for nm, a_, b_ in (("  entry -> address setup done", 0, 10), ("  loads issued -> all returned", 10, 11), ("  first DMA blocks issued", 11, 12), ("  update arithmetic + LDS + stores", 12, 1)):
