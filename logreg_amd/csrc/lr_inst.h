@@ -10,7 +10,35 @@ struct LaunchCfg {
     int mode, G, R, kind;
     hipStream_t stream;
     size_t lds_bytes;
+    int cus;  // compute units of the model's device (0: unknown, no residency cap)
 };
+
+// Residency cap of the fused chain kernels.  A grid of k workgroups per CU finishes in k workgroup times only if the
+// dispatcher spreads it evenly, and it is not obliged to when MORE than k workgroups of the kernel fit on a CU: the
+// matrix-core kernel at 4096 chains (256 workgroups of 118 VGPRs and 6 KB of LDS: four fit) was measured, in about one
+// process out of ten, at the launch time of 8192 or 12 288 chains for a whole run (0.548 / 0.694 ms instead of 0.381:
+// two / three workgroups on one CU; profiles/r3_residency.txt).  Asking for enough LDS per workgroup that only
+// ceil(blocks / CUs) of them fit on a CU leaves the even spread as the only placement.  Returns the DYNAMIC LDS bytes
+// to launch with (>= lds_dynamic); grids of more than 4 workgroups per CU are left alone (the imbalance amortises).
+constexpr size_t kLdsPerCu = 160 * 1024;
+inline size_t capped_lds(uint64_t blocks, int cus, size_t lds_static, size_t lds_dynamic) {
+    if (cus <= 0 || blocks == 0) return lds_dynamic;
+    const uint64_t cap = (blocks + (uint64_t)cus - 1) / (uint64_t)cus;
+    if (cap > 4) return lds_dynamic;
+    const size_t want = ((kLdsPerCu / (cap + 1) + 2048 + 1023) / 1024) * 1024;  // cap fit, cap + 1 do not
+    return lds_static + lds_dynamic >= want ? lds_dynamic : want - lds_static;
+}
+// dynamic LDS beyond 64 KB has to be asked for, per kernel and device
+template <auto Kernel> inline hipError_t allow_lds(size_t dynamic_bytes) {
+    if (dynamic_bytes <= 64 * 1024) return hipSuccess;
+    static size_t granted[64] = {};  // per device ordinal (a race only repeats the call)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
+    if (dev >= 0 && granted[dev] >= dynamic_bytes) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynamic_bytes);
+    if (e == hipSuccess && dev >= 0) granted[dev] = dynamic_bytes;
+    return e;
+}
 
 struct Variant { int mode, G, R; };
 
