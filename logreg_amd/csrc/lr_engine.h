@@ -1,0 +1,394 @@
+// lr_engine.h -- the host side between the C ABI (lr_api.hip) and the kernel launches: packs the by-value kernel argument structs
+// from a model handle, a plan (lr_plan.h) and the caller's options, owns the stepwise engine's workspace and drives its launches
+// (load -> partial -> update per evaluation; the interior leapfrog steps on the reduced-precision kernels where the policy allows).
+// No arithmetic of the path happens here.  Included once, by lr_api.hip (after lr_model.h and lr_plan.h).
+#pragma once
+
+namespace {
+
+template <typename T, int P> lr::ModelArgs<T, P> model_args(const lr_model* m) {
+    lr::ModelArgs<T, P> a;
+    a.rows = static_cast<const T*>(m->d_rows);
+    a.rows_tw = static_cast<const float*>(m->d_rows_tw);
+    a.rows_mf = static_cast<const float*>(m->d_xmf);
+    a.ops_mf = static_cast<const unsigned char*>(m->d_xms);
+    a.n = m->n;
+    for (int j = 0; j < P; ++j) a.prior.inv_var[j] = (T)m->inv_var[j];
+    a.prior.lprior_const = m->lprior_const;
+    return a;
+}
+
+// the chain count every chain-count-dependent choice is made for (lr_run_opts.plan_chains: a shard plans as the whole run)
+int64_t plan_count(const lr_run_opts* o) { return o->plan_chains > 0 ? (int64_t)o->plan_chains : o->n_chains; }
+
+struct RunSpec {
+    int kind;
+    double step;
+    int l;
+    double a[kMaxP], b[kMaxP], c[kMaxP];
+};
+
+template <typename T, int P>
+int do_eval_t(lr_model* m, const Plan& pl, hipStream_t st, int64_t C, const void* beta, void* ll, void* lprior,
+              void* lpost, void* grad) {
+    auto ma = model_args<T, P>(m);
+    lr::EvalArgs<T> ea;
+    ea.beta = static_cast<const T*>(beta);
+    ea.C = C;
+    ea.p = m->p;
+    ea.ll = static_cast<T*>(ll);
+    ea.lprior = static_cast<T*>(lprior);
+    ea.lpost = static_cast<T*>(lpost);
+    ea.grad = static_cast<T*>(grad);
+    lr::LaunchCfg cfg{pl.mode, pl.G, pl.R, 0, st, pl.lds_bytes, m->cus};
+    const int rc = m->table->launch_eval(&cfg, C, &ma, &ea);
+    if (rc != 0) return fail(rc == -3 ? LR_ERR_UNSUPPORTED : LR_ERR_HIP, "eval launch failed (%d): %s", rc,
+                             hipGetErrorString(hipGetLastError()));
+    return LR_OK;
+}
+
+template <typename T, int P>
+int do_chain_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs, const lr_run_opts* o, void* state,
+               double* lp_state, void* out, uint32_t* accepts) {
+    auto ma = model_args<T, P>(m);
+    lr::ChainArgs<T, P> ca;
+    ca.state = static_cast<T*>(state);
+    ca.lp_state = lp_state;
+    ca.out = static_cast<T*>(out);
+    ca.accepts = accepts;
+    ca.C = o->n_chains;
+    ca.chain_offset = o->chain_offset;
+    ca.iters = o->iters;
+    ca.thin = o->thin;
+    ca.iter_offset = o->iter_offset;
+    ca.seed = o->seed;
+    ca.p = m->p;
+    ca.l = rs.l;
+    ca.step = (T)rs.step;
+    for (int j = 0; j < P; ++j) {
+        ca.a[j] = (T)rs.a[j];
+        ca.b[j] = (T)rs.b[j];
+        ca.c[j] = (T)rs.c[j];
+        const double ks = sizeof(T) == 4 ? 1.4426950408889634 : 1.0;  // lr::ExpScale<T>::k
+        ca.d[j] = (T)(rs.b[j] * ks);
+        ca.e[j] = (T)(m->inv_var[j] / ks);
+    }
+    ca.stats = lr::StatsArgs{o->stats, o->stats_batch, o->stats_first};
+    ca.interior_bf16 = rs.kind == lr::KIND_HMC && pl.mode == lr::MODE_MFMA && o->precision != LR_PREC_FULL;
+    lr::LaunchCfg cfg{pl.mode, pl.G, pl.R, rs.kind, st, pl.lds_bytes, m->cus};
+    const int rc = m->table->launch_chain(&cfg, o->n_chains, &ma, &ca);
+    if (rc != 0) return fail(rc == -3 ? LR_ERR_UNSUPPORTED : LR_ERR_HIP, "chain launch failed (%d): %s", rc,
+                             hipGetErrorString(hipGetLastError()));
+    return LR_OK;
+}
+
+template <typename T, int P>
+int setup_tall(lr_model* m, const Plan& pl, hipStream_t st, int64_t C, int64_t Cp, lr::TallArgs<T, P>* pa) {
+    // C: chains of this call (sizes the workspace and the grids);  Cp: chains the slicing decisions are made for
+    lr::TallArgs<T, P>& a = *pa;
+    const int RS = pl.G;
+    auto align = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t vec = align((size_t)C * P * sizeof(T)), dbl = align((size_t)C * sizeof(double));
+    // row slices of the reduced-precision interior leapfrog steps (lr_plan.h)
+    const InteriorPlan ip = plan_interior(m, Cp);
+    const int RS_i = ip.RS_i, rs_waves = ip.waves;
+    const int64_t slice_len_i = ip.slice_len_i;
+    const int RSmax = RS_i > RS ? RS_i : RS;
+    const size_t pg = align((size_t)RSmax * C * P * sizeof(T)), cv = align((size_t)2 * P * sizeof(T));
+    // (second state pair + second partial buffer + constants: the fused interior steps of the row-split kernel)
+    const PersistPlan pp = persist_plan(m, Cp);
+    const size_t xgroups = (size_t)((C + 31) / 32);
+    const size_t xch_bytes = pp.S ? align(2 * xgroups * pp.S * 32 * P * sizeof(float)) : 0, xfl_bytes = pp.S ? align(xgroups * pp.S * 4) : 0;
+    if (xch_bytes > 0xFFFFFFFFull) return fail(LR_ERR_UNSUPPORTED, "exchange buffer of the persistent trajectory kernel exceeds 4 GB");
+    const size_t need = 4 * vec + 2 * dbl + align((size_t)C * 4) + pg + align((size_t)RS * C * sizeof(double)) +
+                        (RS_i > 0 && (m->P > 32 || rs_waves == 16) ? 2 * vec + pg : 0) + cv + xch_bytes + xfl_bytes;
+    lr_model::Ws* slot = nullptr;
+    for (auto& e : m->ws)
+        if (e.stream == st) slot = &e;
+    if (!slot) {
+        if (m->ws.size() >= 16) {  // a caller cycling through streams: drop every workspace once all work is done
+            if (hipDeviceSynchronize() != hipSuccess) return fail(LR_ERR_HIP, "hipDeviceSynchronize failed");
+            for (auto& e : m->ws)
+                if (e.p) (void)hipFree(e.p);
+            m->ws.clear();
+        }
+        m->ws.push_back({st, nullptr, 0});
+        slot = &m->ws.back();
+    }
+    if (need > slot->bytes) {
+        if (slot->p) {
+            // work already enqueued on this stream may still use the old block: hipFree waits for the device
+            (void)hipFree(slot->p);
+        }
+        slot->p = nullptr;
+        slot->bytes = 0;
+        if (hipMalloc(&slot->p, need) != hipSuccess) return fail(LR_ERR_NOMEM, "stepwise workspace of %zu bytes", need);
+        slot->bytes = need;
+    }
+    unsigned char* w = static_cast<unsigned char*>(slot->p);
+    auto carve = [&](size_t b) { unsigned char* r = w; w += b; return r; };
+    std::memset(&a, 0, sizeof(a));
+    a.rows = static_cast<const T*>(m->d_rows);
+    a.rows_tw = static_cast<const float*>(m->d_rows_tw);
+    a.n = m->n;
+    a.slice_len = pl.R;
+    a.RS = RS;
+    for (int j = 0; j < P; ++j) a.prior.inv_var[j] = (T)m->inv_var[j];
+    a.prior.lprior_const = m->lprior_const;
+    a.x = (T*)carve(vec);
+    a.g = (T*)carve(vec);
+    a.q1 = (T*)carve(vec);
+    a.pm = (T*)carve(vec);
+    a.lp = (double*)carve(dbl);
+    a.aux = (double*)carve(dbl);
+    a.nacc = (uint32_t*)carve(align((size_t)C * 4));
+    a.part_g = (T*)carve(pg);
+    a.RS_i = RS_i;
+    a.slice_len_i = slice_len_i;
+    a.rowsplit_waves = rs_waves;
+    a.part_v = (double*)carve(align((size_t)RS * C * sizeof(double)));
+    a.cvec = (const T*)carve(cv);
+    if (RS_i > 0 && (m->P > 32 || rs_waves == 16)) {  // alternates, parked in the *_in fields until do_stepwise_t starts ping-ponging
+        a.q1_in = (const T*)carve(vec);
+        a.pm_in = (const T*)carve(vec);
+        a.part_in = (const T*)carve(pg);
+    }
+    a.traj_S = pp.S;
+    a.traj_nbs = pp.nbs;
+    a.traj_scatter = env_on("LOGREG_WIDE_PERSIST_SCATTER");
+    if (pp.S) {
+        a.xch = (float*)carve(xch_bytes);
+        a.xch_bytes = (uint32_t)xch_bytes;
+        a.xflags = (uint32_t*)carve(xfl_bytes);
+        a.xerr = m->d_xerr;
+    }
+    a.C = C;
+    a.p = m->p;
+    {
+        // wide models: the exact-split bf16 matrix-core kernel (lr_wide_bf16.h) is the default -- same fp32
+        // tolerances, 1.5x the fp32-MFMA kernel; LOGREG_WIDE_BF16=0 selects the fp32-MFMA kernel (lr_wide.h)
+        a.wide_bf16 = (m->P > 32 && m->d_xblk) ? wide_engine(m, Cp) : 0;
+        a.xblk = static_cast<const uint16_t*>(m->d_xblk);
+        a.xblk1 = static_cast<const uint16_t*>(m->d_xblk1);
+        a.xmx = static_cast<const uint16_t*>(m->d_xmx);
+    }
+    return LR_OK;
+}
+
+// lr_eval through the stepwise engine (tall or wide models): load -> partial(value, grad) -> finish
+template <typename T, int P>
+int do_eval_stepwise_t(lr_model* m, const Plan& pl, hipStream_t st, int64_t C, const void* beta, void* ll, void* lprior,
+                       void* lpost, void* grad) {
+    if ((C + 63) / 64 > 65535) return fail(LR_ERR_UNSUPPORTED, "the stepwise engine takes at most %lld chains per call (got %lld)", 65535LL * 64, (long long)C);
+    lr::TallArgs<T, P> a;
+    int rc = setup_tall<T, P>(m, pl, st, C, C, &a);
+    if (rc) return rc;
+    a.state = static_cast<T*>(const_cast<void*>(beta));
+    a.ev_ll = static_cast<T*>(ll);
+    a.ev_lprior = static_cast<T*>(lprior);
+    a.ev_lpost = static_cast<T*>(lpost);
+    a.ev_grad = static_cast<T*>(grad);
+    const lr::InstTable* t = m->table;
+    rc = t->launch_tall_update(st, lr::KIND_HMC, lr::PH_LOAD, 0, -1, 0, &a);
+    if (!rc) rc = t->launch_tall_partial(st, 1, 1, &a);
+    if (!rc) rc = t->launch_tall_update(st, lr::KIND_HMC, lr::PH_EVAL, 0, -1, 0, &a);
+    if (rc) return fail(LR_ERR_HIP, "stepwise eval launch failed (%d): %s", rc, hipGetErrorString(hipGetLastError()));
+    return LR_OK;
+}
+
+template <typename T, int P>
+int do_stepwise_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs, const lr_run_opts* o, void* state,
+                  double* lp_state, void* out, uint32_t* accepts) {
+    const int64_t C = o->n_chains, Cp = plan_count(o);
+    // (chain blocks of 16 .. 128 chains are the grid's y / x dimension of the partial kernels: y is a 16-bit quantity)
+    if ((C + 63) / 64 > 65535) return fail(LR_ERR_UNSUPPORTED, "the stepwise engine takes at most %lld chains per call (got %lld): split the run into shards (chain_offset)", 65535LL * 64, (long long)C);
+    lr::TallArgs<T, P> a;
+    int rc = setup_tall<T, P>(m, pl, st, C, Cp, &a);
+    if (rc) return rc;
+    a.state = static_cast<T*>(state);
+    a.lp_state = lp_state;
+    a.out = static_cast<T*>(out);
+    a.accepts = accepts;
+    a.C = C;
+    a.chain_offset = o->chain_offset;
+    a.seed = o->seed;
+    a.p = m->p;
+    a.l = rs.l;
+    a.step = (T)rs.step;
+    for (int j = 0; j < P; ++j) {
+        a.a[j] = (T)rs.a[j];
+        a.b[j] = (T)rs.b[j];
+        a.c[j] = (T)rs.c[j];
+    }
+    a.stats = lr::StatsArgs{o->stats, o->stats_batch, o->stats_first};
+    const lr::InstTable* t = m->table;
+    auto U = [&](int phase, int64_t iter, int64_t out_row, int bn) {
+        if (!rc) rc = t->launch_tall_update(st, rs.kind, phase, iter, out_row, bn, &a);
+    };
+    auto K = [&](int v, int g) {
+        if (!rc) rc = t->launch_tall_partial(st, v, g, &a);
+    };
+    // interior leapfrog gradients (HMC): reduced precision where the policy allows and a kernel exists
+    const bool bf16_interior = rs.kind == lr::KIND_HMC && o->precision != LR_PREC_FULL &&
+                               (m->d_xblk1 != nullptr || (m->d_xmx != nullptr && !env_on("LOGREG_TALL_NO_MX")));
+    const int RS_exact = a.RS, RS_mid = bf16_interior && a.RS_i > 0 ? a.RS_i : a.RS;
+    if (!bf16_interior) a.RS_i = 0;
+    auto KI = [&]() {
+        a.interior = bf16_interior ? 1 : 0;
+#ifdef LR_STAMPS
+        a.stamps = g_stamp_slot < kStampSlots ? stamp_buffer() : nullptr;
+        a.stamp_slot = g_stamp_slot++;
+        {
+            const char* e = getenv("LOGREG_DEBUG_EXP");
+            a.dbg = e ? atoi(e) : 0;
+        }
+#endif
+        K(0, 1);
+#ifdef LR_STAMPS
+        a.stamps = nullptr;
+#endif
+        a.interior = 0;
+    };
+    // wide models: the whole interior of a trajectory in one launch (k_wide_traj_bf16): no slice partials, no update
+    // launches.  One workgroup streams the whole design per step, so it pays once every CU has a tile of its own and
+    // until the 64-chain workgroups of the chain-split kernel amortise the stream better (config 5 design, us per
+    // evaluation of all chains, trajectory kernel | launch per step: 1024 chains 15.7 | 11.5, 2048: 16.1 | 14.4,
+    // 4096: 22.2 | 25.0, 8192: 39.5 | 44.9, 16 384: 73.4 | 72.5).  LOGREG_WIDE_TRAJ=1 forces it on, LOGREG_WIDE_NO_TRAJ=1 off.
+    const int64_t traj_tiles = (Cp + 15) / 16;
+    const bool traj = P > 32 && bf16_interior && m->d_xblk1 != nullptr && t->launch_tall_traj != nullptr && rs.l > 1 &&
+                      !env_on("LOGREG_WIDE_NO_TRAJ") &&
+                      (env_on("LOGREG_WIDE_TRAJ") || (traj_tiles >= m->cus && traj_tiles < 4LL * m->cus) ||
+                       // small designs (the one-piece image within 256 KB): the per-step stream is cheap, the launch per step is not
+                       // (us per evaluation, launch per step | trajectory kernel: n=500 p=64: 5.5 | 2.8 at 1024 chains; n=300 p=100:
+                       //  7.0 | 4.7; n=1000 p=128: 7.5 | 6.5; n=2000 p=50: 6.2 | 5.3; n=2000 p=128 (512 KB): 8.4 | 9.3)
+                       (traj_tiles < m->cus && (int64_t)m->n * m->P * 2 <= 256 * 1024));
+    // wide models, few chains: the persistent row-split trajectory kernel (lr_wide_persist.h) -- the slices resident in LDS, one
+    // hand-off between the resident workgroups per step; opt-in, see persist_plan
+    const bool persist = P > 32 && bf16_interior && rs.l > 1 && a.traj_S > 0 && !traj;
+    const bool fuse = bf16_interior && a.RS_i > 0 &&
+                      ((P > 32 && a.RS_i <= 4 && !env_on("LOGREG_WIDE_NO_FUSE")) ||         // kFuseSlices (lr_wide_bf16.h)
+                       (P <= 32 && a.rowsplit_waves == 16 && a.RS_i <= 16 && m->d_xmx));   // kMx16FuseSlices (lr_tall_mx.h)
+    T* qb[2] = {a.q1, const_cast<T*>(a.q1_in)};
+    T* pb[2] = {a.pm, const_cast<T*>(a.pm_in)};
+    T* gb[2] = {a.part_g, const_cast<T*>(a.part_in)};
+    int cs = 0, cg = 0;  // which of the pairs holds the current state / the latest partials
+    const int kind = rs.kind;
+    U(lr::PH_LOAD, 0, -1, 0);
+    if (kind == lr::KIND_HMC) K(1, 1);
+    else if (kind != lr::KIND_RWMH) K(0, 1);
+    U(lr::PH_INIT, o->iter_offset, -1, 0);
+    const int64_t total = o->iters * o->thin;
+    for (int64_t tt = 0; tt < total && !rc; ++tt) {
+        if (kind == lr::KIND_HMC) {
+            if (persist) {
+#ifdef LR_STAMPS
+                a.stamps = stamp_buffer();  // (one slot: the phase sums of the latest trajectory)
+                a.stamp_slot = 0;
+#endif
+                if (!rc) rc = t->launch_tall_traj_rs(st, &a);
+#ifdef LR_STAMPS
+                a.stamps = nullptr;
+#endif
+            } else if (traj) {
+                if (!rc) rc = t->launch_tall_traj(st, &a);
+            } else if (fuse) {
+                // row-split interior kernel: every launch but the first finishes the previous leapfrog step in its
+                // own prologue (state and partial buffers ping-pong), so the L - 1 interior steps are L - 1
+                // launches plus ONE update at the end instead of 2 (L - 1) launches
+                for (int i = 0; i < rs.l - 1; ++i) {
+                    if (i > 0) {
+                        a.q1_in = qb[cs];
+                        a.pm_in = pb[cs];
+                        a.part_in = gb[cg];
+                        cs ^= 1;
+                        cg ^= 1;
+                        a.q1 = qb[cs];
+                        a.pm = pb[cs];
+                        a.part_g = gb[cg];
+                    }
+                    a.fuse_mid = i > 0;
+                    KI();
+                    a.fuse_mid = 0;
+                }
+                if (rs.l > 1) {
+                    a.RS = RS_mid;
+                    U(lr::PH_MID, 0, -1, 0);
+                    a.RS = RS_exact;
+                }
+            } else {
+                for (int i = 0; i < rs.l - 1; ++i) {
+                    KI();
+                    a.RS = RS_mid;  // the update sums as many slice partials as the partial kernel just wrote
+                    U(lr::PH_MID, 0, -1, 0);
+                    a.RS = RS_exact;
+                }
+            }
+            K(1, 1);
+        } else if (kind == lr::KIND_MALA) {
+            K(1, 1);
+        } else if (kind == lr::KIND_RWMH) {
+            K(1, 0);
+        } else {
+            K(0, 1);
+        }
+        const int64_t out_row = ((tt + 1) % o->thin == 0) ? (tt + 1) / o->thin - 1 : -1;
+        U(lr::PH_END, o->iter_offset + tt, out_row, tt + 1 < total);
+    }
+    U(lr::PH_STORE, 0, -1, 0);
+    if (rc) return fail(LR_ERR_HIP, "stepwise launch failed (%d): %s", rc, hipGetErrorString(hipGetLastError()));
+    return LR_OK;
+}
+
+#define LR_DISPATCH_TP(m, FN, ...)                                                       \
+    do {                                                                                 \
+        if ((m)->dtype == LR_F32) {                                                      \
+            switch ((m)->P) {                                                            \
+            case 4: return FN<float, 4>(__VA_ARGS__);                                    \
+            case 8: return FN<float, 8>(__VA_ARGS__);                                    \
+            case 16: return FN<float, 16>(__VA_ARGS__);                                  \
+            case 32: return FN<float, 32>(__VA_ARGS__);                                  \
+            }                                                                            \
+        } else {                                                                         \
+            switch ((m)->P) {                                                            \
+            case 4: return FN<double, 4>(__VA_ARGS__);                                   \
+            case 8: return FN<double, 8>(__VA_ARGS__);                                   \
+            case 16: return FN<double, 16>(__VA_ARGS__);                                 \
+            case 32: return FN<double, 32>(__VA_ARGS__);                                 \
+            }                                                                            \
+        }                                                                                \
+        return fail(LR_ERR_UNSUPPORTED, "unsupported padded width %d", (m)->P);          \
+    } while (0)
+
+int do_eval_stepwise(lr_model* m, const Plan& pl, hipStream_t st, int64_t C, const void* beta, void* ll, void* lprior,
+                     void* lpost, void* grad);
+
+int do_eval(lr_model* m, const Plan& pl, hipStream_t st, int64_t C, const void* beta, void* ll, void* lprior,
+            void* lpost, void* grad) {
+    if (pl.mode == lr::MODE_STEPWISE) return do_eval_stepwise(m, pl, st, C, beta, ll, lprior, lpost, grad);
+    LR_DISPATCH_TP(m, do_eval_t, m, pl, st, C, beta, ll, lprior, lpost, grad);
+}
+
+#define LR_DISPATCH_STEP(m, FN, ...)                                                     \
+    do {                                                                                 \
+        if ((m)->dtype == LR_F32 && (m)->P == 64) return FN<float, 64>(__VA_ARGS__);     \
+        if ((m)->dtype == LR_F32 && (m)->P == 128) return FN<float, 128>(__VA_ARGS__);   \
+        LR_DISPATCH_TP(m, FN, __VA_ARGS__);                                              \
+    } while (0)
+
+int do_stepwise(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs, const lr_run_opts* o, void* state,
+                double* lp_state, void* out, uint32_t* accepts) {
+    LR_DISPATCH_STEP(m, do_stepwise_t, m, pl, st, rs, o, state, lp_state, out, accepts);
+}
+
+int do_eval_stepwise(lr_model* m, const Plan& pl, hipStream_t st, int64_t C, const void* beta, void* ll, void* lprior,
+                     void* lpost, void* grad) {
+    LR_DISPATCH_STEP(m, do_eval_stepwise_t, m, pl, st, C, beta, ll, lprior, lpost, grad);
+}
+
+int do_chain(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs, const lr_run_opts* o, void* state,
+             double* lp_state, void* out, uint32_t* accepts) {
+    if (pl.mode == lr::MODE_STEPWISE) return do_stepwise(m, pl, st, rs, o, state, lp_state, out, accepts);
+    LR_DISPATCH_TP(m, do_chain_t, m, pl, st, rs, o, state, lp_state, out, accepts);
+}
+
+}  // namespace

@@ -281,6 +281,60 @@ int check_group_for(const lr_model* m, int group, int mode) {
     return LR_OK;
 }
 
+// Row slices of the reduced-precision INTERIOR leapfrog steps of the stepwise engine (HMC, precision policy permitting): how many
+// slices RS_i of how many rows, and the workgroup shape of the kernel that takes them (waves: 4 / 8 row-split waves of the wide
+// kernel, 4 or 16 waves of the tall matrix-pipe kernel).  RS_i = 0: no interior kernel for this model (the exact kernels run every
+// step).  Cp: the chain count the run is planned for (lr_run_opts.plan_chains).
+struct InteriorPlan { int RS_i; int64_t slice_len_i; int waves; };
+InteriorPlan plan_interior(const lr_model* m, int64_t Cp) {
+    int RS_i = 0, rs_waves = 4;
+    int64_t slice_len_i = 0;
+    // wide models, interior leapfrog steps with few chains: the row-split kernel (lr_wide_bf16.h) wants one chain
+    // tile of 16 per workgroup and as many row slices as fill the chip; each slice a multiple of 128 rows
+    if (m->P > 32 && m->d_xblk1 && !env_on("LOGREG_WIDE_NO_ROWSPLIT")) {
+        const int64_t tiles = (Cp + 15) / 16;
+        const char* envt = std::getenv("LOGREG_WIDE_ROWSPLIT_MAX_TILES");  // tuning override
+        if (tiles <= (envt ? std::atoll(envt) : (long long)m->cus)) {
+            int64_t want = m->cus / tiles;
+            if (want < 1) want = 1;
+            const char* envw = std::getenv("LOGREG_WIDE_ROWSPLIT_WAVES");
+            rs_waves = envw ? std::atoi(envw) : 8;
+            if (rs_waves != 4) rs_waves = 8;
+            const int64_t quantum = 32 * rs_waves;
+            slice_len_i = ((m->n + want - 1) / want + quantum - 1) / quantum * quantum;
+            RS_i = (int)((m->n + slice_len_i - 1) / slice_len_i);
+        }
+    }
+    if (m->P <= 32 && m->d_xmx) {
+        // narrow models, interior leapfrog steps on the matrix pipe (lr_tall_mx.h): 4-wave workgroups of 64 chains;
+        // slices fine enough for ~4 waves per SIMD, each at least 256 rows, whole tile pairs
+        const int64_t blocks = (Cp + 63) / 64;
+        int64_t want = (4LL * 4 * m->cus + 4 * blocks - 1) / (4 * blocks);
+        if (want < 1) want = 1;
+        slice_len_i = ((m->n + want - 1) / want + 31) / 32 * 32;
+        if (slice_len_i < 256) slice_len_i = 256;
+        RS_i = (int)((m->n + slice_len_i - 1) / slice_len_i);
+        // 16-wave workgroups (one per CU) need a quarter of the slices for the same waves per SIMD: few enough to fold
+        // the update launch into the next launch's prologue (k_tall_partial_mx16).  Only with enough rows per slice to
+        // keep the 4 row groups of a workgroup busy, and when the slice count fits the fused prologue.
+        int64_t want16 = (m->cus + blocks - 1) / blocks;
+        if (want16 < 1) want16 = 1;
+        int64_t len16 = ((m->n + want16 - 1) / want16 + 31) / 32 * 32;
+        if (len16 < 1024) len16 = 1024;
+        const int64_t rs16 = (m->n + len16 - 1) / len16;
+        // (and only when those slices still fill the chip: n=5000 p=30 at 1024 chains would get 5 slices x 16 blocks = 80
+        //  workgroups and ran 13.5 -> 17.9 us per step; n=20 000 p=12: 17.8 -> 13.8, config 4: 29.7 -> 27.5)
+        //  at 4096 chains the steps are long enough that the saved launch no longer shows: -3 .. +5 %, so up to 2048 chains)
+        if (!env_on("LOGREG_TALL_NO_MX16") && rs16 >= 1 && rs16 <= 16 && RS_i > rs16 && 4 * rs16 * blocks >= 3LL * m->cus && blocks <= 32) {
+            RS_i = (int)rs16;
+            slice_len_i = len16;
+            rs_waves = 16;
+        }
+    }
+    return InteriorPlan{RS_i, slice_len_i, rs_waves};
+}
+
+
 // ---------------------------------------------------------------------------------------------------------------------------
 // Persistent row-split trajectory kernel for wide models (lr_wide_persist.h): slices S per group of 32 chains and 32-row blocks
 // per slice for Cp chains, or S = 0 when it does not apply: every (group, slice) workgroup must be resident at once (one per

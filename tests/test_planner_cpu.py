@@ -37,7 +37,8 @@ def harness(tmp_path_factory):
         res = []
         for line in r.stdout.strip().split("\n"):
             f = line.split()
-            res.append(("ERR", line) if f[0] == "ERR" else {"mode": MODES[int(f[0])], "group": int(f[1]), "rows_per_lane": int(f[2]), "lds_bytes": int(f[3])})
+            res.append(("ERR", line) if f[0] == "ERR" else {"mode": MODES[int(f[0])], "group": int(f[1]), "rows_per_lane": int(f[2]), "lds_bytes": int(f[3]),
+                                                            "interior": (int(f[4]), int(f[5]), int(f[6]))})
         return res
     return ask
 
@@ -52,7 +53,8 @@ def test_planner_choices_on_the_cpu(harness):
 def test_planner_scales_with_the_cu_count_and_sizes_lds_within_the_chip(harness):
     # thresholds are in chains per CU: a chip of 128 CUs moves HMC to the matrix-core kernel at half the chain counts
     a, b, c = harness([(0, 8, 200, 2048, "hmc", "auto", 0, -1), (0, 8, 200, 1024, "hmc", "auto", 0, -1), (0, 8, 200, 5120, "hmc", "auto", 0, -1)], cus=128)
-    assert a["mode"] == "mfma" and a["group"] == 4 and b["mode"] == "reg" and c == {"mode": "mfma", "group": 1, "rows_per_lane": 13, "lds_bytes": 0}
+    assert a["mode"] == "mfma" and a["group"] == 4 and b["mode"] == "reg"
+    assert {k: c[k] for k in ("mode", "group", "rows_per_lane", "lds_bytes")} == {"mode": "mfma", "group": 1, "rows_per_lane": 13, "lds_bytes": 0}
     # every LDS-resident plan fits the 160 KB of a CU, for every row count up to what the variant accepts (odd tile counts per
     # wave included: round 2 found its LDS-size defect on the GPU)
     reqs = [(0, p, n, C, "hmc", "auto", 0, -1) for p in (8, 12) for n in range(1040, 2600, 37) for C in (2048, 4096, 32768)]
@@ -69,3 +71,27 @@ def test_group_is_validated_per_mode_on_the_cpu(harness):
     assert res[0][0] == "ERR" and res[1][0] == "ERR" and res[3][0] == "ERR"
     assert res[2]["mode"] == "stepwise" and res[2]["group"] == 63  # any slice count up to one per 32-row block
     assert res[4]["mode"] == "stepwise" and res[4]["group"] == 5
+
+
+def test_interior_step_slicing_on_the_cpu(harness):
+    """lr_plan.h plan_interior: the row slices of the reduced-precision interior leapfrog steps (BASELINE configs 4 and 5 and
+    the shapes around the 16-wave kernel's conditions)."""
+    shapes = [(8, 100000, 1024), (128, 4096, 1024), (128, 4096, 8192), (30, 5000, 1024), (12, 20000, 1024), (8, 100000, 4096), (8, 3000, 1024),
+              (100, 300, 64), (8, 200, 4096)]
+    got = [pl["interior"] for pl in harness([(0, p, n, C, "hmc", "auto", 0, 4) for p, n, C in shapes])]
+    cfg4, cfg5, cfg5_all, p30, p12, cfg4_4096, small_tall, small_wide, pima = got
+    assert cfg4 == (16, 6272, 16)          # config 4: 16 slices x 16 chain blocks = one 16-wave workgroup per CU
+    assert cfg5 == (4, 1024, 8)            # config 5 at one GPU's 1024 chains: 64 chain tiles x 4 row slices of 8 waves
+    assert cfg5_all[0] == 0                # 8192 chains: more chain tiles than CUs -> no row split (the trajectory kernel's range)
+    assert p30[2] == 4 and p30[0] * p30[1] >= 5000          # 5 slices of the 16-wave form would leave the chip two-thirds empty
+    assert p12[2] == 16 and p12[0] <= 16 and p12[0] * p12[1] >= 20000
+    assert cfg4_4096[2] == 4               # 4096 chains: the saved launch no longer shows, 4-wave workgroups
+    assert small_tall[0] >= 1 and small_tall[1] >= 256 and small_tall[1] % 32 == 0
+    assert small_wide == (1, 512, 8) or (small_wide[0] * small_wide[1] >= 300 and small_wide[1] % 256 == 0)
+    assert pima[0] == 0                    # no stepwise operand images for Pima-size data
+    # every slicing covers all rows with whole 32-row tile pairs, for a sweep of row counts
+    reqs = [(0, p, n, C, "hmc", "auto", 0, 4) for p in (8, 16, 128) for n in range(4100, 120000, 7919) for C in (64, 1024, 2048) if p <= 32 or n <= 20000]
+    for rq, pl in zip(reqs, harness(reqs)):
+        rs, ln, wv = pl["interior"]
+        if rs:
+            assert rs * ln >= rq[2] and (rs - 1) * ln < rq[2] and ln % 32 == 0 and wv in (4, 8, 16), (rq, pl)
