@@ -40,7 +40,7 @@ int do_eval_t(lr_model* m, const Plan& pl, hipStream_t st, int64_t C, const void
     ea.lprior = static_cast<T*>(lprior);
     ea.lpost = static_cast<T*>(lpost);
     ea.grad = static_cast<T*>(grad);
-    lr::LaunchCfg cfg{pl.mode, pl.G, pl.R, 0, st, pl.lds_bytes, m->cus};
+    lr::LaunchCfg cfg{pl.mode, pl.G, pl.R, 0, st, pl.lds_bytes, env_on("LOGREG_NO_RESIDENCY_CAP") ? 0 : m->cus};
     const int rc = m->table->launch_eval(&cfg, C, &ma, &ea);
     if (rc != 0) return fail(rc == -3 ? LR_ERR_UNSUPPORTED : LR_ERR_HIP, "eval launch failed (%d): %s", rc,
                              hipGetErrorString(hipGetLastError()));
@@ -75,7 +75,7 @@ int do_chain_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs, c
     }
     ca.stats = lr::StatsArgs{o->stats, o->stats_batch, o->stats_first};
     ca.interior_bf16 = rs.kind == lr::KIND_HMC && pl.mode == lr::MODE_MFMA && o->precision != LR_PREC_FULL;
-    lr::LaunchCfg cfg{pl.mode, pl.G, pl.R, rs.kind, st, pl.lds_bytes, m->cus};
+    lr::LaunchCfg cfg{pl.mode, pl.G, pl.R, rs.kind, st, pl.lds_bytes, env_on("LOGREG_NO_RESIDENCY_CAP") ? 0 : m->cus};
     const int rc = m->table->launch_chain(&cfg, o->n_chains, &ma, &ca);
     if (rc != 0) return fail(rc == -3 ? LR_ERR_UNSUPPORTED : LR_ERR_HIP, "chain launch failed (%d): %s", rc,
                              hipGetErrorString(hipGetLastError()));

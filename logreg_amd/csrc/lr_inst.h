@@ -28,6 +28,15 @@ inline size_t capped_lds(uint64_t blocks, int cus, size_t lds_static, size_t lds
     const size_t want = ((kLdsPerCu / (cap + 1) + 2048 + 1023) / 1024) * 1024;  // cap fit, cap + 1 do not
     return lds_static + lds_dynamic >= want ? lds_dynamic : want - lds_static;
 }
+// static LDS of a kernel, from its code object (asked once)
+template <auto Kernel> inline size_t static_lds() {
+    static long cached = -1;
+    if (cached < 0) {
+        hipFuncAttributes at;
+        cached = hipFuncGetAttributes(&at, reinterpret_cast<const void*>(Kernel)) == hipSuccess ? (long)at.sharedSizeBytes : 0;
+    }
+    return (size_t)cached;
+}
 // dynamic LDS beyond 64 KB has to be asked for, per kernel and device
 template <auto Kernel> inline hipError_t allow_lds(size_t dynamic_bytes) {
     if (dynamic_bytes <= 64 * 1024) return hipSuccess;

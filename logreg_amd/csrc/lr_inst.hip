@@ -82,8 +82,8 @@ int launch_eval_v(const LaunchCfg* cfg, int64_t C, const ModelArgs<T, P>& m, con
 
 // one fused chain kernel, its LDS request padded to the residency cap (lr_inst.h: capped_lds)
 template <auto Kernel, typename... Args>
-int launch_capped(const LaunchCfg* cfg, dim3 grid, dim3 block, size_t lds_static, size_t lds_dynamic, const Args&... args) {
-    const size_t lds = capped_lds((uint64_t)grid.x * grid.y, cfg->cus, lds_static, lds_dynamic);
+int launch_capped(const LaunchCfg* cfg, dim3 grid, dim3 block, size_t lds_dynamic, const Args&... args) {
+    const size_t lds = capped_lds((uint64_t)grid.x * grid.y, cfg->cus, static_lds<Kernel>(), lds_dynamic);
     if (allow_lds<Kernel>(lds) != hipSuccess) return -2;
     hipLaunchKernelGGL(Kernel, grid, block, lds, cfg->stream, args...);
     return check(hipGetLastError());
@@ -94,16 +94,15 @@ int launch_chain_v(const LaunchCfg* cfg, int64_t C, const ModelArgs<T, P>& m, co
     const dim3 grid = grid_for(C, G), block(256);
 #if LR_DTYPE == 0 && LR_P == 8
     if constexpr (G == 16 && MODE == MODE_REG) {  // state distributed over the 16 lanes of a chain (lr_kernels.h)
-        constexpr size_t kRs16Static = 8192;      // (its draw batch lives in static LDS)
-        if (cfg->kind == KIND_RWMH) return launch_capped<&k_chain_rs16<R, KIND_RWMH>>(cfg, grid, block, kRs16Static, 0, m, a);
-        if (cfg->kind == KIND_MALA) return launch_capped<&k_chain_rs16<R, KIND_MALA>>(cfg, grid, block, kRs16Static, 0, m, a);
+        if (cfg->kind == KIND_RWMH) return launch_capped<&k_chain_rs16<R, KIND_RWMH>>(cfg, grid, block, 0, m, a);
+        if (cfg->kind == KIND_MALA) return launch_capped<&k_chain_rs16<R, KIND_MALA>>(cfg, grid, block, 0, m, a);
     }
 #endif
     switch (cfg->kind) {
-    case KIND_RWMH: return launch_capped<&k_chain<T, P, G, MODE, R, KIND_RWMH>>(cfg, grid, block, 0, cfg->lds_bytes, m, a);
-    case KIND_MALA: return launch_capped<&k_chain<T, P, G, MODE, R, KIND_MALA>>(cfg, grid, block, 0, cfg->lds_bytes, m, a);
-    case KIND_HMC: return launch_capped<&k_chain<T, P, G, MODE, R, KIND_HMC>>(cfg, grid, block, 0, cfg->lds_bytes, m, a);
-    case KIND_UL: return launch_capped<&k_chain<T, P, G, MODE, R, KIND_UL>>(cfg, grid, block, 0, cfg->lds_bytes, m, a);
+    case KIND_RWMH: return launch_capped<&k_chain<T, P, G, MODE, R, KIND_RWMH>>(cfg, grid, block, cfg->lds_bytes, m, a);
+    case KIND_MALA: return launch_capped<&k_chain<T, P, G, MODE, R, KIND_MALA>>(cfg, grid, block, cfg->lds_bytes, m, a);
+    case KIND_HMC: return launch_capped<&k_chain<T, P, G, MODE, R, KIND_HMC>>(cfg, grid, block, cfg->lds_bytes, m, a);
+    case KIND_UL: return launch_capped<&k_chain<T, P, G, MODE, R, KIND_UL>>(cfg, grid, block, cfg->lds_bytes, m, a);
     default: return -1;
     }
 }
@@ -113,13 +112,12 @@ template <int S, int NTW>
 int launch_mfma_v(const LaunchCfg* cfg, int64_t C, const ModelArgs<T, P>& m, const ChainArgs<T, P>& a) {
     const int64_t per_block = S == 1 ? 64 : 16;
     const dim3 grid((unsigned)((C + per_block - 1) / per_block)), block(S == 1 ? 256 : 64 * S);
-    // (static LDS of the row-split exchange: at most 8 KB at these widths -- an under-estimate only makes the pad larger)
-    const size_t dyn = NTW == 0 ? cfg->lds_bytes : 0, stat = 0;
+    const size_t dyn = NTW == 0 ? cfg->lds_bytes : 0;
     switch (cfg->kind) {
-    case KIND_RWMH: return launch_capped<&k_chain_mfma<P, NTW, S, KIND_RWMH>>(cfg, grid, block, stat, dyn, m, a);
-    case KIND_MALA: return launch_capped<&k_chain_mfma<P, NTW, S, KIND_MALA>>(cfg, grid, block, stat, dyn, m, a);
-    case KIND_HMC: return launch_capped<&k_chain_mfma<P, NTW, S, KIND_HMC>>(cfg, grid, block, stat, dyn, m, a);
-    case KIND_UL: return launch_capped<&k_chain_mfma<P, NTW, S, KIND_UL>>(cfg, grid, block, stat, dyn, m, a);
+    case KIND_RWMH: return launch_capped<&k_chain_mfma<P, NTW, S, KIND_RWMH>>(cfg, grid, block, dyn, m, a);
+    case KIND_MALA: return launch_capped<&k_chain_mfma<P, NTW, S, KIND_MALA>>(cfg, grid, block, dyn, m, a);
+    case KIND_HMC: return launch_capped<&k_chain_mfma<P, NTW, S, KIND_HMC>>(cfg, grid, block, dyn, m, a);
+    case KIND_UL: return launch_capped<&k_chain_mfma<P, NTW, S, KIND_UL>>(cfg, grid, block, dyn, m, a);
     default: return -1;
     }
 }
