@@ -104,7 +104,7 @@ class FusedKernel:
             self._seed = int(np.random.randint(0, 2**31 - 1))
         x = np.asarray(x, dtype=np.float64)
         single = x.ndim == 1
-        st = np.ascontiguousarray(np.atleast_2d(x), dtype=self.model.np_dtype)
+        st = np.array(np.atleast_2d(x), dtype=self.model.np_dtype, order="C")  # a copy: the launch updates it in place, the caller's x stays
         Cn = st.shape[0]
         lp = np.ascontiguousarray(np.broadcast_to(np.asarray(-np.inf if ll is None else ll, dtype=np.float64), (Cn,))).copy()
         opts = RunOpts(n_chains=Cn, chain_offset=0, thin=1, iters=1, iter_offset=self._calls, seed=self._seed,

@@ -1,0 +1,266 @@
+"""The host side of the product in the GPU-less container: logreg_amd's Python face (model closures, kernel objects, ChainSet
+chunking / checkpoint / streaming statistics, mcmc()) and the plain-C client, run against the CPU TEST DOUBLE of the C ABI
+(tests/host/lr_cpu_twin.c, injected by tests/twin.py for this module only).  What is checked here is everything ABOVE the ABI
+-- argument plumbing, iteration counters, thinning, chunk invariance, checkpoints, the statistics pipeline, output formats --
+against the oracle called directly and against the reference's fixtures; the kernels themselves are the GPU tests' business.
+The product is unchanged by this: it loads liblogreg_hip.so only (tests/test_abi.py checks that it fails loudly without a GPU).
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import REPO, load_golden
+
+import twin
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _abi_twin():
+    twin.install()
+    yield
+    twin.uninstall()
+
+
+@pytest.fixture(scope="module")
+def la():
+    import logreg_amd
+    return logreg_amd
+
+
+@pytest.fixture(scope="module")
+def models(la, pima, pscale):
+    X, y = pima
+    return {d: la.LogReg(X, y, pscale, dtype=d) for d in ("float32", "float64")}
+
+
+PRE = np.array([100.0, 1, 1, 1, 1, 1, 25, 1])
+
+
+def test_model_closures_through_the_python_face(models):  # F1
+    g = load_golden("model_eval.json")
+    beta = np.array(g["beta"])
+    m = models["float64"]
+    r = m.eval(beta)
+    for nm in ("ll", "lprior", "lpost", "glp"):
+        np.testing.assert_allclose(r[nm], np.array(g[nm]), rtol=1e-12, atol=1e-9)
+    b = beta[2]  # reference call shapes: beta [p] -> float / ndarray [p]
+    assert isinstance(m.lpost(b), float) and m.glp(b).shape == (8,) and isinstance(m.ll(b), float)
+    assert m.ll(b) == pytest.approx(-93.29888360251877, rel=1e-12)
+    assert set(m.eval(b, ("ll", "glp"))) == {"ll", "glp"}
+    with pytest.raises(ValueError):
+        m.eval(np.zeros(7))
+    # a float32 model hands float32 values back through the same face
+    r32 = models["float32"].eval(beta)
+    np.testing.assert_allclose(r32["lpost"], np.array(g["lpost"]), rtol=2e-5)
+
+
+@pytest.mark.parametrize("kind", ["rwmh", "mala", "hmc", "ul"])
+def test_mcmc_is_the_oracle_run_with_the_same_stream(la, models, oracle_model, map_beta, kind):
+    """mcmc(init, kernel, thin, iters, seed=) through ChainSet and the ABI == one direct oracle run: parameters, thinning
+    (`mat[i]` = state after (i + 1) thin iterations), chain ids, the -inf start of the threaded kernels."""
+    m = models["float64"]
+    kern = {"rwmh": lambda: la.mhKernel(m.lpost, la.rwProposal(0.02 * np.sqrt(PRE))),
+            "mala": lambda: la.malaKernel(m.lpost, m.glp, dt=1e-5, pre=PRE),
+            "hmc": lambda: la.hmcKernel(m.lpost, m.glp, eps=1e-3, l=7, dmm=1 / PRE),
+            "ul": lambda: la.ulKernel(m.glp, dt=1e-6, pre=PRE)}[kind]()
+    assert isinstance(kern, la.kernels.FusedKernel)
+    C, thin, iters, seed = 5, 3, 6, 1234
+    init = map_beta + 0.01 * np.random.default_rng(2).standard_normal((C, 8))
+    mat, info = la.mcmc(init, kern, thin=thin, iters=iters, verb=False, seed=seed, chain_offset=11, return_info=True, chunk=4)
+    step, scale, l = {"rwmh": (0.0, 0.02 * np.sqrt(PRE), 0), "mala": (1e-5, PRE, 0), "hmc": (1e-3, 1 / PRE, 7), "ul": (1e-6, PRE, 0)}[kind]
+    st = init.copy()
+    ref = oracle_model.run(kind, st, step=step, l=l, scale=scale, thin=thin, iters=iters, seed=seed, chain_offset=11, keep=True)
+    np.testing.assert_allclose(mat, ref["out"], rtol=0, atol=1e-13)
+    np.testing.assert_array_equal(info["accepts"], ref["accepts"])
+    assert info["iterations"] == thin * iters and mat.shape == (iters, C, 8)
+    # one chain, reference shapes: [p] in, float64 [iters, p] out
+    one = la.mcmc(init[0], kern, thin=thin, iters=iters, verb=False, seed=seed, chain_offset=11)
+    assert one.shape == (iters, 8) and one.dtype == np.float64
+    np.testing.assert_allclose(one, ref["out"][:, 0, :], atol=1e-13)
+
+
+def test_chunked_and_resumed_runs_continue_bit_for_bit(la, models, map_beta, tmp_path):
+    for dtype in ("float32", "float64"):
+        m = models[dtype]
+        kern = la.malaKernel(m.lpost, m.glp, dt=1e-5, pre=PRE)
+        init = np.tile(map_beta, (4, 1))
+        whole = la.mcmc(init, kern, thin=5, iters=12, verb=False, seed=9)
+        for chunk in (1, 5, 12):
+            np.testing.assert_array_equal(la.mcmc(init, kern, thin=5, iters=12, verb=False, seed=9, chunk=chunk), whole)
+        # ChainSet: advance in pieces, checkpoint to disk in the middle, resume in a "new process"
+        cs = la.ChainSet(kern, init, seed=9)
+        a = cs.advance(5, 5).to_host()
+        path = cs.save(tmp_path / f"ck_{dtype}")
+        assert path.endswith(".npz") and os.path.exists(path)
+        cs2 = la.ChainSet.resume(kern, path)
+        b = cs2.advance(7, 5).to_host()
+        np.testing.assert_array_equal(np.concatenate([a, b]), whole)
+        assert cs2.iter_offset == 60 and cs2.get_accepts().sum() > 0
+        # a checkpoint of another kernel / model is refused
+        other = la.malaKernel(m.lpost, m.glp, dt=2e-5, pre=PRE)
+        with pytest.raises(ValueError, match="param_dt"):
+            la.ChainSet.resume(other, path)
+        with pytest.raises(ValueError, match="hmc"):
+            la.ChainSet.resume(la.hmcKernel(m.lpost, m.glp, eps=1e-3, l=3, dmm=1 / PRE), path)
+
+
+def test_single_step_calls_have_the_reference_signatures(la, models, map_beta):
+    m = models["float64"]
+    np.random.seed(5)
+    k = la.malaKernel(m.lpost, m.glp, dt=1e-5, pre=PRE)
+    x0 = map_beta.copy()
+    x, ll = k(x0, -np.inf)                            # kernel(x, ll) -> (x, ll): fit-np-mala.py:61-70
+    assert x.shape == (8,) and isinstance(ll, float) and np.isfinite(ll)
+    np.testing.assert_array_equal(x0, map_beta)       # the caller's x is not touched (a float64 model once stepped it in place)
+    assert not np.array_equal(x, x0)
+    assert ll == pytest.approx(m.lpost(x), rel=1e-12)  # -inf start: the first proposal is always accepted
+    h = la.hmcKernel(m.lpost, m.glp, eps=1e-3, l=5, dmm=1 / PRE)
+    assert h(map_beta).shape == (8,)                  # kern(q) -> q: fit-np-hmc.py:65-87
+    xs, lls = k(np.tile(map_beta, (3, 1)), np.full(3, -np.inf))
+    assert xs.shape == (3, 8) and lls.shape == (3,)
+
+
+def test_mcmc_prints_and_seeds_like_the_reference(la, models, map_beta, capsys):
+    m = models["float64"]
+    kern = la.hmcKernel(m.lpost, m.glp, eps=1e-3, l=3, dmm=1 / PRE)
+    np.random.seed(3)
+    a = la.mcmc(map_beta, kern, thin=2, iters=4)
+    out = capsys.readouterr().out
+    assert out.startswith("4 iterations\n") and "Done." in out  # fit-np-hmc.py:91-102
+    np.random.seed(3)
+    b = la.mcmc(map_beta, kern, thin=2, iters=4, verb=False)
+    np.testing.assert_array_equal(a, b)                # np.random.seed(s) makes a run reproducible, as for the reference
+    assert capsys.readouterr().out == ""
+
+
+def test_summary_only_equals_numpy_on_the_samples(la, models, map_beta):
+    """mcmc(summary_only=True): the streaming statistics of the ABI + lr_stats_reduce + diagnostics.summary_from_sums against the
+    same statistics computed from the full sample matrix."""
+    m = models["float64"]
+    kern = la.malaKernel(m.lpost, m.glp, dt=1e-5, pre=PRE)
+    C, thin, iters = 6, 20, 96
+    init = map_beta + 0.02 * np.random.default_rng(4).standard_normal((C, 8))
+    res = la.mcmc(init, kern, thin=thin, iters=iters, verb=False, seed=77, summary_only=True, max_batches=16, chunk=10)
+    mat = la.mcmc(init, kern, thin=thin, iters=iters, verb=False, seed=77)
+    pooled = mat.reshape(-1, 8)
+    np.testing.assert_allclose(res["mean"], pooled.mean(axis=0), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(res["sd"], pooled.std(axis=0, ddof=1), rtol=1e-8)
+    np.testing.assert_allclose(res["rhat"], la.split_rhat(mat), rtol=1e-8)
+    from logreg_amd.diagnostics import batch_sums, summary_from_sums
+    ref = summary_from_sums(batch_sums(mat, res["batch"], init[0]), C, iters, res["batch"], init[0])
+    np.testing.assert_allclose(res["ess"], ref["ess"], rtol=1e-8)
+    np.testing.assert_allclose(res["state"], mat[-1], atol=0)
+    assert 0.0 < res["accept_rate"] <= 1.0 and res["plan"]["mode"] == "global"
+
+
+def test_errors_reach_python_as_exceptions(la, models, map_beta):
+    m = models["float64"]
+    with pytest.raises(la.LogregHipError, match="prop_sd"):
+        la.mcmc(map_beta, la.mhKernel(m.lpost, la.rwProposal(np.zeros(8))), thin=1, iters=1, verb=False, seed=1)
+    with pytest.raises(la.LogregHipError, match="thin"):
+        la.ChainSet(la.ulKernel(m.glp, dt=1e-6, pre=PRE), map_beta, seed=1).advance(1, 0)
+    with pytest.raises(ValueError):
+        la.LogReg(np.zeros((5, 2)), np.zeros(4), 1.0)
+    with pytest.raises(la.LogregHipError, match="y\\["):
+        la.LogReg(np.ones((3, 2)), np.array([0.0, 2.0, 1.0]), 1.0)
+
+
+def test_find_map_and_output_writer_on_the_python_face(la, models, map_beta, tmp_path):
+    m = models["float64"]
+    b, info = la.find_map(m)
+    assert info["converged"] and np.max(np.abs(b - map_beta)) < 1e-5            # F2
+    assert info["lpost"] == pytest.approx(-100.44943693563212, rel=1e-10)
+    kern = la.hmcKernel(m.lpost, m.glp, eps=1e-3, l=5, dmm=1 / PRE)
+    out = la.mcmc(b, kern, thin=2, iters=10, verb=False, seed=2)
+    path = str(tmp_path / "fit-np-hmc.parquet")
+    la.write_parquet(out, path)
+    import pandas as pd
+    assert list(pd.read_parquet(path).columns) == [f"b{j}" for j in range(8)]    # fit-np-hmc.py:111-112
+    np.testing.assert_array_equal(la.read_parquet(path), out)
+
+
+def test_plain_c_client_on_the_cpu(tmp_path):
+    """examples/fit_bayes.c (the counterpart of the reference's C/fit-bayes.c) linked against the CPU test double: the program's
+    own logic -- reading the data file, the run parameters of C/fit-bayes.c, the output format of :104-118 -- and a short chain's
+    posterior against the reference's seeded RWMH run (a native RWMH CLI on the CPU restatement)."""
+    lib = twin.build()
+    exe = tmp_path / "fit_bayes"
+    subprocess.run(["gcc", "-O2", "-I", os.path.join(REPO, "include"), os.path.join(REPO, "examples", "fit_bayes.c"), lib,
+                    "-Wl,-rpath," + os.path.dirname(lib), "-lm", "-o", str(exe)], check=True, capture_output=True)
+    r = subprocess.run([str(exe), os.path.join(REPO, "logreg_amd", "data", "Pima.tr.txt"), "400", "250"], capture_output=True, text=True,
+                       check=True)
+    lines = r.stdout.strip().split("\n")
+    assert lines[0].split() == [f"beta{j}" for j in range(8)]  # C/fit-bayes.c:104-107
+    a = np.array([[float(v) for v in ln.split()] for ln in lines[1:]])
+    assert a.shape == (400, 8) and np.isfinite(a).all()
+    ref = load_golden("posterior_rwmh.json")["pooled"]
+    # 10^5 iterations of one chain: a coarse check (|z| < 5 with the chain's own Geyer MCSE) that it samples the right posterior
+    import logreg_amd as la
+    summ = la.summarise(a[100:, None, :], max_chains=None)
+    z = (summ["mean"] - np.array(ref["mean"])) / np.sqrt(summ["mcse"] ** 2 + np.array(ref["mcse"]) ** 2)
+    assert np.max(np.abs(z)) < 5.0, z
+
+
+def _worker_sharded_on_twin(rank, world, port, C, tmp):
+    import sys
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    import twin as tw
+    tw.install()
+    import logreg_amd as la
+    from logreg_amd.distributed import mcmc_sharded
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    X, y = la.load_pima()
+    init = np.load(os.path.join(tmp, "init.npy"))
+
+    def make_kernel(dev):
+        m = la.LogReg(X, y, [10, 1, 1, 1, 1, 1, 1, 1], dtype="float64", device=0)
+        return la.hmcKernel(m.lpost, m.glp, eps=1e-3, l=5, dmm=1 / PRE)
+
+    class HostChainSet(la.ChainSet):  # the product's ChainSet; only the hand-over to torch differs (no CUDA tensors here)
+        def advance(self, iters, thin, keep=True, **kw):
+            out = super().advance(iters, thin, keep=keep, **kw)
+            return out.to_host() if keep else None
+    out = mcmc_sharded(init, make_kernel, thin=2, iters=8, seed=31, chunk=3, chainset_factory=HostChainSet)
+    glob = mcmc_sharded(init, make_kernel, thin=2, iters=8, seed=31, chunk=5, chainset_factory=HostChainSet, plan="global", precision="full")
+    summ = mcmc_sharded(init, make_kernel, thin=2, iters=8, seed=31, summary_only=True, max_batches=4, chainset_factory=HostChainSet)
+    if rank == 0:
+        assert np.array_equal(out.numpy(), glob.numpy())
+        np.save(os.path.join(tmp, "gathered.npy"), out.numpy())
+    else:
+        assert out is None and glob is None
+    np.savez(os.path.join(tmp, f"summary{rank}.npz"), **{k: v for k, v in summ.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+    tw.uninstall()
+
+
+@pytest.mark.parametrize("C", [7, 1])
+def test_mcmc_sharded_with_the_products_chainset(tmp_path, oracle_model, map_beta, C):
+    """world size 2 over gloo, the product's own ChainSet on the ABI twin (tests/test_distributed_gloo.py drives mcmc_sharded
+    with a stand-in chain set): ragged shards (4 + 3) and an empty one, global chain ids, chunked launches, the gather and the
+    statistics all-reduce -- equal to ONE oracle run of all chains."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    init = map_beta + 0.01 * np.random.default_rng(1).standard_normal((C, 8))
+    np.save(tmp_path / "init.npy", init)
+    mp.spawn(_worker_sharded_on_twin, args=(2, port, C, str(tmp_path)), nprocs=2, join=True)
+    ref = oracle_model.run("hmc", init, step=1e-3, l=5, scale=1 / PRE, thin=2, iters=8, seed=31)
+    got = np.load(tmp_path / "gathered.npy")
+    assert got.shape == (8, C, 8)
+    np.testing.assert_allclose(got, ref["out"], rtol=0, atol=1e-13)
+    flat = ref["out"].reshape(-1, 8)
+    for rank in range(2):
+        sm = np.load(tmp_path / f"summary{rank}.npz")
+        assert int(sm["n"]) == flat.shape[0] and int(sm["chains"]) == C
+        np.testing.assert_allclose(sm["mean"], flat.mean(0), rtol=1e-11)
+        np.testing.assert_allclose(sm["sd"], flat.std(0, ddof=1), rtol=1e-8)
+        assert float(sm["accept_rate"]) == pytest.approx(ref["accepts"].sum() / (C * 16))
