@@ -512,6 +512,11 @@ def test_mcmc_signature_and_shapes_like_the_reference(la, models, map_beta, caps
     assert np.isfinite(ll)
     u = la.ulKernel(m.glp, dt=1e-6, pre=PRE)(map_beta)
     assert u.shape == (8,)
+    # the caller's x stays what it was, whatever the model's dtype (a float64 model once stepped it in place)
+    m64 = models["float64"]
+    x0 = map_beta.copy()
+    x1, _ = la.malaKernel(m64.lpost, m64.glp, dt=1e-5, pre=PRE)(x0, -np.inf)
+    assert np.array_equal(x0, map_beta) and not np.array_equal(x1, x0)
 
 
 def test_generic_composition_with_device_closures_replays_reference_draws(la, models):
