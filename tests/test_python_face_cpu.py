@@ -264,3 +264,76 @@ def test_mcmc_sharded_with_the_products_chainset(tmp_path, oracle_model, map_bet
         np.testing.assert_allclose(sm["mean"], flat.mean(0), rtol=1e-11)
         np.testing.assert_allclose(sm["sd"], flat.std(0, ddof=1), rtol=1e-8)
         assert float(sm["accept_rate"]) == pytest.approx(ref["accepts"].sum() / (C * 16))
+
+
+@pytest.mark.parametrize("kind", ["hmc", "mala", "rwmh"])
+def test_reference_composition_with_our_closures_replays_the_recorded_run(la, models, kind):  # F6 through the Python face
+    """The drop-in claim itself: the reference's higher-order functions (mhKernel / malaKernel / hmcKernel / mcmc, generic path)
+    composed with OUR model closures; seeding NumPy as the fixture generator did reproduces the reference's recorded states,
+    because the generic kernels draw randn / rand in the reference's order (fit-np-hmc.py:56-103, fit-np-mala.py:61-95)."""
+    g = load_golden("accept_replay.json")[kind]
+    m = models["float64"]
+    lpost, glp = (lambda b: m.lpost(b)), (lambda b: m.glp(b))  # plain callables: forces the generic path
+    if kind == "hmc":
+        kern = la.hmcKernel(lpost, glp, eps=1e-3, l=50, dmm=1 / PRE)
+    elif kind == "mala":
+        kern = la.malaKernel(lpost, glp, dt=1e-5, pre=PRE)
+    else:
+        pre = np.array([10.0, 1, 1, 1, 1, 1, 5, 1])
+        kern = la.mhKernel(lpost, lambda beta: beta + 0.02 * pre * np.random.randn(8))  # fit-numpy.py:81-84
+    assert not isinstance(kern, la.kernels.FusedKernel)
+    np.random.seed(1000 + len(kind))
+    nrep = 24
+    out = la.mcmc(np.array(g["init"]), kern, thin=1, iters=nrep, verb=False)
+    np.testing.assert_allclose(out, np.array(g["states"])[:nrep], rtol=1e-9, atol=1e-11)
+
+
+def test_example_script_runs_end_to_end(tmp_path):
+    """examples/fit_hmc.py (the reference's fit-np-hmc.py on the drop-in) as a child process with the twin injected through
+    sitecustomize-free means: a two-line launcher that installs the twin and runs the script."""
+    launcher = tmp_path / "run.py"
+    out = tmp_path / "fit.parquet"
+    launcher.write_text(
+        "import runpy, sys\n"
+        f"sys.path[:0] = [{REPO!r}, {os.path.join(REPO, 'tests')!r}]\n"
+        "import twin; twin.install()\n"
+        f"sys.argv = ['fit_hmc.py', '--iters', '30', '--out', {str(out)!r}]\n"
+        f"runpy.run_path({os.path.join(REPO, 'examples', 'fit_hmc.py')!r}, run_name='__main__')\n"
+        "twin.uninstall()\n")
+    import sys
+    r = subprocess.run([sys.executable, str(launcher)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    assert "MAP:" in r.stdout and "HMC:" in r.stdout and "30 iterations" in r.stdout and "Done." in r.stdout and "ESS:" in r.stdout
+    import pandas as pd
+    df = pd.read_parquet(out)
+    assert df.shape == (30, 8) and list(df.columns) == [f"b{j}" for j in range(8)] and np.isfinite(df.to_numpy()).all()
+
+
+def test_chainset_edges(la, models, map_beta):
+    m = models["float32"]
+    kern = la.mhKernel(m.lpost, la.rwProposal(0.02 * np.sqrt(PRE)))
+    # a given threaded log-density is used (no free first acceptance), chain ids offset the stream
+    ll0 = float(m.lpost(map_beta))
+    a = la.mcmc(map_beta, kern, thin=1, iters=20, verb=False, seed=4, ll=ll0, chain_offset=3)
+    b = la.mcmc(map_beta, kern, thin=1, iters=20, verb=False, seed=4, chain_offset=3)
+    assert not np.array_equal(a, b)          # -inf start accepts the first proposal, the threaded value may not
+    c = la.mcmc(np.tile(map_beta, (5, 1)), kern, thin=1, iters=20, verb=False, seed=4, ll=ll0)
+    np.testing.assert_array_equal(c[:, 3, :].astype(np.float64), a)   # chain 3 of a 5-chain run = the one-chain run at chain_offset 3
+    # device-array views and stats misuse
+    cs = la.ChainSet(kern, np.tile(map_beta, (4, 1)), seed=1)
+    out = cs.advance(6, 2)
+    np.testing.assert_array_equal(out.rows(2, 5).to_host(), out.to_host()[2:5])
+    with pytest.raises(ValueError, match="enable_stats"):
+        cs.advance(1, 1, stats=True)
+    with pytest.raises(ValueError, match="statistics window"):
+        cs.stats_sums()
+    cs.enable_stats(batch=2, slots=2)
+    cs.advance(4, 1, keep=False)
+    with pytest.raises(la.LogregHipError, match="window"):
+        cs.advance(1, 1, keep=False)     # the window is full: the ABI refuses instead of writing past the buffer
+    with pytest.raises(KeyError):
+        la.ChainSet(kern, map_beta, seed=1, precision="half")
+    mm = la.LogReg(np.ones((3, 2)), np.array([0.0, 1.0, 1.0]), 1.0)
+    mm.close()
+    with pytest.raises(la.LogregHipError, match="closed"):
+        mm.lpost(np.zeros(2))
