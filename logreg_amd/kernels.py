@@ -79,7 +79,7 @@ class FusedKernel:
         return np.ascontiguousarray(np.broadcast_to(np.asarray(self.params[name], dtype=np.float64), (self.model.p,)))
 
     def launch(self, opts: RunOpts, state_ptr, lp_ptr, out_ptr, acc_ptr):
-        L = _lib.load()
+        L = self.model._L
         h = self.model.handle
         if self.kind == "rwmh":
             v = self._vec("prop_sd")
@@ -235,7 +235,7 @@ class ChainSet:
         self.lp = DeviceArray.from_host(m.device, lp0, dtype=np.float64)
         self.acc = DeviceArray(m.device, (self.C,), np.uint32)
         self.acc.zero_()
-        check(_lib.load().lr_stream_sync(m.device, None))
+        check(m._L.lr_stream_sync(m.device, None))
         # streaming statistics (enable_stats): device buffer [slots, C, 2, p], batch length, kept samples folded in
         self.stats = None
         self.stats_batch = 0
@@ -246,7 +246,7 @@ class ChainSet:
         """The kernel variant `advance` launches for this chain set (family- and precision-aware: `lr_plan_run`)."""
         opts = RunOpts(n_chains=self.C, group=self.group, mode=self.mode, precision=self.precision, plan_chains=self.plan_chains)
         m, g, r = C.c_int32(), C.c_int32(), C.c_int32()
-        check(_lib.load().lr_plan_run(self.model.handle, _lib.KIND_BY_NAME[self.kernel.kind], C.byref(opts), C.byref(m),
+        check(self.model._L.lr_plan_run(self.model.handle, _lib.KIND_BY_NAME[self.kernel.kind], C.byref(opts), C.byref(m),
                                       C.byref(g), C.byref(r)))
         return {"mode": _lib.MODE_NAMES[m.value], "group": g.value, "rows_per_lane": r.value}
 
@@ -293,7 +293,7 @@ class ChainSet:
         m = self.model
         piv = np.ascontiguousarray(self.pivot, dtype=np.float64)
         sums = np.empty((_lib.STATS_ROWS, m.p), dtype=np.float64)
-        check(_lib.load().lr_stats_reduce(m.device, self.stats.ptr, self.C, m.p, self.stats_batch, self.stats_kept,
+        check(m._L.lr_stats_reduce(m.device, self.stats.ptr, self.C, m.p, self.stats_batch, self.stats_kept,
                                           piv.ctypes.data, sums.ctypes.data, self.stream))
         return sums
 
@@ -303,7 +303,7 @@ class ChainSet:
         return summary_from_sums(self.stats_sums(), self.C, self.stats_kept, self.stats_batch, self.pivot)
 
     def sync(self):
-        check(_lib.load().lr_stream_sync(self.model.device, self.stream))
+        check(self.model._L.lr_stream_sync(self.model.device, self.stream))
 
     def get_state(self):
         self.sync()

@@ -35,7 +35,8 @@ class DeviceArray:
         self.dtype = np.dtype(dtype)
         self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
         p = C.c_void_p()
-        check(_lib.load().lr_malloc(self.device, self.nbytes, C.byref(p)))
+        self._L = _lib.load()  # an allocation is used and released through the library handle that made it
+        check(self._L.lr_malloc(self.device, self.nbytes, C.byref(p)))
         self.ptr = p.value
 
     @classmethod
@@ -48,17 +49,17 @@ class DeviceArray:
     def copy_from(self, arr, stream=None):
         a = np.ascontiguousarray(arr, dtype=self.dtype)
         assert a.nbytes == self.nbytes, (a.shape, self.shape)
-        check(_lib.load().lr_memcpy_h2d(self.device, self.ptr, a.ctypes.data, self.nbytes, stream))
+        check(self._L.lr_memcpy_h2d(self.device, self.ptr, a.ctypes.data, self.nbytes, stream))
 
     def to_host(self, stream=None) -> np.ndarray:
         out = np.empty(self.shape, dtype=self.dtype)
-        check(_lib.load().lr_memcpy_d2h(self.device, out.ctypes.data, self.ptr, self.nbytes, stream))
+        check(self._L.lr_memcpy_d2h(self.device, out.ctypes.data, self.ptr, self.nbytes, stream))
         return out
 
     def rows(self, i0: int, i1: int) -> "DeviceArray":
         """Non-owning view of rows [i0, i1) along the first axis."""
         v = DeviceArray.__new__(DeviceArray)
-        v.device, v.dtype = self.device, self.dtype
+        v.device, v.dtype, v._L = self.device, self.dtype, self._L
         v.shape = (i1 - i0,) + self.shape[1:]
         row_bytes = self.nbytes // max(self.shape[0], 1)
         v.nbytes = (i1 - i0) * row_bytes
@@ -67,7 +68,7 @@ class DeviceArray:
         return v
 
     def zero_(self, stream=None):
-        check(_lib.load().lr_memset(self.device, self.ptr, 0, self.nbytes, stream))
+        check(self._L.lr_memset(self.device, self.ptr, 0, self.nbytes, stream))
 
     @property
     def __cuda_array_interface__(self):
@@ -80,7 +81,7 @@ class DeviceArray:
             return
         if getattr(self, "ptr", None):
             try:
-                _lib.load().lr_free(self.device, self.ptr)
+                self._L.lr_free(self.device, self.ptr)
             finally:
                 self.ptr = None
 
@@ -133,7 +134,7 @@ class LogReg:
         h = C.c_void_p()
         check(L.lr_model_create(X.ctypes.data, y.ctypes.data, self.n, self.p, self.pscale.ctypes.data,
                                 self.dtype_id, self.device, C.byref(h)))
-        self._h = h
+        self._h, self._L = h, L  # (the handle belongs to the library that made it)
         self.ll = ModelFn(self, "ll")
         self.lprior = ModelFn(self, "lprior")
         self.lpost = ModelFn(self, "lpost")
@@ -148,7 +149,7 @@ class LogReg:
 
     def close(self):
         if getattr(self, "_h", None) is not None:
-            _lib.load().lr_model_destroy(self._h)
+            self._L.lr_model_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -163,7 +164,7 @@ class LogReg:
     def plan(self, chains: int, group: int = 0, mode: str = "auto") -> dict:
         """Kernel variant the library will launch for `chains` chains."""
         m, g, r = C.c_int32(), C.c_int32(), C.c_int32()
-        check(_lib.load().lr_plan(self.handle, int(chains), int(group), _lib.MODE_BY_NAME[mode], C.byref(m),
+        check(self._L.lr_plan(self.handle, int(chains), int(group), _lib.MODE_BY_NAME[mode], C.byref(m),
                                   C.byref(g), C.byref(r)))
         return {"mode": _lib.MODE_NAMES[m.value], "group": g.value, "rows_per_lane": r.value}
 
@@ -176,7 +177,7 @@ class LogReg:
         lp = C.c_double()
         g = np.empty(self.p)
         H = np.empty((self.p, self.p))
-        check(_lib.load().lr_hessian(self.handle, b.ctypes.data, C.byref(lp), g.ctypes.data, H.ctypes.data, None))
+        check(self._L.lr_hessian(self.handle, b.ctypes.data, C.byref(lp), g.ctypes.data, H.ctypes.data, None))
         return lp.value, g, H
 
     # ------------------------------------------------------------------------------------------
@@ -193,7 +194,7 @@ class LogReg:
         def ptr(k):
             return bufs[k].ctypes.data if k in bufs else None
         opts = RunOpts(n_chains=Cn, group=group, mode=_lib.MODE_BY_NAME[mode], on_device=0)
-        check(_lib.load().lr_eval(self.handle, b2.ctypes.data, ptr("ll"), ptr("lprior"), ptr("lpost"), ptr("glp"),
+        check(self._L.lr_eval(self.handle, b2.ctypes.data, ptr("ll"), ptr("lprior"), ptr("lpost"), ptr("glp"),
                                   C.byref(opts)))
         out = {}
         for k, v in bufs.items():
