@@ -239,11 +239,19 @@ __global__ void __launch_bounds__(256) k_chain_rs16(ModelArgs<float, 8> m, Chain
     }
     DrawBatch<float, P, G> draws;
     draws.reset();
+#ifdef LR_STAMPS  // development builds: shader cycles per phase of an iteration, printed by the first wave (tools: see profiles/r3_mala_phases.txt)
+    unsigned long long ph[4] = {0, 0, 0, 0}, tp = __builtin_amdgcn_s_memtime();
+#define LR_RS16_PHASE(k) do { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); ph[k] += tn_ - tp; tp = tn_; } while (0)
+#else
+#define LR_RS16_PHASE(k) do { } while (0)
+#endif
     for (int64_t it = 0; it < a.iters; ++it) {
         for (int64_t jt = 0; jt < a.thin; ++jt) {
             const uint64_t iter = (uint64_t)(a.iter_offset + it * a.thin + jt);
             float zx, zy, logu_f;
+            LR_RS16_PHASE(3);
             draws.next_pair(a.seed, gchain, iter, gl, q, zx, zy, logu_f);
+            LR_RS16_PHASE(0);
             const f32x2 zq = {zx, zy};
             const double logu = (double)logu_f;
             f32x2 xp, gp = {0.0f, 0.0f};
@@ -256,6 +264,7 @@ __global__ void __launch_bounds__(256) k_chain_rs16(ModelArgs<float, 8> m, Chain
                 const f32x2 advx = __builtin_elementwise_fma(aq, gq, xq);  // advance(x)             fit-np-mala.py:76
                 xp = __builtin_elementwise_fma(bq, zq, advx);
                 evaluate(True{}, True{}, xp, gp, llp, lprp);
+                LR_RS16_PHASE(1);
                 const f32x2 advp = __builtin_elementwise_fma(aq, gp, xp);
                 const f32x2 d1 = xq - advp, d2 = xp - advx;
                 const f32x2 t = cq * __builtin_elementwise_fma(-d2, d2, d1 * d1);
@@ -268,6 +277,7 @@ __global__ void __launch_bounds__(256) k_chain_rs16(ModelArgs<float, 8> m, Chain
             }
             xq = acc ? xp : xq;
             if constexpr (KIND == KIND_MALA) gq = acc ? gp : gq;
+            LR_RS16_PHASE(2);
         }
         if ((a.out || a.stats.buf) && live) {  // group-uniform: the kept sample, gathered back into the writer lane
             f32x2 all[4];
@@ -296,6 +306,12 @@ __global__ void __launch_bounds__(256) k_chain_rs16(ModelArgs<float, 8> m, Chain
             a.lp_state[chain] = lp;
         }
     }
+#ifdef LR_STAMPS
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.iters * a.thin >= 100)
+        printf("k_chain_rs16 kind %d, %lld iterations, shader cycles per iteration: draws %.1f, proposal + evaluation %.1f, accept %.1f, loop %.1f\n", KIND,
+               (long long)(a.iters * a.thin), (double)ph[0] / (a.iters * a.thin), (double)ph[1] / (a.iters * a.thin), (double)ph[2] / (a.iters * a.thin),
+               (double)ph[3] / (a.iters * a.thin));
+#endif
 }
 
 // --------------------------------------------------------------------------------------------
