@@ -337,3 +337,19 @@ def test_chainset_edges(la, models, map_beta):
     mm.close()
     with pytest.raises(la.LogregHipError, match="closed"):
         mm.lpost(np.zeros(2))
+
+
+def test_plain_c_client_under_the_sanitizers(tmp_path):
+    """The C client and the ABI test double compiled into ONE program with AddressSanitizer + UndefinedBehaviorSanitizer (CPU only:
+    GPU sanitizers are not available on the pool): the example's buffer handling, the twin and the oracle underneath run clean."""
+    exe = tmp_path / "fit_bayes_asan"
+    cc = subprocess.run(["gcc", "-O1", "-g", "-std=gnu99", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-I", os.path.join(REPO, "include"),
+                         os.path.join(REPO, "examples", "fit_bayes.c"), os.path.join(REPO, "tests", "host", "lr_cpu_twin.c"), "-lm", "-o", str(exe)],
+                        capture_output=True, text=True)
+    if cc.returncode != 0 and "sanitize" in cc.stderr:
+        pytest.skip("no sanitizer runtime in this toolchain")
+    assert cc.returncode == 0, cc.stderr[-2000:]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    r = subprocess.run([str(exe), os.path.join(REPO, "logreg_amd", "data", "Pima.tr.txt"), "40", "25"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "ERROR" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
+    assert len(r.stdout.strip().split("\n")) == 41
