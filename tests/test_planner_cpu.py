@@ -24,16 +24,19 @@ def harness(tmp_path_factory):
     obj, exe = str(out / "plan_harness.o"), str(out / "plan_harness")
     hipcc = b._hipcc()
     inc = ["-I", os.path.join(REPO, "logreg_amd", "csrc"), "-I", os.path.join(REPO, "include")]
-    subprocess.run([hipcc, "--offload-arch=gfx950", "-O1", "-std=c++17", *inc, "-c", os.path.join(REPO, "tests", "host", "plan_harness.hip"),
+    # host code under AddressSanitizer + UBSan (host side only: -Xarch_host; a finding aborts the harness and fails the test)
+    san = ["-Xarch_host", "-fsanitize=address,undefined", "-Xarch_host", "-fno-sanitize-recover=undefined"]
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O1", "-g", "-std=c++17", *san, *inc, "-c", os.path.join(REPO, "tests", "host", "plan_harness.hip"),
                     "-o", obj], check=True, capture_output=True)
     objs = sorted(os.path.join(b.OBJDIR, f) for f in os.listdir(b.OBJDIR) if f.startswith("lr_inst_") and f.endswith(".o"))
     assert len(objs) == 10
-    subprocess.run([hipcc, "--offload-arch=gfx950", obj, *objs, "-o", exe], check=True, capture_output=True)
+    subprocess.run([hipcc, "--offload-arch=gfx950", *san[:2], obj, *objs, "-o", exe], check=True, capture_output=True)
 
     def ask(requests, cus=256):
         """requests: (dtype, p, n, chains, kind, precision, group, mode) -> plan dicts or ("ERR", text)"""
         text = "".join(f"{d} {p} {n} {c} {KIND[k]} {PREC[pr]} {g} {m} {cus}\n" for d, p, n, c, k, pr, g, m in requests)
-        r = subprocess.run([exe], input=text, capture_output=True, text=True, check=True)
+        r = subprocess.run([exe], input=text, capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+        assert r.returncode == 0, r.stderr[-3000:]
         res = []
         for line in r.stdout.strip().split("\n"):
             f = line.split()
