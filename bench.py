@@ -292,8 +292,8 @@ PEAK_FP64_TFLOPS = 78.6  # MI355X vector FP64 (cdna_hip_programming.md section 1
 
 def f64_run(la, L, check, dev, stream, X, y, pscale, q0, steps):
     """The headline workload on the float64 instantiation of the kernels (the reference's NumPy arithmetic is float64:
-    fit-np-hmc.py:18-19).  The f64 path is the validation-grade one (rows in LDS, no packed math, no matrix pipe): the
-    number says what the dtype choice of `value` buys, not what a tuned fp64 kernel could do."""
+    fit-np-hmc.py:18-19).  The f64 path keeps its rows in registers (32 lanes x 7 rows per chain) but has no packed math
+    and no matrix pipe: the number says what the dtype choice of `value` buys."""
     timer = Timer(L, check, dev, stream)
     m64 = la.LogReg(X, y, pscale, dtype="float64", device=dev)
     k64 = la.hmcKernel(m64.lpost, m64.glp, eps=EPS, l=LEAP, dmm=np.ones(N_PAR))
@@ -328,14 +328,16 @@ def ess_per_draw(la, model, kern, q0, dev, plan, precision):
 
 class Exchange:
     """The multi-process side of the bench -- the ONE data-path collective (gather of the thinned samples to rank 0:
-    RCCL over xGMI on GPUs) plus the barrier and the two scalar reductions of the timing contract.  One object for
-    the real run (backend "nccl", CUDA tensors viewing the library's sample buffer in place) and for `--dry-run`
-    (backend "gloo", CPU tensors), so the CPU tests execute the very code the 8-GPU run does.  world = 1 without
-    LOGREG_BENCH_FORCE_DIST: every method is a no-op / identity."""
+    RCCL over xGMI on GPUs), the `summary_only` alternative (one all-reduce of 7p + 1 doubles of on-device statistics),
+    the barrier and the scalar reductions of the timing contract, and the small all-gathers the self-check of the
+    line needs.  One object for the real run (backend "nccl", CUDA tensors viewing the library's sample buffers in
+    place) and for `--dry-run` / the CPU tests (backend "gloo", CPU tensors), so the CPU tests execute the very code
+    the 8-GPU run does.  world = 1 without LOGREG_BENCH_FORCE_DIST: every method is a no-op / identity."""
 
     def __init__(self, backend, rank, world, local_rank, force=False):
         self.rank, self.world, self.dist, self.torch, self.dev = rank, world, None, None, "cpu"
-        self.gathered = self.tout = None
+        self.backend = backend
+        self._bufs = {}
         if world > 1 or force:
             import torch
             import torch.distributed as dist
@@ -352,39 +354,77 @@ class Exchange:
     def active(self):
         return self.dist is not None
 
-    def attach(self, samples):
-        """`samples`: this rank's [steps, C, p] sample buffer (a DeviceArray viewed in place, or a CPU tensor)."""
+    def tensor(self, samples):
+        """This rank's sample buffer (a DeviceArray viewed in place on its GPU, or a CPU tensor / ndarray) as a tensor on
+        the exchange's device."""
         if not self.active:
-            return
-        self.tout = samples if isinstance(samples, self.torch.Tensor) else self.torch.as_tensor(samples, device=self.dev)
-        self.gathered = [self.torch.empty_like(self.tout) for _ in range(self.world)] if self.rank == 0 else None
+            return None
+        if isinstance(samples, self.torch.Tensor):
+            return samples
+        return self.torch.as_tensor(samples, device=self.dev)
 
     def sync(self):
         if self.active and self.dev != "cpu":
             self.torch.cuda.synchronize()
 
     def barrier(self):
-        """barrier + device synchronize: the bracket of the timed region"""
+        """barrier + device synchronize: the bracket of a timed region"""
         if self.active:
             self.dist.barrier()
             self.sync()
 
-    def gather(self) -> float:
-        """Gather every rank's samples to rank 0; returns this rank's wall seconds for it (complete on return)."""
+    def gather(self, t):
+        """Gather every rank's block `t` to rank 0 -> (this rank's wall seconds, the list of blocks on rank 0 / None);
+        complete on return.  The receive buffers are allocated once per block shape."""
         if not self.active:
-            return 0.0
-        t = time.perf_counter()
-        self.dist.gather(self.tout, self.gathered, dst=0)
+            return 0.0, None
+        key = (tuple(t.shape), t.dtype)
+        if self.rank == 0 and key not in self._bufs:
+            self._bufs[key] = [self.torch.empty_like(t) for _ in range(self.world)]
+        bufs = self._bufs.get(key)
+        t0 = time.perf_counter()
+        self.dist.gather(t, bufs, dst=0)
         self.sync()
-        return time.perf_counter() - t
+        return time.perf_counter() - t0, bufs
 
     def reduce(self, value, op="max"):
-        """max (float) or sum (int) over the ranks"""
+        """max / min (float) or sum (int) over the ranks"""
         if not self.active:
             return value
-        t = self.torch.tensor([value], device=self.dev, dtype=self.torch.float64 if op == "max" else self.torch.int64)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX if op == "max" else self.dist.ReduceOp.SUM)
-        return float(t.item()) if op == "max" else int(t.item())
+        ops = {"max": self.dist.ReduceOp.MAX, "min": self.dist.ReduceOp.MIN, "sum": self.dist.ReduceOp.SUM}
+        t = self.torch.tensor([value], device=self.dev, dtype=self.torch.int64 if op == "sum" else self.torch.float64)
+        self.dist.all_reduce(t, op=ops[op])
+        return int(t.item()) if op == "sum" else float(t.item())
+
+    def all_gather_i64(self, value):
+        """every rank's integer, on every rank"""
+        if not self.active:
+            return [int(value)]
+        t = self.torch.tensor([int(value)], device=self.dev, dtype=self.torch.int64)
+        out = [self.torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return [int(o.item()) for o in out]
+
+    def all_gather_str(self, text, width=192):
+        """every rank's (short) string, on every rank"""
+        if not self.active:
+            return [text]
+        raw = text.encode()[:width].ljust(width, b"\0")
+        t = self.torch.tensor(list(raw), device=self.dev, dtype=self.torch.uint8)
+        out = [self.torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return [bytes(o.cpu().tolist()).rstrip(b"\0").decode() for o in out]
+
+    def all_reduce_stats(self, sums, n_chains_local):
+        """The `summary_only` exchange: logreg_amd.distributed.reduce_stats (what mcmc_sharded(summary_only=True) does) --
+        one all-reduce of the [7, p] statistics sums + the chain count -> (sums, chains, this rank's wall seconds)."""
+        if not self.active:
+            return sums, n_chains_local, 0.0
+        from logreg_amd.distributed import reduce_stats
+        t0 = time.perf_counter()
+        tot, ctot = reduce_stats(sums, n_chains_local, device=None if self.dev == "cpu" else self.dev)
+        self.sync()
+        return tot, ctot, time.perf_counter() - t0
 
     def close(self):
         if self.active:
@@ -392,33 +432,186 @@ class Exchange:
             self.dist.destroy_process_group()
 
 
+CHECK_CHAINS = 64  # chains of another rank's block that rank 0 re-runs for `gather_bitexact`
+
+
+def self_check(ex, ident, kernel_ms, gathered, check_rank, rerun):
+    """What makes an N > 1 line verifiable from the line alone (every rank calls this; rank 0 gets the dict):
+      ranks_seen        all-reduce of ones: the ranks the collective library actually connected
+      devices           every rank's GPU identity (lr_device_info: PCI bus id, uuid), `devices_distinct`
+      kernel_ms_min/max this rank's average launch duration (HIP events on its launch stream), min / max over the ranks
+      gather_bitexact   rank 0 re-runs, on its own GPU and outside the timed region, the first CHECK_CHAINS chains of
+                        rank `check_rank`'s block -- same start, same global chain ids (chain_offset), planned for the
+                        block's chain count (plan_chains), the same launches -- and compares the kept samples with what
+                        the gather delivered for that rank, bit for bit: the global-chain-id contract and
+                        the gather's block order shown on the hardware of the very run that is reported."""
+    seen = ex.reduce(1, "sum")
+    devices = ex.all_gather_str(ident)
+    kmin, kmax = ex.reduce(kernel_ms, "min"), ex.reduce(kernel_ms, "max")
+    if ex.rank != 0:
+        return None
+    res = {"ranks_seen": seen, "devices": devices, "devices_distinct": len(set(devices)) == len(devices),
+           "kernel_ms_min": kmin, "kernel_ms_max": kmax}
+    if gathered is not None and rerun is not None:
+        got = gathered[check_rank].cpu().numpy()
+        ref = rerun(check_rank)
+        k = ref.shape[1]
+        res.update(gather_bitexact=bool(np.array_equal(got[:, :k, :], ref)), gather_checked_rank=check_rank,
+                   gather_checked_chains=k,
+                   gather_check="rank 0 re-ran chains [rank*C, rank*C + %d) of rank %d (chain_offset = rank*C, plan_chains = C, "
+                                "the same launches) and compared with that rank's gathered block" % (k, check_rank))
+    return res
+
+
+def dist_configs(la, L, check, dev, stream, ex, rank, world, scale=1):
+    """BASELINE.json configs 3 and 5 AS STATED -- multi-GPU: 8192 MALA chains per rank (65 536 at N = 8) with the RCCL
+    gather of a kept block and, separately, the `summary_only` all-reduce of 7p + 1 doubles; 1024 wide-model HMC chains per
+    rank (8192 at N = 8) with the gather -- each timed like `value`: barrier + device synchronise on both sides, wall
+    time max over ranks, whole-job units / that time; plus each rank's kernel time (HIP events) min / max over ranks.
+    Every rank runs this; rank 0 returns the rows.  `scale` > 1 divides chain counts and run lengths (CPU tests only:
+    the rows are then marked `scaled_down` and are not measurements of the configs)."""
+    timer = Timer(L, check, dev, stream)
+    rows = []
+    tag = {"scaled_down": scale} if scale != 1 else {}
+
+    def timed(launch, exchange):
+        """barrier | launch (HIP events) + sync + exchange | barrier -> (wall max over ranks, kernel ms min, max, exchange s max, payload)"""
+        ex.barrier()
+        t0 = time.perf_counter()
+        timer.start()
+        launch()
+        kms = timer.stop_ms()  # synchronises on the stop event: the launches are complete
+        xs, payload = exchange()
+        ex.barrier()
+        wall = ex.reduce(time.perf_counter() - t0, "max")
+        return wall, ex.reduce(kms, "min"), ex.reduce(kms, "max"), ex.reduce(xs, "max"), payload
+
+    # ---- config 3: MALA dt=1e-5 pre=[100,1,..,25,1] on Pima, thin 1000, 8192 chains per rank
+    X, y = la.load_pima()
+    pre = np.array([100.0, 1, 1, 1, 1, 1, 25, 1])
+    bmap = np.array([-9.19131622, 0.09705401, 0.03112265, -0.00564495, -0.00062272, 0.0814371, 1.26032561, 0.03939102])
+    m = la.LogReg(X, y, np.array([10.0, 1, 1, 1, 1, 1, 1, 1]), device=dev)
+    k3 = la.malaKernel(m.lpost, m.glp, dt=1e-5, pre=pre)
+    C3, KEEP3, THIN3 = max(16, 8192 // scale), 4, max(10, 1000 // scale)
+    cs = la.ChainSet(k3, np.tile(bmap, (C3, 1)), seed=3, chain_offset=rank * C3, stream=stream)
+    out3 = la.DeviceArray(dev, (KEEP3, C3, 8), np.float32)
+    t3 = ex.tensor(out3)
+    cs.advance(1, THIN3, keep=False)
+    cs.sync()
+    ex.gather(t3)  # untimed first use of this block shape
+    wall, kmin, kmax, xs, bufs = timed(lambda: cs.advance(KEEP3, THIN3, keep=True, out=out3), lambda: ex.gather(t3))
+    its = world * C3 * KEEP3 * THIN3
+    fg = flops_per_grad_eval(200, 8)
+    # the same chains' on-device statistics instead of their samples: 7p + 1 doubles per rank, one all-reduce
+    cs.enable_stats(KEEP3 // 2, 2, pivot=bmap)
+
+    def summary_exchange():  # device reduction over this rank's chains (lr_stats_reduce), then the all-reduce
+        t0 = time.perf_counter()
+        tot, ctot, _ = ex.all_reduce_stats(cs.stats_sums(), C3)
+        return time.perf_counter() - t0, (tot, ctot)
+    wall_s, kmin_s, kmax_s, xs_s, summ = timed(lambda: cs.advance(KEEP3, THIN3, keep=False), summary_exchange)
+    if rank == 0:
+        ach = its * fg / wall / world / 1e12
+        blocks_ok = all(tuple(b.shape) == (KEEP3, C3, 8) and bool(np.isfinite(b.cpu().numpy()).all()) for b in bufs)
+        rows.append({"config": 3, **tag, "n_gpus": world,
+                     "workload": f"MALA dt=1e-5 pre=[100,1,..,25,1] on Pima n=200 p=8, thin {THIN3}, {C3} chains per GPU = "
+                                 f"{world * C3} chains (BASELINE.json configs[2]: 65 536 over 8 GPUs), {KEEP3} kept samples",
+                     "kernel_variant": cs.plan(), "chains_total": world * C3,
+                     "with_gather": {"chain_iterations_per_s": its / wall, "wall_ms": wall * 1e3, "gather_ms": xs * 1e3,
+                                     "gathered_bytes_per_rank": KEEP3 * C3 * 8 * 4, "blocks_ok": blocks_ok,
+                                     "kernel_ms_min": kmin, "kernel_ms_max": kmax,
+                                     "exchange": "gather of the kept [iters, C, p] block of every rank to rank 0 (RCCL)"},
+                     "summary_only": {"chain_iterations_per_s": its / wall_s, "wall_ms": wall_s * 1e3, "allreduce_ms": xs_s * 1e3,
+                                      "doubles_per_rank": 7 * 8 + 1, "chains_counted": int(summ[1]),
+                                      "kernel_ms_min": kmin_s, "kernel_ms_max": kmax_s,
+                                      "exchange": "lr_stats_reduce on every rank + ONE all-reduce of 7p + 1 doubles (no samples stored or moved)"},
+                     "roofline": {"bound": "valu_fp32", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s per GPU",
+                                  "frac": ach / PEAK_FP32_TFLOPS, "flops_per_iteration": fg,
+                                  "note": "whole-job flops / wall (max over ranks, gather included) / GPUs"}})
+    out3.free()
+    # ---- config 5: HMC L=50 on synthetic n=4096 p=128, 1024 chains per rank
+    fix = json.load(open(os.path.join(REPO, "tests", "golden", "fullsize_cfg5.json")))
+    n, p, C5 = fix["n"], fix["p"], max(16, 1024 // scale)
+    X, y, _ = la.synthetic_logreg(n, p, seed=fix["data_seed"], beta_sd=fix["beta_sd"])
+    m5 = la.LogReg(X, y, np.array(fix["pscale"]), device=dev)
+    k5 = la.hmcKernel(m5.lpost, m5.glp, eps=fix["eps"], l=fix["l"], dmm=np.array(fix["dmm"]))
+    rng = np.random.Generator(np.random.Philox(4005 + 1000 * rank))
+    q0 = np.array(fix["map"]) + np.array(fix["laplace_sd"]) * rng.standard_normal((C5, p))
+    cs = la.ChainSet(k5, q0, seed=5, chain_offset=rank * C5, stream=stream)
+    iters = 4 if scale == 1 else 1
+    out5 = la.DeviceArray(dev, (iters, C5, p), np.float32)
+    t5 = ex.tensor(out5)
+    cs.advance(1, 1, keep=False)
+    cs.sync()
+    ex.gather(t5)
+    a0 = int(cs.get_accepts().astype(np.int64).sum())
+    wall, kmin, kmax, xs, bufs = timed(lambda: cs.advance(iters, 1, keep=True, out=out5), lambda: ex.gather(t5))
+    acc = ex.reduce(int(cs.get_accepts().astype(np.int64).sum()) - a0, "sum")
+    if rank == 0:
+        evals = iters * fix["l"]
+        fg = flops_per_grad_eval(n, p)
+        ach = world * C5 * evals * fg / wall / world / 1e12
+        rows.append({"config": 5, **tag, "n_gpus": world,
+                     "workload": f"HMC L={fix['l']} eps={fix['eps']} unit mass, synthetic n={n} p={p}, {C5} chains per GPU = {world * C5} "
+                                 f"chains (BASELINE.json configs[4]: 8192 over 8 GPUs), {iters} iterations, every sample kept",
+                     "kernel_variant": cs.plan(), "chains_total": world * C5,
+                     "interior_precision": "auto (bf16 matrix pipe for the L-1 interior gradients; end points exact)",
+                     "chain_iterations_per_s": world * C5 * iters / wall, "grad_evals_per_s": world * C5 * evals / wall,
+                     "accept_rate": acc / (world * C5 * iters), "wall_ms": wall * 1e3, "gather_ms": xs * 1e3,
+                     "gathered_bytes_per_rank": iters * C5 * p * 4, "kernel_ms_min": kmin, "kernel_ms_max": kmax,
+                     "us_per_evaluation_all_chains_of_a_gpu": wall / evals * 1e6,
+                     "blocks_ok": all(tuple(b.shape) == (iters, C5, p) for b in bufs),
+                     "roofline": {"bound": "mfma", "pipe": "bf16 MFMA (v_mfma_f32_16x16x32_bf16), fp32 accumulate",
+                                  "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s per GPU", "frac": ach / PEAK_BF16_TFLOPS,
+                                  "flops_per_grad_eval": fg, "note": "whole-job flops / wall (max over ranks, gather included) / GPUs"}})
+    out5.free()
+    return rows if rank == 0 else None
+
+
 def dry_run(a, rank, world, local_rank):
-    """Launch plumbing without a GPU: the same Exchange object as the real run on the gloo backend -- shard offsets,
-    gather to rank 0, barrier, max/sum over ranks -- with a CPU tensor standing in for the sample buffer."""
+    """Launch plumbing without a GPU and without any sampler: the same Exchange object and the same `self_check` as the
+    real run on the gloo backend -- shard offsets, gather to rank 0, barrier, reductions, rank / device roll call, and the
+    gather_bitexact re-run -- with a pure function of (global chain id, step) standing in for the sample buffer."""
     import torch
     ex = Exchange("gloo", rank, world, local_rank)
     C = a.chains
-    lo = rank * C  # weak scaling: chain_offset of this rank
-    ex.attach(torch.full((a.steps, C, N_PAR), float(rank)))
-    ex.gather()  # untimed first use, as in the real run
+
+    def stand_in(r, chains):  # "samples" of chains [r*C, r*C + chains) at every step
+        g = (r * C + np.arange(chains))[None, :, None]
+        return (np.sin(0.001 * g + np.arange(a.steps)[:, None, None]) + 0.01 * np.arange(N_PAR)[None, None, :]).astype(np.float32)
+    t = ex.tensor(torch.from_numpy(stand_in(rank, C)))
+    ex.gather(t)  # untimed first use, as in the real run
     ex.barrier()
     t0 = time.perf_counter()
-    gather_s = ex.gather()
+    gather_s, gathered = ex.gather(t)
     ex.barrier()
     wall = ex.reduce(time.perf_counter() - t0, "max")
     gather_s = ex.reduce(gather_s, "max")
     nacc = ex.reduce(rank + 1, "sum")
+    chk = self_check(ex, f"pci=dry:{rank} uuid={rank:032x} name=dry-run cus=0", 0.1 * (rank + 1), gathered, min(1, world - 1),
+                     lambda r: stand_in(r, min(CHECK_CHAINS, C)))
     if rank == 0:
-        ok = world == 1 or ([tuple(g.shape) for g in ex.gathered] == [(a.steps, C, N_PAR)] * world and
-                            all(float(g[0, 0, 0]) == r and float(g[-1, -1, -1]) == r for r, g in enumerate(ex.gathered)))
+        ok = world == 1 or ([tuple(g.shape) for g in gathered] == [(a.steps, C, N_PAR)] * world and
+                            all(np.array_equal(g.numpy(), stand_in(r, C)) for r, g in enumerate(gathered)))
         print(json.dumps({"dry_run": True, "metric": "MCMC iterations/sec x chains for HMC (L=50) on n=200,p=8", "value": None,
                           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "chain_offsets": [r * C for r in range(world)],
-                          "this_rank_offset": lo, "gather_ok": bool(ok), "gather_ms": gather_s * 1e3, "wall_ms": wall * 1e3,
-                          "sum_over_ranks_ok": nacc == world * (world + 1) // 2, "scaling": "weak"}), flush=True)
+                          "this_rank_offset": rank * C, "gather_ok": bool(ok), "gather_ms": gather_s * 1e3, "wall_ms": wall * 1e3,
+                          "sum_over_ranks_ok": nacc == world * (world + 1) // 2, "scaling": "weak", **(chk or {})}), flush=True)
     ex.close()
 
 
-def main():
+# MAP of the headline design (BFGS on the float64 oracle, computed once offline)
+INIT = np.array([-0.65920504, -0.18123564, -0.64985465, -0.19187958, -0.11223836, -0.51230749, -0.10401207, -0.8432688])
+
+
+def headline_init(rank, C):
+    """Start of rank `rank`'s chains: MAP + 0.1 * posterior-sd scale * N(0,1), from a
+    generator keyed by the rank, so that any rank can regenerate any other's block (`gather_bitexact`)."""
+    rng = np.random.Generator(np.random.Philox(SEED + 1000 * rank))
+    return INIT + 0.1 * 0.17 * rng.standard_normal((C, N_PAR))
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -433,7 +626,11 @@ def main():
     ap.add_argument("--no-ess", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the configs 1/3/4/5 sub-results")
     ap.add_argument("--dry-run", action="store_true", help="launch plumbing only (gloo, no GPU work)")
-    a = ap.parse_args()
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend (gloo: the CPU tests)")
+    ap.add_argument("--scale", type=int, default=1, help="divide the chain counts / run lengths of the multi-GPU configs 3 and 5 "
+                    "(CPU tests only; rows are marked scaled_down)")
+    ap.add_argument("--prewarm", type=float, default=PREWARM_S, help="seconds of untimed load before the warm-up steps")
+    a = ap.parse_args(argv)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -444,25 +641,23 @@ def main():
     if a.dry_run:
         return dry_run(a, rank, world, local_rank)
     # (LOGREG_BENCH_FORCE_DIST=1 runs the RCCL path at N = 1: tests/test_gpu_distributed.py)
-    ex = Exchange("nccl", rank, world, local_rank, force=os.environ.get("LOGREG_BENCH_FORCE_DIST") == "1")
+    ex = Exchange(a.backend, rank, world, local_rank, force=os.environ.get("LOGREG_BENCH_FORCE_DIST") == "1")
 
     import logreg_amd as la
     from logreg_amd import _lib
 
     X, y, _ = la.synthetic_logreg(N_ROWS, N_PAR, seed=20240001)
     pscale = np.array([10.0] + [1.0] * (N_PAR - 1))
-    # MAP of this design (BFGS on the float64 oracle, computed once offline); chains start at
-    # MAP + 0.1*N(0,1)*posterior-sd-scale, as SURVEY.md section 8(d) config 2 prescribes
-    init = np.array([-0.65920504, -0.18123564, -0.64985465, -0.19187958, -0.11223836, -0.51230749, -0.10401207,
-                     -0.8432688])
+    init = INIT
     C = a.chains
-    rng = np.random.Generator(np.random.Philox(SEED + 1000 * rank))
-    q0 = init + 0.1 * 0.17 * rng.standard_normal((C, N_PAR))
+    q0 = headline_init(rank, C)
 
-    dev = local_rank if ex.active else 0
+    dev = local_rank if ex.active and a.backend == "nccl" else 0
     model = la.LogReg(X, y, pscale, dtype="float32", device=dev)
     kern = la.hmcKernel(model.lpost, model.glp, eps=EPS, l=LEAP, dmm=np.ones(N_PAR))
     L = _lib.load()
+    from logreg_amd import build as lib_build
+    dev_flags = lib_build.built_extra()
     stream = Ct.c_void_p()
     _lib.check(L.lr_stream_create(dev, Ct.byref(stream)))
     cs = la.ChainSet(kern, q0, seed=SEED, chain_offset=rank * C, group=a.group, mode=a.mode, stream=stream, precision=a.precision)
@@ -476,7 +671,7 @@ def main():
     # 50 timed steps run at 0.417-0.424 ms after 5 warm-up steps = 2 ms of load, at 0.389-0.391 ms after 200 or 1000), and
     # `value` is meant to be the sustained rate whatever W the caller picks.  Same launches as the timed ones.
     t_pre, n_pre = time.perf_counter(), 0
-    while time.perf_counter() - t_pre < PREWARM_S:
+    while time.perf_counter() - t_pre < a.prewarm:
         for _ in range(20):
             one_step(n_pre, True)
             n_pre += 1
@@ -486,8 +681,8 @@ def main():
     cs.sync()
 
     timer = Timer(L, _lib.check, dev, stream)
-    ex.attach(out)
-    ex.gather()  # untimed first use: RCCL sets up its p2p channels
+    tout = ex.tensor(out)
+    ex.gather(tout)  # untimed first use: RCCL sets up its p2p channels
     acc0 = cs.get_accepts().astype(np.int64).sum()
     ex.barrier()  # barrier + device synchronize on both sides of the timed region
     t0 = time.perf_counter()
@@ -496,7 +691,7 @@ def main():
         one_step(i, True)
     _lib.check(L.lr_event_record(dev, timer.e1, stream))
     cs.sync()
-    gather_s = ex.gather()  # the ONE exchange of the path: RCCL gather of the thinned samples to rank 0
+    gather_s, gathered = ex.gather(tout)  # the ONE exchange of the path: RCCL gather of the thinned samples to rank 0
     ex.barrier()
     t1 = time.perf_counter()
     ms = Ct.c_float()
@@ -505,6 +700,28 @@ def main():
     wall = ex.reduce(t1 - t0, "max")
     gather_s = ex.reduce(gather_s, "max")
     acc = ex.reduce(int(cs.get_accepts().astype(np.int64).sum() - acc0), "sum")
+
+    check_block = None
+    if ex.active:
+        launches_before = ex.all_gather_i64(n_pre + a.warmup)  # the pre-warm is time-bounded: every rank's own count
+
+        def rerun(r):
+            k = min(CHECK_CHAINS, C)
+            c2 = la.ChainSet(kern, headline_init(r, C)[:k], seed=SEED, chain_offset=r * C, group=a.group, mode=a.mode,
+                             stream=stream, precision=a.precision, plan_chains=C)
+            for _ in range(launches_before[r]):
+                c2.advance(1, THIN, keep=False)
+            buf = la.DeviceArray(dev, (a.steps, k, N_PAR), np.float32)
+            for i in range(a.steps):
+                c2.advance(1, THIN, keep=True, out=buf.rows(i, i + 1))
+            c2.sync()
+            res = buf.to_host()
+            buf.free()
+            return res
+        check_block = self_check(ex, _lib.device_info(dev), kernel_ms_total / a.steps, gathered, min(1, world - 1), rerun)
+    dist_rows = None
+    if ex.active and not a.no_extra:
+        dist_rows = dist_configs(la, L, _lib.check, dev, stream, ex, rank, world, a.scale)
 
     if rank == 0:
         iters_total = world * C * a.steps * THIN
@@ -525,7 +742,7 @@ def main():
             # the exchange's share of the timed region (max over ranks; 0 without a process group): separates compute from
             # the gather in a 1 -> 8 GPU curve
             "gather_ms": gather_s * 1e3,
-            "prewarm": {"seconds": PREWARM_S, "steps": n_pre, "note": "untimed launches before the W warm-up steps, until the GPU holds its clocks"},
+            "prewarm": {"seconds": a.prewarm, "steps": n_pre, "note": "untimed launches before the W warm-up steps, until the GPU holds its clocks"},
             "higher_is_better": True,
             "scaling": "weak",
             # BASELINE.md's number for this metric: the reference's own fit-np-hmc.py, 1 368 it/s x 1 chain (1 core)
@@ -558,9 +775,13 @@ def main():
                          "note": "X lives in VGPRs for the whole launch: the path is compute-bound on the fp32 vector "
                                  "ALU, not HBM-bound (8 TB/s: see hbm_frac) and not on the matrix cores; DESIGN.md section 5"},
         }
+        if dev_flags:  # a development build (e.g. -DLR_STAMPS) is not what `value` is meant to measure: say so in the line
+            line["development_build_flags"] = dev_flags
+        if check_block is not None:
+            line["multi_gpu"] = check_block
         # HBM traffic of the same launch from the committed rocprofv3 PMC passes (profiles/), if they
         # were taken for this kernel variant and shape
-        for name in ("r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
+        for name in ("r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
             try:
                 tr = json.load(open(os.path.join(REPO, "profiles", name)))
                 if tr["kernel_variant"] == plan and tr["chains"] == C and tr["thin"] == THIN:
@@ -586,7 +807,10 @@ def main():
                                                   "extra.configs[config=2_pima]"}
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(X, y, pscale, init)
-        if world == 1 and not a.no_extra:
+        if dist_rows is not None:
+            # N > 1 (or the forced one-rank process group): BASELINE configs 3 and 5 as stated, across the ranks
+            line["extra"] = {"configs": dist_rows}
+        elif world == 1 and not a.no_extra:
             line["extra"] = {"configs": extra_configs(la, L, _lib.check, dev, stream),
                              "default_policy": default_policy_runs(la, L, _lib.check, dev, stream, kern, init, a.steps),
                              "f64": f64_run(la, L, _lib.check, dev, stream, X, y, pscale, q0, a.steps)}

@@ -118,6 +118,10 @@ LR_API int lr_sizeof_run_opts(void);
 LR_API int lr_device_count(void);
 /* number of compute units of `device` (<0 on error) */
 LR_API int lr_device_cus(int device);
+/* identity of `device` as a NUL-terminated string "pci=<domain:bus:dev.fn> uuid=<32 hex digits> name=<marketing name> cus=<n>"
+ * written to buf (at most len bytes, always terminated): what a multi-process run compares across its ranks to show that
+ * every rank drives a different GPU (bench.py: `devices`).  The reference has no counterpart (single process, CPU). */
+LR_API int lr_device_info(int device, char* buf, int len);
 
 /*
  * Model = data block + model closures.

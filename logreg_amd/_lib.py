@@ -41,6 +41,7 @@ SYMBOLS = {
     "lr_sizeof_run_opts": (C.c_int, []),
     "lr_device_count": (C.c_int, []),
     "lr_device_cus": (C.c_int, [C.c_int]),
+    "lr_device_info": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     "lr_model_create": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _i32, _i32, C.POINTER(_vp)]),
     "lr_model_destroy": (None, [_vp]),
     "lr_model_info": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
@@ -109,6 +110,13 @@ def check(rc: int):
 
 def device_count() -> int:
     return int(load().lr_device_count())
+
+
+def device_info(device: int = 0) -> str:
+    """"pci=... uuid=... name=... cus=..." of `device` (lr_device_info)."""
+    buf = C.create_string_buffer(256)
+    check(load().lr_device_info(int(device), buf, 256))
+    return buf.value.decode()
 
 
 def require_gpu():

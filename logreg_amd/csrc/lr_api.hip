@@ -173,6 +173,18 @@ int lr_device_cus(int device) {
     return prop.multiProcessorCount;
 }
 
+int lr_device_info(int device, char* buf, int len) {
+    if (!buf || len <= 0) return fail(LR_ERR_INVALID, "NULL / empty buffer");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return fail(LR_ERR_HIP, "hipGetDeviceProperties failed");
+    char pci[32] = "?";
+    if (hipDeviceGetPCIBusId(pci, sizeof pci, device) != hipSuccess) snprintf(pci, sizeof pci, "?");
+    char uuid[33];
+    for (int i = 0; i < 16; ++i) snprintf(uuid + 2 * i, 3, "%02x", (unsigned)(unsigned char)prop.uuid.bytes[i]);
+    snprintf(buf, (size_t)len, "pci=%s uuid=%s name=%s cus=%d", pci, uuid, prop.name, prop.multiProcessorCount);
+    return LR_OK;
+}
+
 int lr_model_create(const double* X, const double* y, int64_t n, int32_t p, const double* prior_sd, int32_t dtype,
                     int32_t device, lr_model** out) {
     if (!X || !y || !prior_sd || !out) return fail(LR_ERR_INVALID, "NULL argument");

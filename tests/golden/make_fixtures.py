@@ -14,6 +14,7 @@ the cwd set so that "../pima.parquet" resolves.
     python tests/golden/make_fixtures.py posterior-hmc  --seeds 42 43 44 45   (~2.5 min each, parallel)
     python tests/golden/make_fixtures.py posterior-mala --seeds 42            (~35 min)
     python tests/golden/make_fixtures.py posterior-rwmh --seeds 42            (~26 min)
+    python tests/golden/make_fixtures.py posterior-ul   --seeds 42 43         (~8 min each, parallel; fit-np-ul.py:88)
 
 Fixture ids follow SURVEY.md section 8(c).
 """
@@ -343,7 +344,7 @@ def make_posterior(kind: str, seeds):
     mcse = np.sqrt(np.sum([r["mcse"] ** 2 for r in runs], axis=0)) / len(runs)
     sd = np.sqrt(np.mean([r["sd"] ** 2 for r in runs], axis=0))
     ess = np.sum([r["ess"] for r in runs], axis=0)
-    thin = {"hmc": 20, "mala": 1000, "rwmh": 1000}[kind]
+    thin = {"hmc": 20, "mala": 1000, "rwmh": 1000, "ul": 2000}[kind]
     jdump(f"posterior_{kind}.json", {
         "source": f"full unmodified Python/{SCRIPTS[kind]} after np.random.seed(seed); 10000 kept x thin {thin}",
         "runs": runs, "pooled": {"mean": mean, "sd": sd, "ess": ess, "mcse": mcse,
@@ -352,7 +353,7 @@ def make_posterior(kind: str, seeds):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["small", "posterior-hmc", "posterior-mala", "posterior-rwmh"])
+    ap.add_argument("what", choices=["small", "posterior-hmc", "posterior-mala", "posterior-rwmh", "posterior-ul"])
     ap.add_argument("--seeds", type=int, nargs="+", default=[42])
     a = ap.parse_args()
     if not os.path.isdir(REF):

@@ -21,6 +21,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
+#include <unistd.h>
 
 #include "../../oracle/lr_oracle.c"
 
@@ -47,6 +49,12 @@ LR_API const char *lr_build_id(void) { return "cpu-twin (tests/host/lr_cpu_twin.
 LR_API int lr_sizeof_run_opts(void) { return (int)sizeof(lr_run_opts); }
 LR_API int lr_device_count(void) { return 1; }
 LR_API int lr_device_cus(int device) { return device == 0 ? 256 : fail(LR_ERR_INVALID, "no device %d", device); }
+LR_API int lr_device_info(int device, char *buf, int len) {
+    if (!buf || len <= 0) return fail(LR_ERR_INVALID, "NULL / empty buffer");
+    if (device != 0) return fail(LR_ERR_INVALID, "no device %d", device);
+    snprintf(buf, (size_t)len, "pci=twin:%ld uuid=%032lx name=cpu-twin cus=256", (long)getpid(), (long)getpid());
+    return LR_OK;
+}
 
 LR_API int lr_model_create(const double *X, const double *y, int64_t n, int32_t p, const double *prior_sd, int32_t dtype,
                            int32_t device, lr_model **out) {
@@ -364,18 +372,21 @@ LR_API int lr_stream_sync(int device, void *stream) {
     (void)stream;
     return LR_OK;
 }
-LR_API int lr_event_create(int device, void **event) { return lr_malloc(device, 1, event); }
+/* events hold the wall clock of their record call (the work is synchronous, so that is when it finished) */
+LR_API int lr_event_create(int device, void **event) { return lr_malloc(device, sizeof(double), event); }
 LR_API int lr_event_destroy(int device, void *event) { return lr_free(device, event); }
 LR_API int lr_event_record(int device, void *event, void *stream) {
     (void)device;
-    (void)event;
     (void)stream;
+    if (!event) return fail(LR_ERR_INVALID, "NULL event");
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    *(double *)event = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
     return LR_OK;
 }
 LR_API int lr_event_elapsed_ms(int device, void *start, void *stop, float *ms) {
     (void)device;
-    (void)start;
-    (void)stop;
-    if (ms) *ms = 0.0f;
+    if (!start || !stop) return fail(LR_ERR_INVALID, "NULL event");
+    if (ms) *ms = (float)(*(double *)stop - *(double *)start);
     return LR_OK;
 }

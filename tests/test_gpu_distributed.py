@@ -32,11 +32,11 @@ def test_mcmc_sharded_over_rccl_single_rank():
     assert "bit-exact vs single process" in r.stdout and "summary_only over 1000 chains" in r.stdout
 
 
-def _bench(extra_env, *launcher):
+def _bench(extra_env, *launcher, extra=False):
     import json
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
-    cmd = [sys.executable, *launcher, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "1", "--no-extra",
-           "--no-ess", "--no-cpu-baseline"]
+    cmd = [sys.executable, *launcher, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "1",
+           "--no-ess", "--no-cpu-baseline"] + ([] if extra else ["--no-extra"])
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -52,7 +52,7 @@ def test_bench_rccl_branch_runs_on_a_gpu_under_torchrun():
     of the same command: same workload, same acceptance rate (same seed and chain ids), throughput within 15 %."""
     plain = _bench({})
     dist = _bench({"LOGREG_BENCH_FORCE_DIST": "1"}, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
-                  "--master-addr", "127.0.0.1", "--master-port", str(_free_port()))
+                  "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), extra=True)
     for d in (plain, dist):
         assert d["n_gpus"] == 1 and d["steps"] == 5 and d["scaling"] == "weak" and d["dtype"] == "f32"
         assert d["config"]["kernel_variant"] == {"mode": "reg", "group": 16, "rows_per_lane": 13}
@@ -62,3 +62,19 @@ def test_bench_rccl_branch_runs_on_a_gpu_under_torchrun():
     assert dist["accept_rate"] == plain["accept_rate"]
     # 5 timed steps = 2 ms: the gather (0.66 MB device-to-device at N = 1) is inside the timed region of the distributed run
     assert dist["value"] > 0.85 * plain["value"] * (1 - dist["gather_ms"] / (5 * dist["ms_per_step"])), (plain["value"], dist["value"])
+    # the self-check block of a multi-process line, produced on the hardware of this very run
+    mg = dist["multi_gpu"]
+    assert mg["ranks_seen"] == 1 and len(mg["devices"]) == 1 and mg["devices"][0].startswith("pci=") and "uuid=" in mg["devices"][0]
+    assert mg["devices_distinct"] and 0 < mg["kernel_ms_min"] == mg["kernel_ms_max"]
+    assert abs(mg["kernel_ms_max"] - dist["roofline"]["kernel_ms"]) < 1e-6
+    # rank 0 re-ran 64 chains of the checked block (at one rank: its own) planned for 4096 chains; bit-identical to the gather
+    assert mg["gather_bitexact"] is True and mg["gather_checked_chains"] == 64 and mg["gather_checked_rank"] == 0
+    # BASELINE configs 3 and 5 through the multi-process code (8192 MALA chains / 1024 wide-model chains per rank)
+    rows = {r["config"]: r for r in dist["extra"]["configs"]}
+    assert set(rows) == {3, 5} and "scaled_down" not in rows[3]
+    c3, c5 = rows[3], rows[5]
+    assert c3["chains_total"] == 8192 and c3["with_gather"]["blocks_ok"] and c3["with_gather"]["gathered_bytes_per_rank"] == 4 * 8192 * 32
+    assert c3["with_gather"]["chain_iterations_per_s"] > 3e9 and c3["summary_only"]["chain_iterations_per_s"] > 3e9
+    assert c3["summary_only"]["chains_counted"] == 8192 and c3["roofline"]["frac"] > 0.15
+    assert c5["chains_total"] == 1024 and c5["blocks_ok"] and 0.6 < c5["accept_rate"] < 0.9
+    assert c5["us_per_evaluation_all_chains_of_a_gpu"] < 14 and c5["roofline"]["frac"] > 0.06

@@ -191,3 +191,67 @@ def test_bench_launch_plumbing_under_torchrun_gloo(world):
     d = json.loads(lines[0])
     assert d["n_gpus"] == world and d["chain_offsets"] == [4096 * r for r in range(world)] and d["scaling"] == "weak"
     assert d["gather_ok"] and d["sum_over_ranks_ok"] and d["gather_ms"] > 0 and d["wall_ms"] >= d["gather_ms"]
+    # the self-check block of an N > 1 line (bench.self_check, the code the GPU run executes)
+    assert d["ranks_seen"] == world and len(d["devices"]) == world and d["devices_distinct"]
+    assert d["kernel_ms_min"] == pytest.approx(0.1) and d["kernel_ms_max"] == pytest.approx(0.1 * world)
+    assert d["gather_bitexact"] is True and d["gather_checked_rank"] == 1 and d["gather_checked_chains"] == 64
+
+
+def _torchrun(world, script, *args, timeout=900):
+    import json
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), script, *args],
+                       capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1  # rank 0 only
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_multi_gpu_line_on_the_abi_test_double(world):
+    """bench.py's REAL main() at N > 1 -- the product's ChainSets with global chain ids, the gather inside the timed region,
+    the self-check block (ranks seen, device identities, kernel time min / max, rank 0 re-running 64 chains of rank 1's block and
+    comparing them bit for bit with what the gather delivered) and BASELINE configs 3 and 5 across the ranks (MALA with the
+    gather AND with the summary all-reduce; wide-model HMC with the gather) -- under torch.distributed.run on gloo, the C ABI
+    being the CPU test double (tests/bench_on_twin.py injects it; chain counts scaled down 64x, marked in the rows)."""
+    import os
+    d = _torchrun(world, os.path.join(REPO, "tests", "bench_on_twin.py"), "--gpus", str(world), "--chains", "80", "--steps", "2",
+                  "--warmup", "1", "--prewarm", "0.02", "--scale", "64")
+    assert d["n_gpus"] == world and d["config"]["chains_per_gpu"] == 80 and d["value"] > 0 and d["gather_ms"] > 0
+    mg = d["multi_gpu"]
+    assert mg["ranks_seen"] == world and len(mg["devices"]) == world and mg["devices_distinct"]
+    assert 0 < mg["kernel_ms_min"] <= mg["kernel_ms_max"]
+    assert mg["gather_bitexact"] is True and mg["gather_checked_rank"] == 1 and mg["gather_checked_chains"] == 64
+    rows = {r["config"]: r for r in d["extra"]["configs"]}
+    assert set(rows) == {3, 5} and all(r["n_gpus"] == world and r["scaled_down"] == 64 for r in rows.values())
+    c3, c5 = rows[3], rows[5]
+    assert c3["chains_total"] == world * 128 and c3["with_gather"]["blocks_ok"] and c3["with_gather"]["gather_ms"] > 0
+    assert c3["summary_only"]["chains_counted"] == world * 128 and c3["summary_only"]["doubles_per_rank"] == 57
+    assert c3["summary_only"]["allreduce_ms"] > 0 and c3["roofline"]["frac"] > 0
+    assert c5["chains_total"] == world * 16 and c5["blocks_ok"] and 0.3 < c5["accept_rate"] <= 1.0 and c5["roofline"]["bound"] == "mfma"
+    assert c5["gathered_bytes_per_rank"] == 16 * 128 * 4
+
+
+def test_bench_self_check_detects_a_wrong_block():
+    """gather_bitexact is a real comparison: a re-run that differs in one element, or a gather that delivered the blocks in
+    another order, reads false."""
+    import sys
+    import torch
+    sys.path.insert(0, REPO)
+    import bench
+    ex = bench.Exchange("gloo", 0, 1, 0)  # no process group: reductions are identities
+    blocks = [torch.arange(3 * 70 * 8, dtype=torch.float32).reshape(3, 70, 8) + 1000 * r for r in range(2)]
+    good = bench.self_check(ex, "pci=a", 0.5, blocks, 1, lambda r: blocks[r][:, :64].numpy().copy())
+    assert good["gather_bitexact"] is True and good["ranks_seen"] == 1 and good["kernel_ms_min"] == good["kernel_ms_max"] == 0.5
+    off = blocks[1][:, :64].numpy().copy()
+    off[2, 63, 7] = np.nextafter(off[2, 63, 7], np.float32(np.inf))
+    assert bench.self_check(ex, "pci=a", 0.5, blocks, 1, lambda r: off)["gather_bitexact"] is False
+    assert bench.self_check(ex, "pci=a", 0.5, blocks[::-1], 1, lambda r: blocks[r][:, :64].numpy())["gather_bitexact"] is False
