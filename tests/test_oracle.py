@@ -198,3 +198,23 @@ def test_oracle_matches_reference_at_other_shapes(name):
     np.testing.assert_allclose(p, lf["p1_negated"], rtol=1e-9, atol=1e-10)
     assert m.alpi(lf["q0"], lf["p0"], dmm) == pytest.approx(lf["alpi0"], rel=1e-12)
     assert m.alpi(q, p, dmm) == pytest.approx(lf["alpi1"], rel=1e-11)
+
+
+def test_oracle_ul_posterior_matches_the_reference_run(oracle_model, map_beta):
+    """Unadjusted Langevin end to end on the CPU restatement against the seeded full runs of the unmodified fit-np-ul.py
+    (tests/golden/posterior_ul.json: dt = 1e-6, pre, thin 2000; UL is biased by construction, so the target is the
+    reference's own output): 96 chains from the MAP, 200 000 iterations dropped, 40 kept x thin 2000, standard errors from
+    the spread between the independent chains, 3.5 combined standard errors over the 16 statistics."""
+    pre = np.array([100.0, 1, 1, 1, 1, 1, 25, 1])
+    C = 96
+    r = oracle_model.run("ul", np.tile(map_beta, (C, 1)), step=1e-6, scale=pre, thin=200000, iters=1, seed=17, threads=0)
+    r = oracle_model.run("ul", r["state"], step=1e-6, scale=pre, thin=2000, iters=40, seed=17, iter_offset=200000, threads=0)
+    s = r["out"]
+    ref = load_golden("posterior_ul.json")["pooled"]
+    mean, sd = s.reshape(-1, 8).mean(axis=0), s.reshape(-1, 8).std(axis=0, ddof=1)
+    mcse = s.mean(axis=0).std(axis=0, ddof=1) / np.sqrt(C)
+    se_sd = ((s - mean) ** 2).mean(axis=0).std(axis=0, ddof=1) / np.sqrt(C) / (2 * sd)
+    zm = (mean - np.array(ref["mean"])) / np.sqrt(mcse ** 2 + np.array(ref["mcse"]) ** 2)
+    zs = (sd - np.array(ref["sd"])) / np.sqrt(se_sd ** 2 + np.array(ref["se_sd"]) ** 2)
+    print("oracle UL z(mean)", np.round(zm, 2), "z(sd)", np.round(zs, 2))
+    assert np.max(np.abs(zm)) < 3.5 and np.max(np.abs(zs)) < 3.5
