@@ -77,6 +77,15 @@ def load():
     if _lib is not None:
         return _lib
     from . import build as _build
+    if _build.built_extra() and _build.EXTRA_ENV not in os.environ:
+        # a development build (e.g. -DLR_STAMPS: clock reads and printf in hot loops) left behind by a profiling tool must
+        # never be what an ordinary run times or tests: replace it with the production build, or refuse
+        try:
+            _build.build(force=True, verbose=False)
+        except Exception as e:
+            raise LogregHipError(
+                f"{LIB_PATH} is a development build (flags {_build.built_extra()!r}) and the production library could not be "
+                f"rebuilt: {e}.  Run `python -m logreg_amd.build --force`, or set {_build.EXTRA_ENV} to use it on purpose.") from e
     if _build.needs_build():  # missing, or older than a kernel source / the header: never run stale kernels
         try:
             _build.build(verbose=False)

@@ -51,7 +51,7 @@ int check_opts(const lr_model* m, const lr_run_opts* o, bool run) {
     if (!o) return fail(LR_ERR_INVALID, "opts is NULL");
     if (m->h_xerr && *(volatile uint32_t*)m->h_xerr)  // sticky: the samples since then are poisoned with NaN
         return fail(LR_ERR_HIP, "an earlier HMC run on this model timed out inside the persistent trajectory kernel (its workgroups "
-                                "were not all resident: is the GPU shared?); recreate the model and set LOGREG_WIDE_NO_PERSIST=1");
+                                "were not all resident: is the GPU shared?); the kernel is opt-in: unset LOGREG_WIDE_PERSIST and recreate the model");
     if (o->n_chains <= 0) return fail(LR_ERR_INVALID, "n_chains must be positive (got %lld)", (long long)o->n_chains);
     if (o->plan_chains < 0) return fail(LR_ERR_INVALID, "plan_chains must be 0 (= n_chains) or positive (got %d)", o->plan_chains);
     if (const int rcg = check_group_for(m, o->group, o->mode)) return rcg;

@@ -22,7 +22,10 @@ struct LaunchCfg {
 // to launch with (>= lds_dynamic); grids of more than 4 workgroups per CU are left alone (the imbalance amortises).
 constexpr size_t kLdsPerCu = 160 * 1024;
 inline size_t capped_lds(uint64_t blocks, int cus, size_t lds_static, size_t lds_dynamic) {
-    if (cus <= 0 || blocks == 0) return lds_dynamic;
+    // only where the imbalance was observed: 1 .. 4 full rounds of workgroups.  A grid smaller than the chip (a single chain,
+    // a few chains per launch) is left alone: nothing can double up that matters, and its small LDS footprint lets launches on
+    // other streams share its CUs (two chain sets of one model on two streams).
+    if (cus <= 0 || blocks < (uint64_t)cus) return lds_dynamic;
     const uint64_t cap = (blocks + (uint64_t)cus - 1) / (uint64_t)cus;
     if (cap > 4) return lds_dynamic;
     const size_t want = ((kLdsPerCu / (cap + 1) + 2048 + 1023) / 1024) * 1024;  // cap fit, cap + 1 do not

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "lr_inst.h"
@@ -22,8 +23,10 @@ LR_DECLARE_INST(f64_p4)
 LR_DECLARE_INST(f64_p8)
 LR_DECLARE_INST(f64_p16)
 LR_DECLARE_INST(f64_p32)
-LR_DECLARE_INST(f32_p64)   // wide models: stepwise engine with the MFMA partial kernel only
+LR_DECLARE_INST(f32_p64)   // wide models: stepwise engine with the MFMA partial kernels only
 LR_DECLARE_INST(f32_p128)
+LR_DECLARE_INST(f64_p64)   // wide float64 models: stepwise engine on the float64 matrix pipe (lr_wide_f64.h)
+LR_DECLARE_INST(f64_p128)
 
 namespace {
 
@@ -47,16 +50,52 @@ const lr::InstTable* find_table(int dtype, int P) {
     const lr::InstTable* all[] = {lr_inst_table_f32_p4(),  lr_inst_table_f32_p8(), lr_inst_table_f32_p16(),
                                   lr_inst_table_f32_p32(), lr_inst_table_f64_p4(), lr_inst_table_f64_p8(),
                                   lr_inst_table_f64_p16(), lr_inst_table_f64_p32(), lr_inst_table_f32_p64(),
-                                  lr_inst_table_f32_p128()};
+                                  lr_inst_table_f32_p128(), lr_inst_table_f64_p64(), lr_inst_table_f64_p128()};
     for (const lr::InstTable* t : all)
         if (t->dtype == dtype && t->P == P) return t;
     return nullptr;
 }
 
-// tuning / A-B switches: set to a non-zero number to turn the named feature off
-bool env_on(const char* name) {
-    const char* v = std::getenv(name);
-    return v && std::atoi(v) != 0;
+// ---------------------------------------------------------------------------------------------------------------------------
+// A/B switches of the run path.  ONE environment variable, LOGREG_DEBUG_OPTS="key=value,key=value", is parsed ONCE per model
+// (lr_model_create) into this struct; nothing on the plan or launch path reads the environment.  Defaults are the measured
+// best; lr_model_debug_opts() reports what a model runs with, so that a benchmark line can say it was a default run.
+struct DebugOpts {
+    int residency_cap = 1;  // 0: fused chain kernels without the LDS request that spreads a grid evenly over the CUs (lr_inst.h)
+    int tall_mx16 = 1;      // 0: tall models run their interior leapfrog steps on the 4-wave kernel with separate update launches
+                            //    instead of the 16-wave kernel that finishes the previous step in its prologue (lr_tall_mx.h)
+    int wide_traj = -1;     // wide models: 1 forces / 0 forbids the one-launch trajectory kernel (-1: by chain count; lr_engine.h)
+    int wide_waves = 0;     // wide models: 4 | 8 waves (64 | 128 chains) per workgroup of the exact and chain-split kernels (0: by chain count)
+    bool is_default() const { return residency_cap == 1 && tall_mx16 == 1 && wide_traj == -1 && wide_waves == 0; }
+};
+// returns false (and names the culprit) on an unknown key or a value outside its range
+inline bool parse_debug_opts(const char* text, DebugOpts* out, char* bad, size_t bad_len) {
+    *out = DebugOpts{};
+    if (!text) return true;
+    std::string s(text);
+    size_t pos = 0;
+    while (pos < s.size()) {
+        size_t end = s.find(',', pos);
+        if (end == std::string::npos) end = s.size();
+        const std::string item = s.substr(pos, end - pos);
+        pos = end + 1;
+        if (item.empty()) continue;
+        const size_t eq = item.find('=');
+        const std::string key = item.substr(0, eq);
+        char* rest = nullptr;
+        const long v = eq == std::string::npos ? 0 : std::strtol(item.c_str() + eq + 1, &rest, 10);
+        bool ok = eq != std::string::npos && rest && *rest == 0 && eq + 1 < item.size();
+        if (ok && key == "residency_cap") ok = (v == 0 || v == 1), out->residency_cap = (int)v;
+        else if (ok && key == "tall_mx16") ok = (v == 0 || v == 1), out->tall_mx16 = (int)v;
+        else if (ok && key == "wide_traj") ok = (v == 0 || v == 1), out->wide_traj = (int)v;
+        else if (ok && key == "wide_waves") ok = (v == 4 || v == 8), out->wide_waves = (int)v;
+        else ok = false;
+        if (!ok) {
+            std::snprintf(bad, bad_len, "%s", item.c_str());
+            return false;
+        }
+    }
+    return true;
 }
 
 constexpr int kMaxP = 128;
@@ -76,7 +115,7 @@ struct lr_model {
     double inv_var[kMaxP];
     double lprior_const = 0;
     const lr::InstTable* table = nullptr;
-    void* d_xblk = nullptr;  // wide models: per-32-row-block bf16-piece images of the rows (lr_wide_bf16.h)
+    void* d_xblk = nullptr;  // wide float32 models: per-32-row-block bf16-piece images of the rows (lr_wide_bf16.h)
     void* d_xblk1 = nullptr;  // wide models: single-piece round-to-nearest images (interior leapfrog steps)
     void* d_xmx = nullptr;    // float32, P = 8: two-piece bf16 tile images for interior leapfrog steps (lr_tall_mx.h)
     void* d_xmf = nullptr;    // float32, P = 8 / 16, data beyond the register variants of the matrix-core chain kernel:
@@ -85,9 +124,7 @@ struct lr_model {
     // stepwise-engine workspaces, one per stream (grow-only, owned by the handle): calls enqueued on ONE stream
     // run in order, so they may share a workspace; calls on different streams overlap on the device and get
     // disjoint ones (two ChainSets of one model on two streams, or an eval on the NULL stream beside a run)
-    // time-out word of the persistent trajectory kernel (lr_wide_persist.h): host memory the device writes and every API entry reads
-    uint32_t* h_xerr = nullptr;
-    uint32_t* d_xerr = nullptr;  // the same word as the device addresses it
+    DebugOpts dbg;  // A/B switches, parsed once at creation (LOGREG_DEBUG_OPTS)
     struct Ws { hipStream_t stream; void* p; size_t bytes; };
     std::vector<Ws> ws;
     size_t esize() const { return dtype == LR_F32 ? 4 : 8; }
@@ -110,7 +147,7 @@ inline ModelImages model_images(int64_t n, int P, int dtype) {
     ModelImages im{};
     im.tall_mx = P >= 8 && P <= 32 && dtype == LR_F32 && (size_t)n * P * 4 > 64 * 1024;
     im.mf_end = P >= 8 && P <= 32 && dtype == LR_F32 && n > (P == 32 ? 16 * 4 * 8 : (P == 8 ? 16 * 13 : 16 * 4 * 16)) && n <= kMfmaStreamMaxRows;
-    im.wide = P > 32;
+    im.wide = P > 32 && dtype == LR_F32;
     return im;
 }
 inline int padded_width(int p) { return p <= 4 ? 4 : p <= 8 ? 8 : p <= 16 ? 16 : p <= 32 ? 32 : p <= 64 ? 64 : 128; }

@@ -242,7 +242,9 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
             // the register family by the launch-time model of kPlanConst (the lowest predicted time wins; ties: fewer padded rows)
             const int64_t wps = (waves + want_waves - 1) / want_waves;
             const double cost = ((double)v.R + kPlanConst.reg_fixed_rows) * (1.0 + kPlanConst.reg_corun * (double)(wps - 1));
-            score = 2900000L - (long)(cost * 1000.0) - v.R;
+            // (the model orders the variants INSIDE the register tier only: mapped into the tier's width (0, 900000], so that at very
+            //  large chain counts -- many waves per SIMD, large modelled cost -- a register variant still scores above the LDS tier)
+            score = 2000000L + (long)(900000.0 / (1.0 + cost / 64.0)) - v.R;
         } else if (v.mode == lr::MODE_REG) {
             score -= v.R;  // exact-fit R before padded R
         }

@@ -73,26 +73,39 @@ __device__ __forceinline__ mx_u32x2 mx_read_tr16(const uint16_t* p) {
     return __builtin_bit_cast(mx_u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) mx_s16x4*)(p)));
 }
 
-// The eta operand: the lane's 8 bytes [xh_a xl_a xh_b xl_b] of a (set, tile) image, duplicated into 4 registers by ONE
-// ds_read2_b64 whose two offsets are equal -- the duplicate comes out of the LDS unit, which has the slack, not out of v_mov
-// on the vector ALU, which has none.  Inline asm (told about the two identical halves the compiler reads once and copies);
-// the compiler does not count this read: mx_wait_dup names the destinations behind an lgkmcnt(0) before their first use.
-// OFF8: byte offset / 8 from `lds_addr`; the instruction's offsets are 8-bit (units of 8 bytes): what exceeds them is added to the
-// address (one v_add per 2 KB window, shared by the reads of the window).
 // the transposing read by LDS byte address (constant offsets fold into the instruction)
 __device__ __forceinline__ mx_u32x2 mx_read_tr16_at(uint32_t lds_addr) {
     return __builtin_bit_cast(mx_u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) mx_s16x4*)(uintptr_t)lds_addr));
 }
-template <int OFF8> __device__ __forceinline__ void mx_read_dup(uint32_t lds_addr, mx_u32x4& a) {
-    asm volatile("ds_read2_b64 %0, %1 offset0:%2 offset1:%2" : "=&v"(a) : "v"(lds_addr + 8u * (OFF8 & ~255)), "i"(OFF8 & 255) : "memory");
+// The eta operands of a trip: the lane's 8 bytes [xh_a xl_a xh_b xl_b] of every (tile, set) image, each duplicated into 4 registers
+// by ONE ds_read2_b64 whose two offsets are equal -- the duplicate comes out of the LDS unit, which has the slack, not out of v_mov
+// on the vector ALU, which has none.  Inline asm (told about the two identical halves the compiler reads once and copies).  The
+// compiler does not count an asm read, so the reads of a trip AND the wait for them are ONE asm statement: no copy or spill of a
+// destination register can be scheduled between a read and its data (two statements -- reads, then an s_waitcnt naming the
+// destinations -- only happened to stay adjacent).  Image I = tile * NS + set sits 512 I bytes behind `lds_addr`; the
+// instruction's offsets are 8-bit in units of 8 bytes, so four images share an address register (one v_add per 2 KB window).
+#define LR_MX_RD(o, a, imm) "ds_read2_b64 %" #o ", %" #a " offset0:" #imm " offset1:" #imm "\n\t"
+#define LR_MX_RD4(o0, o1, o2, o3, a) LR_MX_RD(o0, a, 0) LR_MX_RD(o1, a, 64) LR_MX_RD(o2, a, 128) LR_MX_RD(o3, a, 192)
+template <int N> __device__ __forceinline__ void mx_read_dup_all(uint32_t lds_addr, mx_u32x4* x) {
+    static_assert(N == 2 || N == 4 || N == 8 || N == 16, "images per trip");
+    if constexpr (N == 2)
+        asm volatile(LR_MX_RD(0, 2, 0) LR_MX_RD(1, 2, 64) "s_waitcnt lgkmcnt(0)" : "=&v"(x[0]), "=&v"(x[1]) : "v"(lds_addr) : "memory");
+    else if constexpr (N == 4)
+        asm volatile(LR_MX_RD4(0, 1, 2, 3, 4) "s_waitcnt lgkmcnt(0)" : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]) : "v"(lds_addr) : "memory");
+    else if constexpr (N == 8)
+        asm volatile(LR_MX_RD4(0, 1, 2, 3, 8) LR_MX_RD4(4, 5, 6, 7, 9) "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5]), "=&v"(x[6]), "=&v"(x[7])
+                     : "v"(lds_addr), "v"(lds_addr + 2048u)
+                     : "memory");
+    else
+        asm volatile(LR_MX_RD4(0, 1, 2, 3, 16) LR_MX_RD4(4, 5, 6, 7, 17) LR_MX_RD4(8, 9, 10, 11, 18) LR_MX_RD4(12, 13, 14, 15, 19) "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5]), "=&v"(x[6]), "=&v"(x[7]), "=&v"(x[8]), "=&v"(x[9]),
+                       "=&v"(x[10]), "=&v"(x[11]), "=&v"(x[12]), "=&v"(x[13]), "=&v"(x[14]), "=&v"(x[15])
+                     : "v"(lds_addr), "v"(lds_addr + 2048u), "v"(lds_addr + 4096u), "v"(lds_addr + 6144u)
+                     : "memory");
 }
-
-// every (tile t, set st) of a trip, I = t NS + st (a fold: the offsets are immediates)
-template <int P, int NT, int... I>
-__device__ __forceinline__ void mx_read_dup_all(uint32_t eta_lds, mx_u32x4 (&xa)[NT][MxGeom<P>::NS], std::integer_sequence<int, I...>) {
-    constexpr int NS = MxGeom<P>::NS, TILE = MxGeom<P>::TILE;
-    (mx_read_dup<((I / NS) * TILE + (I % NS) * kMxSetElems) * 2 / 8>(eta_lds, xa[I / NS][I % NS]), ...);
-}
+#undef LR_MX_RD4
+#undef LR_MX_RD
 
 // NPAIR (1 or 2) adjacent tile pairs of one wave's 16 chains: eta of every tile (K = 32 MFMA per coordinate set), w = sigma(-eta)
 // rounded to one bf16 piece, gradient MFMA per pair and set.  Two pairs per call leave the compiler one pair's MFMAs to place
@@ -103,24 +116,14 @@ template <int P, int NPAIR>
 __device__ __forceinline__ void mx_pairs(uint32_t eta_lds, uint32_t tr_lds, const mx_u32x4 (&b32)[MxGeom<P>::NS], mx_f32x4 (&gacc)[MxGeom<P>::NS]) {
     using G = MxGeom<P>;
     constexpr int NS = G::NS, TILE = G::TILE, NT = 2 * NPAIR;
-    mx_u32x4 xa[NT][NS];
-    mx_read_dup_all<P, NT>(eta_lds, xa, std::make_integer_sequence<int, NT * NS>{});
-    mx_u32x2 xt[NT][NS];  // the gradient operands (transposing reads of the same images)
+    static_assert(kMxSetElems * 2 == 512 && TILE * 2 == 512 * NS, "image I = tile * NS + set sits 512 I bytes behind the first");
+    mx_u32x2 xt[NT][NS];  // the gradient operands (transposing reads of the same images), requested first
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int st = 0; st < NS; ++st) xt[t][st] = mx_read_tr16_at(tr_lds + (uint32_t)(t * TILE + st * kMxSetElems) * 2);
-    // (every read above has returned: the asm reads are not counted by the compiler, and the counter is in order)
-    if constexpr (NT == 2 && NS == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xa[0][0]), "+v"(xa[1][0])::"memory");
-    else if constexpr (NT == 4 && NS == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xa[0][0]), "+v"(xa[1][0]), "+v"(xa[2][0]), "+v"(xa[3][0])::"memory");
-    else if constexpr (NT == 2 && NS == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xa[0][0]), "+v"(xa[0][1]), "+v"(xa[1][0]), "+v"(xa[1][1])::"memory");
-    else if constexpr (NT == 4 && NS == 2)
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xa[0][0]), "+v"(xa[0][1]), "+v"(xa[1][0]), "+v"(xa[1][1]), "+v"(xa[2][0]), "+v"(xa[2][1]), "+v"(xa[3][0]), "+v"(xa[3][1])::"memory");
-    else if constexpr (NT == 2 && NS == 4)
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xa[0][0]), "+v"(xa[0][1]), "+v"(xa[0][2]), "+v"(xa[0][3]), "+v"(xa[1][0]), "+v"(xa[1][1]), "+v"(xa[1][2]), "+v"(xa[1][3])::"memory");
-    else
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xa[0][0]), "+v"(xa[0][1]), "+v"(xa[0][2]), "+v"(xa[0][3]), "+v"(xa[1][0]), "+v"(xa[1][1]), "+v"(xa[1][2]), "+v"(xa[1][3]),
-                     "+v"(xa[2][0]), "+v"(xa[2][1]), "+v"(xa[2][2]), "+v"(xa[2][3]), "+v"(xa[3][0]), "+v"(xa[3][1]), "+v"(xa[3][2]), "+v"(xa[3][3])::"memory");
+    mx_u32x4 xa[NT][NS];
+    mx_read_dup_all<NT * NS>(eta_lds, &xa[0][0]);  // (reads + lgkmcnt(0) in one statement; the LDS counter is in order: xt has landed too)
     mx_f32x4 e[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {

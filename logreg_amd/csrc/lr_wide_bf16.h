@@ -478,13 +478,18 @@ __global__ void __launch_bounds__((64 * NW)) __attribute__((amdgpu_waves_per_eu(
             if (a.stamps && lane == 0) LR_STAMP_AT(a, 10) = __builtin_amdgcn_s_memrealtime();
             asm volatile("" ::: "memory");
 #endif
+            // (timing experiments of a -DLR_STAMPS build, results knowingly wrong: LOGREG_DEBUG_EXP bit 2 reads ONE slice partial
+            //  instead of RS_i, bit 3 none and no momentum either -- is the prologue fetch bound by volume or by latency?)
+            const int nread = LR_DBG(a, 3) ? 0 : (LR_DBG(a, 2) ? 1 : a.RS_i);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
 #pragma unroll
-                for (int r = 0; r < kFuseSlices; ++r)
-                    if (r < a.RS_i) pg[r][h] = *reinterpret_cast<const f32x4*>(a.part_in + ((int64_t)r * a.C) * P + at + 4 * h);
+                for (int r = 0; r < kFuseSlices; ++r) {
+                    pg[r][h] = f32x4{0, 0, 0, 0};
+                    if (r < nread) pg[r][h] = *reinterpret_cast<const f32x4*>(a.part_in + ((int64_t)r * a.C) * P + at + 4 * h);
+                }
                 vq[h] = *reinterpret_cast<const f32x4*>(a.q1_in + at + 4 * h);
-                vp[h] = *reinterpret_cast<const f32x4*>(a.pm_in + at + 4 * h);
+                vp[h] = LR_DBG(a, 3) ? vq[h] : *reinterpret_cast<const f32x4*>(a.pm_in + at + 4 * h);
                 vb[h] = *reinterpret_cast<const f32x4*>(a.cvec + 32 * m + 8 * kg + 4 * h);
                 vi[h] = *reinterpret_cast<const f32x4*>(a.cvec + P + 32 * m + 8 * kg + 4 * h);
             }

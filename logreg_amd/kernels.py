@@ -54,6 +54,57 @@ def _model_of(fn, kind):
     return fn.model if isinstance(fn, ModelFn) and fn.kind == kind else None
 
 
+def _recognise_random_walk(rprop, p):
+    """The proposal scale `sd` if the Python callable `rprop` is the reference's random-walk proposal
+    `beta + sd * np.random.randn(p)` (fit-numpy.py:81-84, `sd = 0.02*pre`), else None.
+
+    The script's own `rprop` is an opaque function, so it is PROBED, with `np.random.randn` replaced by recorded stand-ins
+    (NumPy's global generator is not touched): zeros must give the identity, unit vectors the diagonal scale, and two
+    random draws at two random points must reproduce `x + sd * z` to the last bit or two; exactly one `randn` call of p
+    values per proposal.  Anything else -- another generator, a dense or state-dependent scale, side effects that raise --
+    is not recognised and the kernel stays on the generic path."""
+    if isinstance(rprop, RandomWalkProposal):
+        return rprop.sd
+    if not callable(rprop):
+        return None
+    saved = np.random.randn
+    calls = []
+
+    def probe(x, z):
+        def fake(*shape):
+            calls.append(shape)
+            return np.array(z, dtype=np.float64).reshape(shape if shape else ())
+        np.random.randn = fake
+        try:
+            out = rprop(np.array(x, dtype=np.float64))
+        finally:
+            np.random.randn = saved
+        out = np.asarray(out, dtype=np.float64)
+        if out.shape != (p,) or not np.all(np.isfinite(out)):
+            raise ValueError("not a [p] -> [p] map")
+        return out
+    try:
+        x0 = np.linspace(-1.0, 1.0, p) * 0.37 + 0.11
+        if not np.array_equal(probe(x0, np.zeros(p)), x0):
+            return None
+        sd = np.empty(p)
+        for j in range(p):
+            d = probe(np.zeros(p), np.eye(p)[j])  # at the origin: 0 + sd_j * 1 is sd_j to the last bit
+            if np.any(d[np.arange(p) != j] != 0.0):
+                return None  # a dense proposal covariance
+            sd[j] = d[j]
+        if np.any(sd < 0) or len(calls) != p + 1 or any(int(np.prod(c)) != p for c in calls):
+            return None
+        rng = np.random.RandomState(12345)  # a private generator: the caller's seeding of the global one stays as it is
+        for _ in range(2):
+            x, z = 3.0 * rng.standard_normal(p), rng.standard_normal(p)
+            if not np.allclose(probe(x, z), x + sd * z, rtol=1e-14, atol=1e-300):
+                return None
+    except Exception:
+        return None
+    return sd
+
+
 # ------------------------------------------------------------------------------------------------
 class FusedKernel:
     """A transition kernel whose whole step runs inside the HIP chain kernel.
@@ -123,13 +174,17 @@ class FusedKernel:
 def mhKernel(lpost, rprop, dprop=_default_dprop):
     """Metropolis-Hastings kernel constructor.
 
-    Fused when `lpost` is a LogReg's lpost and `rprop` a `rwProposal(sd)` (random-walk MH,
-    fit-numpy.py:53-62,81-84).  Otherwise the reference's generic composition: the returned
+    Fused when `lpost` is a LogReg's lpost and `rprop` is a random-walk proposal `beta + sd * N(0, I)` -- a
+    `rwProposal(sd)`, or the script's own Python function `rprop` (fit-numpy.py:81-84), recognised by probing it
+    (`_recognise_random_walk`) -- so that the reference's call `mhKernel(lpost, rprop)` runs fused unchanged
+    (fit-numpy.py:53-62,86).  Otherwise the reference's generic composition: the returned
     `kernel(x, ll)` threads the current log-density (fit-numpy.py:54-61); called as `kernel(x)`
     it re-evaluates both ends like the HMC script's variant (fit-np-hmc.py:56-63)."""
     model = _model_of(lpost, "lpost")
-    if model is not None and isinstance(rprop, RandomWalkProposal) and dprop is _default_dprop:
-        return FusedKernel("rwmh", model, prop_sd=rprop.sd)
+    if model is not None and dprop is _default_dprop:
+        sd = _recognise_random_walk(rprop, model.p)  # a rwProposal, or the script's own `rprop` recognised by probing it
+        if sd is not None:
+            return FusedKernel("rwmh", model, prop_sd=sd)
 
     def kernel(x, ll=None):
         prop = rprop(x)

@@ -532,6 +532,31 @@ def test_generic_composition_with_device_closures_replays_reference_draws(la, mo
     np.testing.assert_allclose(out, np.array(g["hmc"]["states"])[:12], rtol=1e-7, atol=1e-9)
 
 
+def test_the_reference_rwmh_call_runs_fused_unchanged(la, models, map_beta):
+    """fit-numpy.py:81-86 as the script has it -- a Python FUNCTION `rprop` handed to mhKernel -- is recognised by probing and
+    runs on the fused kernel: same samples as the proposal stated as data, F5's recorded (x, z) pairs reproduce the
+    reference's proposals with the recognised scale, and the device lpost at those proposals gives the reference's
+    log acceptance ratios."""
+    from logreg_amd import kernels as K
+    m = models["float32"]
+    pre = np.array([10.0, 1, 1, 1, 1, 1, 5, 1])
+    p = 8
+
+    def rprop(beta):
+        return beta + 0.02 * pre * np.random.randn(p)
+    k = la.mhKernel(m.lpost, rprop)
+    assert isinstance(k, K.FusedKernel) and k.kind == "rwmh"
+    g = load_golden("rwmh_terms.json")
+    np.testing.assert_allclose(np.array(g["x"]) + k.params["prop_sd"] * np.array(g["z"]), np.array(g["prop"]), rtol=1e-15)
+    a_dev = m.lpost(np.array(g["prop"])) - m.lpost(np.array(g["x"]))
+    assert np.max(np.abs(a_dev - np.array(g["a"]))) < 1e-4  # SURVEY 8(c) F5: fp32 1e-4 abs on `a`
+    np.random.seed(77)
+    a = la.mcmc(map_beta, k, thin=1000, iters=20, verb=False)  # the reference's call shape: seed from NumPy's global generator
+    np.random.seed(77)
+    b = la.mcmc(map_beta, la.mhKernel(m.lpost, la.rwProposal(0.02 * pre)), thin=1000, iters=20, verb=False)
+    assert a.shape == (20, 8) and np.array_equal(a, b) and np.any(a[-1] != map_beta)
+
+
 def test_device_map_finder_matches_bfgs_fixture(la, models, map_beta, pima, oracle_model):  # F2, section 8(f) item 1
     """Newton with the closed-form Hessian kernel (lr_hessian: X^T W X + prior, one pass, float64)."""
     g = load_golden("map.json")

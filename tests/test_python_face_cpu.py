@@ -353,3 +353,39 @@ def test_plain_c_client_under_the_sanitizers(tmp_path):
     r = subprocess.run([str(exe), os.path.join(REPO, "logreg_amd", "data", "Pima.tr.txt"), "40", "25"], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and "ERROR" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
     assert len(r.stdout.strip().split("\n")) == 41
+
+
+def test_the_scripts_own_rprop_is_recognised_and_fused(la, models, map_beta):
+    """fit-numpy.py:81-86 passes a Python FUNCTION `rprop` to mhKernel.  The constructor probes it (zeros, unit vectors, random
+    draws through a stand-in for np.random.randn) and fuses it when it is `beta + sd * randn(p)`: the reference's call runs
+    unchanged on the fused kernel, with the same samples as the proposal stated as data; other proposals stay generic and the
+    probing consumes nothing from NumPy's global generator."""
+    from logreg_amd import kernels as K
+    m = models["float64"]
+    pre = np.array([10.0, 1, 1, 1, 1, 1, 5, 1])
+    p = 8
+
+    def rprop(beta):  # the reference's text
+        return beta + 0.02 * pre * np.random.randn(p)
+    np.random.seed(5)
+    before = np.random.get_state()[1].copy()
+    k = la.mhKernel(m.lpost, rprop)
+    assert np.array_equal(np.random.get_state()[1], before)  # the probes drew nothing from the global generator
+    assert isinstance(k, K.FusedKernel) and k.kind == "rwmh"
+    np.testing.assert_allclose(k.params["prop_sd"], 0.02 * pre, rtol=1e-15)
+    # F5 through it: the recorded (x, z) pairs of the reference reproduce its proposals with the recognised scale
+    g = load_golden("rwmh_terms.json")
+    np.testing.assert_allclose(np.array(g["x"]) + k.params["prop_sd"] * np.array(g["z"]), np.array(g["prop"]), rtol=1e-15)
+    np.testing.assert_allclose(m.lpost(np.array(g["prop"])) - m.lpost(np.array(g["x"])), np.array(g["a"]), rtol=1e-9, atol=1e-9)
+    a = la.mcmc(map_beta, k, thin=7, iters=30, verb=False, seed=3)
+    b = la.mcmc(map_beta, la.mhKernel(m.lpost, la.rwProposal(0.02 * pre)), thin=7, iters=30, verb=False, seed=3)
+    assert np.array_equal(a, b)
+    # not of the form: dense scale, state-dependent scale, another generator, a drift -- all stay generic
+    rng = np.random.default_rng(0)
+    A = np.eye(p) + 0.1
+    for other in (lambda beta: beta + A @ np.random.randn(p), lambda beta: beta + 0.1 * (1 + beta ** 2) * np.random.randn(p),
+                  lambda beta: beta + 0.02 * rng.standard_normal(p), lambda beta: 0.999 * beta + 0.02 * np.random.randn(p),
+                  lambda beta: beta + 0.02 * np.random.randn(p) * np.random.randn(p)):
+        assert not isinstance(la.mhKernel(m.lpost, other), K.FusedKernel)
+    # a custom dprop keeps the generic path too (the fused kernel is the symmetric random walk)
+    assert not isinstance(la.mhKernel(m.lpost, rprop, lambda new, old: 0.0), K.FusedKernel)

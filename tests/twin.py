@@ -42,8 +42,9 @@ def install():
 
 
 def uninstall():
-    """Restore the product's own handle.  Objects made on the twin (models, device arrays) free themselves through whatever
-    library is current, so they must be gone first: collect the garbage (exception tracebacks keep frames alive in cycles)."""
+    """Restore the product's own handle.  Objects made on the twin (models, device arrays) keep the handle of the library that made
+    them and release themselves through it, whatever is current; the garbage is collected here only so that they do not
+    outlive the test module (exception tracebacks keep frames alive in cycles)."""
     import gc
     from logreg_amd import _lib
     gc.collect()
