@@ -45,6 +45,7 @@ SYMBOLS = {
     "lr_model_create": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _i32, _i32, C.POINTER(_vp)]),
     "lr_model_destroy": (None, [_vp]),
     "lr_model_info": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
+    "lr_model_debug_opts": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "lr_eval": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _op]),
     "lr_run_rwmh": (C.c_int, [_vp, _vp, _vp, _vp, _op, _vp, _vp]),
     "lr_run_mala": (C.c_int, [_vp, _vp, _vp, C.c_double, _vp, _op, _vp, _vp]),

@@ -140,12 +140,13 @@ def _build_locked(jobs: int | None, verbose: bool) -> str:
         objs.append(obj)
         jobs_list.append([hipcc, *COMMON, f"-DLR_T={ctype}", f"-DLR_P={p}", f"-DLR_SFX={sfx}",
                           f"-DLR_DTYPE={dtype_id}", "-c", os.path.join(CSRC, "lr_inst.hip"), "-o", obj])
-    for p in (64, 128):  # wide models: MFMA stepwise engine, float32 only
-        sfx = f"f32_p{p}"
-        obj = os.path.join(OBJDIR, f"lr_inst_{sfx}.o")
-        objs.append(obj)
-        jobs_list.append([hipcc, *COMMON, f"-DLR_P={p}", f"-DLR_SFX={sfx}", "-c",
-                          os.path.join(CSRC, "lr_inst_wide.hip"), "-o", obj])
+    for dt, dtype_id in (("f32", 0), ("f64", 1)):  # wide models: MFMA stepwise engine (bf16 pipe for float32, f64 pipe for float64)
+        for p in (64, 128):
+            sfx = f"{dt}_p{p}"
+            obj = os.path.join(OBJDIR, f"lr_inst_{sfx}.o")
+            objs.append(obj)
+            jobs_list.append([hipcc, *COMMON, f"-DLR_P={p}", f"-DLR_SFX={sfx}", f"-DLR_DTYPE={dtype_id}", "-c",
+                              os.path.join(CSRC, "lr_inst_wide.hip"), "-o", obj])
     api_obj = os.path.join(OBJDIR, "lr_api.o")
     objs.append(api_obj)
     bid = source_hash(extra)

@@ -6,6 +6,7 @@
 #include "../../include/logreg_hip.h"
 
 #include <hip/hip_runtime.h>
+#define LR_STAMPS_HOST  // this unit also gets the host side of the development instrumentation (lr_stamps.h: empty in production builds)
 
 #include <cmath>
 #include <cstdarg>
@@ -25,22 +26,6 @@
 
 #include "lr_model.h"
 
-namespace {
-
-#ifdef LR_STAMPS  // development builds only: time stamps of the first kStampSlots interior-step launches (tools/stamps.py)
-constexpr int kStampSlots = 64, kStampWgs = 512;
-int g_stamp_slot = 0;
-unsigned long long* g_stamp_buf = nullptr;
-constexpr size_t kStampBytes = (size_t)kStampSlots * kStampWgs * 16 * 16 * sizeof(unsigned long long);
-unsigned long long* stamp_buffer() {
-    if (!g_stamp_buf && (hipMalloc(&g_stamp_buf, kStampBytes) != hipSuccess || hipMemset(g_stamp_buf, 0, kStampBytes) != hipSuccess))
-        g_stamp_buf = nullptr;
-    return g_stamp_buf;
-}
-#endif
-
-}  // namespace
-
 #include "lr_plan.h"
 #include "lr_engine.h"
 
@@ -49,9 +34,6 @@ namespace {
 int check_opts(const lr_model* m, const lr_run_opts* o, bool run) {
     if (!m) return fail(LR_ERR_INVALID, "model is NULL");
     if (!o) return fail(LR_ERR_INVALID, "opts is NULL");
-    if (m->h_xerr && *(volatile uint32_t*)m->h_xerr)  // sticky: the samples since then are poisoned with NaN
-        return fail(LR_ERR_HIP, "an earlier HMC run on this model timed out inside the persistent trajectory kernel (its workgroups "
-                                "were not all resident: is the GPU shared?); the kernel is opt-in: unset LOGREG_WIDE_PERSIST and recreate the model");
     if (o->n_chains <= 0) return fail(LR_ERR_INVALID, "n_chains must be positive (got %lld)", (long long)o->n_chains);
     if (o->plan_chains < 0) return fail(LR_ERR_INVALID, "plan_chains must be 0 (= n_chains) or positive (got %d)", o->plan_chains);
     if (const int rcg = check_group_for(m, o->group, o->mode)) return rcg;
@@ -147,19 +129,6 @@ const char* lr_last_error(void) { return g_err; }
 const char* lr_build_id(void) { return LR_BUILD_ID; }
 int lr_sizeof_run_opts(void) { return (int)sizeof(lr_run_opts); }
 
-#ifdef LR_STAMPS
-// development builds only: copy the stamp buffer [slots][512 workgroups][16 waves][16] to the host, restart the slot counter
-LR_API int lr_debug_read_stamps(unsigned long long* out, int* slots, int* wgs) {
-    if (slots) *slots = kStampSlots;
-    if (wgs) *wgs = kStampWgs;
-    if (!g_stamp_buf || !out) return LR_OK;
-    LR_HIP(hipDeviceSynchronize());
-    LR_HIP(hipMemcpy(out, g_stamp_buf, kStampBytes, hipMemcpyDeviceToHost));
-    LR_HIP(hipMemset(g_stamp_buf, 0, kStampBytes));
-    g_stamp_slot = 0;
-    return LR_OK;
-}
-#endif
 
 int lr_device_count(void) {
     int n = 0;
@@ -190,7 +159,6 @@ int lr_model_create(const double* X, const double* y, int64_t n, int32_t p, cons
     if (!X || !y || !prior_sd || !out) return fail(LR_ERR_INVALID, "NULL argument");
     if (n <= 0 || p <= 0) return fail(LR_ERR_INVALID, "n and p must be positive");
     if (p > kMaxP) return fail(LR_ERR_UNSUPPORTED, "p=%d > %d is not supported", p, kMaxP);
-    if (p > 32 && dtype != LR_F32) return fail(LR_ERR_UNSUPPORTED, "p=%d > 32 is float32 only (MFMA stepwise engine)", p);
     if (dtype != LR_F32 && dtype != LR_F64) return fail(LR_ERR_INVALID, "dtype must be LR_F32 or LR_F64");
     int rc = positive_vec("prior_sd", prior_sd, p);
     if (rc) return rc;
@@ -202,6 +170,14 @@ int lr_model_create(const double* X, const double* y, int64_t n, int32_t p, cons
     LR_HIP(hipSetDevice(device));
 
     lr_model* m = new lr_model();
+    {
+        char bad[64];
+        if (!parse_debug_opts(std::getenv("LOGREG_DEBUG_OPTS"), &m->dbg, bad, sizeof bad)) {
+            delete m;
+            return fail(LR_ERR_INVALID, "LOGREG_DEBUG_OPTS: unknown or out-of-range item '%s' (keys: residency_cap=0|1, tall_mx16=0|1, "
+                                        "wide_traj=0|1, wide_waves=4|8)", bad);
+        }
+    }
     m->device = device;
     m->dtype = dtype;
     m->n = n;
@@ -297,18 +273,7 @@ int lr_model_create(const double* X, const double* y, int64_t n, int32_t p, cons
             }
         }
     }
-    if (m->P > 32) {  // wide models: the time-out word of the persistent trajectory kernel (host memory, mapped for the device)
-        void* hp = nullptr;
-        void* dp = nullptr;
-        if (hipHostMalloc(&hp, sizeof(uint32_t), hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
-            m->h_xerr = static_cast<uint32_t*>(hp);
-            m->d_xerr = static_cast<uint32_t*>(dp);
-            *m->h_xerr = 0;
-        } else if (hp) {
-            (void)hipHostFree(hp);  // (without the word the kernel is simply not used)
-        }
-    }
-    if (m->P > 32) {  // wide models: bf16-piece block images for the exact-split matrix-core kernel
+    if (images.wide) {  // wide float32 models: bf16-piece block images for the exact-split matrix-core kernels
         const float* hrows = reinterpret_cast<const float*>(host.data());
         const int64_t nblk = (n + 31) / 32;
         const size_t elems_blk = m->P == 64 ? (size_t)lr::WideBf16Geom<64>::BUF : (size_t)lr::WideBf16Geom<128>::BUF;
@@ -346,8 +311,15 @@ void lr_model_destroy(lr_model* m) {
     if (m->d_xmx) (void)hipFree(m->d_xmx);
     if (m->d_xmf) (void)hipFree(m->d_xmf);
     if (m->d_xms) (void)hipFree(m->d_xms);
-    if (m->h_xerr) (void)hipHostFree(m->h_xerr);
     delete m;
+}
+
+int lr_model_debug_opts(const lr_model* m, char* buf, int len) {
+    if (!m || !buf || len <= 0) return fail(LR_ERR_INVALID, "NULL argument / empty buffer");
+    const DebugOpts& d = m->dbg;
+    if (d.is_default()) snprintf(buf, (size_t)len, "%s", "");
+    else snprintf(buf, (size_t)len, "residency_cap=%d,tall_mx16=%d,wide_traj=%d,wide_waves=%d", d.residency_cap, d.tall_mx16, d.wide_traj, d.wide_waves);
+    return LR_OK;
 }
 
 int lr_model_info(const lr_model* m, int64_t* n, int32_t* p, int32_t* dtype, int32_t* device, int32_t* padded_p) {

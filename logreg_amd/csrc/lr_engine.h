@@ -40,7 +40,7 @@ int do_eval_t(lr_model* m, const Plan& pl, hipStream_t st, int64_t C, const void
     ea.lprior = static_cast<T*>(lprior);
     ea.lpost = static_cast<T*>(lpost);
     ea.grad = static_cast<T*>(grad);
-    lr::LaunchCfg cfg{pl.mode, pl.G, pl.R, 0, st, pl.lds_bytes, env_on("LOGREG_NO_RESIDENCY_CAP") ? 0 : m->cus};
+    lr::LaunchCfg cfg{pl.mode, pl.G, pl.R, 0, st, pl.lds_bytes, m->dbg.residency_cap ? m->cus : 0};
     const int rc = m->table->launch_eval(&cfg, C, &ma, &ea);
     if (rc != 0) return fail(rc == -3 ? LR_ERR_UNSUPPORTED : LR_ERR_HIP, "eval launch failed (%d): %s", rc,
                              hipGetErrorString(hipGetLastError()));
@@ -75,7 +75,7 @@ int do_chain_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs, c
     }
     ca.stats = lr::StatsArgs{o->stats, o->stats_batch, o->stats_first};
     ca.interior_bf16 = rs.kind == lr::KIND_HMC && pl.mode == lr::MODE_MFMA && o->precision != LR_PREC_FULL;
-    lr::LaunchCfg cfg{pl.mode, pl.G, pl.R, rs.kind, st, pl.lds_bytes, env_on("LOGREG_NO_RESIDENCY_CAP") ? 0 : m->cus};
+    lr::LaunchCfg cfg{pl.mode, pl.G, pl.R, rs.kind, st, pl.lds_bytes, m->dbg.residency_cap ? m->cus : 0};
     const int rc = m->table->launch_chain(&cfg, o->n_chains, &ma, &ca);
     if (rc != 0) return fail(rc == -3 ? LR_ERR_UNSUPPORTED : LR_ERR_HIP, "chain launch failed (%d): %s", rc,
                              hipGetErrorString(hipGetLastError()));
@@ -95,13 +95,9 @@ int setup_tall(lr_model* m, const Plan& pl, hipStream_t st, int64_t C, int64_t C
     const int64_t slice_len_i = ip.slice_len_i;
     const int RSmax = RS_i > RS ? RS_i : RS;
     const size_t pg = align((size_t)RSmax * C * P * sizeof(T)), cv = align((size_t)2 * P * sizeof(T));
-    // (second state pair + second partial buffer + constants: the fused interior steps of the row-split kernel)
-    const PersistPlan pp = persist_plan(m, Cp);
-    const size_t xgroups = (size_t)((C + 31) / 32);
-    const size_t xch_bytes = pp.S ? align(2 * xgroups * pp.S * 32 * P * sizeof(float)) : 0, xfl_bytes = pp.S ? align(xgroups * pp.S * 4) : 0;
-    if (xch_bytes > 0xFFFFFFFFull) return fail(LR_ERR_UNSUPPORTED, "exchange buffer of the persistent trajectory kernel exceeds 4 GB");
+    // (second state pair + second partial buffer + constants: the fused interior steps of the row-split kernels)
     const size_t need = 4 * vec + 2 * dbl + align((size_t)C * 4) + pg + align((size_t)RS * C * sizeof(double)) +
-                        (RS_i > 0 && (m->P > 32 || rs_waves == 16) ? 2 * vec + pg : 0) + cv + xch_bytes + xfl_bytes;
+                        (RS_i > 0 && (m->P > 32 || rs_waves == 16) ? 2 * vec + pg : 0) + cv;
     lr_model::Ws* slot = nullptr;
     for (auto& e : m->ws)
         if (e.stream == st) slot = &e;
@@ -153,20 +149,10 @@ int setup_tall(lr_model* m, const Plan& pl, hipStream_t st, int64_t C, int64_t C
         a.pm_in = (const T*)carve(vec);
         a.part_in = (const T*)carve(pg);
     }
-    a.traj_S = pp.S;
-    a.traj_nbs = pp.nbs;
-    a.traj_scatter = env_on("LOGREG_WIDE_PERSIST_SCATTER");
-    if (pp.S) {
-        a.xch = (float*)carve(xch_bytes);
-        a.xch_bytes = (uint32_t)xch_bytes;
-        a.xflags = (uint32_t*)carve(xfl_bytes);
-        a.xerr = m->d_xerr;
-    }
     a.C = C;
     a.p = m->p;
     {
-        // wide models: the exact-split bf16 matrix-core kernel (lr_wide_bf16.h) is the default -- same fp32
-        // tolerances, 1.5x the fp32-MFMA kernel; LOGREG_WIDE_BF16=0 selects the fp32-MFMA kernel (lr_wide.h)
+        // wide float32 models: the exact-split bf16 matrix-core kernels (lr_wide_bf16.h), 4 or 8 waves per workgroup
         a.wide_bf16 = (m->P > 32 && m->d_xblk) ? wide_engine(m, Cp) : 0;
         a.xblk = static_cast<const uint16_t*>(m->d_xblk);
         a.xblk1 = static_cast<const uint16_t*>(m->d_xblk1);
@@ -230,43 +216,31 @@ int do_stepwise_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs
     };
     // interior leapfrog gradients (HMC): reduced precision where the policy allows and a kernel exists
     const bool bf16_interior = rs.kind == lr::KIND_HMC && o->precision != LR_PREC_FULL &&
-                               (m->d_xblk1 != nullptr || (m->d_xmx != nullptr && !env_on("LOGREG_TALL_NO_MX")));
+                               (m->d_xblk1 != nullptr || m->d_xmx != nullptr);
     const int RS_exact = a.RS, RS_mid = bf16_interior && a.RS_i > 0 ? a.RS_i : a.RS;
     if (!bf16_interior) a.RS_i = 0;
     auto KI = [&]() {
         a.interior = bf16_interior ? 1 : 0;
-#ifdef LR_STAMPS
-        a.stamps = g_stamp_slot < kStampSlots ? stamp_buffer() : nullptr;
-        a.stamp_slot = g_stamp_slot++;
-        {
-            const char* e = getenv("LOGREG_DEBUG_EXP");
-            a.dbg = e ? atoi(e) : 0;
-        }
-#endif
+        LR_STAMPS_ARM(a);
         K(0, 1);
-#ifdef LR_STAMPS
-        a.stamps = nullptr;
-#endif
+        LR_STAMPS_DISARM(a);
         a.interior = 0;
     };
     // wide models: the whole interior of a trajectory in one launch (k_wide_traj_bf16): no slice partials, no update
     // launches.  One workgroup streams the whole design per step, so it pays once every CU has a tile of its own and
     // until the 64-chain workgroups of the chain-split kernel amortise the stream better (config 5 design, us per
     // evaluation of all chains, trajectory kernel | launch per step: 1024 chains 15.7 | 11.5, 2048: 16.1 | 14.4,
-    // 4096: 22.2 | 25.0, 8192: 39.5 | 44.9, 16 384: 73.4 | 72.5).  LOGREG_WIDE_TRAJ=1 forces it on, LOGREG_WIDE_NO_TRAJ=1 off.
+    // 4096: 22.2 | 25.0, 8192: 39.5 | 44.9, 16 384: 73.4 | 72.5).  LOGREG_DEBUG_OPTS wide_traj=1 forces it on, wide_traj=0 off.
     const int64_t traj_tiles = (Cp + 15) / 16;
     const bool traj = P > 32 && bf16_interior && m->d_xblk1 != nullptr && t->launch_tall_traj != nullptr && rs.l > 1 &&
-                      !env_on("LOGREG_WIDE_NO_TRAJ") &&
-                      (env_on("LOGREG_WIDE_TRAJ") || (traj_tiles >= m->cus && traj_tiles < 4LL * m->cus) ||
+                      m->dbg.wide_traj != 0 &&
+                      (m->dbg.wide_traj == 1 || (traj_tiles >= m->cus && traj_tiles < 4LL * m->cus) ||
                        // small designs (the one-piece image within 256 KB): the per-step stream is cheap, the launch per step is not
                        // (us per evaluation, launch per step | trajectory kernel: n=500 p=64: 5.5 | 2.8 at 1024 chains; n=300 p=100:
                        //  7.0 | 4.7; n=1000 p=128: 7.5 | 6.5; n=2000 p=50: 6.2 | 5.3; n=2000 p=128 (512 KB): 8.4 | 9.3)
                        (traj_tiles < m->cus && (int64_t)m->n * m->P * 2 <= 256 * 1024));
-    // wide models, few chains: the persistent row-split trajectory kernel (lr_wide_persist.h) -- the slices resident in LDS, one
-    // hand-off between the resident workgroups per step; opt-in, see persist_plan
-    const bool persist = P > 32 && bf16_interior && rs.l > 1 && a.traj_S > 0 && !traj;
     const bool fuse = bf16_interior && a.RS_i > 0 &&
-                      ((P > 32 && a.RS_i <= 4 && !env_on("LOGREG_WIDE_NO_FUSE")) ||         // kFuseSlices (lr_wide_bf16.h)
+                      ((P > 32 && a.RS_i <= 4) ||                                            // kFuseSlices (lr_wide_bf16.h)
                        (P <= 32 && a.rowsplit_waves == 16 && a.RS_i <= 16 && m->d_xmx));   // kMx16FuseSlices (lr_tall_mx.h)
     T* qb[2] = {a.q1, const_cast<T*>(a.q1_in)};
     T* pb[2] = {a.pm, const_cast<T*>(a.pm_in)};
@@ -280,16 +254,7 @@ int do_stepwise_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs
     const int64_t total = o->iters * o->thin;
     for (int64_t tt = 0; tt < total && !rc; ++tt) {
         if (kind == lr::KIND_HMC) {
-            if (persist) {
-#ifdef LR_STAMPS
-                a.stamps = stamp_buffer();  // (one slot: the phase sums of the latest trajectory)
-                a.stamp_slot = 0;
-#endif
-                if (!rc) rc = t->launch_tall_traj_rs(st, &a);
-#ifdef LR_STAMPS
-                a.stamps = nullptr;
-#endif
-            } else if (traj) {
+            if (traj) {
                 if (!rc) rc = t->launch_tall_traj(st, &a);
             } else if (fuse) {
                 // row-split interior kernel: every launch but the first finishes the previous leapfrog step in its
@@ -372,6 +337,8 @@ int do_eval(lr_model* m, const Plan& pl, hipStream_t st, int64_t C, const void* 
     do {                                                                                 \
         if ((m)->dtype == LR_F32 && (m)->P == 64) return FN<float, 64>(__VA_ARGS__);     \
         if ((m)->dtype == LR_F32 && (m)->P == 128) return FN<float, 128>(__VA_ARGS__);   \
+        if ((m)->dtype == LR_F64 && (m)->P == 64) return FN<double, 64>(__VA_ARGS__);    \
+        if ((m)->dtype == LR_F64 && (m)->P == 128) return FN<double, 128>(__VA_ARGS__);  \
         LR_DISPATCH_TP(m, FN, __VA_ARGS__);                                              \
     } while (0)
 

@@ -71,9 +71,6 @@ struct InstTable {
     // this width) and the one-off build into `store`; may be null
     size_t (*mfma_image_bytes)(int64_t n);
     int (*launch_mfma_image)(hipStream_t, const void* rows, int64_t n, void* store);
-    // wide models: persistent row-split trajectory kernel (lr_wide_persist.h) and its LDS need per blocks-per-slice; may be null
-    int (*launch_tall_traj_rs)(hipStream_t, const void* tall_args);
-    size_t (*traj_rs_lds_bytes)(int blocks_per_slice);
 };
 
 }  // namespace lr

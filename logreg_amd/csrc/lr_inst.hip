@@ -196,7 +196,7 @@ int launch_tall_update(hipStream_t st, int kind, int phase, int64_t iter, int64_
 }
 
 const InstTable kTable = {LR_DTYPE, P, (int)(sizeof(kVariants) / sizeof(kVariants[0])), kVariants, &launch_eval,
-                          &launch_chain, &launch_tall_partial, &launch_tall_update, nullptr, LR_MFMA_IMAGE_HOOKS, nullptr, nullptr};
+                          &launch_chain, &launch_tall_partial, &launch_tall_update, nullptr, LR_MFMA_IMAGE_HOOKS};
 
 }  // namespace
 }  // namespace lr

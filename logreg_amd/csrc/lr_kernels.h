@@ -5,6 +5,7 @@
 #include <type_traits>
 
 #include "lr_device.h"
+#include "lr_stamps.h"
 
 namespace lr {
 
@@ -239,12 +240,7 @@ __global__ void __launch_bounds__(256) k_chain_rs16(ModelArgs<float, 8> m, Chain
     }
     DrawBatch<float, P, G> draws;
     draws.reset();
-#ifdef LR_STAMPS  // development builds: shader cycles per phase of an iteration, printed by the first wave (tools: see profiles/r3_mala_phases.txt)
-    unsigned long long ph[4] = {0, 0, 0, 0}, tp = __builtin_amdgcn_s_memtime();
-#define LR_RS16_PHASE(k) do { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); ph[k] += tn_ - tp; tp = tn_; } while (0)
-#else
-#define LR_RS16_PHASE(k) do { } while (0)
-#endif
+    LR_RS16_PHASES_BEGIN  // development builds: shader cycles per phase of an iteration (lr_stamps.h; profiles/r3_mala_phases.txt)
     for (int64_t it = 0; it < a.iters; ++it) {
         for (int64_t jt = 0; jt < a.thin; ++jt) {
             const uint64_t iter = (uint64_t)(a.iter_offset + it * a.thin + jt);
@@ -306,12 +302,7 @@ __global__ void __launch_bounds__(256) k_chain_rs16(ModelArgs<float, 8> m, Chain
             a.lp_state[chain] = lp;
         }
     }
-#ifdef LR_STAMPS
-    if (blockIdx.x == 0 && threadIdx.x == 0 && a.iters * a.thin >= 100)
-        printf("k_chain_rs16 kind %d, %lld iterations, shader cycles per iteration: draws %.1f, proposal + evaluation %.1f, accept %.1f, loop %.1f\n", KIND,
-               (long long)(a.iters * a.thin), (double)ph[0] / (a.iters * a.thin), (double)ph[1] / (a.iters * a.thin), (double)ph[2] / (a.iters * a.thin),
-               (double)ph[3] / (a.iters * a.thin));
-#endif
+    LR_RS16_PHASES_REPORT(KIND, a.iters * a.thin)
 }
 
 // --------------------------------------------------------------------------------------------

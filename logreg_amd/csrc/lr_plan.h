@@ -38,17 +38,15 @@ struct PlanConst {
     // (tools/wide_nsweep.py: 4096 chains, n = 2048 35.6 vs 36.6 us per step for 4 vs 8 waves, n = 8192 102 vs 85; n = 512 18.9 vs 25.9)
     int64_t wide_8wave_chains = 4096;
     int64_t wide_8wave_min_slice_rows = 512;
-    // wide models, fp32-MFMA engine only (LOGREG_WIDE_BF16=0): two workgroups per CU once each still gets this many 16-row tiles
-    int64_t wide_fp32_two_per_cu_tiles = 32;
 };
 constexpr PlanConst kPlanConst{};
 
-// wide models: 0 = fp32-MFMA kernel (LOGREG_WIDE_BF16=0), 1 = bf16x3 with 4 waves (64 chains) per workgroup,
-// 2 = bf16x3 with 8 waves (128 chains) per workgroup: the 128-chain workgroup halves the staging per chain but needs twice the
-// row slices to fill the chip
+// wide models, exact-split and chain-split bf16 kernels: 1 = 4 waves (64 chains) per workgroup, 2 = 8 waves (128 chains): the
+// 128-chain workgroup halves the staging per chain but needs twice the row slices to fill the chip.  Float64 models: 0 (their one
+// kernel, lr_wide_f64.h, takes 64 chains per workgroup).
 int wide_engine(const lr_model* m, int64_t C) {
-    const char* env = std::getenv("LOGREG_WIDE_BF16");
-    if (env) return std::atoi(env);
+    if (m->dtype != LR_F32) return 0;
+    if (m->dbg.wide_waves) return m->dbg.wide_waves == 8 ? 2 : 1;
     if (C < kPlanConst.wide_8wave_chains) return 1;
     const int64_t blocks2 = (C + 127) / 128, rs2 = (m->cus + blocks2 - 1) / blocks2;
     return m->n / rs2 >= kPlanConst.wide_8wave_min_slice_rows ? 2 : 1;
@@ -143,11 +141,10 @@ bool mfma_variant_fits(const lr_model* m, int S, Store st, Plan* out) {
 }
 
 bool plan_mfma_hmc(const lr_model* m, int64_t C, Plan* out) {
-    if (m->dtype != LR_F32 || m->P < 8 || m->P > 32 || env_on("LOGREG_NO_MFMA_INTERIOR")) return false;
+    if (m->dtype != LR_F32 || m->P < 8 || m->P > 32) return false;
     for (const MfmaRule& r : kMfmaRules) {
         if (r.P != m->P || m->n <= r.n_lo || m->n > r.n_hi) continue;
         if (C < (int64_t)r.cpc_lo * m->cus || (r.cpc_hi && C >= (int64_t)r.cpc_hi * m->cus)) continue;
-        if (r.store == ST_LDS && r.S == 1 && env_on("LOGREG_NO_MFMA_S1_LDS")) continue;
         if (r.s8 && mfma_variant_fits(m, 8, r.store, out)) return true;
         if (r.s8 && r.store == ST_LDS && r.cpc_lo < 16 && m->P == 8) continue;  // (the 8-chains-per-CU row is the 8-wave split's own)
         if (mfma_variant_fits(m, r.S, r.store, out)) return true;
@@ -167,18 +164,15 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
     long best_score = -1;
     if (hmc_bf16 && !for_eval && mode == LR_MODE_AUTO && group == 0 && plan_mfma_hmc(m, C, out)) return LR_OK;
     if (m->P > 32) {
-        // wide models (32 < p <= 128): only the stepwise engine exists; its partial kernel is an MFMA
-        // GEMM over blocks of 64 chains x row slices (lr_wide.h).
+        // wide models (32 < p <= 128): only the stepwise engine exists; its partial kernels are MFMA GEMMs over blocks of
+        // 64 / 128 chains x row slices (lr_wide_bf16.h; float64 models: lr_wide_f64.h).
         if (mode != LR_MODE_AUTO && mode != LR_MODE_STEPWISE)
             return fail(LR_ERR_UNSUPPORTED, "p=%d > 32 runs on the stepwise engine only (mode=%d requested)", m->p, mode);
         const int64_t cpb = wide_chains_per_block(m, C);
         const int64_t blocks = (C + cpb - 1) / cpb;
-        const char* env = std::getenv("LOGREG_WIDE_WG_PER_CU");  // tuning override
-        const int64_t tiles_at_2 = (m->n / 16) * blocks / (2LL * m->cus);
-        // bf16 kernels (48-64 KB of LDS: 2-3 workgroups per CU would fit): one per CU -- the fewest row
-        // slices -- measured fastest (8192 chains: 188 / 170 / 155 TFLOP/s at 1 / 2 / 3 per CU)
-        const int64_t per_cu = env && std::atoi(env) > 0 ? std::atoi(env)
-                               : (wide_engine(m, C) != 0 ? 1 : (tiles_at_2 >= kPlanConst.wide_fp32_two_per_cu_tiles ? 2 : 1));
+        // one workgroup per CU -- the fewest row slices -- measured fastest for the bf16 kernels (48-64 KB of LDS: 2-3 per CU
+        // would fit; 8192 chains: 188 / 170 / 155 TFLOP/s at 1 / 2 / 3 per CU)
+        const int64_t per_cu = 1;
         int64_t RS = (per_cu * m->cus + blocks - 1) / blocks;
         if (group > 0) RS = group;  // explicit slice count: pins the summation order whatever the chain count
         int64_t slice_len = (m->n + RS - 1) / RS;
@@ -293,15 +287,12 @@ InteriorPlan plan_interior(const lr_model* m, int64_t Cp) {
     int64_t slice_len_i = 0;
     // wide models, interior leapfrog steps with few chains: the row-split kernel (lr_wide_bf16.h) wants one chain
     // tile of 16 per workgroup and as many row slices as fill the chip; each slice a multiple of 128 rows
-    if (m->P > 32 && m->d_xblk1 && !env_on("LOGREG_WIDE_NO_ROWSPLIT")) {
+    if (m->P > 32 && m->d_xblk1) {
         const int64_t tiles = (Cp + 15) / 16;
-        const char* envt = std::getenv("LOGREG_WIDE_ROWSPLIT_MAX_TILES");  // tuning override
-        if (tiles <= (envt ? std::atoll(envt) : (long long)m->cus)) {
+        if (tiles <= (int64_t)m->cus) {
             int64_t want = m->cus / tiles;
             if (want < 1) want = 1;
-            const char* envw = std::getenv("LOGREG_WIDE_ROWSPLIT_WAVES");
-            rs_waves = envw ? std::atoi(envw) : 8;
-            if (rs_waves != 4) rs_waves = 8;
+            rs_waves = 8;  // (4 waves per workgroup measured slower at every chain count the row split is used for)
             const int64_t quantum = 32 * rs_waves;
             slice_len_i = ((m->n + want - 1) / want + quantum - 1) / quantum * quantum;
             RS_i = (int)((m->n + slice_len_i - 1) / slice_len_i);
@@ -327,7 +318,7 @@ InteriorPlan plan_interior(const lr_model* m, int64_t Cp) {
         // (and only when those slices still fill the chip: n=5000 p=30 at 1024 chains would get 5 slices x 16 blocks = 80
         //  workgroups and ran 13.5 -> 17.9 us per step; n=20 000 p=12: 17.8 -> 13.8, config 4: 29.7 -> 27.5)
         //  at 4096 chains the steps are long enough that the saved launch no longer shows: -3 .. +5 %, so up to 2048 chains)
-        if (!env_on("LOGREG_TALL_NO_MX16") && rs16 >= 1 && rs16 <= 16 && RS_i > rs16 && 4 * rs16 * blocks >= 3LL * m->cus && blocks <= 32) {
+        if (m->dbg.tall_mx16 && rs16 >= 1 && rs16 <= 16 && RS_i > rs16 && 4 * rs16 * blocks >= 3LL * m->cus && blocks <= 32) {
             RS_i = (int)rs16;
             slice_len_i = len16;
             rs_waves = 16;
@@ -336,31 +327,5 @@ InteriorPlan plan_interior(const lr_model* m, int64_t Cp) {
     return InteriorPlan{RS_i, slice_len_i, rs_waves};
 }
 
-
-// ---------------------------------------------------------------------------------------------------------------------------
-// Persistent row-split trajectory kernel for wide models (lr_wide_persist.h): slices S per group of 32 chains and 32-row blocks
-// per slice for Cp chains, or S = 0 when it does not apply: every (group, slice) workgroup must be resident at once (one per
-// CU), the slice's block images + 32 KB have to fit the LDS, and the grid should fill at least half the chip.
-struct PersistPlan { int S, nbs; };
-PersistPlan persist_plan(const lr_model* m, int64_t Cp) {
-    PersistPlan none{0, 0};
-    // OPT-IN (LOGREG_WIDE_PERSIST=1): built, measured and, at config 5, slower than a launch per step -- 12.8 vs 10.3 us per
-    // evaluation (tools/stamps_persist.py, us per step: row loop 3.5, the 8 waves' gradients through LDS 2.5 [128 KB of ds_write at
-    // ~79 B/clk], publish 0.9, poll 1.2, gather of the 8 slices' partials 3.1 [128 KB per workgroup through the ~15 B/clk a CU gets
-    // from beyond its L2], operand build 0.5).  Kept with its tests as the measured answer to "why not a persistent kernel".
-    if (m->P <= 32 || !m->d_xblk1 || !m->table->launch_tall_traj_rs || !m->h_xerr || !env_on("LOGREG_WIDE_PERSIST")) return none;
-    const int64_t groups = (Cp + 31) / 32;
-    if (groups > m->cus) return none;
-    const int nblk = (int)((m->n + 31) / 32);
-    int S = (int)(m->cus / groups);
-    if (S > 16) S = 16;
-    if (const char* e = std::getenv("LOGREG_WIDE_PERSIST_SLICES")) S = std::atoi(e);  // tuning override
-    if (S < 1 || S > 64 || groups * S > m->cus) return none;
-    if (S > nblk) S = nblk;
-    const int nbs = (nblk + S - 1) / S;
-    if (m->table->traj_rs_lds_bytes(nbs) > kLdsBudget) return none;
-    if (groups * S * 2 < m->cus) return none;
-    return PersistPlan{S, nbs};
-}
 
 }  // namespace

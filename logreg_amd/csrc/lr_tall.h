@@ -88,38 +88,13 @@ template <typename T, int P> struct TallArgs {
     int RS_i;               // row-split interior kernel (k_wide_partial_bf16r): slices, 0 = not used for this run
     int64_t slice_len_i;    //   and rows per slice (a multiple of 32 * rowsplit_waves: whole 32-row blocks per wave)
     int rowsplit_waves;     //   4 or 8 waves per workgroup (wide); 16: the 16-wave tall kernel k_tall_partial_mx16 is in use
-    // persistent row-split trajectory kernel (lr_wide_persist.h): slices per chain group, 32-row blocks per slice, the exchange
-    // buffer [2][groups][S][32][P] with its size, the step flags [groups][S] (zeroed before every launch), the time-out word
-    int traj_S, traj_nbs;
-    int traj_scatter;  // test switch: lay a group's slices out across the XCDs instead of within one (results must not change)
-    float* xch;
-    uint32_t xch_bytes;
-    uint32_t* xflags;
-    uint32_t* xerr;
     int p, l;
     T step;
     T a[P], b[P], c[P];
     StatsArgs stats;  // streaming statistics of the kept samples (lr_device.h); buf = null: off
-#ifdef LR_STAMPS  // development builds only (LOGREG_HIPCC_FLAGS=-DLR_STAMPS): per-wave time stamps of the partial kernels
-    unsigned long long* stamps;  // [launch slot][workgroup][16 waves][16]
-    int stamp_slot;
-    int dbg;  // experiment switches (LOGREG_DEBUG_EXP): timing experiments that knowingly break the results
-#endif
+    LR_STAMP_FIELDS  // development builds only (lr_stamps.h)
 };
 
-// LR_STAMP(a, k): lane 0 of every wave records the 100 MHz wall clock at point k < 8 of the kernel; LR_STAMP_CLK(a, k),
-// 8 <= k < 16: the shader clock (development builds only)
-#ifdef LR_STAMPS
-#define LR_STAMP_AT(a, k)                                                                                                    \
-    (a).stamps[((((size_t)(a).stamp_slot * (gridDim.x * gridDim.y) + blockIdx.y * gridDim.x + blockIdx.x) * 16) + (threadIdx.x >> 6)) * 16 + (k)]
-#define LR_STAMP(a, k) do { if ((a).stamps && (threadIdx.x & 63) == 0) LR_STAMP_AT(a, k) = __builtin_amdgcn_s_memrealtime(); } while (0)
-#define LR_STAMP_CLK(a, k) do { if ((a).stamps && (threadIdx.x & 63) == 0) LR_STAMP_AT(a, k) = __builtin_amdgcn_s_memtime(); } while (0)
-#define LR_DBG(a, bit) (((a).dbg >> (bit)) & 1)
-#else
-#define LR_DBG(a, bit) 0
-#define LR_STAMP(a, k) do { } while (0)
-#define LR_STAMP_CLK(a, k) do { } while (0)
-#endif
 
 // ---------------------------------------------------------------------------------------------
 // Workgroup = NW waves x 64 chains: wave w of the group takes the w-th sub-slice of the group's

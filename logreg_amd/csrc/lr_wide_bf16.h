@@ -39,7 +39,8 @@
 #pragma once
 #include <cstring>
 
-#include "lr_wide.h"
+#include "lr_mfma.h"
+#include "lr_tall.h"
 
 namespace lr {
 

@@ -161,6 +161,12 @@ class LogReg:
     def __repr__(self):
         return f"LogReg(n={self.n}, p={self.p}, dtype={np.dtype(self.np_dtype).name}, device={self.device})"
 
+    def debug_opts(self) -> str:
+        """The A/B switches this model was created with (LOGREG_DEBUG_OPTS, read once at creation): "" = the defaults."""
+        buf = C.create_string_buffer(128)
+        check(self._L.lr_model_debug_opts(self.handle, buf, 128))
+        return buf.value.decode()
+
     def plan(self, chains: int, group: int = 0, mode: str = "auto") -> dict:
         """Kernel variant the library will launch for `chains` chains."""
         m, g, r = C.c_int32(), C.c_int32(), C.c_int32()

@@ -98,6 +98,11 @@ LR_API void lr_model_destroy(lr_model *m) {
     free(m);
 }
 
+LR_API int lr_model_debug_opts(const lr_model *m, char *buf, int len) {
+    if (!m || !buf || len <= 0) return fail(LR_ERR_INVALID, "NULL argument / empty buffer");
+    buf[0] = 0; /* the double has no switches */
+    return LR_OK;
+}
 LR_API int lr_model_info(const lr_model *m, int64_t *n, int32_t *p, int32_t *dtype, int32_t *device, int32_t *padded_p) {
     if (!m) return fail(LR_ERR_INVALID, "model is NULL");
     if (n) *n = m->n;

@@ -25,7 +25,7 @@ int main() {
         m.P = padded_width(p);
         m.cus = cus;
         m.table = find_table(dtype, m.P);
-        if (!m.table || (m.P > 32 && dtype != LR_F32)) {
+        if (!m.table) {
             std::printf("ERR %d no kernels for dtype=%d padded p=%d\n", LR_ERR_UNSUPPORTED, dtype, m.P);
             continue;
         }

@@ -55,6 +55,13 @@ CASES = [
     # float64 (p <= 8: rows in registers as well; wider: LDS / global only)
     (200, 8, 4096, "hmc", "full", {"dtype": "float64", "mode": "reg", "group": 32, "rows_per_lane": 7}),
     (200, 12, 4096, "hmc", "full", {"dtype": "float64", "mode": "lds"}),
+    # float64 wide models: the stepwise engine on the f64 matrix pipe (lr_wide_f64.h), 64 chains per workgroup
+    (4096, 128, 1024, "hmc", "auto", {"dtype": "float64", "mode": "stepwise", "group": 16}),
+    (300, 100, 64, "mala", "auto", {"dtype": "float64", "mode": "stepwise"}),
+    # rows beyond the scalar cache, very many chains: the register tier keeps its rank whatever the modelled cost (the
+    # unbounded model term let lds / global variants overtake from ~98 304 chains, with no measurement behind the flip)
+    (800, 8, 1 << 17, "mala", "auto", {"mode": "reg"}), (800, 8, 1 << 19, "hmc", "full", {"mode": "reg"}),
+    (500, 16, 1 << 17, "mala", "auto", {"mode": "reg"}),
 ]
 
 

@@ -122,8 +122,6 @@ def test_model_closures_match_the_reference_at_other_shapes(la, name):
     beta = np.array(g["beta"])
     colsum = np.abs(X).sum(axis=0)
     for dtype, tol in (("float32", 2e-6), ("float64", 1e-11)):
-        if dtype == "float64" and g["p"] > 32:
-            continue  # wide models are float32 only (bf16 matrix pipe with exact three-piece splits)
         m = la.LogReg(X, y, np.array(g["pscale"]), dtype=dtype)
         r = m.eval(beta)
         for nm in ("ll", "lprior", "lpost"):

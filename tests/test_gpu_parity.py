@@ -315,21 +315,21 @@ def test_planner_engine_choice_by_size(la):
     assert la.device_count() >= 1
 
 
-@pytest.mark.parametrize("engine", ["bf16x3", "fp32"])
+@pytest.mark.parametrize("engine", ["bf16x3", "bf16x3_8waves"])
 @pytest.mark.parametrize("p,n,C", [(128, 1000, 70), (100, 513, 64), (40, 300, 130)])
 def test_wide_models_run_on_the_matrix_cores(la, p, n, C, engine, monkeypatch):
-    """32 < p <= 128: X.beta over a chain block is a dense GEMM -> fp32 MFMA partial kernel of the
-    stepwise engine (lr_wide.h).  fp32-in/fp32-accumulate MFMA is an exact fmaf chain, so the
-    tolerances are the fp32 ones."""
+    """32 < p <= 128: X.beta over a chain block is a dense GEMM -> the partial kernels of the stepwise engine on the bf16
+    matrix pipe with every fp32 operand split exactly into three bf16 pieces (lr_wide_bf16.h): results in the fp32
+    rounding class, so the tolerances are the fp32 ones.  Both workgroup shapes of the exact kernel (4 waves x 16 chains,
+    the default at these chain counts; 8 waves x 16 chains, LOGREG_DEBUG_OPTS wide_waves=8)."""
     from oracle.oracle import OracleModel
-    # default engine: bf16 matrix pipe with every fp32 operand split exactly into three bf16 pieces
-    # (lr_wide_bf16.h); LOGREG_WIDE_BF16=0: fp32-input MFMA (lr_wide.h).  Same tolerances for both.
-    monkeypatch.setenv("LOGREG_WIDE_BF16", "1" if engine == "bf16x3" else "0")
+    if engine == "bf16x3_8waves":
+        monkeypatch.setenv("LOGREG_DEBUG_OPTS", "wide_waves=8")  # read once, when the model is created
     X, y, _ = la.synthetic_logreg(n, p, seed=20240005 + p, beta_sd=0.1)
     ps = np.full(p, 1.5)
     orc = OracleModel(X, y, ps)
     m = la.LogReg(X, y, ps)
-    assert m.plan(C)["mode"] == "stepwise"
+    assert m.plan(C)["mode"] == "stepwise" and m.debug_opts() == ("" if engine == "bf16x3" else "residency_cap=1,tall_mx16=1,wide_traj=-1,wide_waves=8")
     rng = np.random.default_rng(p)
     b = 0.1 * rng.standard_normal((C, p))
     r = m.eval(b)
@@ -354,7 +354,7 @@ def test_wide_models_run_on_the_matrix_cores(la, p, n, C, engine, monkeypatch):
         assert np.max(np.abs(out[:, ok] - ref["out"][:, ok])) < 5e-4, kind
         again = la.mcmc(b, k, thin=1, iters=2, verb=False, seed=6, ll=ll0, chunk=1, precision="full")
         assert np.array_equal(out, again)
-        if kind == "hmc" and engine == "bf16x3":
+        if kind == "hmc":
             # default policy: interior leapfrog gradients in reduced precision (one-piece rows, two-piece beta).
             # The trajectory stays within ~1e-2 of the exact one, decisions agree away from near-ties, reruns and
             # chunked runs are bit-identical, and lr_eval (always exact) is untouched.
@@ -738,23 +738,22 @@ def test_plain_c_client_runs_the_reference_c_program(tmp_path):
     assert np.max(np.abs(zm)) < 3.0 and np.max(np.abs(zs)) < 3.0
 
 
-def test_wide_bf16_split_stays_in_the_fp32_error_class(la, monkeypatch):
-    """|bf16x3 - oracle| is of the size of |fp32 MFMA - oracle| (the split drops only 2^-24 terms)."""
+def test_wide_bf16_split_stays_in_the_fp32_error_class(la):
+    """The exact-split bf16 kernel drops only 2^-24 terms of every product: its error against the float64 oracle is of fp32
+    size, and the float64 wide engine (lr_wide_f64.h, f64 matrix pipe) sits at float64 size on the same inputs."""
     from oracle.oracle import OracleModel
     n, p, C = 2000, 128, 64
     X, y, _ = la.synthetic_logreg(n, p, seed=99, beta_sd=0.1)
     orc = OracleModel(X, y, np.ones(p))
-    m = la.LogReg(X, y, np.ones(p))
     b = 0.1 * np.random.default_rng(1).standard_normal((C, p))
     ref_lp, ref_g = orc.lpost(b), orc.glp(b)
     err = {}
-    for eng in ("1", "0"):
-        monkeypatch.setenv("LOGREG_WIDE_BF16", eng)
-        r = m.eval(b)
-        err[eng] = (np.max(np.abs(r["lpost"] - ref_lp) / np.abs(ref_lp)), np.max(np.abs(r["glp"] - ref_g)))
-    print("rel lpost err / abs grad err: bf16x3", err["1"], "fp32-mfma", err["0"])
-    assert err["1"][0] < 3e-6 and err["0"][0] < 3e-6
-    assert err["1"][1] < 3.0 * err["0"][1] + 1e-4
+    for dtype in ("float32", "float64"):
+        r = la.LogReg(X, y, np.ones(p), dtype=dtype).eval(b)
+        err[dtype] = (np.max(np.abs(r["lpost"] - ref_lp) / np.abs(ref_lp)), np.max(np.abs(r["glp"] - ref_g)))
+    print("rel lpost err / abs grad err: bf16x3", err["float32"], "f64 mfma", err["float64"])
+    assert err["float32"][0] < 3e-6 and err["float32"][1] < 2e-4 * np.sqrt(n)
+    assert err["float64"][0] < 1e-13 and err["float64"][1] < 1e-10
 
 
 def test_randomised_parity_fuzz():
@@ -833,7 +832,7 @@ def test_wide_many_chains_use_the_chain_split_interior_kernel(la, engine, monkey
     A 64-chain subset against the oracle: decisions away from near-ties, trajectories within the reduced-precision
     tolerance; exact mode at the exact tolerance; reruns bit-identical."""
     from oracle.oracle import OracleModel
-    monkeypatch.setenv("LOGREG_WIDE_NO_TRAJ" if engine == "chain_split" else "LOGREG_WIDE_TRAJ", "1")
+    monkeypatch.setenv("LOGREG_DEBUG_OPTS", "wide_traj=0" if engine == "chain_split" else "wide_traj=1")  # read at model creation
     n, p, C = 700, 64, 4200
     X, y, _ = la.synthetic_logreg(n, p, seed=77, beta_sd=0.1)
     ps = np.full(p, 1.5)
@@ -1035,49 +1034,11 @@ def test_tall_sixteen_wave_interior_kernel_with_the_update_folded_in(la, n, p, L
     assert np.array_equal(info["accepts"][:64][ok], ref["accepts"][ok].astype(np.uint32))
     assert np.max(np.abs(out[:, :64][:, ok] - ref["out"][:, ok])) < 3e-2 / np.sqrt(n) + 1e-5
     assert np.array_equal(out, la.mcmc(b, k, thin=1, iters=2, verb=False, seed=9, chunk=1))
-    monkeypatch.setenv("LOGREG_TALL_NO_MX16", "1")
-    old, oi = la.mcmc(b, k, thin=1, iters=2, verb=False, seed=9, return_info=True)
+    monkeypatch.setenv("LOGREG_DEBUG_OPTS", "tall_mx16=0")  # read once per model: a second model runs the 4-wave form
+    m4 = la.LogReg(X, y, ps)
+    k4 = la.hmcKernel(m4.lpost, m4.glp, eps=eps, l=L, dmm=np.ones(p))
+    old, oi = la.mcmc(b, k4, thin=1, iters=2, verb=False, seed=9, return_info=True)
     assert not np.array_equal(old, out)  # (other slice count, other summation order: the 16-wave kernel did run above)
-    same = oi["accepts"] == info["accepts"]
-    assert same.mean() > 0.99
-    assert np.max(np.abs(old[:, same] - out[:, same])) < 1e-3 / np.sqrt(n)
-
-
-@pytest.mark.parametrize("n,p,C,L", [(2048, 128, 1024, 5), (1500, 100, 1000, 4), (4100, 50, 1024, 3), (4096, 128, 1024, 6)])
-def test_wide_persistent_row_split_trajectory_kernel(la, n, p, C, L, monkeypatch):
-    """k_wide_traj_rs (lr_wide_persist.h; opt-in with LOGREG_WIDE_PERSIST=1 -- it lost to the launch-per-step path at config 5,
-    12.8 vs 10.3 us per evaluation, and is kept as that measurement; wide models from half a chip of chain groups): the L - 1 interior steps
-    of a trajectory in ONE launch, row slices resident in LDS, the slices' partial gradients handed between the resident
-    workgroups through device memory once per step.  Against the float64 oracle at the reduced-precision tolerance (64-chain
-    subset, decisions away from near-ties), against the launch-per-step path (same posterior arithmetic class, other
-    summation order), bit-exact reruns / chunking / shards planned for the whole run, ragged last chain group (C = 1000),
-    p padded to 128 and to 64, and -- the hand-off protocol may not depend on placement -- identical results when the
-    chain groups are laid out ACROSS the XCDs instead of within one."""
-    from oracle.oracle import OracleModel
-    X, y, _ = la.synthetic_logreg(n, p, seed=n + p, beta_sd=0.4 / np.sqrt(p))
-    ps = np.full(p, 2.0)
-    orc = OracleModel(X, y, ps)
-    m = la.LogReg(X, y, ps)
-    b = 0.02 * np.random.default_rng(L).standard_normal((C, p))
-    eps = 0.4 / np.sqrt(n)
-    k = la.hmcKernel(m.lpost, m.glp, eps=eps, l=L, dmm=np.ones(p))
-    ref = orc.run("hmc", b[:64], step=eps, l=L, scale=np.ones(p), thin=1, iters=2, seed=9, threads=0)
-    monkeypatch.setenv("LOGREG_WIDE_PERSIST", "1")
-    out, info = la.mcmc(b, k, thin=1, iters=2, verb=False, seed=9, return_info=True)
-    assert info["plan"]["mode"] == "stepwise" and np.all(np.isfinite(out))
-    ok = ref["margin"] > 0.1
-    assert ok.mean() > 0.5
-    assert np.array_equal(info["accepts"][:64][ok], ref["accepts"][ok].astype(np.uint32))
-    assert np.max(np.abs(out[:, :64][:, ok] - ref["out"][:, ok])) < 3e-2 / np.sqrt(n) + 1e-5
-    assert np.array_equal(out, la.mcmc(b, k, thin=1, iters=2, verb=False, seed=9, chunk=1))
-    lo, hi = 96, 192
-    assert np.array_equal(out[:, lo:hi], la.mcmc(b[lo:hi], k, thin=1, iters=2, verb=False, seed=9, chain_offset=lo, plan_chains=C))
-    monkeypatch.setenv("LOGREG_WIDE_PERSIST_SCATTER", "1")  # groups across XCDs: a speed matter only
-    assert np.array_equal(out, la.mcmc(b, k, thin=1, iters=2, verb=False, seed=9))
-    monkeypatch.delenv("LOGREG_WIDE_PERSIST_SCATTER")
-    monkeypatch.delenv("LOGREG_WIDE_PERSIST")
-    old, oi = la.mcmc(b, k, thin=1, iters=2, verb=False, seed=9, return_info=True)
-    assert not np.array_equal(old, out)  # (the persistent kernel did run above)
     same = oi["accepts"] == info["accepts"]
     assert same.mean() > 0.99
     assert np.max(np.abs(old[:, same] - out[:, same])) < 1e-3 / np.sqrt(n)

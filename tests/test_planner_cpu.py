@@ -29,7 +29,7 @@ def harness(tmp_path_factory):
     subprocess.run([hipcc, "--offload-arch=gfx950", "-O1", "-g", "-std=c++17", *san, *inc, "-c", os.path.join(REPO, "tests", "host", "plan_harness.hip"),
                     "-o", obj], check=True, capture_output=True)
     objs = sorted(os.path.join(b.OBJDIR, f) for f in os.listdir(b.OBJDIR) if f.startswith("lr_inst_") and f.endswith(".o"))
-    assert len(objs) == 10
+    assert len(objs) == 12
     subprocess.run([hipcc, "--offload-arch=gfx950", *san[:2], obj, *objs, "-o", exe], check=True, capture_output=True)
 
     def ask(requests, cus=256):

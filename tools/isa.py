@@ -11,7 +11,7 @@ out = f"/tmp/lr_{dt}_p{p}.s"
 if rest[:1] == ["-o"]:
     out, rest = rest[1], rest[2:]
 if p > 32:
-    cmd = [B._hipcc(), *B.COMMON, f"-DLR_P={p}", f"-DLR_SFX={dt}_p{p}", os.path.join(B.CSRC, "lr_inst_wide.hip")]
+    cmd = [B._hipcc(), *B.COMMON, f"-DLR_P={p}", f"-DLR_SFX={dt}_p{p}", f"-DLR_DTYPE={0 if dt == 'f32' else 1}", os.path.join(B.CSRC, "lr_inst_wide.hip")]
 else:
     cmd = [B._hipcc(), *B.COMMON, f"-DLR_T={'float' if dt == 'f32' else 'double'}", f"-DLR_P={p}", f"-DLR_SFX={dt}_p{p}",
            f"-DLR_DTYPE={0 if dt == 'f32' else 1}", os.path.join(B.CSRC, "lr_inst.hip")]
