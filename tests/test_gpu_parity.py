@@ -1042,3 +1042,42 @@ def test_tall_sixteen_wave_interior_kernel_with_the_update_folded_in(la, n, p, L
     same = oi["accepts"] == info["accepts"]
     assert same.mean() > 0.99
     assert np.max(np.abs(old[:, same] - out[:, same])) < 1e-3 / np.sqrt(n)
+
+
+@pytest.mark.parametrize("p,n,C", [(128, 1000, 70), (100, 513, 64), (40, 300, 130)])
+def test_float64_wide_models_run_on_the_f64_matrix_pipe(la, p, n, C):
+    """LogReg(dtype="float64") at 32 < p <= 128 -- the arithmetic the reference computes in (fit-np-hmc.py:17-19) at config 5's
+    width -- runs the stepwise engine with its partial kernel on v_mfma_f64_16x16x4_f64 (lr_wide_f64.h): closures at float64
+    tolerances, two iterations of every kernel step for step with the float64 oracle on the shared Philox stream (free-running:
+    same decisions, states to 1e-9), reruns / chunks / shards bit-identical.  No precision policy applies to float64 models."""
+    from oracle.oracle import OracleModel
+    X, y, _ = la.synthetic_logreg(n, p, seed=20240005 + p, beta_sd=0.1)
+    ps = np.full(p, 1.5)
+    orc = OracleModel(X, y, ps)
+    m = la.LogReg(X, y, ps, dtype="float64")
+    assert m.plan(C)["mode"] == "stepwise"
+    b = 0.1 * np.random.default_rng(p).standard_normal((C, p))
+    r = m.eval(b)
+    for nm in ("ll", "lprior", "lpost"):
+        np.testing.assert_allclose(r[nm], getattr(orc, nm)(b), rtol=1e-12)
+    assert np.max(np.abs(r["glp"] - orc.glp(b)) / np.abs(X).sum(axis=0)) < 1e-13
+    assert isinstance(m.lpost(b[0]), float) and m.glp(b[0]).shape == (p,)
+    eps, L = 0.02, 6
+    for kind, kw in (("hmc", dict(step=eps, l=L, scale=np.ones(p))), ("mala", dict(step=1e-3, scale=np.ones(p))),
+                     ("rwmh", dict(scale=np.full(p, 0.02))), ("ul", dict(step=1e-3, scale=np.ones(p)))):
+        k = {"hmc": lambda: la.hmcKernel(m.lpost, m.glp, eps=eps, l=L, dmm=np.ones(p)),
+             "mala": lambda: la.malaKernel(m.lpost, m.glp, dt=1e-3, pre=np.ones(p)),
+             "rwmh": lambda: la.mhKernel(m.lpost, la.rwProposal(np.full(p, 0.02))),
+             "ul": lambda: la.ulKernel(m.glp, dt=1e-3, pre=np.ones(p))}[kind]()
+        ll0 = orc.lpost(b) if kind in ("mala", "rwmh") else None
+        ref = orc.run(kind, b, thin=1, iters=2, seed=6, ll_state=ll0, threads=0, **kw)
+        out, info = la.mcmc(b, k, thin=1, iters=2, verb=False, seed=6, ll=ll0, return_info=True)
+        ok = ref["margin"] > 1e-8
+        assert ok.all(), kind
+        assert np.array_equal(info["accepts"], ref["accepts"].astype(np.uint32)), kind
+        assert np.max(np.abs(out - ref["out"])) < 1e-9, kind
+        assert np.array_equal(out, la.mcmc(b, k, thin=1, iters=2, verb=False, seed=6, ll=ll0, chunk=1))
+        lo, hi = 16, 48
+        sub = la.mcmc(b[lo:hi], k, thin=1, iters=2, verb=False, seed=6, ll=None if ll0 is None else ll0[lo:hi], chain_offset=lo,
+                      mode="stepwise", group=info["plan"]["group"])
+        assert np.array_equal(sub, out[:, lo:hi]), kind
