@@ -735,7 +735,9 @@ __device__ __forceinline__ void pair_term(const f32x2 (&q)[P], const f32x2 (&bb)
         ts = __builtin_elementwise_fma(q[j], bb[j / 2], ts);
         ts = __builtin_elementwise_fma(q[j + 1], __builtin_shufflevector(bb[j / 2], bb[j / 2], 1, 0), ts);
     }
-    if constexpr (VALUE) ts = f2{__builtin_fminf(ts.x, 100.0f), __builtin_fminf(ts.y, 100.0f)};
+    // (the per-row form clamps ts so that 2^ts stays finite; the product form needs no clamp: an overflowing factor makes the lane's
+    //  product infinite, which the caller detects and answers with the per-row form -- one v_min per row saved on the fast path)
+    if constexpr (VALUE && !PROD) ts = f2{__builtin_fminf(ts.x, 100.0f), __builtin_fminf(ts.y, 100.0f)};
     const f2 d = f2{ExpScale<float>::exp_scaled(ts.x), ExpScale<float>::exp_scaled(ts.y)} + f2{1.0f, 1.0f};
     if constexpr (GRAD) {
         const f2 w = {fast_rcp(d.x), fast_rcp(d.y)};  // sigma(-t); exp overflow -> rcp(inf) = 0
@@ -756,7 +758,7 @@ __device__ __forceinline__ void pair_term(const f32x2 (&q)[P], const f32x2 (&bb)
 // all rows of a RegRowPairs lane: gradient partial sums into gp[P/2] = (g_j, g_{j+1}) pairs, value into v.
 // The value of a lane's rows is sum_i (ts_i - log2(1 + 2^ts_i)) = sum_i ts_i - log2(prod_i (1 + 2^ts_i)): the rows sit in registers, so
 // the product of the lane's <= 16 factors replaces all but two of its quarter-rate v_log by full-rate multiplies (MALA at 13 rows
-// per lane: 39 -> 28 transcendentals per lane and iteration).  Every factor is >= 1 and <= 1 + 2^100 (ts is clamped), so the
+// per lane: 39 -> 28 transcendentals per lane and iteration).  Every factor is >= 1 (ts is NOT clamped on this path), so the
 // product can only fail by OVERFLOW (positive logits summing beyond ~127 in one lane); a lane whose product overflowed takes the
 // per-row form instead -- a per-LANE select, so a chain's value never depends on which chains share its wave; the per-row pass
 // itself runs (wave-uniformly) only when some lane needs it.  Same cancellation class as the per-row form: ulp(sum ts) per lane.
@@ -780,7 +782,7 @@ __device__ __forceinline__ void row_pairs_eval(const RegRowPairs<P, R, G>& rows,
 #pragma unroll
         for (int j = 1; j < P / 2; ++j) acc = __builtin_elementwise_fma(rows.s[j], bb[j], acc);
         float ts = acc.x + acc.y;
-        if constexpr (VALUE) ts = __builtin_fminf(ts, 100.0f);
+        if constexpr (VALUE && !PROD) ts = __builtin_fminf(ts, 100.0f);
         const float d = 1.0f + ExpScale<float>::exp_scaled(ts);
         if constexpr (GRAD) {
             const float w = fast_rcp(d);
@@ -804,7 +806,10 @@ __device__ __forceinline__ void row_pairs_eval(const RegRowPairs<P, R, G>& rows,
 #pragma unroll
             for (int k = 0; k < RegRowPairs<P, R, G>::RP; ++k) pair_term<P, true, false, false>(rows.q[k], bb, g0, h0, va);
             float vo = 0.0f;
-            if constexpr (RegRowPairs<P, R, G>::ODD) vo = ts_odd - __builtin_amdgcn_logf(1.0f + ExpScale<float>::exp_scaled(ts_odd));
+            if constexpr (RegRowPairs<P, R, G>::ODD) {
+                const float tc = __builtin_fminf(ts_odd, 100.0f);
+                vo = tc - __builtin_amdgcn_logf(1.0f + ExpScale<float>::exp_scaled(tc));
+            }
             const float safe = (va.x + va.y) + vo;
             val = bad ? safe : val;
         }

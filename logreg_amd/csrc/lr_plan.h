@@ -157,7 +157,8 @@ bool plan_mfma_hmc(const lr_model* m, int64_t C, Plan* out) {
 // smallest available G that still gives every SIMD a wavefront (C*G/64 >= 4*CUs), else the largest; an explicit `group`
 // request is honoured exactly.
 // `hmc_bf16`: the run is HMC and its interior leapfrog gradients may use the bf16 matrix pipe (LR_PREC_AUTO / BF16)
-int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool for_eval = false, bool hmc_bf16 = false) {
+// `kind`: LR_KIND_* of the run, -1 = not a run of a known family (lr_plan, lr_eval)
+int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool for_eval = false, bool hmc_bf16 = false, int kind = -1) {
     const lr::InstTable* t = m->table;
     const int64_t want_waves = 4LL * m->cus;
     int best = -1;
@@ -225,6 +226,9 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
         }
         if (mode != LR_MODE_AUTO && v.mode != mode) continue;
         if (group != 0 && v.G != group) continue;
+        // 8 lanes per chain exists for the threaded-ll kernels only (k_chain_rs8: MALA / RWMH, float32, padded p = 8), and only on
+        // request (group = 8): by instruction count it does not beat 16 lanes per chain (lr_chain8.h)
+        if (v.mode == lr::MODE_REG && v.G == 8 && (for_eval || group != 8 || (kind != LR_KIND_RWMH && kind != LR_KIND_MALA))) continue;
         if (v.mode == lr::MODE_REG && (int64_t)v.G * v.R < m->n) continue;
         if (v.mode == lr::MODE_LDS && (size_t)m->n * m->P * m->esize() > kLdsBudget) continue;
         // score: residency tier first (REG > LDS > GLOBAL), then group fitness, then fewer padded rows

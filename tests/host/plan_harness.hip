@@ -38,7 +38,7 @@ int main() {
         m.d_xblk = m.d_xblk1 = im.wide ? yes : nullptr;
         Plan pl{};
         int rc = check_group_for(&m, group, mode);
-        if (rc == LR_OK) rc = make_plan(&m, chains, group, mode, &pl, false, kind == LR_KIND_HMC && prec != LR_PREC_FULL);
+        if (rc == LR_OK) rc = make_plan(&m, chains, group, mode, &pl, false, kind == LR_KIND_HMC && prec != LR_PREC_FULL, kind);
         if (rc != LR_OK) std::printf("ERR %d %s\n", rc, g_err);
         else {
             const InteriorPlan ip = plan_interior(&m, chains);

@@ -151,26 +151,28 @@ def test_single_hmc_iteration_every_variant(la, models, oracle_model, map_beta, 
     assert np.max((np.abs(out - ref["out"][0]) / POST_SD)[clear]) < 1e-3
 
 
+@pytest.mark.parametrize("group", [16, 8])
 @pytest.mark.parametrize("kind", ["mala", "rwmh"])
-def test_distributed_state_kernel_for_mala_and_rwmh(la, models, oracle_model, map_beta, kind):
+def test_distributed_state_kernel_for_mala_and_rwmh(la, models, oracle_model, map_beta, kind, group):
     """reg / 16 lanes per chain, MALA and RWMH: k_chain_rs16 keeps a chain's state distributed over its lanes for the
-    whole launch (what AUTO runs from 4096 chains).  Step-level parity, threaded ll, -inf start, invariances."""
+    whole launch (what AUTO runs from 4096 chains); reg / 8 lanes per chain: k_chain_rs8 (lr_chain8.h: 8 chains per wave, 12 of a
+    lane's 25 rows in registers and 13 in LDS; on request only).  Step-level parity, threaded ll, -inf start, invariances."""
     C = 130
     rng = np.random.default_rng(29)
     q0 = (map_beta + 0.7 * POST_SD * rng.standard_normal((C, 8))).astype(np.float32).astype(np.float64)
     ll0 = oracle_model.lpost(q0)
     for it in (0, 4, 2**33 + 7):  # 4: the fifth iteration of a generator refill; 2^33: high word of the counter
         ref = oracle_model.run(kind, q0, thin=1, iters=1, seed=5, iter_offset=it, ll_state=ll0, threads=0, **KW[kind])
-        out, acc, llo = one_step(la, models["float32"], kind, q0, 5, it, ll=ll0, group=16, mode="reg")
+        out, acc, llo = one_step(la, models["float32"], kind, q0, 5, it, ll=ll0, group=group, mode="reg")
         clear = ref["margin"] > 1e-3
         assert clear.mean() > 0.9
         assert np.array_equal(acc[clear], ref["accepts"][clear].astype(np.uint32))
         assert np.max((np.abs(out - ref["out"][0]) / POST_SD)[clear]) < 1e-3
         np.testing.assert_allclose(llo[clear], ref["ll"][clear], rtol=2e-5)
     k = make_kernel(la, models["float32"], kind)
-    kw = dict(thin=7, iters=6, verb=False, seed=3, group=16, mode="reg")
+    kw = dict(thin=7, iters=6, verb=False, seed=3, group=group, mode="reg")
     full, info = la.mcmc(q0, k, return_info=True, **kw)  # ll = -inf: the first proposal is accepted (fit-np-mala.py:82)
-    assert np.all(info["accepts"] >= 1)
+    assert np.all(info["accepts"] >= 1) and info["plan"] == {"mode": "reg", "group": group, "rows_per_lane": 13 if group == 16 else 25}
     assert np.array_equal(full, la.mcmc(q0, k, chunk=4, **kw))
     a = la.mcmc(q0[:50], k, **kw)
     b = la.mcmc(q0[50:], k, chain_offset=50, **kw)

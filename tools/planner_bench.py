@@ -25,7 +25,7 @@ SHAPES = [
     (200, 8, 8192, "mala", "auto"), (200, 8, 3072, "mala", "auto"),
 ]
 # forced alternatives tried for every shape (those the library rejects for the shape are skipped)
-ALTERNATIVES = [("reg", 16), ("reg", 32), ("reg", 64), ("lds", 1), ("lds", 8), ("lds", 64), ("global", 1), ("mfma", 1), ("mfma", 4), ("mfma", 8),
+ALTERNATIVES = [("reg", 8), ("reg", 16), ("reg", 32), ("reg", 64), ("lds", 1), ("lds", 8), ("lds", 64), ("global", 1), ("mfma", 1), ("mfma", 4), ("mfma", 8),
                 ("stepwise", 0)]
 
 
@@ -56,6 +56,8 @@ def candidates(n, p, C, kind, precision, L=20):
     eps = 0.9 / np.sqrt(np.max(np.linalg.eigvalsh(info["hessian"]))) / p ** 0.25
     if kind == "hmc":
         k, thin = la.hmcKernel(m.lpost, m.glp, eps=eps, l=L, dmm=np.ones(p)), 5
+    elif kind == "rwmh":
+        k, thin = la.mhKernel(m.lpost, la.rwProposal(0.3 * eps * np.ones(p))), 100
     else:
         k, thin = la.malaKernel(m.lpost, m.glp, dt=eps * eps, pre=np.ones(p)), 100
     q0 = bmap + info["sd"] * np.random.default_rng(1).standard_normal((C, p))
