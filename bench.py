@@ -708,7 +708,7 @@ def main(argv=None):
         def rerun(r):
             k = min(CHECK_CHAINS, C)
             c2 = la.ChainSet(kern, headline_init(r, C)[:k], seed=SEED, chain_offset=r * C, group=a.group, mode=a.mode,
-                             stream=stream, precision=a.precision, plan_chains=C)
+                             stream=stream, precision=a.precision, plan_chains=C, plan_first=r * C)
             for _ in range(launches_before[r]):
                 c2.advance(1, THIN, keep=False)
             buf = la.DeviceArray(dev, (a.steps, k, N_PAR), np.float32)

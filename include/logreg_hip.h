@@ -85,6 +85,11 @@ typedef struct lr_run_opts {
                            * run's chain count, so that every choice that depends on the chain count (kernel variant, row
                            * slicing of the stepwise engine and of its interior kernels, trajectory kernels) is the one-GPU
                            * run's and the shard's output is bit-identical to the same chains of that run */
+    int64_t plan_first;   /* read only when plan_chains > 0: global id (chain_offset units) of the FIRST chain of the run being
+                           * planned for.  A run planned in two parts (lr_plan_info.split: an exactly-filled head on narrow lane
+                           * groups, the remainder on wide ones) assigns a chain to its part by its position in the WHOLE run,
+                           * chain_offset + c - plan_first, so a shard needs to know where the run starts.  0 for a run whose
+                           * chains are numbered from 0 (logreg_amd.distributed.mcmc_sharded). */
 } lr_run_opts;
 
 /*
@@ -226,6 +231,20 @@ LR_API int lr_plan(const lr_model* m, int64_t n_chains, int32_t group, int32_t m
 enum { LR_KIND_RWMH = 0, LR_KIND_MALA = 1, LR_KIND_HMC = 2, LR_KIND_UL = 3 };
 LR_API int lr_plan_run(const lr_model* m, int32_t kind, const lr_run_opts* opts, int32_t* mode_out, int32_t* group_out,
                        int32_t* rows_out);
+/*
+ * The same plan in full.  Chain counts between the ones that fill the chip exactly lose to wave quantisation (5120 chains on 16
+ * lanes per chain: two waves on a quarter of the SIMDs, one on the rest, and the launch takes the time of 8192): the planner then
+ * splits a run of register-resident kernels in TWO launches -- chains [0, split) of the run on (group, rows), the exactly-filled
+ * head; chains [split, n) on (tail_group, tail_rows), wider lane groups that finish the remainder in one short launch.
+ * split = 0: one part (every field of the tail is 0).  A chain's variant is a function of its position in the planned run
+ * (lr_run_opts.plan_chains / plan_first), so chunked and sharded runs reproduce the one-launch-sequence run bit for bit.
+ */
+typedef struct lr_plan_info {
+    int32_t mode, group, rows;     /* as lr_plan_run */
+    int32_t tail_group, tail_rows; /* the remainder's variant (mode is the same) */
+    int64_t split;                 /* chains of the planned run in the first part; 0 = no second part */
+} lr_plan_info;
+LR_API int lr_plan_run_info(const lr_model* m, int32_t kind, const lr_run_opts* opts, lr_plan_info* out);
 
 /* device memory + stream + event helpers so a host language needs no other GPU runtime */
 LR_API int lr_malloc(int device, uint64_t bytes, void** dptr);

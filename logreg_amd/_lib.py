@@ -29,7 +29,12 @@ class RunOpts(C.Structure):
                 ("iter_offset", C.c_int64), ("seed", C.c_uint64), ("group", C.c_int32), ("mode", C.c_int32),
                 ("on_device", C.c_int32), ("stream", C.c_void_p),
                 ("stats", C.c_void_p), ("stats_batch", C.c_int64), ("stats_first", C.c_int64), ("stats_slots", C.c_int64),
-                ("precision", C.c_int32), ("plan_chains", C.c_int32)]
+                ("precision", C.c_int32), ("plan_chains", C.c_int32), ("plan_first", C.c_int64)]
+
+
+class PlanInfo(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("group", C.c_int32), ("rows", C.c_int32), ("tail_group", C.c_int32), ("tail_rows", C.c_int32),
+                ("split", C.c_int64)]
 
 
 # name -> (restype, argtypes); every symbol include/logreg_hip.h declares
@@ -54,6 +59,7 @@ SYMBOLS = {
     "lr_hessian": (C.c_int, [_vp, _vp, _dp, _vp, _vp, _vp]),
     "lr_stats_reduce": (C.c_int, [C.c_int, _vp, _i64, _i32, _i64, _i64, _vp, _vp, _vp]),
     "lr_plan_run": (C.c_int, [_vp, _i32, _op, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
+    "lr_plan_run_info": (C.c_int, [_vp, _i32, _op, C.c_void_p]),
     "lr_plan": (C.c_int, [_vp, _i64, _i32, _i32, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
     "lr_malloc": (C.c_int, [C.c_int, _u64, C.POINTER(_vp)]),
     "lr_free": (C.c_int, [C.c_int, _vp]),

@@ -36,6 +36,9 @@ int check_opts(const lr_model* m, const lr_run_opts* o, bool run) {
     if (!o) return fail(LR_ERR_INVALID, "opts is NULL");
     if (o->n_chains <= 0) return fail(LR_ERR_INVALID, "n_chains must be positive (got %lld)", (long long)o->n_chains);
     if (o->plan_chains < 0) return fail(LR_ERR_INVALID, "plan_chains must be 0 (= n_chains) or positive (got %d)", o->plan_chains);
+    if (o->plan_chains > 0 && run && (o->plan_first < 0 || o->plan_first > o->chain_offset || o->chain_offset + o->n_chains > o->plan_first + o->plan_chains))
+        return fail(LR_ERR_INVALID, "chains [%lld, %lld) are not inside the planned run [%lld, %lld) (plan_first, plan_chains)", (long long)o->chain_offset,
+                    (long long)(o->chain_offset + o->n_chains), (long long)o->plan_first, (long long)(o->plan_first + o->plan_chains));
     if (const int rcg = check_group_for(m, o->group, o->mode)) return rcg;
     if (run) {
         if (o->thin <= 0 || o->iters < 0) return fail(LR_ERR_INVALID, "thin must be > 0 and iters >= 0");
@@ -343,6 +346,18 @@ int lr_plan(const lr_model* m, int64_t n_chains, int32_t group, int32_t mode, in
     if (mode_out) *mode_out = pl.mode;
     if (group_out) *group_out = pl.G;
     if (rows_out) *rows_out = pl.R;
+    return LR_OK;
+}
+
+int lr_plan_run_info(const lr_model* m, int32_t kind, const lr_run_opts* o, lr_plan_info* out) {
+    if (!out) return fail(LR_ERR_INVALID, "out is NULL");
+    int rc = check_opts(m, o, false);
+    if (rc) return rc;
+    if (kind < LR_KIND_RWMH || kind > LR_KIND_UL) return fail(LR_ERR_INVALID, "kind must be one of LR_KIND_*");
+    Plan pl;
+    rc = make_plan(m, plan_count(o), o->group, o->mode, &pl, false, kind == LR_KIND_HMC && o->precision != LR_PREC_FULL, kind);
+    if (rc) return rc;
+    *out = lr_plan_info{pl.mode, pl.G, pl.R, pl.G2, pl.R2, pl.split};
     return LR_OK;
 }
 

@@ -75,10 +75,18 @@ int do_chain_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs, c
     }
     ca.stats = lr::StatsArgs{o->stats, o->stats_batch, o->stats_first};
     ca.interior_bf16 = rs.kind == lr::KIND_HMC && pl.mode == lr::MODE_MFMA && o->precision != LR_PREC_FULL;
-    lr::LaunchCfg cfg{pl.mode, pl.G, pl.R, rs.kind, st, pl.lds_bytes, m->dbg.residency_cap ? m->cus : 0};
-    const int rc = m->table->launch_chain(&cfg, o->n_chains, &ma, &ca);
-    if (rc != 0) return fail(rc == -3 ? LR_ERR_UNSUPPORTED : LR_ERR_HIP, "chain launch failed (%d): %s", rc,
-                             hipGetErrorString(hipGetLastError()));
+    // a plan in two parts: chains whose position in the PLANNED run is below pl.split go to (G, R), the rest to (G2, R2)
+    const int64_t C = o->n_chains, pos0 = o->plan_chains > 0 ? o->chain_offset - o->plan_first : 0;
+    const int64_t head = pl.split > 0 ? (pl.split - pos0 < 0 ? 0 : (pl.split - pos0 > C ? C : pl.split - pos0)) : C;
+    for (int part = 0; part < 2; ++part) {
+        ca.first = part == 0 ? 0 : head;
+        ca.count = part == 0 ? head : C - head;
+        if (ca.count <= 0) continue;
+        lr::LaunchCfg cfg{pl.mode, part == 0 ? pl.G : pl.G2, part == 0 ? pl.R : pl.R2, rs.kind, st, pl.lds_bytes, m->dbg.residency_cap ? m->cus : 0};
+        const int rc = m->table->launch_chain(&cfg, ca.count, &ma, &ca);
+        if (rc != 0) return fail(rc == -3 ? LR_ERR_UNSUPPORTED : LR_ERR_HIP, "chain launch failed (%d): %s", rc,
+                                 hipGetErrorString(hipGetLastError()));
+    }
     return LR_OK;
 }
 

@@ -9,9 +9,6 @@
 #if LR_DTYPE == 0 && LR_P >= 8
 #include "lr_tall_mx.h"
 #endif
-#if LR_DTYPE == 0 && LR_P == 8
-#include "lr_chain8.h"
-#endif
 
 #ifndef LR_T
 #error "compile with -DLR_T=<float|double> -DLR_P=<4|8|16|32> -DLR_SFX=<suffix> -DLR_DTYPE=<0|1>"
@@ -66,18 +63,9 @@ constexpr int P = LR_P;
 #define LR_MFMA_VARIANTS(X)
 #endif
 
-// 8 lanes per chain, 25 rows per lane (12 of them in registers, 13 in LDS): MALA / RWMH only (k_chain_rs8, lr_chain8.h) -- outside
-// LR_VARIANTS, so that no generic kernel is instantiated for it; the planner offers it to those two families only
-#if LR_DTYPE == 0 && LR_P == 8
-constexpr int kRs8Rows = 25, kRs8RegPairs = 6;
-#define LR_RS8_ROW {MODE_REG, 8, kRs8Rows},
-#else
-#define LR_RS8_ROW
-#endif
-
 #define LR_VARIANT_ROW(M_, G_, R_) {M_, G_, R_},
 #define LR_MFMA_ROW(S_, N_) {MODE_MFMA, S_, N_},
-const Variant kVariants[] = {LR_VARIANTS(LR_VARIANT_ROW) LR_RS8_ROW LR_MFMA_VARIANTS(LR_MFMA_ROW)};
+const Variant kVariants[] = {LR_VARIANTS(LR_VARIANT_ROW) LR_MFMA_VARIANTS(LR_MFMA_ROW)};
 
 inline int check(hipError_t e) { return e == hipSuccess ? 0 : -2; }
 
@@ -167,14 +155,6 @@ int launch_eval(const LaunchCfg* cfg, int64_t C, const void* model_args, const v
 int launch_chain(const LaunchCfg* cfg, int64_t C, const void* model_args, const void* chain_args) {
     const auto& m = *static_cast<const ModelArgs<T, P>*>(model_args);
     const auto& a = *static_cast<const ChainArgs<T, P>*>(chain_args);
-#if LR_DTYPE == 0 && LR_P == 8
-    if (cfg->mode == MODE_REG && cfg->G == 8 && cfg->R == kRs8Rows) {
-        const dim3 grid = grid_for(C, 8), block(256);
-        if (cfg->kind == KIND_RWMH) return launch_capped<&k_chain_rs8<kRs8Rows, kRs8RegPairs, KIND_RWMH>>(cfg, grid, block, 0, m, a);
-        if (cfg->kind == KIND_MALA) return launch_capped<&k_chain_rs8<kRs8Rows, kRs8RegPairs, KIND_MALA>>(cfg, grid, block, 0, m, a);
-        return -3;
-    }
-#endif
 #define LR_DISPATCH_CHAIN(M_, G_, R_) \
     if (cfg->mode == M_ && cfg->G == G_ && cfg->R == R_) return launch_chain_v<G_, M_, R_>(cfg, C, m, a);
     LR_VARIANTS(LR_DISPATCH_CHAIN)

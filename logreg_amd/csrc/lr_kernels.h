@@ -44,7 +44,9 @@ template <typename T, int P> struct ChainArgs {
     double* lp_state;   // [C] threaded log-density of RWMH/MALA (in/out, -inf allowed); null for HMC/UL
     T* out;             // [iters][C][p] or null
     uint32_t* accepts;  // [C], incremented; or null
-    int64_t C;
+    int64_t C;             // chains of the CALL: the stride of out / stats, the bound of state / lp_state / accepts
+    int64_t first, count;  // the chains THIS LAUNCH advances: [first, first + count) of the call's arrays (a call planned in two
+                           // parts -- lr_plan.h: exactly-filled head on narrow groups, remainder on wide ones -- is two launches)
     int64_t chain_offset;  // global id of local chain 0 (Philox counter)
     int64_t iters, thin;
     int64_t iter_offset;  // global index of this launch's first iteration (Philox counter)
@@ -190,9 +192,9 @@ __global__ void __launch_bounds__(256) k_chain_rs16(ModelArgs<float, 8> m, Chain
     static_assert(KIND == KIND_MALA || KIND == KIND_RWMH, "threaded-ll kernels");
     constexpr int P = 8, G = 16;
     const int gl = threadIdx.x % G;
-    int64_t chain = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
-    const bool live = chain < a.C;
-    if (!live) chain = a.C - 1;
+    int64_t chain = a.first + ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const bool live = chain < a.first + a.count;
+    if (!live) chain = a.first + a.count - 1;
     const bool writer = live && gl == 0;
     RegRowPairs<P, R, G> rows;
     rows.load(m.rows, m.n, gl);
@@ -311,9 +313,9 @@ template <typename T, int P, int G, int MODE, int R, int KIND>
 __global__ void __launch_bounds__(256) k_chain(ModelArgs<T, P> m, ChainArgs<T, P> a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int gl = threadIdx.x % G;
-    int64_t chain = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
-    const bool live = chain < a.C;
-    if (!live) chain = a.C - 1;  // whole waves stay converged for the DPP reductions; stores are masked
+    int64_t chain = a.first + ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const bool live = chain < a.first + a.count;
+    if (!live) chain = a.first + a.count - 1;  // whole waves stay converged for the DPP reductions; stores are masked
     const bool writer = live && gl == 0;
     const auto rows = make_rows<T, P, G, MODE, R>(m, gl, reinterpret_cast<T*>(smem_raw));
     const uint64_t gchain = (uint64_t)(a.chain_offset + chain);

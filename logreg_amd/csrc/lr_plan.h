@@ -11,7 +11,13 @@
 
 namespace {
 
-struct Plan { int mode, G, R; size_t lds_bytes; };
+struct Plan {
+    int mode, G, R;
+    size_t lds_bytes;
+    // two-part plans (register family): chains [0, split) of the planned run on (G, R), [split, n) on (G2, R2); split = 0: one part
+    int64_t split = 0;
+    int G2 = 0, R2 = 0;
+};
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // thresholds outside the matrix-core table
@@ -30,6 +36,9 @@ struct PlanConst {
     // and MALA at 3072 chains on G = 32 (2.72e9) against 3.30e9.
     double reg_fixed_rows = 11.0;
     double reg_corun = 0.88;
+    // a run is planned in two parts (exactly-filled head + remainder on its own variant) when the model prices the pair below
+    // this fraction of the single launch (two launches, two sets of prologue row loads: not for a few per cent)
+    double split_gain = 0.95;
     // lane-per-chain with rows from the scalar unit: from this many waves per SIMD (HMC n=200 p=8: 2.20 / 2.46 / 2.64e8 it/s at
     // 2 / 4 / 8 waves per SIMD against 2.21e8 for rows in registers), rows within the 16 KB scalar cache
     int scalar_rows_waves_per_simd = 3;
@@ -226,9 +235,6 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
         }
         if (mode != LR_MODE_AUTO && v.mode != mode) continue;
         if (group != 0 && v.G != group) continue;
-        // 8 lanes per chain exists for the threaded-ll kernels only (k_chain_rs8: MALA / RWMH, float32, padded p = 8), and only on
-        // request (group = 8): by instruction count it does not beat 16 lanes per chain (lr_chain8.h)
-        if (v.mode == lr::MODE_REG && v.G == 8 && (for_eval || group != 8 || (kind != LR_KIND_RWMH && kind != LR_KIND_MALA))) continue;
         if (v.mode == lr::MODE_REG && (int64_t)v.G * v.R < m->n) continue;
         if (v.mode == lr::MODE_LDS && (size_t)m->n * m->P * m->esize() > kLdsBudget) continue;
         // score: residency tier first (REG > LDS > GLOBAL), then group fitness, then fewer padded rows
@@ -258,6 +264,47 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
     const lr::Variant& v = t->variants[best];
     *out = Plan{v.mode, v.G, v.R, v.mode == lr::MODE_LDS ? (size_t)m->n * m->P * m->esize()
                                   : (v.mode == lr::MODE_MFMA && v.R == 0 ? mfma_lds_bytes(m, v.G) : 0)};
+    // Wave quantisation of the register family.  Between the chain counts that fill the chip exactly a launch takes the time of
+    // its fullest SIMD (5120 chains on 16 lanes per chain: 1.43e8 it/s where 4096 run 2.13e8, profiles/r3_chain_grid.txt).  A run
+    // left to the planner (AUTO, no group) is then planned in two parts: the largest exactly-filled head on the variant the model
+    // prefers for that count, the remainder on whatever variant the model prefers for IT (usually a wider group that finishes
+    // in one short wave), when the model prices the two launches kPlanConst.split_gain below the single one.
+    if (v.mode == lr::MODE_REG && mode == LR_MODE_AUTO && group == 0 && !for_eval && kind >= 0) {
+        auto cost_of = [&](const lr::Variant& u, int64_t chains) {
+            const int64_t waves = (chains * u.G + 63) / 64, wps = (waves + want_waves - 1) / want_waves;
+            return ((double)u.R + kPlanConst.reg_fixed_rows) * (1.0 + kPlanConst.reg_corun * (double)(wps - 1));
+        };
+        auto best_reg = [&](int64_t chains, double* cost) {
+            int bi = -1;
+            for (int i = 0; i < t->nvariants; ++i) {
+                const lr::Variant& u = t->variants[i];
+                if (u.mode != lr::MODE_REG || (int64_t)u.G * u.R < m->n) continue;
+                const double c = cost_of(u, chains) + 1e-3 * u.R;
+                if (bi < 0 || c < *cost) { bi = i; *cost = c; }
+            }
+            return bi;
+        };
+        const double whole = cost_of(v, C);
+        double best_total = whole * kPlanConst.split_gain;
+        for (int i = 0; i < t->nvariants; ++i) {  // head variant A: any register variant, its exactly-filling quantum
+            const lr::Variant& a = t->variants[i];
+            if (a.mode != lr::MODE_REG || (int64_t)a.G * a.R < m->n) continue;
+            const int64_t quantum = want_waves * 64 / a.G;
+            if (quantum <= 0 || C <= quantum || C % quantum == 0) continue;
+            const int64_t head = C / quantum * quantum;
+            double cb = 0;
+            const int bi = best_reg(C - head, &cb);
+            if (bi < 0) continue;
+            const double total = cost_of(a, head) + cb;
+            if (total < best_total) {
+                best_total = total;
+                *out = Plan{a.mode, a.G, a.R, 0};
+                out->split = head;
+                out->G2 = t->variants[bi].G;
+                out->R2 = t->variants[bi].R;
+            }
+        }
+    }
     return LR_OK;
 }
 

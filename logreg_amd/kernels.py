@@ -266,7 +266,7 @@ class ChainSet:
     """
 
     def __init__(self, kernel: FusedKernel, init, seed: int, chain_offset: int = 0, ll=None, group: int = 0,
-                 mode: str = "auto", stream=None, precision: str = "auto", plan_chains: int = 0):
+                 mode: str = "auto", stream=None, precision: str = "auto", plan_chains: int = 0, plan_first: int = 0):
         self.kernel = kernel
         self.model = kernel.model
         m = self.model
@@ -284,6 +284,8 @@ class ChainSet:
         # chain count every chain-count-dependent choice is made for (0 = this set's own): a shard of a larger run passes the
         # whole run's count and reproduces the one-GPU run bit for bit (lr_run_opts.plan_chains)
         self.plan_chains = int(plan_chains)
+        # ... and the global id of that run's first chain (a two-part plan assigns a chain to its part by its position in the run)
+        self.plan_first = int(plan_first)
         self.stream = stream
         self.state = DeviceArray.from_host(m.device, st)
         lp0 = np.full(self.C, -np.inf) if ll is None else np.broadcast_to(np.asarray(ll, dtype=np.float64), (self.C,))
@@ -299,11 +301,14 @@ class ChainSet:
 
     def plan(self):
         """The kernel variant `advance` launches for this chain set (family- and precision-aware: `lr_plan_run`)."""
-        opts = RunOpts(n_chains=self.C, group=self.group, mode=self.mode, precision=self.precision, plan_chains=self.plan_chains)
-        m, g, r = C.c_int32(), C.c_int32(), C.c_int32()
-        check(self.model._L.lr_plan_run(self.model.handle, _lib.KIND_BY_NAME[self.kernel.kind], C.byref(opts), C.byref(m),
-                                      C.byref(g), C.byref(r)))
-        return {"mode": _lib.MODE_NAMES[m.value], "group": g.value, "rows_per_lane": r.value}
+        opts = RunOpts(n_chains=self.C, group=self.group, mode=self.mode, precision=self.precision, plan_chains=self.plan_chains,
+                       chain_offset=self.chain_offset, plan_first=self.plan_first)
+        info = _lib.PlanInfo()
+        check(self.model._L.lr_plan_run_info(self.model.handle, _lib.KIND_BY_NAME[self.kernel.kind], C.byref(opts), C.byref(info)))
+        plan = {"mode": _lib.MODE_NAMES[info.mode], "group": info.group, "rows_per_lane": info.rows}
+        if info.split > 0:  # a run planned in two parts: chains [split, n) of the planned run on wider lane groups
+            plan["tail"] = {"from": int(info.split), "group": info.tail_group, "rows_per_lane": info.tail_rows}
+        return plan
 
     def enable_stats(self, batch: int, slots: int, pivot=None):
         """Start a statistics window: from now on every kept sample is folded, on the device, into the running
@@ -327,7 +332,7 @@ class ChainSet:
             out = DeviceArray(m.device, (iters, self.C, m.p), m.np_dtype)
         opts = RunOpts(n_chains=self.C, chain_offset=self.chain_offset, thin=int(thin), iters=int(iters),
                        iter_offset=self.iter_offset, seed=self.seed, group=self.group, mode=self.mode, on_device=1,
-                       stream=self.stream, precision=self.precision, plan_chains=self.plan_chains)
+                       stream=self.stream, precision=self.precision, plan_chains=self.plan_chains, plan_first=self.plan_first)
         use_stats = self.stats is not None if stats is None else bool(stats)
         if use_stats:
             if self.stats is None:
@@ -444,7 +449,7 @@ def _auto_chunk(kernel: FusedKernel, C: int, thin: int, iters: int) -> int:
 
 
 def mcmc(init, kernel, thin=10, iters=10000, verb=True, *, seed=None, chunk=None, chain_offset=0, ll=None,
-         group=0, mode="auto", return_info=False, summary_only=False, max_batches=16, precision="auto", plan_chains=0):
+         group=0, mode="auto", return_info=False, summary_only=False, max_batches=16, precision="auto", plan_chains=0, plan_first=0):
     """Run a chain (or C chains): `mat[i]` = state after (i+1)*thin iterations (fit-np-hmc.py:89-103).
 
     Fused kernels run on the device; `init` of shape [p] returns a float64 `[iters, p]` matrix
@@ -461,7 +466,8 @@ def mcmc(init, kernel, thin=10, iters=10000, verb=True, *, seed=None, chunk=None
     pipe where such a kernel exists (the end-point value + gradient and the Metropolis test stay in the model's dtype, so
     the sampler stays exact; the acceptance rate is the only thing that can move); "full" keeps every evaluation in the
     model's dtype (step-for-step comparable with the float64 reference); see include/logreg_hip.h LR_PREC_*.
-    `plan_chains`: chain count to plan the kernel variant for (a shard of a larger run: the whole run's count).
+    `plan_chains`, `plan_first`: chain count to plan the kernel variant for and the global id of that run's first chain (a shard of
+    a larger run passes the whole run's: its chains then run on the variants they have in the whole run, bit for bit).
     """
     if not isinstance(kernel, FusedKernel):
         return _mcmc_generic(init, kernel, thin, iters, verb)
@@ -470,7 +476,7 @@ def mcmc(init, kernel, thin=10, iters=10000, verb=True, *, seed=None, chunk=None
     if seed is None:
         seed = int(np.random.randint(0, 2**31 - 1))
     cs = ChainSet(kernel, init, seed, chain_offset=chain_offset, ll=ll, group=group, mode=mode, precision=precision,
-                  plan_chains=plan_chains)
+                  plan_chains=plan_chains, plan_first=plan_first)
     m = kernel.model
     if chunk is None:
         chunk = _auto_chunk(kernel, cs.C, thin, iters)

@@ -98,6 +98,11 @@ LR_API void lr_model_destroy(lr_model *m) {
     free(m);
 }
 
+LR_API int lr_plan_run_info(const lr_model *m, int32_t kind, const lr_run_opts *opts, lr_plan_info *out) {
+    if (!out) return fail(LR_ERR_INVALID, "out is NULL");
+    memset(out, 0, sizeof *out);
+    return lr_plan_run(m, kind, opts, &out->mode, &out->group, &out->rows); /* the double has one variant, never a second part */
+}
 LR_API int lr_model_debug_opts(const lr_model *m, char *buf, int len) {
     if (!m || !buf || len <= 0) return fail(LR_ERR_INVALID, "NULL argument / empty buffer");
     buf[0] = 0; /* the double has no switches */

@@ -21,6 +21,13 @@ CASES = [
     # narrower ones sharing it
     (200, 8, 1024, "mala", "auto", REG(64, 4)), (200, 8, 2048, "mala", "auto", REG(32, 7)), (200, 8, 2560, "mala", "auto", REG(16, 13)),
     (200, 8, 5120, "mala", "auto", REG(16, 13)), (200, 8, 64, "mala", "auto", {"mode": "reg", "group": 64}),
+    # ... and beyond an exactly-filled count the run is planned in two parts: the filled head on 16 lanes per chain, the remainder
+    # on the group width the model prefers for it (one short wave per SIMD); no second part where the model sees no gain
+    (200, 8, 5120, "mala", "auto", {**REG(16, 13), "tail": {"from": 4096, "group": 64, "rows_per_lane": 4}}),
+    (200, 8, 6144, "hmc", "full", {**REG(16, 13), "tail": {"from": 4096, "group": 32, "rows_per_lane": 7}}),
+    (200, 8, 9216, "mala", "auto", {**REG(16, 13), "tail": {"from": 8192, "group": 64, "rows_per_lane": 4}}),
+    (200, 8, 4096, "mala", "auto", {"no_tail": True}), (200, 8, 8192, "mala", "auto", {"no_tail": True}),
+    (200, 8, 7168, "mala", "auto", {"no_tail": True}), (200, 8, 2560, "mala", "auto", {"no_tail": True}),
     (200, 8, 1 << 18, "mala", "auto", {"mode": "global", "group": 1}),
     (300, 8, 4096, "mala", "auto", REG(32, 16)), (600, 8, 4096, "mala", "auto", REG(64, 12)), (1000, 8, 4096, "mala", "auto", REG(64, 16)),
     (1500, 8, 4096, "mala", "auto", {"mode": "lds"}),
@@ -68,4 +75,6 @@ CASES = [
 def matches(plan: dict, expect: dict) -> bool:
     if "not_mode" in expect:
         return plan["mode"] != expect["not_mode"]
-    return all(plan[k] == v for k, v in expect.items() if k != "dtype")
+    if expect.get("no_tail") and "tail" in plan:
+        return False
+    return all(plan.get(k) == v for k, v in expect.items() if k not in ("dtype", "no_tail"))

@@ -151,12 +151,12 @@ def test_single_hmc_iteration_every_variant(la, models, oracle_model, map_beta, 
     assert np.max((np.abs(out - ref["out"][0]) / POST_SD)[clear]) < 1e-3
 
 
-@pytest.mark.parametrize("group", [16, 8])
+@pytest.mark.parametrize("group", [16])
 @pytest.mark.parametrize("kind", ["mala", "rwmh"])
 def test_distributed_state_kernel_for_mala_and_rwmh(la, models, oracle_model, map_beta, kind, group):
     """reg / 16 lanes per chain, MALA and RWMH: k_chain_rs16 keeps a chain's state distributed over its lanes for the
-    whole launch (what AUTO runs from 4096 chains); reg / 8 lanes per chain: k_chain_rs8 (lr_chain8.h: 8 chains per wave, 12 of a
-    lane's 25 rows in registers and 13 in LDS; on request only).  Step-level parity, threaded ll, -inf start, invariances."""
+    whole launch (what AUTO runs from 4096 chains).  Step-level parity, threaded ll, -inf start, invariances.  (The 8-lanes-per-chain
+    form, k_chain_rs8, passed this test with group = 8 before it moved to tools/experiments: profiles/r4_mala_rs8.txt.)"""
     C = 130
     rng = np.random.default_rng(29)
     q0 = (map_beta + 0.7 * POST_SD * rng.standard_normal((C, 8))).astype(np.float32).astype(np.float64)
@@ -312,8 +312,8 @@ def test_planner_engine_choice_by_size(la):
              else la.malaKernel(m.lpost, m.glp, dt=1e-3, pre=np.ones(p)))
         plan = la.ChainSet(k, np.zeros((C, p)), seed=0, precision=prec).plan()
         assert matches(plan, expect), (n, p, C, kind, prec, plan, expect)
-        if kind == "mala":  # the family-blind entry point (lr_plan) agrees
-            assert m.plan(C) == plan
+        if kind == "mala":  # the family-blind entry point (lr_plan) agrees (it never plans a second part)
+            assert m.plan(C) == {k_: v for k_, v in plan.items() if k_ != "tail"}
     assert la.device_count() >= 1
 
 
@@ -424,6 +424,46 @@ def test_bit_exact_rerun_chunk_and_shard_invariance(la, models, map_beta, kind):
     assert np.array_equal(full, np.concatenate([a, b], axis=1))
     other = la.mcmc(q0, k, thin=3, iters=8, verb=False, seed=1235)
     assert not np.array_equal(full, other)
+
+
+@pytest.mark.parametrize("kind", ["hmc", "mala", "rwmh", "ul"])
+def test_two_part_plans_between_exactly_filled_chain_counts(la, models, oracle_model, map_beta, kind):
+    """5120 chains: the planner gives the exactly-filled first 4096 chains to 16 lanes per chain and the remaining 1024 to 64
+    lanes per chain (two launches; lr_plan_info.split).  Every chain must be the chain of a one-variant run of ITS variant, bit
+    for bit (head = forced reg 16, tail = forced reg 64 with the global chain ids); chunked runs and shards planned for the
+    whole run (plan_chains, plan_first -- a shard that straddles the split included, and a run whose ids do not start at 0)
+    reproduce it; a subset against the oracle on both sides of the split."""
+    C, split = 5120, 4096
+    m = models["float32"]
+    rng = np.random.default_rng(3)
+    q0 = (map_beta + 0.5 * POST_SD * rng.standard_normal((C, 8))).astype(np.float32).astype(np.float64)
+    k = make_kernel(la, m, kind)
+    ll0 = oracle_model.lpost(q0) if kind in ("mala", "rwmh") else None
+    kw = dict(thin=2, iters=3, verb=False, seed=8, precision="full")
+    full, info = la.mcmc(q0, k, return_info=True, ll=ll0, **kw)
+    assert info["plan"] == {"mode": "reg", "group": 16, "rows_per_lane": 13, "tail": {"from": split, "group": 64, "rows_per_lane": 4}}
+    head = la.mcmc(q0[:split], k, ll=None if ll0 is None else ll0[:split], mode="reg", group=16, **kw)
+    tail = la.mcmc(q0[split:], k, ll=None if ll0 is None else ll0[split:], mode="reg", group=64, chain_offset=split, **kw)
+    assert np.array_equal(full[:, :split], head) and np.array_equal(full[:, split:], tail)
+    assert np.array_equal(full, la.mcmc(q0, k, ll=ll0, chunk=2, **kw))
+    for lo, hi in ((0, 1000), (3900, 4300), (4096, 5120), (5000, 5120)):  # shards of the planned run; (3900, 4300) straddles the split
+        part = la.mcmc(q0[lo:hi], k, ll=None if ll0 is None else ll0[lo:hi], chain_offset=lo, plan_chains=C, plan_first=0, **kw)
+        assert np.array_equal(part, full[:, lo:hi]), (lo, hi)
+    # the same run with its chains numbered from 700 000: another Philox stream, the same split position
+    base = 700000
+    moved = la.mcmc(q0, k, ll=ll0, chain_offset=base, **kw)
+    part = la.mcmc(q0[4000:4200], k, ll=None if ll0 is None else ll0[4000:4200], chain_offset=base + 4000, plan_chains=C, plan_first=base, **kw)
+    assert np.array_equal(part, moved[:, 4000:4200]) and not np.array_equal(moved, full)
+    with pytest.raises(la.LogregHipError, match="not inside the planned run"):
+        la.mcmc(q0[:10], k, chain_offset=C - 5, plan_chains=C, plan_first=0, **kw)
+    # both parts against the oracle (first kept sample = 2 iterations, decisions away from near-ties)
+    # (the oracle numbers its chains from chain_offset: the two sides of the split with their global ids)
+    ref_a = oracle_model.run(kind, q0[4000:4096], thin=2, iters=1, seed=8, chain_offset=4000, ll_state=None if ll0 is None else ll0[4000:4096], threads=0, **KW[kind])
+    ref_b = oracle_model.run(kind, q0[4096:4192], thin=2, iters=1, seed=8, chain_offset=4096, ll_state=None if ll0 is None else ll0[4096:4192], threads=0, **KW[kind])
+    for r, sl in ((ref_a, slice(4000, 4096)), (ref_b, slice(4096, 4192))):
+        ok = r["margin"] > 2e-3
+        assert ok.mean() > 0.8
+        assert np.max(np.abs(full[0, sl][ok] - r["out"][0][ok]) / POST_SD) < (5e-2 if kind == "mala" else 5e-3)
 
 
 def test_groups_agree_statistically_not_bitwise(la, models, map_beta):

@@ -40,8 +40,13 @@ def harness(tmp_path_factory):
         res = []
         for line in r.stdout.strip().split("\n"):
             f = line.split()
-            res.append(("ERR", line) if f[0] == "ERR" else {"mode": MODES[int(f[0])], "group": int(f[1]), "rows_per_lane": int(f[2]), "lds_bytes": int(f[3]),
-                                                            "interior": (int(f[4]), int(f[5]), int(f[6]))})
+            if f[0] == "ERR":
+                res.append(("ERR", line))
+                continue
+            plan = {"mode": MODES[int(f[0])], "group": int(f[1]), "rows_per_lane": int(f[2]), "lds_bytes": int(f[3]), "interior": (int(f[4]), int(f[5]), int(f[6]))}
+            if int(f[7]) > 0:
+                plan["tail"] = {"from": int(f[7]), "group": int(f[8]), "rows_per_lane": int(f[9])}
+            res.append(plan)
         return res
     return ask
 

@@ -3,8 +3,10 @@
 // 8 KB of finished position instead of 48 KB of partials + state) than to do it in every workgroup's prologue as today?
 // Same grid as k_wide_partial_bf16r at 1024 chains (64 tiles x 4 slices, 512 threads; a tile's slices share an XCD), same bytes:
 //   variant 0 (today)         prologue: 4 slice partials + q + p (48 KB per workgroup), update arithmetic;  tail: store 8 KB partial
-//   variant 1 (last arriver)  prologue: q (8 KB);  tail: store 8 KB partial, fence, one atomic per workgroup, the last arriver of
-//                             the tile loads the other partials + p (32 KB, L1-bypassing), updates, stores q, p (16 KB)
+//   variant 1 (last arriver)  prologue: q (8 KB);  tail: write-through store of the 8 KB partial, drained, one relaxed agent-scope
+//                             atomic per workgroup, the last arriver of the tile loads the other partials (sc1) + p (32 KB),
+//                             updates, stores q, p (16 KB).  (A first version used __threadfence(): an agent-scope release
+//                             writes the L2 back -- 38 us per launch.)
 // Both spin T us in between (the row loop).  N dependent launches back to back; prints the period per launch minus T, and for
 // variant 1 the tail's phases from the last arrivers' 100 MHz stamps.
 //   hipcc --offload-arch=gfx950 -O3 tools/last_arriver_probe.hip -o tools/bin/last_arriver_probe && tools/bin/last_arriver_probe
@@ -25,7 +27,10 @@ struct Bufs {
     unsigned long long* stamps;  // [tile][4]
 };
 
-__device__ __forceinline__ f4 ld_bypass(const f4* p) { return __builtin_nontemporal_load(p); }
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+// write-through store / L1-bypassing load (sc1) through a buffer resource, as the persistent kernel of round 3 used them
+__device__ __forceinline__ void st_wt(__amdgpu_buffer_rsrc_t r, unsigned off, f4 v) { __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), r, off, 0, 16); }
+__device__ __forceinline__ f4 ld_sc1(__amdgpu_buffer_rsrc_t r, unsigned off) { return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16)); }
 
 template <int VARIANT>
 __global__ void __launch_bounds__(NT) step(Bufs b, int cur, int ticks, unsigned launch_no) {
@@ -59,31 +64,36 @@ __global__ void __launch_bounds__(NT) step(Bufs b, int cur, int ticks, unsigned 
     while (__builtin_amdgcn_s_memrealtime() - ts < (unsigned long long)ticks) __builtin_amdgcn_s_sleep(1);
     // ---- tail: this workgroup's partial
     const f4 mine = {sink * 1e-3f, acc.y * 1e-3f, acc.z * 1e-3f, acc.w * 1e-3f + (float)slice};
-    reinterpret_cast<f4*>(b.part[cur] + ((size_t)slice * TILES + tile) * TILE_FLOATS)[tid] = mine;
-    if (VARIANT == 1) {
+    if (VARIANT == 0) {
+        reinterpret_cast<f4*>(b.part[cur] + ((size_t)slice * TILES + tile) * TILE_FLOATS)[tid] = mine;
+    } else {
+        // no agent-scope FENCE: on this chip it writes the whole L2 back (measured: 38 us per launch).  The four workgroups of a
+        // tile share an XCD, i.e. an L2: write-through stores, drained (vmcnt 0), then a relaxed agent-scope atomic; the last
+        // arriver reads with L1-bypassing loads.
+        const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(b.part[cur], 0, SLICES * TILES * TILE_FLOATS * 4, 0x00020000);
         __shared__ unsigned arrived;
         const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
-        __threadfence();  // the partial is visible at device scope before the count
+        st_wt(pr, (unsigned)(((size_t)slice * TILES + tile) * TILE_FLOATS * 4 + tid * 16), mine);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) arrived = atomicAdd(&b.count[tile], 1u);
+        if (tid == 0) arrived = __hip_atomic_fetch_add(&b.count[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         const unsigned long long t2 = __builtin_amdgcn_s_memrealtime();
         if (arrived == launch_no * SLICES + SLICES - 1) {  // the last of the tile's four
-            __threadfence();
             f4 gs = mine;
 #pragma unroll
             for (int s = 0; s < SLICES; ++s)
                 if (s != slice) {
-                    const f4 g = ld_bypass(reinterpret_cast<const f4*>(b.part[cur] + ((size_t)s * TILES + tile) * TILE_FLOATS) + tid);
+                    const f4 g = ld_sc1(pr, (unsigned)(((size_t)s * TILES + tile) * TILE_FLOATS * 4 + tid * 16));
                     gs.x += g.x; gs.y += g.y; gs.z += g.z; gs.w += g.w;
                 }
             f4 p = reinterpret_cast<const f4*>(b.p[prev] + (size_t)tile * TILE_FLOATS)[tid];
             p.x += 0.01f * gs.x; p.y += 0.01f * gs.y; p.z += 0.01f * gs.z; p.w += 0.01f * gs.w;
-            const unsigned long long t3 = __builtin_amdgcn_s_memrealtime();
+            const unsigned long long t3 = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(__builtin_amdgcn_readfirstlane(p.x == 1234.5f ? 1 : 0));
             reinterpret_cast<f4*>(b.q[cur] + (size_t)tile * TILE_FLOATS)[tid] = f4{acc.x + 0.02f * p.x, acc.y + 0.02f * p.y, acc.z + 0.02f * p.z, acc.w + 0.02f * p.w};
             reinterpret_cast<f4*>(b.p[cur] + (size_t)tile * TILE_FLOATS)[tid] = p;
             if (tid == 0) {
-                b.stamps[tile * 4 + 0] = t2 - t1;  // fence + barrier + atomic + barrier
+                b.stamps[tile * 4 + 0] = t2 - t1;  // write-through store drained + barrier + atomic + barrier
                 b.stamps[tile * 4 + 1] = t3 - t2;  // loads of the other partials + momentum, sums
                 b.stamps[tile * 4 + 2] = __builtin_amdgcn_s_memrealtime() - t3;  // stores issued
             }
@@ -134,7 +144,7 @@ int main() {
         for (int t = 0; t < TILES; ++t)
             for (int k = 0; k < 3; ++k) ph[k] += s[t * 4 + k] * 0.01 / TILES;
         printf("row loop %d us: period per launch  today (48 KB prologue) %.2f us   last arriver (8 KB prologue + tail) %.2f us   "
-               "[last arriver's tail, mean over tiles: fence + atomic %.2f, loads + sums %.2f, stores issued %.2f us]\n",
+               "[last arriver's tail, mean over tiles: store drained + atomic %.2f, loads + sums %.2f, stores issued %.2f us]\n",
                us, per[0], per[1], ph[0], ph[1], ph[2]);
     }
     return 0;

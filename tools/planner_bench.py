@@ -25,7 +25,7 @@ SHAPES = [
     (200, 8, 8192, "mala", "auto"), (200, 8, 3072, "mala", "auto"),
 ]
 # forced alternatives tried for every shape (those the library rejects for the shape are skipped)
-ALTERNATIVES = [("reg", 8), ("reg", 16), ("reg", 32), ("reg", 64), ("lds", 1), ("lds", 8), ("lds", 64), ("global", 1), ("mfma", 1), ("mfma", 4), ("mfma", 8),
+ALTERNATIVES = [("reg", 16), ("reg", 32), ("reg", 64), ("lds", 1), ("lds", 8), ("lds", 64), ("global", 1), ("mfma", 1), ("mfma", 4), ("mfma", 8),
                 ("stepwise", 0)]
 
 
