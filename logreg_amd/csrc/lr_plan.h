@@ -36,6 +36,17 @@ struct PlanConst {
     // and MALA at 3072 chains on G = 32 (2.72e9) against 3.30e9.
     double reg_fixed_rows = 11.0;
     double reg_corun = 0.88;
+    // All-fp32 families (MALA / RWMH / UL, HMC with precision FULL) whose register variant is ONE chain per wave (64 lanes per chain:
+    // 64 copies of the state, a 6-level reduction per evaluation) -- round 4, tools/planner_bench.py, profiles/r4_planner_bench_many_chains.txt:
+    //  * 9 <= p <= 16, rows within the register tiles of the fp32 matrix-core kernel (n <= 512): from 16 chains per CU the
+    //    fp32-MFMA kernel (S = 4) runs 1.6-1.7x the register kernel (n=500 p=16, MALA: 4096 chains 0.88 | 1.43e9 it/s, 8192 0.89 | 1.63,
+    //    65 536 0.90 | 1.76; HMC all-fp32 4096 chains 0.73 | 1.23e8; n=300 p=12 likewise).  At p <= 8 it never does (n=800: 1.43 | 0.99).
+    //  * from 64 chains per CU with rows within 28 KB: LDS rows with 8 lanes per chain (8 chains per wave) overtake one chain per
+    //    wave (MALA, 16 384 chains, reg | lds 8: n=600 p=8 1.64 | 1.89e9, n=800 p=8 1.43 | 1.47 (1.44 | 1.64 at 65 536), n=300 p=12
+    //    0.89 | 2.25, n=400 p=16 0.89 | 1.82; not at 32 KB: n=1000 p=8 1.42 | 1.19, n=500 p=16 mfma 1.69 | lds 8 1.52)
+    int mfma_fp32_p16_chains_per_cu = 16;
+    int lds8_chains_per_cu = 64;
+    size_t lds8_max_row_bytes = 28 * 1024;
     // a run is planned in two parts (exactly-filled head + remainder on its own variant) when the model prices the pair below
     // this fraction of the single launch (two launches, two sets of prologue row loads: not for a few per cent)
     double split_gain = 0.95;
@@ -261,6 +272,15 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
     if (best < 0)
         return fail(LR_ERR_UNSUPPORTED, "no kernel variant for dtype=%d p=%d (padded %d) n=%lld group=%d mode=%d",
                     m->dtype, m->p, m->P, (long long)m->n, group, mode);
+    // one chain per wave in registers, many chains: the measured better homes for the rows (kPlanConst)
+    if (mode == LR_MODE_AUTO && group == 0 && !for_eval && m->dtype == LR_F32 && t->variants[best].mode == lr::MODE_REG && t->variants[best].G == 64) {
+        if (C >= (int64_t)kPlanConst.lds8_chains_per_cu * m->cus && row_bytes <= kPlanConst.lds8_max_row_bytes) {
+            for (int i = 0; i < t->nvariants; ++i)
+                if (t->variants[i].mode == lr::MODE_LDS && t->variants[i].G == 8) best = i;
+        } else if (m->P == 16 && C >= (int64_t)kPlanConst.mfma_fp32_p16_chains_per_cu * m->cus && mfma_variant_fits(m, 4, ST_REG, out)) {
+            return LR_OK;
+        }
+    }
     const lr::Variant& v = t->variants[best];
     *out = Plan{v.mode, v.G, v.R, v.mode == lr::MODE_LDS ? (size_t)m->n * m->P * m->esize()
                                   : (v.mode == lr::MODE_MFMA && v.R == 0 ? mfma_lds_bytes(m, v.G) : 0)};

@@ -67,8 +67,14 @@ CASES = [
     (300, 100, 64, "mala", "auto", {"dtype": "float64", "mode": "stepwise"}),
     # rows beyond the scalar cache, very many chains: the register tier keeps its rank whatever the modelled cost (the
     # unbounded model term let lds / global variants overtake from ~98 304 chains, with no measurement behind the flip)
-    (800, 8, 1 << 17, "mala", "auto", {"mode": "reg"}), (800, 8, 1 << 19, "hmc", "full", {"mode": "reg"}),
-    (500, 16, 1 << 17, "mala", "auto", {"mode": "reg"}),
+    (1000, 8, 1 << 17, "mala", "auto", {"mode": "reg"}), (1000, 8, 1 << 19, "hmc", "full", {"mode": "reg"}),
+    # one chain per wave in registers and many chains (round 4, profiles/r4_planner_bench_many_chains.txt): 9 <= p <= 16 moves to the
+    # fp32 matrix-core kernel from 16 chains per CU in all-fp32 arithmetic too; rows within 28 KB to LDS with 8 lanes per chain from 64
+    (500, 16, 4096, "mala", "auto", MFMA(4, 8)), (500, 16, 4096, "hmc", "full", MFMA(4, 8)), (500, 16, 2048, "mala", "auto", REG(64, 8)),
+    (300, 12, 8192, "mala", "auto", MFMA(4, 8)), (300, 12, 16384, "mala", "auto", {"mode": "lds", "group": 8}),
+    (500, 16, 1 << 16, "mala", "auto", MFMA(4, 8)),   # 32 KB of rows: not LDS
+    (600, 8, 16384, "mala", "auto", {"mode": "lds", "group": 8}), (600, 8, 8192, "mala", "auto", REG(64, 12)),
+    (800, 8, 1 << 17, "hmc", "full", {"mode": "lds", "group": 8}), (400, 8, 16384, "mala", "auto", REG(32, 16)),
 ]
 
 

@@ -23,6 +23,8 @@ SHAPES = [
     (2000, 8, 1024, "hmc", "auto"), (2000, 8, 2048, "hmc", "auto"), (3000, 8, 2048, "hmc", "auto"), (3000, 8, 4096, "hmc", "auto"),
     (200, 12, 1024, "hmc", "auto"), (500, 16, 1024, "hmc", "auto"), (500, 16, 2048, "hmc", "auto"), (200, 24, 1024, "hmc", "auto"),
     (200, 8, 8192, "mala", "auto"), (200, 8, 3072, "mala", "auto"),
+    # round 4: all-fp32 families where the register variant is one chain per wave
+    (500, 16, 4096, "mala", "auto"), (500, 16, 8192, "hmc", "full"), (300, 12, 16384, "mala", "auto"), (600, 8, 16384, "mala", "auto"),
 ]
 # forced alternatives tried for every shape (those the library rejects for the shape are skipped)
 ALTERNATIVES = [("reg", 16), ("reg", 32), ("reg", 64), ("lds", 1), ("lds", 8), ("lds", 64), ("global", 1), ("mfma", 1), ("mfma", 4), ("mfma", 8),
