@@ -24,6 +24,7 @@ At N = 1 the line also carries, outside the timed region:
                  own roofline block, and "2_pima": the reference's own HMC run (Pima, eps=1e-3,
                  dmm=1/pre) at 4096 chains with like-for-like it/s and min-ESS/s
   extra.f64      the headline workload on the float64 instantiation (the reference computes in float64)
+  extra.f64_wide config 5's shape on a float64 model (f64 matrix pipe)
 
 `--dry-run` exercises the launch plumbing without a GPU (gloo instead of RCCL, no kernels): rank/world parsing,
 shard offsets, the gather and the max-over-ranks reduction -- what tests/test_host_logic.py runs on CPU.
@@ -313,6 +314,31 @@ def f64_run(la, L, check, dev, stream, X, y, pscale, q0, steps):
             "accept_rate": float((cs.get_accepts().astype(np.int64).sum() - a0) / (C * n * THIN)),
             "algorithmic_TFLOPs": tf, "peak": PEAK_FP64_TFLOPS, "frac_of_fp64_vector_peak": tf / PEAK_FP64_TFLOPS,
             "note": f"same workload, {C} chains, {n} launches of {THIN} iterations, HIP-event timed, not part of `value`"}
+
+
+def f64_wide_run(la, L, check, dev, stream):
+    """BASELINE config 5 (n = 4096, p = 128, HMC L = 50, 1024 chains) on LogReg(dtype="float64"): the reference's own arithmetic at
+    the wide shape, on the f64 matrix pipe (lr_wide_f64.h).  Every evaluation exact (there is no reduced-precision policy for
+    float64 models); 2 iterations = 100 evaluations, HIP-event timed."""
+    timer = Timer(L, check, dev, stream)
+    fix = json.load(open(os.path.join(REPO, "tests", "golden", "fullsize_cfg5.json")))
+    n, p, C = fix["n"], fix["p"], 1024
+    X, y, _ = la.synthetic_logreg(n, p, seed=fix["data_seed"], beta_sd=fix["beta_sd"])
+    m = la.LogReg(X, y, np.array(fix["pscale"]), dtype="float64", device=dev)
+    k = la.hmcKernel(m.lpost, m.glp, eps=fix["eps"], l=fix["l"], dmm=np.array(fix["dmm"]))
+    rng = np.random.Generator(np.random.Philox(4005))
+    q0 = np.array(fix["map"]) + np.array(fix["laplace_sd"]) * rng.standard_normal((C, p))
+    cs = la.ChainSet(k, q0, seed=5, stream=stream)
+    iters = 2
+    ms = _timed_chainset(la, timer, cs, iters, 1, repeats=2)
+    evals = iters * (fix["l"] + 1)  # end points included: all evaluations run the same kernel
+    per_eval_s = ms * 1e-3 / evals
+    tf = C * flops_per_grad_eval(n, p) / per_eval_s / 1e12
+    return {"dtype": "f64", "workload": f"HMC L={fix['l']} eps={fix['eps']}, synthetic n={n} p={p}, {C} chains, float64 model", "kernel_variant": cs.plan(),
+            "chain_iterations_per_s": C * iters / (ms * 1e-3), "us_per_evaluation_all_chains": per_eval_s * 1e6,
+            "accept_rate": float(cs.get_accepts().sum() / (C * (2 * iters + 1))), "algorithmic_TFLOPs": tf, "peak": PEAK_FP64_TFLOPS,
+            "frac_of_fp64_matrix_peak": tf / PEAK_FP64_TFLOPS,
+            "note": "v_mfma_f64_16x16x4_f64; not part of `value`"}
 
 
 def ess_per_draw(la, model, kern, q0, dev, plan, precision):
@@ -775,6 +801,8 @@ def main(argv=None):
                          "note": "X lives in VGPRs for the whole launch: the path is compute-bound on the fp32 vector "
                                  "ALU, not HBM-bound (8 TB/s: see hbm_frac) and not on the matrix cores; DESIGN.md section 5"},
         }
+        if model.debug_opts():  # A/B switches (LOGREG_DEBUG_OPTS) in effect: not a default run
+            line["debug_opts"] = model.debug_opts()
         if dev_flags:  # a development build (e.g. -DLR_STAMPS) is not what `value` is meant to measure: say so in the line
             line["development_build_flags"] = dev_flags
         if check_block is not None:
@@ -813,7 +841,8 @@ def main(argv=None):
         elif world == 1 and not a.no_extra:
             line["extra"] = {"configs": extra_configs(la, L, _lib.check, dev, stream),
                              "default_policy": default_policy_runs(la, L, _lib.check, dev, stream, kern, init, a.steps),
-                             "f64": f64_run(la, L, _lib.check, dev, stream, X, y, pscale, q0, a.steps)}
+                             "f64": f64_run(la, L, _lib.check, dev, stream, X, y, pscale, q0, a.steps),
+                             "f64_wide": f64_wide_run(la, L, _lib.check, dev, stream)}
         print(json.dumps(line), flush=True)
     ex.close()
 
