@@ -27,7 +27,7 @@ SHAPES = [
     (500, 16, 4096, "mala", "auto"), (500, 16, 8192, "hmc", "full"), (300, 12, 16384, "mala", "auto"), (600, 8, 16384, "mala", "auto"),
 ]
 # forced alternatives tried for every shape (those the library rejects for the shape are skipped)
-ALTERNATIVES = [("reg", 16), ("reg", 32), ("reg", 64), ("lds", 1), ("lds", 8), ("lds", 64), ("global", 1), ("mfma", 1), ("mfma", 4), ("mfma", 8),
+ALTERNATIVES = [("reg", 16), ("reg", 32), ("reg", 64), ("lds", 1), ("lds", 8), ("lds", 16), ("lds", 64), ("global", 1), ("mfma", 1), ("mfma", 4), ("mfma", 8),
                 ("stepwise", 0)]
 
 
@@ -53,7 +53,7 @@ def rate(cs, C, thin, seconds=0.08):
 
 def candidates(n, p, C, kind, precision, L=20):
     X, y, _ = la.synthetic_logreg(n, p, seed=n + p, beta_sd=0.5 / np.sqrt(p))
-    m = la.LogReg(X, y, np.ones(p))
+    m = la.LogReg(X, y, np.ones(p), dtype=os.environ.get("PLANNER_BENCH_DTYPE", "float32"))  # (the tool's own switch, not the library's)
     bmap, info = la.find_map(m)
     eps = 0.9 / np.sqrt(np.max(np.linalg.eigvalsh(info["hessian"]))) / p ** 0.25
     if kind == "hmc":
