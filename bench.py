@@ -293,8 +293,8 @@ PEAK_FP64_TFLOPS = 78.6  # MI355X vector FP64 (cdna_hip_programming.md section 1
 
 def f64_run(la, L, check, dev, stream, X, y, pscale, q0, steps):
     """The headline workload on the float64 instantiation of the kernels (the reference's NumPy arithmetic is float64:
-    fit-np-hmc.py:18-19).  The f64 path keeps its rows in registers (32 lanes x 7 rows per chain) but has no packed math
-    and no matrix pipe: the number says what the dtype choice of `value` buys."""
+    fit-np-hmc.py:18-19).  The f64 path has no packed math and no matrix pipe at this width (rows in LDS, 16 lanes per chain
+    at 4096 chains: lr_plan.h): the number says what the dtype choice of `value` buys."""
     timer = Timer(L, check, dev, stream)
     m64 = la.LogReg(X, y, pscale, dtype="float64", device=dev)
     k64 = la.hmcKernel(m64.lpost, m64.glp, eps=EPS, l=LEAP, dmm=np.ones(N_PAR))

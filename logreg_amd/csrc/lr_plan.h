@@ -44,6 +44,12 @@ struct PlanConst {
     //  * from 64 chains per CU with rows within 28 KB: LDS rows with 8 lanes per chain (8 chains per wave) overtake one chain per
     //    wave (MALA, 16 384 chains, reg | lds 8: n=600 p=8 1.64 | 1.89e9, n=800 p=8 1.43 | 1.47 (1.44 | 1.64 at 65 536), n=300 p=12
     //    0.89 | 2.25, n=400 p=16 0.89 | 1.82; not at 32 KB: n=1000 p=8 1.42 | 1.19, n=500 p=16 mfma 1.69 | lds 8 1.52)
+    // float64, p <= 8, rows that fit the register variants (n <= 256): 32 lanes x 7 rows pads 200 rows to 224 and pays a 5-level
+    // f64 reduction (30 % of its leapfrog loop); rows in LDS with 16 lanes per chain from one wave per SIMD, 8 lanes per chain
+    // (8 x 25 = 200 exactly) from two (round 4, HMC L=20 n=200, it/s, reg 32x7 | lds 16 | lds 8: 2048 chains 7.6 | 4.4 | 2.8e7,
+    // 4096: 7.7 | 8.7 | 5.6, 8192: 7.7 | 8.7 | 11.2, 16 384: 7.7 | 8.8 | 11.3; MALA 8192: 5.3 | 7.2 | 7.2e8)
+    int f64_lds16_chains_per_cu = 16;
+    int f64_lds8_chains_per_cu = 32;
     int mfma_fp32_p16_chains_per_cu = 16;
     int lds8_chains_per_cu = 64;
     size_t lds8_max_row_bytes = 28 * 1024;
@@ -280,6 +286,11 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
         } else if (m->P == 16 && C >= (int64_t)kPlanConst.mfma_fp32_p16_chains_per_cu * m->cus && mfma_variant_fits(m, 4, ST_REG, out)) {
             return LR_OK;
         }
+    }
+    if (mode == LR_MODE_AUTO && group == 0 && !for_eval && m->dtype == LR_F64 && m->P == 8 && t->variants[best].mode == lr::MODE_REG) {
+        const int want_g = C >= (int64_t)kPlanConst.f64_lds8_chains_per_cu * m->cus ? 8 : (C >= (int64_t)kPlanConst.f64_lds16_chains_per_cu * m->cus ? 16 : 0);
+        for (int i = 0; want_g && i < t->nvariants; ++i)
+            if (t->variants[i].mode == lr::MODE_LDS && t->variants[i].G == want_g) best = i;
     }
     const lr::Variant& v = t->variants[best];
     *out = Plan{v.mode, v.G, v.R, v.mode == lr::MODE_LDS ? (size_t)m->n * m->P * m->esize()

@@ -60,7 +60,10 @@ CASES = [
     (3000, 16, 1024, "hmc", "auto", MFMA(4, -1)), (5000, 16, 1024, "hmc", "auto", {"mode": "stepwise"}),
     (9000, 8, 4096, "hmc", "auto", {"mode": "stepwise"}), (20000, 8, 4096, "hmc", "auto", {"mode": "stepwise"}),
     # float64 (p <= 8: rows in registers as well; wider: LDS / global only)
-    (200, 8, 4096, "hmc", "full", {"dtype": "float64", "mode": "reg", "group": 32, "rows_per_lane": 7}),
+    (200, 8, 2048, "hmc", "full", {"dtype": "float64", "mode": "reg", "group": 32, "rows_per_lane": 7}),
+    # ... from one wave per SIMD in LDS with 16 lanes per chain, from two with 8 (8 x 25 rows = 200 exactly; round 4)
+    (200, 8, 4096, "hmc", "full", {"dtype": "float64", "mode": "lds", "group": 16}),
+    (200, 8, 8192, "mala", "auto", {"dtype": "float64", "mode": "lds", "group": 8}),
     (200, 12, 4096, "hmc", "full", {"dtype": "float64", "mode": "lds"}),
     # float64 wide models: the stepwise engine on the f64 matrix pipe (lr_wide_f64.h), 64 chains per workgroup
     (4096, 128, 1024, "hmc", "auto", {"dtype": "float64", "mode": "stepwise", "group": 16}),
