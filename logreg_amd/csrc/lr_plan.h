@@ -38,19 +38,22 @@ struct PlanConst {
     double reg_corun = 0.88;
     // All-fp32 families (MALA / RWMH / UL, HMC with precision FULL) whose register variant is ONE chain per wave (64 lanes per chain:
     // 64 copies of the state, a 6-level reduction per evaluation) -- round 4, tools/planner_bench.py, profiles/r4_planner_bench_many_chains.txt:
-    //  * 9 <= p <= 16, rows within the register tiles of the fp32 matrix-core kernel (n <= 512): from 16 chains per CU the
-    //    fp32-MFMA kernel (S = 4) runs 1.6-1.7x the register kernel (n=500 p=16, MALA: 4096 chains 0.88 | 1.43e9 it/s, 8192 0.89 | 1.63,
-    //    65 536 0.90 | 1.76; HMC all-fp32 4096 chains 0.73 | 1.23e8; n=300 p=12 likewise).  At p <= 8 it never does (n=800: 1.43 | 0.99).
+    //  * 9 <= p <= 32, rows within the register tiles of the fp32 matrix-core kernel (n <= 1024 at p <= 16, 512 beyond): from 16
+    //    chains per CU the fp32-MFMA kernel (S = 4) beats every vector-ALU variant (MALA, 4096 chains, AUTO before | mfma, it/s:
+    //    n=500 p=16 reg 64x8 0.88 | 1.43e9, n=200 p=12 reg 32x7 1.87 | 2.08, n=250 p=16 HMC all-fp32 1.47 | 1.91e8, n=200 p=24
+    //    reg 64x4 0.47 | 1.27e9, n=400 p=30 lds 64 0.22 | 0.86e9; at 2048 chains n=200 p=12 1.85 | 1.04: not below).  At p <= 8
+    //    it never does (n=800: 1.43 | 0.99).
     //  * from 64 chains per CU with rows within 28 KB: LDS rows with 8 lanes per chain (8 chains per wave) overtake one chain per
     //    wave (MALA, 16 384 chains, reg | lds 8: n=600 p=8 1.64 | 1.89e9, n=800 p=8 1.43 | 1.47 (1.44 | 1.64 at 65 536), n=300 p=12
-    //    0.89 | 2.25, n=400 p=16 0.89 | 1.82; not at 32 KB: n=1000 p=8 1.42 | 1.19, n=500 p=16 mfma 1.69 | lds 8 1.52)
+    //    0.89 | 2.25, n=400 p=16 0.89 | 1.82; not at 32 KB: n=1000 p=8 1.42 | 1.19, n=500 p=16 mfma 1.69 | lds 8 1.52; not at
+    //    p > 16: n=200 p=24, 4096 chains, lds 8 0.41 | mfma 1.27e9)
     // float64, p <= 8, rows that fit the register variants (n <= 256): 32 lanes x 7 rows pads 200 rows to 224 and pays a 5-level
     // f64 reduction (30 % of its leapfrog loop); rows in LDS with 16 lanes per chain from one wave per SIMD, 8 lanes per chain
     // (8 x 25 = 200 exactly) from two (round 4, HMC L=20 n=200, it/s, reg 32x7 | lds 16 | lds 8: 2048 chains 7.6 | 4.4 | 2.8e7,
     // 4096: 7.7 | 8.7 | 5.6, 8192: 7.7 | 8.7 | 11.2, 16 384: 7.7 | 8.8 | 11.3; MALA 8192: 5.3 | 7.2 | 7.2e8)
     int f64_lds16_chains_per_cu = 16;
     int f64_lds8_chains_per_cu = 32;
-    int mfma_fp32_p16_chains_per_cu = 16;
+    int mfma_fp32_chains_per_cu = 16;
     int lds8_chains_per_cu = 64;
     size_t lds8_max_row_bytes = 28 * 1024;
     // a run is planned in two parts (exactly-filled head + remainder on its own variant) when the model prices the pair below
@@ -278,12 +281,14 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
     if (best < 0)
         return fail(LR_ERR_UNSUPPORTED, "no kernel variant for dtype=%d p=%d (padded %d) n=%lld group=%d mode=%d",
                     m->dtype, m->p, m->P, (long long)m->n, group, mode);
-    // one chain per wave in registers, many chains: the measured better homes for the rows (kPlanConst)
-    if (mode == LR_MODE_AUTO && group == 0 && !for_eval && m->dtype == LR_F32 && t->variants[best].mode == lr::MODE_REG && t->variants[best].G == 64) {
-        if (C >= (int64_t)kPlanConst.lds8_chains_per_cu * m->cus && row_bytes <= kPlanConst.lds8_max_row_bytes) {
+    // all-fp32 families on the vector-ALU kernels: the measured better homes (kPlanConst; HMC under the default precision policy never
+    // gets here with enough chains: plan_mfma_hmc above)
+    if (mode == LR_MODE_AUTO && group == 0 && !for_eval && m->dtype == LR_F32 && t->variants[best].mode != lr::MODE_GLOBAL) {
+        const bool one_chain_per_wave = t->variants[best].mode == lr::MODE_REG && t->variants[best].G == 64;
+        if (m->P <= 16 && one_chain_per_wave && C >= (int64_t)kPlanConst.lds8_chains_per_cu * m->cus && row_bytes <= kPlanConst.lds8_max_row_bytes) {
             for (int i = 0; i < t->nvariants; ++i)
                 if (t->variants[i].mode == lr::MODE_LDS && t->variants[i].G == 8) best = i;
-        } else if (m->P == 16 && C >= (int64_t)kPlanConst.mfma_fp32_p16_chains_per_cu * m->cus && mfma_variant_fits(m, 4, ST_REG, out)) {
+        } else if (m->P >= 16 && C >= (int64_t)kPlanConst.mfma_fp32_chains_per_cu * m->cus && mfma_variant_fits(m, 4, ST_REG, out)) {
             return LR_OK;
         }
     }

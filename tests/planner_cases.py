@@ -36,7 +36,7 @@ CASES = [
     (4000, 8, 4096, "mala", "auto", {"mode": "stepwise"}),   # same rows, enough chains to fill the chip per slice
     (6000, 8, 64, "mala", "auto", {"mode": "stepwise"}),     # beyond LDS
     (300, 100, 64, "mala", "auto", {"mode": "stepwise"}),
-    (200, 12, 4096, "mala", "auto", REG(32, 7)),
+    (200, 12, 2048, "mala", "auto", REG(32, 7)),
     # ---- HMC whose interior gradients may use the bf16 matrix pipe moves to the fused matrix-core kernels once there are enough
     # ---- chains; "full" precision never does
     (200, 8, 2048, "hmc", "auto", {"mode": "reg"}), (200, 8, 4096, "hmc", "auto", MFMA(4, 4)), (200, 8, 4096, "hmc", "full", REG(16, 13)),
@@ -46,7 +46,8 @@ CASES = [
     (700, 8, 4096, "hmc", "auto", MFMA(4, 16)), (700, 8, 2048, "hmc", "auto", {"mode": "reg"}),
     # wider models (9 <= p <= 32): the same kernel family from 4 chains per CU; no variant beyond 8 tiles per wave at p > 16
     (200, 12, 1024, "hmc", "auto", MFMA(4, 4)), (200, 12, 16384, "hmc", "auto", MFMA(1, 13)), (200, 12, 512, "hmc", "auto", {"mode": "reg"}),
-    (200, 12, 4096, "hmc", "full", {"mode": "reg"}), (500, 32, 4096, "hmc", "auto", MFMA(4, 8)), (900, 16, 4096, "hmc", "auto", MFMA(4, 16)),
+    (200, 12, 4096, "hmc", "full", MFMA(4, 4)), (200, 12, 2048, "hmc", "full", {"mode": "reg"}),   # (round 4: the fp32 matrix-core kernel from 16 chains per CU)
+    (500, 32, 4096, "hmc", "auto", MFMA(4, 8)), (900, 16, 4096, "hmc", "auto", MFMA(4, 16)),
     (900, 32, 4096, "hmc", "auto", MFMA(4, -1)),   # p > 16 beyond 8 tiles per wave: operands in device memory
     (900, 32, 1024, "hmc", "auto", MFMA(4, -1)),   # (p > 16, n <= 2048: from 4 chains per CU)
     (900, 32, 512, "hmc", "auto", {"not_mode": "mfma"}), (3000, 32, 1024, "hmc", "auto", {"not_mode": "mfma"}),
@@ -77,6 +78,8 @@ CASES = [
     (300, 12, 8192, "mala", "auto", MFMA(4, 8)), (300, 12, 16384, "mala", "auto", {"mode": "lds", "group": 8}),
     (500, 16, 1 << 16, "mala", "auto", MFMA(4, 8)),   # 32 KB of rows: not LDS
     (600, 8, 16384, "mala", "auto", {"mode": "lds", "group": 8}), (600, 8, 8192, "mala", "auto", REG(64, 12)),
+    (200, 12, 4096, "mala", "auto", MFMA(4, 4)), (200, 24, 4096, "hmc", "full", MFMA(4, 4)), (400, 30, 4096, "mala", "auto", MFMA(4, 8)),
+    (200, 24, 1 << 15, "mala", "auto", MFMA(4, 4)), (900, 16, 4096, "mala", "auto", MFMA(4, 16)), (900, 30, 4096, "mala", "auto", {"not_mode": "mfma"}),
     (800, 8, 1 << 17, "hmc", "full", {"mode": "lds", "group": 8}), (400, 8, 16384, "mala", "auto", REG(32, 16)),
 ]
 
