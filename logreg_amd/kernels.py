@@ -393,7 +393,8 @@ class ChainSet:
         self.sync()
         ck = {"state": self.state.to_host(), "ll": self.lp.to_host(), "accepts": self.acc.to_host(),
               "iter_offset": np.int64(self.iter_offset), "seed": np.uint64(self.seed),
-              "chain_offset": np.int64(self.chain_offset), **self._fingerprint()}
+              "chain_offset": np.int64(self.chain_offset), "plan_chains": np.int64(self.plan_chains),
+              "plan_first": np.int64(self.plan_first), **self._fingerprint()}
         if self.stats is not None:  # the statistics window travels with the run
             ck.update(stats=self.stats.to_host(), stats_batch=np.int64(self.stats_batch), stats_kept=np.int64(self.stats_kept),
                       stats_pivot=np.asarray(self.pivot, dtype=np.float64))
@@ -418,8 +419,11 @@ class ChainSet:
             ckpt = dict(np.load(path, allow_pickle=False))
         if str(ckpt["kind"]) != kernel.kind:
             raise ValueError(f"checkpoint is for a {ckpt['kind']} kernel, got {kernel.kind}")
+        # (a shard resumes as the shard of the same planned run: its chains keep the kernel variants they had)
         cs = cls(kernel, ckpt["state"], int(ckpt["seed"]), chain_offset=int(ckpt["chain_offset"]), ll=ckpt["ll"],
-                 group=group, mode=mode, stream=stream, precision=precision)
+                 group=group, mode=mode, stream=stream, precision=precision,
+                 plan_chains=int(ckpt["plan_chains"]) if "plan_chains" in ckpt else 0,
+                 plan_first=int(ckpt["plan_first"]) if "plan_first" in ckpt else 0)
         want = cs._fingerprint()
         for key, val in want.items():
             if key not in ckpt:

@@ -161,3 +161,28 @@ def test_statistics_window_survives_checkpoint_and_resume(la, pima, map_beta, tm
     sa, sc = a.stats_summary(), c.stats_summary()
     for key in ("mean", "sd", "rhat", "ess"):
         assert np.array_equal(sa[key], sc[key])
+
+
+@pytest.mark.parametrize("kind", ["hmc", "mala"])
+def test_device_statistics_of_a_run_planned_in_two_parts(la, pima, map_beta, kind, tmp_path):
+    """4608 chains: the planner runs the first 4096 on 16 lanes per chain and the last 512 on 64 (two launches per call).  The
+    statistics buffer and the sample matrix are indexed by the chain's position in the CALL, whichever launch advances it:
+    device statistics = NumPy on the gathered samples; a checkpoint taken between launches resumes bit for bit."""
+    X, y = pima
+    m = la.LogReg(X, y, PSCALE)
+    k = (la.hmcKernel(m.lpost, m.glp, eps=1e-3, l=10, dmm=1 / PRE) if kind == "hmc" else la.malaKernel(m.lpost, m.glp, dt=1e-5, pre=PRE))
+    Cn, iters, thin, batch = 4608, 12, 2, 3
+    q0 = map_beta + 0.01 * np.random.default_rng(2).standard_normal((Cn, 8))
+    cs = la.ChainSet(k, q0, seed=6, precision="full")
+    assert cs.plan()["tail"] == {"from": 4096, "group": 64, "rows_per_lane": 4}
+    cs.enable_stats(batch, iters // batch)
+    first = cs.advance(5, thin)
+    path = cs.save(tmp_path / "two_part")
+    rest = cs.advance(7, thin)
+    samples = np.concatenate([first.to_host(), rest.to_host()])
+    _check(la, cs, samples, batch)
+    resumed = la.ChainSet.resume(k, path, precision="full")
+    assert resumed.plan() == cs.plan()
+    again = resumed.advance(7, thin).to_host()
+    assert np.array_equal(again, rest.to_host())
+    np.testing.assert_array_equal(resumed.stats_sums(), cs.stats_sums())
