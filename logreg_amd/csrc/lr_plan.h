@@ -57,8 +57,9 @@ struct PlanConst {
     int lds8_chains_per_cu = 64;
     size_t lds8_max_row_bytes = 28 * 1024;
     // a run is planned in two parts (exactly-filled head + remainder on its own variant) when the model prices the pair below
-    // this fraction of the single launch (two launches, two sets of prologue row loads: not for a few per cent)
-    double split_gain = 0.95;
+    // this fraction of the single launch (two launches, two sets of prologue row loads: not for a couple of per cent; the model's
+    // sequential pricing is within a point or two of the measured gains: profiles/r4_chain_grid.txt)
+    double split_gain = 0.97;
     // lane-per-chain with rows from the scalar unit: from this many waves per SIMD (HMC n=200 p=8: 2.20 / 2.46 / 2.64e8 it/s at
     // 2 / 4 / 8 waves per SIMD against 2.21e8 for rows in registers), rows within the 16 KB scalar cache
     int scalar_rows_waves_per_simd = 3;

@@ -26,6 +26,8 @@ CASES = [
     (200, 8, 5120, "mala", "auto", {**REG(16, 13), "tail": {"from": 4096, "group": 64, "rows_per_lane": 4}}),
     (200, 8, 6144, "hmc", "full", {**REG(16, 13), "tail": {"from": 4096, "group": 32, "rows_per_lane": 7}}),
     (200, 8, 9216, "mala", "auto", {**REG(16, 13), "tail": {"from": 8192, "group": 64, "rows_per_lane": 4}}),
+    (200, 8, 10240, "hmc", "full", {**REG(16, 13), "tail": {"from": 8192, "group": 32, "rows_per_lane": 7}}),
+    (200, 8, 12288, "mala", "auto", {"no_tail": True}),
     (200, 8, 4096, "mala", "auto", {"no_tail": True}), (200, 8, 8192, "mala", "auto", {"no_tail": True}),
     (200, 8, 7168, "mala", "auto", {"no_tail": True}), (200, 8, 2560, "mala", "auto", {"no_tail": True}),
     (200, 8, 1 << 18, "mala", "auto", {"mode": "global", "group": 1}),
