@@ -236,6 +236,8 @@ LR_API int lr_plan_run(const lr_model* m, int32_t kind, const lr_run_opts* opts,
  * lanes per chain: two waves on a quarter of the SIMDs, one on the rest, and the launch takes the time of 8192): the planner then
  * splits a run of register-resident kernels in TWO launches -- chains [0, split) of the run on (group, rows), the exactly-filled
  * head; chains [split, n) on (tail_group, tail_rows), wider lane groups that finish the remainder in one short launch.
+ * The remainder's launch runs beside the head's on a stream owned by the model handle, forked from opts->stream (after everything
+ * enqueued there so far) and joined back into it before the call returns: to the caller the call is still "enqueued on opts->stream".
  * split = 0: one part (every field of the tail is 0).  A chain's variant is a function of its position in the planned run
  * (lr_run_opts.plan_chains / plan_first), so chunked and sharded runs reproduce the one-launch-sequence run bit for bit.
  */

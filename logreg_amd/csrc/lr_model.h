@@ -125,6 +125,10 @@ struct lr_model {
     // run in order, so they may share a workspace; calls on different streams overlap on the device and get
     // disjoint ones (two ChainSets of one model on two streams, or an eval on the NULL stream beside a run)
     DebugOpts dbg;  // A/B switches, parsed once at creation (LOGREG_DEBUG_OPTS)
+    // two-part plans (lr_plan.h): the remainder's launch runs beside the head's on a stream of the handle's own, forked from and
+    // joined back into the caller's stream with these events (created on first use)
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     struct Ws { hipStream_t stream; void* p; size_t bytes; };
     std::vector<Ws> ws;
     size_t esize() const { return dtype == LR_F32 ? 4 : 8; }
