@@ -81,9 +81,12 @@ int do_chain_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs, c
     // Both parts present: the remainder runs CO-RESIDENT with the head, on the handle's side stream -- fork from the caller's
     // stream (everything enqueued so far), join back into it.  The head is VALU-issue-bound on one wave per SIMD, the remainder
     // (wide lane groups) mostly waits on cross-lane reductions: together 0.542 instead of 0.639 ms per step at 5120 chains
-    // (profiles/r4_two_part_corun.txt).  The head keeps its residency cap (one workgroup per CU); the remainder asks for none,
-    // so that it fits beside the head.
-    const bool both = head > 0 && head < C;
+    // (profiles/r4_two_part_corun.txt, r4_two_part_check.txt).  The head keeps its residency cap (one workgroup per CU); the
+    // remainder asks for none, so that it fits beside the head.
+    // ... while the head is at most two waves per SIMD: beside a head of three the remainder only gets in the way (HMC, 13 312 chains:
+    // 1.32 ms back to back, 1.47 co-resident, 1.40 as one launch; profiles/r4_chain_grid_corun_all.txt) -- then the parts run in turn
+    const bool two = head > 0 && head < C;
+    const bool both = two && head * pl.G / 64 <= 2LL * 4 * m->cus;
     if (both && !m->side_stream) {
         if (hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess ||
