@@ -81,8 +81,8 @@ int do_chain_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs, c
     // Both parts present: the remainder runs CO-RESIDENT with the head, on the handle's side stream -- fork from the caller's
     // stream (everything enqueued so far), join back into it.  The head is VALU-issue-bound on one wave per SIMD, the remainder
     // (wide lane groups) mostly waits on cross-lane reductions: together 0.542 instead of 0.639 ms per step at 5120 chains
-    // (profiles/r4_two_part_corun.txt, r4_two_part_check.txt).  Both keep a residency cap: the head's as always, the remainder's
-    // sized to what the head's workgroups leave of a CU's LDS.
+    // (profiles/r4_two_part_corun.txt, r4_two_part_check.txt).  The head keeps its residency cap (one workgroup per CU); the
+    // remainder asks for none, so that it fits beside the head.
     // ... while the head is at most two waves per SIMD: beside a head of three the remainder only gets in the way (HMC, 13 312 chains:
     // 1.32 ms back to back, 1.47 co-resident, 1.40 as one launch; profiles/r4_chain_grid_corun_all.txt) -- then the parts run in turn
     const bool two = head > 0 && head < C;
@@ -103,16 +103,7 @@ int do_chain_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs, c
         if (ca.count <= 0) continue;
         const bool side = both && part == 1;
         lr::LaunchCfg cfg{pl.mode, part == 0 ? pl.G : pl.G2, part == 0 ? pl.R : pl.R2, rs.kind, side ? m->side_stream : st, pl.lds_bytes,
-                          m->dbg.residency_cap ? m->cus : 0};
-        if (side && m->dbg.residency_cap) {
-            // the remainder is capped like any launch (one workgroup per CU), but never beyond what the head's workgroups leave of
-            // a CU's LDS: one remainder workgroup fits beside them, a second does not
-            const uint64_t head_blocks = ((uint64_t)head * pl.G + 255) / 256;
-            const size_t head_wg = lr::cap_target(head_blocks, m->cus);
-            const uint64_t head_per_cu = (head_blocks + m->cus - 1) / m->cus;
-            cfg.lds_ceiling = head_wg && lr::kLdsPerCu > head_per_cu * head_wg ? lr::kLdsPerCu - head_per_cu * head_wg : 0;
-            if (cfg.lds_ceiling == 0) cfg.cus = 0;  // (nothing to size against: no cap for the remainder)
-        }
+                          m->dbg.residency_cap && !side ? m->cus : 0};
         const int rc = m->table->launch_chain(&cfg, ca.count, &ma, &ca);
         if (rc != 0) return fail(rc == -3 ? LR_ERR_UNSUPPORTED : LR_ERR_HIP, "chain launch failed (%d): %s", rc,
                                  hipGetErrorString(hipGetLastError()));

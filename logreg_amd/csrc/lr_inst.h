@@ -11,7 +11,6 @@ struct LaunchCfg {
     hipStream_t stream;
     size_t lds_bytes;
     int cus;  // compute units of the model's device (0: unknown, no residency cap)
-    size_t lds_ceiling = 0;  // > 0: the residency cap may not ask for more LDS than this (a launch meant to sit BESIDE another one's workgroups)
 };
 
 // Residency cap of the fused chain kernels.  A grid of k workgroups per CU finishes in k workgroup times only if the
@@ -22,12 +21,6 @@ struct LaunchCfg {
 // ceil(blocks / CUs) of them fit on a CU leaves the even spread as the only placement.  Returns the DYNAMIC LDS bytes
 // to launch with (>= lds_dynamic); grids of more than 4 workgroups per CU are left alone (the imbalance amortises).
 constexpr size_t kLdsPerCu = 160 * 1024;
-// total LDS (static + dynamic) a workgroup holds under the cap for a grid of `blocks` workgroups, 0 = no cap applies
-inline size_t cap_target(uint64_t blocks, int cus) {
-    if (cus <= 0 || blocks < (uint64_t)cus) return 0;
-    const uint64_t cap = (blocks + (uint64_t)cus - 1) / (uint64_t)cus;
-    return cap > 4 ? 0 : ((kLdsPerCu / (cap + 1) + 2048 + 1023) / 1024) * 1024;
-}
 inline size_t capped_lds(uint64_t blocks, int cus, size_t lds_static, size_t lds_dynamic) {
     // only where the imbalance was observed: 1 .. 4 full rounds of workgroups.  A grid smaller than the chip (a single chain,
     // a few chains per launch) is left alone: nothing can double up that matters, and its small LDS footprint lets launches on

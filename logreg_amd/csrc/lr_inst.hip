@@ -83,9 +83,7 @@ int launch_eval_v(const LaunchCfg* cfg, int64_t C, const ModelArgs<T, P>& m, con
 // one fused chain kernel, its LDS request padded to the residency cap (lr_inst.h: capped_lds)
 template <auto Kernel, typename... Args>
 int launch_capped(const LaunchCfg* cfg, dim3 grid, dim3 block, size_t lds_dynamic, const Args&... args) {
-    size_t lds = capped_lds((uint64_t)grid.x * grid.y, cfg->cus, static_lds<Kernel>(), lds_dynamic);
-    if (cfg->lds_ceiling > 0 && static_lds<Kernel>() + lds > cfg->lds_ceiling)  // beside another launch's workgroups: never more than what they leave
-        lds = cfg->lds_ceiling > static_lds<Kernel>() + lds_dynamic ? cfg->lds_ceiling - static_lds<Kernel>() : lds_dynamic;
+    const size_t lds = capped_lds((uint64_t)grid.x * grid.y, cfg->cus, static_lds<Kernel>(), lds_dynamic);
     if (allow_lds<Kernel>(lds) != hipSuccess) return -2;
     hipLaunchKernelGGL(Kernel, grid, block, lds, cfg->stream, args...);
     return check(hipGetLastError());
