@@ -86,7 +86,8 @@ int do_chain_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs, c
     // ... while the head is at most two waves per SIMD: beside a head of three the remainder only gets in the way (HMC, 13 312 chains:
     // 1.32 ms back to back, 1.47 co-resident, 1.40 as one launch; profiles/r4_chain_grid_corun_all.txt) -- then the parts run in turn
     const bool two = head > 0 && head < C;
-    const bool both = two && head * pl.G / 64 <= 2LL * 4 * m->cus;
+    // (the threaded-ll kernels gain from the overlap at three waves as well: MALA +6 %, RWMH +10 % co-resident against -2 % / -1 % in turn)
+    const bool both = two && (rs.kind != lr::KIND_HMC || head * pl.G / 64 <= 2LL * 4 * m->cus);
     if (both && !m->side_stream) {
         if (hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess ||
