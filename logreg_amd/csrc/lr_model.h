@@ -85,11 +85,17 @@ inline bool parse_debug_opts(const char* text, DebugOpts* out, char* bad, size_t
         char* rest = nullptr;
         const long v = eq == std::string::npos ? 0 : std::strtol(item.c_str() + eq + 1, &rest, 10);
         bool ok = eq != std::string::npos && rest && *rest == 0 && eq + 1 < item.size();
-        if (ok && key == "residency_cap") ok = (v == 0 || v == 1), out->residency_cap = (int)v;
-        else if (ok && key == "tall_mx16") ok = (v == 0 || v == 1), out->tall_mx16 = (int)v;
-        else if (ok && key == "wide_traj") ok = (v == 0 || v == 1), out->wide_traj = (int)v;
-        else if (ok && key == "wide_waves") ok = (v == 4 || v == 8), out->wide_waves = (int)v;
-        else ok = false;
+        // key -> (field, the two values it accepts)
+        struct { const char* key; int* field; long a, b; } const table[] = {
+            {"residency_cap", &out->residency_cap, 0, 1}, {"tall_mx16", &out->tall_mx16, 0, 1},
+            {"wide_traj", &out->wide_traj, 0, 1}, {"wide_waves", &out->wide_waves, 4, 8}};
+        bool known = false;
+        for (const auto& e : table)
+            if (ok && key == e.key && (v == e.a || v == e.b)) {
+                *e.field = (int)v;
+                known = true;
+            }
+        ok = ok && known;
         if (!ok) {
             std::snprintf(bad, bad_len, "%s", item.c_str());
             return false;

@@ -183,165 +183,198 @@ bool plan_mfma_hmc(const lr_model* m, int64_t C, Plan* out) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// Choose the kernel variant.  REG (rows in VGPRs) whenever the data fit (G*R >= n), then LDS, then GLOBAL.  Group size: the
-// smallest available G that still gives every SIMD a wavefront (C*G/64 >= 4*CUs), else the largest; an explicit `group`
-// request is honoured exactly.
-// `hmc_bf16`: the run is HMC and its interior leapfrog gradients may use the bf16 matrix pipe (LR_PREC_AUTO / BF16)
-// `kind`: LR_KIND_* of the run, -1 = not a run of a known family (lr_plan, lr_eval)
-int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool for_eval = false, bool hmc_bf16 = false, int kind = -1) {
+// make_plan and its steps.  Order: (1) HMC with reduced-precision interior steps -> kMfmaRules; (2) wide models -> stepwise;
+// (3) rows off chip (or forced) -> stepwise; (4) the best variant by residency tier and the register family's launch-time model;
+// (5) measured overrides of vector-ALU plans; (6) a second part for the remainder between exactly-filled chain counts.
+struct PlanReq {
+    const lr_model* m;
+    int64_t C;       // chains to plan for
+    int group, mode; // the caller's request (0 / LR_MODE_AUTO: the planner's choice)
+    bool for_eval;   // lr_eval: no matrix-core / stepwise / two-part plans
+    int kind;        // LR_KIND_* of the run, -1 = not a run of a known family (lr_plan, lr_eval)
+    bool automatic() const { return mode == LR_MODE_AUTO && group == 0 && !for_eval; }
+};
+
+// (2) wide models (32 < p <= 128): only the stepwise engine exists; its partial kernels are MFMA GEMMs over blocks of 64 / 128
+// chains x row slices (lr_wide_bf16.h; float64 models: lr_wide_f64.h).  One workgroup per CU -- the fewest row slices -- measured
+// fastest for the bf16 kernels (48-64 KB of LDS: 2-3 per CU would fit; 8192 chains: 188 / 170 / 155 TFLOP/s at 1 / 2 / 3 per CU).
+int plan_wide(const PlanReq& q, Plan* out) {
+    const lr_model* m = q.m;
+    if (q.mode != LR_MODE_AUTO && q.mode != LR_MODE_STEPWISE)
+        return fail(LR_ERR_UNSUPPORTED, "p=%d > 32 runs on the stepwise engine only (mode=%d requested)", m->p, q.mode);
+    const int64_t cpb = wide_chains_per_block(m, q.C);
+    const int64_t blocks = (q.C + cpb - 1) / cpb;
+    int64_t RS = (m->cus + blocks - 1) / blocks;
+    if (q.group > 0) RS = q.group;  // explicit slice count: pins the summation order whatever the chain count
+    int64_t slice_len = (m->n + RS - 1) / RS;
+    slice_len = (slice_len + 31) / 32 * 32;  // whole 32-row blocks (the bf16 kernel's K = 32)
+    RS = (m->n + slice_len - 1) / slice_len;
+    *out = Plan{lr::MODE_STEPWISE, (int)RS, (int)slice_len, 0};
+    return LR_OK;
+}
+
+// (3) tall data: neither VGPRs nor LDS can hold the rows -> stepwise engine (lr_tall.h): the rows split into RS slices so that every
+// evaluation occupies the whole chip with ~4 waves per SIMD.  Measured (tools/midn_sweep.py, HMC, p = 8, chain-rows/s): rows
+// streamed from L2 by every group never beat the stepwise engine (n = 6000-8000: 0.4-1.0e12 vs 0.6-2.0e12).
+void plan_tall(const PlanReq& q, Plan* out) {
+    const lr_model* m = q.m;
+    const int64_t want_waves = 4LL * m->cus;
+    // a workgroup = NW waves x 64 chains working on one slice (NW as lr::TallGeom: LDS-limited)
+    const int raw = 2048 / (m->P * (int)m->esize());
+    const int64_t NW = raw >= 16 ? 16 : (raw >= 8 ? 8 : 4);
+    const int64_t waves_per_slice = NW * ((q.C + 63) / 64);
+    int64_t RS = (4 * want_waves + waves_per_slice - 1) / waves_per_slice;
+    if (q.mode == LR_MODE_STEPWISE && q.group > 0) RS = q.group;  // explicit slice count (see plan_wide)
+    int64_t slice_len = (m->n + RS - 1) / RS;
+    if (slice_len < 16 * NW) slice_len = 16 * NW;  // at least 16 rows per wave
+    slice_len = (slice_len + 1) & ~(int64_t)1;      // even: the float32 kernel walks row pairs
+    if (m->d_xmx) slice_len = (slice_len + 31) / 32 * 32;  // whole tile pairs: the matrix-pipe interior kernel
+    RS = (m->n + slice_len - 1) / slice_len;
+    *out = Plan{lr::MODE_STEPWISE, (int)RS, (int)slice_len, 0};
+}
+
+// the register family's launch-time model (kPlanConst): predicted time of `chains` chains on variant u, in rows
+double reg_cost(const lr_model* m, const lr::Variant& u, int64_t chains) {
+    const int64_t want_waves = 4LL * m->cus, waves = (chains * u.G + 63) / 64, wps = (waves + want_waves - 1) / want_waves;
+    return ((double)u.R + kPlanConst.reg_fixed_rows) * (1.0 + kPlanConst.reg_corun * (double)(wps - 1));
+}
+
+// (4) index of the best instantiated variant for the request, -1 if none: residency tier first (REG > LDS > GLOBAL), then group
+// fitness (the register family by its launch-time model), then fewer padded rows; matrix-core variants only on request
+int pick_variant(const PlanReq& q) {
+    const lr_model* m = q.m;
     const lr::InstTable* t = m->table;
     const int64_t want_waves = 4LL * m->cus;
+    const size_t row_bytes = (size_t)m->n * m->P * m->esize();
     int best = -1;
     long best_score = -1;
-    if (hmc_bf16 && !for_eval && mode == LR_MODE_AUTO && group == 0 && plan_mfma_hmc(m, C, out)) return LR_OK;
-    if (m->P > 32) {
-        // wide models (32 < p <= 128): only the stepwise engine exists; its partial kernels are MFMA GEMMs over blocks of
-        // 64 / 128 chains x row slices (lr_wide_bf16.h; float64 models: lr_wide_f64.h).
-        if (mode != LR_MODE_AUTO && mode != LR_MODE_STEPWISE)
-            return fail(LR_ERR_UNSUPPORTED, "p=%d > 32 runs on the stepwise engine only (mode=%d requested)", m->p, mode);
-        const int64_t cpb = wide_chains_per_block(m, C);
-        const int64_t blocks = (C + cpb - 1) / cpb;
-        // one workgroup per CU -- the fewest row slices -- measured fastest for the bf16 kernels (48-64 KB of LDS: 2-3 per CU
-        // would fit; 8192 chains: 188 / 170 / 155 TFLOP/s at 1 / 2 / 3 per CU)
-        const int64_t per_cu = 1;
-        int64_t RS = (per_cu * m->cus + blocks - 1) / blocks;
-        if (group > 0) RS = group;  // explicit slice count: pins the summation order whatever the chain count
-        int64_t slice_len = (m->n + RS - 1) / RS;
-        slice_len = (slice_len + 31) / 32 * 32;  // whole 32-row blocks (the bf16 kernel's K = 32)
-        RS = (m->n + slice_len - 1) / slice_len;
-        *out = Plan{lr::MODE_STEPWISE, (int)RS, (int)slice_len, 0};
-        return LR_OK;
-    }
-    if (for_eval && (mode == LR_MODE_MFMA || mode == LR_MODE_STEPWISE)) { mode = LR_MODE_AUTO; group = 0; }
-    // tall data: neither VGPRs nor LDS can hold the rows -> stepwise engine (lr_tall.h): split the rows into
-    // RS slices so that every evaluation occupies the whole chip with ~4 waves per SIMD
-    // measured (tools/midn_sweep.py, HMC, p = 8, chain-rows/s): rows streamed from L2 by every group never beat
-    // the stepwise engine (n = 6000-8000: 0.4-1.0e12 vs 0.6-2.0e12)
-    const size_t row_bytes = (size_t)m->n * m->P * m->esize();
-    const bool fits_lds = row_bytes <= kLdsBudget;
-    const bool prefer_stepwise = !fits_lds || (row_bytes > kPlanConst.lds_rows_prefer_stepwise_bytes && C >= kPlanConst.lds_rows_prefer_stepwise_chains);
-    if (!for_eval && (mode == LR_MODE_STEPWISE || (mode == LR_MODE_AUTO && group == 0 && prefer_stepwise))) {
-        // a workgroup = NW waves x 64 chains working on one slice (NW as lr::TallGeom: LDS-limited)
-        const int raw = 2048 / (m->P * (int)m->esize());
-        const int64_t NW = raw >= 16 ? 16 : (raw >= 8 ? 8 : 4);
-        const int64_t waves_per_slice = NW * ((C + 63) / 64);
-        int64_t RS = (4 * want_waves + waves_per_slice - 1) / waves_per_slice;
-        if (mode == LR_MODE_STEPWISE && group > 0) RS = group;  // explicit slice count (see the wide branch)
-        int64_t slice_len = (m->n + RS - 1) / RS;
-        if (slice_len < 16 * NW) slice_len = 16 * NW;  // at least 16 rows per wave
-        slice_len = (slice_len + 1) & ~(int64_t)1;      // even: the float32 kernel walks row pairs
-        if (m->d_xmx) slice_len = (slice_len + 31) / 32 * 32;  // whole tile pairs: the matrix-pipe interior kernel
-        RS = (m->n + slice_len - 1) / slice_len;
-        *out = Plan{lr::MODE_STEPWISE, (int)RS, (int)slice_len, 0};
-        return LR_OK;
-    }
     for (int i = 0; i < t->nvariants; ++i) {
         const lr::Variant& v = t->variants[i];
         if (v.mode == lr::MODE_MFMA) {
-            // fp32 matrix-core variants; G = row-split ways S, R = tiles per wave.  In all-fp32 arithmetic opt-in only
-            // (mode = LR_MODE_MFMA): fp32 MFMA shares the fp32 multipliers with the vector ALU, and since the vector kernels
-            // went fully packed (v_pk_fma_f32 + fused v_add_f32_dpp) reg 16x13 is faster at every chain count measured
-            // (1.93e8 vs 1.65e8 it/s at 16 384 chains, 2.00e8 vs 1.86e8 at 65 536).
-            if (for_eval) continue;
+            // fp32 matrix-core variants; G = row-split ways S, R = tiles per wave.  Here only on request (mode = LR_MODE_MFMA); the
+            // planner's own uses are plan_mfma_hmc and measured_overrides.
+            if (q.for_eval || q.mode != LR_MODE_MFMA) continue;
             if (v.R < 0 ? m->d_xms == nullptr
                         : (v.R == 0 ? mfma_lds_bytes(m, v.G) > mfma_lds_budget(m, v.G) : (int64_t)16 * v.G * v.R < m->n)) continue;
-            const bool filled = C >= 16LL * want_waves;
-            if (mode == LR_MODE_MFMA) {
-                if (group != 0 && v.G != group) continue;
-                // operands in LDS / device memory: only when no register variant fits
-                const long score = v.R <= 0 ? 0 : ((filled ? (v.G == 1) : (v.G == 4)) ? 2 : 1);
-                if (score > best_score) { best_score = score; best = i; }
-            }
+            if (q.group != 0 && v.G != q.group) continue;
+            const bool filled = q.C >= 16LL * want_waves;
+            // operands in LDS / device memory: only when no register variant fits
+            const long score = v.R <= 0 ? 0 : ((filled ? (v.G == 1) : (v.G == 4)) ? 2 : 1);
+            if (score > best_score) { best_score = score; best = i; }
             continue;
         }
-        if (mode != LR_MODE_AUTO && v.mode != mode) continue;
-        if (group != 0 && v.G != group) continue;
+        if (q.mode != LR_MODE_AUTO && v.mode != q.mode) continue;
+        if (q.group != 0 && v.G != q.group) continue;
         if (v.mode == lr::MODE_REG && (int64_t)v.G * v.R < m->n) continue;
-        if (v.mode == lr::MODE_LDS && (size_t)m->n * m->P * m->esize() > kLdsBudget) continue;
-        // score: residency tier first (REG > LDS > GLOBAL), then group fitness, then fewer padded rows
-        const int64_t waves = (C * v.G + 63) / 64;
+        if (v.mode == lr::MODE_LDS && row_bytes > kLdsBudget) continue;
+        const int64_t waves = (q.C * v.G + 63) / 64;
         long score = (2 - v.mode) * 1000000L;
         if (waves >= want_waves) score += 100000L - 1000L * v.G;  // filled: prefer small groups
         else score += 10L * v.G;                                   // not filled: prefer large groups
-        if (v.mode == lr::MODE_REG && group == 0) {
-            // the register family by the launch-time model of kPlanConst (the lowest predicted time wins; ties: fewer padded rows)
-            const int64_t wps = (waves + want_waves - 1) / want_waves;
-            const double cost = ((double)v.R + kPlanConst.reg_fixed_rows) * (1.0 + kPlanConst.reg_corun * (double)(wps - 1));
-            // (the model orders the variants INSIDE the register tier only: mapped into the tier's width (0, 900000], so that at very
-            //  large chain counts -- many waves per SIMD, large modelled cost -- a register variant still scores above the LDS tier)
-            score = 2000000L + (long)(900000.0 / (1.0 + cost / 64.0)) - v.R;
+        if (v.mode == lr::MODE_REG && q.group == 0) {
+            // the lowest predicted time wins (ties: fewer padded rows); mapped into the tier's width (0, 900000], so that at very large
+            // chain counts -- many waves per SIMD, large modelled cost -- a register variant still scores above the LDS tier
+            score = 2000000L + (long)(900000.0 / (1.0 + reg_cost(m, v, q.C) / 64.0)) - v.R;
         } else if (v.mode == lr::MODE_REG) {
             score -= v.R;  // exact-fit R before padded R
         }
         // lane-per-chain with rows broadcast from the scalar unit has no replicated work and no reductions
-        if (mode == LR_MODE_AUTO && group == 0 && v.mode == lr::MODE_GLOBAL && v.G == 1 &&
-            waves >= kPlanConst.scalar_rows_waves_per_simd * want_waves && (size_t)m->n * m->P * m->esize() <= kPlanConst.scalar_rows_max_bytes)
+        if (q.mode == LR_MODE_AUTO && q.group == 0 && v.mode == lr::MODE_GLOBAL && v.G == 1 &&
+            waves >= kPlanConst.scalar_rows_waves_per_simd * want_waves && row_bytes <= kPlanConst.scalar_rows_max_bytes)
             score = 4000000L;
         if (score > best_score) { best_score = score; best = i; }
     }
+    return best;
+}
+
+// (5) vector-ALU plans the measurements overrule (kPlanConst).  Returns true when *out is final (a matrix-core plan); else `best`
+// may have been moved to another variant of the table.
+bool measured_overrides(const PlanReq& q, int* best, Plan* out) {
+    const lr_model* m = q.m;
+    const lr::InstTable* t = m->table;
+    const lr::Variant& b = t->variants[*best];
+    const size_t row_bytes = (size_t)m->n * m->P * m->esize();
+    auto move_to_lds = [&](int g) {
+        for (int i = 0; i < t->nvariants; ++i)
+            if (t->variants[i].mode == lr::MODE_LDS && t->variants[i].G == g) *best = i;
+    };
+    if (m->dtype == LR_F32 && b.mode != lr::MODE_GLOBAL) {
+        // all-fp32 families (HMC under the default precision policy never gets here with enough chains: plan_mfma_hmc)
+        const bool one_chain_per_wave = b.mode == lr::MODE_REG && b.G == 64;
+        if (m->P <= 16 && one_chain_per_wave && q.C >= (int64_t)kPlanConst.lds8_chains_per_cu * m->cus && row_bytes <= kPlanConst.lds8_max_row_bytes)
+            move_to_lds(8);
+        else if (m->P >= 16 && q.C >= (int64_t)kPlanConst.mfma_fp32_chains_per_cu * m->cus && mfma_variant_fits(m, 4, ST_REG, out))
+            return true;
+    }
+    if (m->dtype == LR_F64 && m->P == 8 && b.mode == lr::MODE_REG) {
+        if (q.C >= (int64_t)kPlanConst.f64_lds8_chains_per_cu * m->cus) move_to_lds(8);
+        else if (q.C >= (int64_t)kPlanConst.f64_lds16_chains_per_cu * m->cus) move_to_lds(16);
+    }
+    return false;
+}
+
+// (6) Wave quantisation of the register family.  Between the chain counts that fill the chip exactly a launch takes the time of its
+// fullest SIMD (5120 chains on 16 lanes per chain: 1.43e8 it/s where 4096 run 2.13e8, profiles/r3_chain_grid.txt).  A run left to the
+// planner is then planned in two parts: the largest exactly-filled head on the variant the model prefers for that count, the
+// remainder on whatever variant the model prefers for IT (usually a wider group that finishes in one short wave), when the model
+// prices the two launches kPlanConst.split_gain below the single one.  *out holds the one-part plan on entry.
+void plan_second_part(const PlanReq& q, const lr::Variant& whole, Plan* out) {
+    const lr_model* m = q.m;
+    const lr::InstTable* t = m->table;
+    const int64_t want_waves = 4LL * m->cus;
+    auto fits = [&](const lr::Variant& u) { return u.mode == lr::MODE_REG && (int64_t)u.G * u.R >= m->n; };
+    auto best_reg = [&](int64_t chains, double* cost) {
+        int bi = -1;
+        for (int i = 0; i < t->nvariants; ++i) {
+            if (!fits(t->variants[i])) continue;
+            const double c = reg_cost(m, t->variants[i], chains) + 1e-3 * t->variants[i].R;
+            if (bi < 0 || c < *cost) { bi = i; *cost = c; }
+        }
+        return bi;
+    };
+    double best_total = reg_cost(m, whole, q.C) * kPlanConst.split_gain;
+    for (int i = 0; i < t->nvariants; ++i) {  // head variant: any register variant, its exactly-filling quantum
+        const lr::Variant& a = t->variants[i];
+        if (!fits(a)) continue;
+        const int64_t quantum = want_waves * 64 / a.G;
+        if (quantum <= 0 || q.C <= quantum || q.C % quantum == 0) continue;
+        const int64_t head = q.C / quantum * quantum;
+        double cb = 0;
+        const int bi = best_reg(q.C - head, &cb);
+        if (bi < 0) continue;
+        const double total = reg_cost(m, a, head) + cb;
+        if (total < best_total) {
+            best_total = total;
+            *out = Plan{a.mode, a.G, a.R, 0};
+            out->split = head;
+            out->G2 = t->variants[bi].G;
+            out->R2 = t->variants[bi].R;
+        }
+    }
+}
+
+// `hmc_bf16`: the run is HMC and its interior leapfrog gradients may use the bf16 matrix pipe (LR_PREC_AUTO / BF16)
+// `kind`: LR_KIND_* of the run, -1 = not a run of a known family (lr_plan, lr_eval)
+int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool for_eval = false, bool hmc_bf16 = false, int kind = -1) {
+    if (for_eval && (mode == LR_MODE_MFMA || mode == LR_MODE_STEPWISE) && m->P <= 32) { mode = LR_MODE_AUTO; group = 0; }
+    const PlanReq q{m, C, group, mode, for_eval, kind};
+    if (hmc_bf16 && q.automatic() && plan_mfma_hmc(m, C, out)) return LR_OK;
+    if (m->P > 32) return plan_wide(q, out);
+    const size_t row_bytes = (size_t)m->n * m->P * m->esize();
+    const bool prefer_stepwise = row_bytes > kLdsBudget ||
+                                 (row_bytes > kPlanConst.lds_rows_prefer_stepwise_bytes && C >= kPlanConst.lds_rows_prefer_stepwise_chains);
+    if (!for_eval && (mode == LR_MODE_STEPWISE || (mode == LR_MODE_AUTO && group == 0 && prefer_stepwise))) {
+        plan_tall(q, out);
+        return LR_OK;
+    }
+    int best = pick_variant(q);
     if (best < 0)
         return fail(LR_ERR_UNSUPPORTED, "no kernel variant for dtype=%d p=%d (padded %d) n=%lld group=%d mode=%d",
                     m->dtype, m->p, m->P, (long long)m->n, group, mode);
-    // all-fp32 families on the vector-ALU kernels: the measured better homes (kPlanConst; HMC under the default precision policy never
-    // gets here with enough chains: plan_mfma_hmc above)
-    if (mode == LR_MODE_AUTO && group == 0 && !for_eval && m->dtype == LR_F32 && t->variants[best].mode != lr::MODE_GLOBAL) {
-        const bool one_chain_per_wave = t->variants[best].mode == lr::MODE_REG && t->variants[best].G == 64;
-        if (m->P <= 16 && one_chain_per_wave && C >= (int64_t)kPlanConst.lds8_chains_per_cu * m->cus && row_bytes <= kPlanConst.lds8_max_row_bytes) {
-            for (int i = 0; i < t->nvariants; ++i)
-                if (t->variants[i].mode == lr::MODE_LDS && t->variants[i].G == 8) best = i;
-        } else if (m->P >= 16 && C >= (int64_t)kPlanConst.mfma_fp32_chains_per_cu * m->cus && mfma_variant_fits(m, 4, ST_REG, out)) {
-            return LR_OK;
-        }
-    }
-    if (mode == LR_MODE_AUTO && group == 0 && !for_eval && m->dtype == LR_F64 && m->P == 8 && t->variants[best].mode == lr::MODE_REG) {
-        const int want_g = C >= (int64_t)kPlanConst.f64_lds8_chains_per_cu * m->cus ? 8 : (C >= (int64_t)kPlanConst.f64_lds16_chains_per_cu * m->cus ? 16 : 0);
-        for (int i = 0; want_g && i < t->nvariants; ++i)
-            if (t->variants[i].mode == lr::MODE_LDS && t->variants[i].G == want_g) best = i;
-    }
-    const lr::Variant& v = t->variants[best];
-    *out = Plan{v.mode, v.G, v.R, v.mode == lr::MODE_LDS ? (size_t)m->n * m->P * m->esize()
-                                  : (v.mode == lr::MODE_MFMA && v.R == 0 ? mfma_lds_bytes(m, v.G) : 0)};
-    // Wave quantisation of the register family.  Between the chain counts that fill the chip exactly a launch takes the time of
-    // its fullest SIMD (5120 chains on 16 lanes per chain: 1.43e8 it/s where 4096 run 2.13e8, profiles/r3_chain_grid.txt).  A run
-    // left to the planner (AUTO, no group) is then planned in two parts: the largest exactly-filled head on the variant the model
-    // prefers for that count, the remainder on whatever variant the model prefers for IT (usually a wider group that finishes
-    // in one short wave), when the model prices the two launches kPlanConst.split_gain below the single one.
-    if (v.mode == lr::MODE_REG && mode == LR_MODE_AUTO && group == 0 && !for_eval && kind >= 0) {
-        auto cost_of = [&](const lr::Variant& u, int64_t chains) {
-            const int64_t waves = (chains * u.G + 63) / 64, wps = (waves + want_waves - 1) / want_waves;
-            return ((double)u.R + kPlanConst.reg_fixed_rows) * (1.0 + kPlanConst.reg_corun * (double)(wps - 1));
-        };
-        auto best_reg = [&](int64_t chains, double* cost) {
-            int bi = -1;
-            for (int i = 0; i < t->nvariants; ++i) {
-                const lr::Variant& u = t->variants[i];
-                if (u.mode != lr::MODE_REG || (int64_t)u.G * u.R < m->n) continue;
-                const double c = cost_of(u, chains) + 1e-3 * u.R;
-                if (bi < 0 || c < *cost) { bi = i; *cost = c; }
-            }
-            return bi;
-        };
-        const double whole = cost_of(v, C);
-        double best_total = whole * kPlanConst.split_gain;
-        for (int i = 0; i < t->nvariants; ++i) {  // head variant A: any register variant, its exactly-filling quantum
-            const lr::Variant& a = t->variants[i];
-            if (a.mode != lr::MODE_REG || (int64_t)a.G * a.R < m->n) continue;
-            const int64_t quantum = want_waves * 64 / a.G;
-            if (quantum <= 0 || C <= quantum || C % quantum == 0) continue;
-            const int64_t head = C / quantum * quantum;
-            double cb = 0;
-            const int bi = best_reg(C - head, &cb);
-            if (bi < 0) continue;
-            const double total = cost_of(a, head) + cb;
-            if (total < best_total) {
-                best_total = total;
-                *out = Plan{a.mode, a.G, a.R, 0};
-                out->split = head;
-                out->G2 = t->variants[bi].G;
-                out->R2 = t->variants[bi].R;
-            }
-        }
-    }
+    if (q.automatic() && measured_overrides(q, &best, out)) return LR_OK;
+    const lr::Variant& v = m->table->variants[best];
+    *out = Plan{v.mode, v.G, v.R, v.mode == lr::MODE_LDS ? row_bytes : (v.mode == lr::MODE_MFMA && v.R == 0 ? mfma_lds_bytes(m, v.G) : 0)};
+    if (v.mode == lr::MODE_REG && q.automatic() && kind >= 0) plan_second_part(q, v, out);
     return LR_OK;
 }
 
