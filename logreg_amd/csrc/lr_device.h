@@ -52,13 +52,18 @@ constexpr uint32_t TAG_UNIFORM = 0x80000000u;
 template <typename T> __device__ __forceinline__ T u01(uint32_t w) {
     return (T(w >> 8) + T(0.5)) * T(1.0 / 16777216.0);
 }
+// log of the 24-bit uniform in float: v_log_f32 (1 ulp) times ln 2
+__device__ __forceinline__ float log_u01(uint32_t w) { return 0.693147180559945309f * __builtin_amdgcn_logf(u01<float>(w)); }
 
+// float: on the hardware transcendentals -- v_log_f32 (log2), v_sqrt_f32, v_sin_f32 / v_cos_f32 (argument in REVOLUTIONS, which is
+// what Box-Muller has: 2 pi u).  10 instructions per pair where logf / sqrtf / sincospif with their range handling took ~65; the
+// normals agree with the float64 oracle's to ~1e-6 (tests/test_gpu_parity.py::test_device_normals_against_the_oracle), far inside
+// every parity tolerance, and every kernel shares this function, so variants still agree with each other.
 __device__ __forceinline__ void box_muller(uint32_t wa, uint32_t wb, float& z0, float& z1) {
-    const float r = sqrtf(-2.0f * logf(u01<float>(wa)));
-    float s, c;
-    sincospif(2.0f * u01<float>(wb), &s, &c);
-    z0 = r * c;
-    z1 = r * s;
+    const float r = __builtin_amdgcn_sqrtf(-1.38629436111989062f * __builtin_amdgcn_logf(u01<float>(wa)));  // sqrt(-2 ln u), ln u = ln 2 * log2 u
+    const float t = u01<float>(wb);
+    z0 = r * __builtin_amdgcn_cosf(t);
+    z1 = r * __builtin_amdgcn_sinf(t);
 }
 __device__ __forceinline__ void box_muller(uint32_t wa, uint32_t wb, double& z0, double& z1) {
     const double r = sqrt(-2.0 * log(u01<double>(wa)));
@@ -91,7 +96,7 @@ template <typename T>
 __device__ __forceinline__ T draw_log_uniform(uint64_t seed, uint64_t chain, uint64_t iter) {
     const U4 w = philox4x32_10((uint32_t)chain, (uint32_t)iter, (uint32_t)(iter >> 32), TAG_UNIFORM,
                                (uint32_t)seed, (uint32_t)(seed >> 32));
-    if constexpr (sizeof(T) == 4) return logf(u01<float>(w.x));
+    if constexpr (sizeof(T) == 4) return log_u01(w.x);
     else return log(u01<double>(w.x));
 }
 
@@ -320,7 +325,7 @@ __device__ __forceinline__ void draw_group(uint64_t seed, uint64_t chain, uint64
         T mine[2];
         box_muller(wa, wb, mine[0], mine[1]);
         T lu;
-        if constexpr (sizeof(T) == 4) lu = logf(u01<float>(w.x));
+        if constexpr (sizeof(T) == 4) lu = log_u01(w.x);
         else lu = log(u01<double>(w.x));
         bcast_pairs<T, P, G>(mine, z);
         logu = group_bcast<G, NP>(lu);
@@ -333,7 +338,7 @@ __device__ __forceinline__ void draw_group(uint64_t seed, uint64_t chain, uint64
         box_muller(w.x, w.y, mine[0], mine[1]);
         box_muller(w.z, w.w, mine[2], mine[3]);
         T lu;
-        if constexpr (sizeof(T) == 4) lu = logf(u01<float>(w.x));
+        if constexpr (sizeof(T) == 4) lu = log_u01(w.x);
         else lu = log(u01<double>(w.x));
         bcast_blocks<T, P, G>(mine, z);
         logu = group_bcast<G, NB>(lu);
@@ -343,30 +348,37 @@ __device__ __forceinline__ void draw_group(uint64_t seed, uint64_t chain, uint64
     }
 }
 
-// Draws for SEVERAL consecutive iterations at once.  An iteration needs BPI = ceil(P/4) + 1 Philox blocks (the
-// normal blocks and the accept uniform); the G lanes of a group all execute the generator anyway, so lane gl computes
-// block gl % BPI of iteration base + gl / BPI: NB = G / BPI iterations are covered by ONE Philox + Box-Muller + log per
-// lane, and every iteration then only collects its values from the lanes that hold them (ds_bpermute: a runtime lane
-// index, so the chain loop is not unrolled).  At G = 16, P = 8: 5 iterations per refill (the generator was ~150 of
-// the ~490 instructions of a MALA iteration; now ~45); at one chain per wave (G = 64) 21 iterations per refill.
-// The VALUES are those of draw_normals / draw_log_uniform bit for bit: only who computes them, and when, changes.
+// Draws for SEVERAL consecutive iterations at once, in two kinds of generator pass.  An iteration needs NBn = ceil(P/4) NORMAL
+// blocks (Philox + two Box-Muller pairs each) and one UNIFORM block (Philox + one log; only word 0 is used).  The G lanes of a group
+// all execute the generator anyway, so
+//   a normals pass:   lane gl computes normal block gl % NBn of iteration base + gl / NBn    -> NIn = G / NBn iterations per pass
+//   a uniforms pass:  lane gl computes the uniform block of iteration base + gl               -> NIu = G iterations per pass
+// and every iteration then only collects its values from the lanes that hold them (ds_bpermute: a runtime lane index, so the chain
+// loop is not unrolled).  Roles are uniform across the wave inside a pass, so no lane runs a Box-Muller whose result nobody reads
+// (round 3 mixed the two kinds in one pass: a third of the lanes did; per 16 iterations at G = 16, P = 8: 3.2 passes of ~220
+// instructions then, 2 + 1 passes of ~135 / ~105 now).  The VALUES are those of draw_normals / draw_log_uniform bit for bit: only who
+// computes them, and when, changes.
 template <typename T, int P, int G> struct DrawBatch {
-    static constexpr int NBn = (P + 3) / 4, BPI = NBn + 1, NB = G / BPI;
-    static constexpr bool kEnabled = NB >= 2;
-    T mine[4];   // this lane's four normals (normal block) -- garbage for the uniform block's lane
-    T lu;        // log(u) of this lane's block word 0 (meaningful in the uniform block's lane)
-    int pos;     // iterations already served from the current refill (NB = refill before use)
-    __device__ __forceinline__ void reset() { pos = NB; }
-    __device__ __forceinline__ void refill(uint64_t seed, uint64_t chain, uint64_t iter_base, int gl) {
-        const int io = gl / BPI, b = gl - io * BPI;
+    static constexpr int NBn = (P + 3) / 4, NIn = G / NBn, NIu = G;
+    static constexpr bool kEnabled = NIn >= 2;
+    T mine[4];   // this lane's four normals of its normal block
+    T lu;        // log(u) of this lane's uniform block
+    int posn, posu;  // iterations already served from the current normals / uniforms pass
+    __device__ __forceinline__ void reset() { posn = NIn; posu = NIu; }
+    __device__ __forceinline__ void refill_normals(uint64_t seed, uint64_t chain, uint64_t iter_base, int gl) {
+        const int io = gl / NBn, b = gl - io * NBn;  // (lanes beyond NIn * NBn run ahead of what is read: harmless)
         const uint64_t it = iter_base + (uint64_t)io;
-        const uint32_t blk = b == NBn ? TAG_UNIFORM : (uint32_t)b;
-        const U4 w = philox4x32_10((uint32_t)chain, (uint32_t)it, (uint32_t)(it >> 32), blk, (uint32_t)seed, (uint32_t)(seed >> 32));
+        const U4 w = philox4x32_10((uint32_t)chain, (uint32_t)it, (uint32_t)(it >> 32), (uint32_t)b, (uint32_t)seed, (uint32_t)(seed >> 32));
         box_muller(w.x, w.y, mine[0], mine[1]);
         box_muller(w.z, w.w, mine[2], mine[3]);
-        if constexpr (sizeof(T) == 4) lu = logf(u01<float>(w.x));
+        posn = 0;
+    }
+    __device__ __forceinline__ void refill_uniforms(uint64_t seed, uint64_t chain, uint64_t iter_base, int gl) {
+        const uint64_t it = iter_base + (uint64_t)gl;
+        const U4 w = philox4x32_10((uint32_t)chain, (uint32_t)it, (uint32_t)(it >> 32), TAG_UNIFORM, (uint32_t)seed, (uint32_t)(seed >> 32));
+        if constexpr (sizeof(T) == 4) lu = log_u01(w.x);
         else lu = log(u01<double>(w.x));
-        pos = 0;
+        posu = 0;
     }
     static __device__ __forceinline__ float fetch(float v, int lane_byte) {
         return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(lane_byte, __builtin_bit_cast(int, v)));
@@ -377,25 +389,33 @@ template <typename T, int P, int G> struct DrawBatch {
         const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(lane_byte, (int)(uint32_t)(bits >> 32));
         return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
     }
+    // (iterations must be requested consecutively; both refills are wave-uniform)
+    __device__ __forceinline__ void advance_to(uint64_t seed, uint64_t chain, uint64_t iter, int gl) {
+        if (posn >= NIn) refill_normals(seed, chain, iter, gl);
+        if (posu >= NIu) refill_uniforms(seed, chain, iter, gl);
+    }
     // the two normals of coordinates 2q, 2q + 1 and log(u) only (state distributed over the group: k_chain_rs16)
     __device__ __forceinline__ void next_pair(uint64_t seed, uint64_t chain, uint64_t iter, int gl, int q, T& zx, T& zy, T& logu) {
-        if (pos >= NB) refill(seed, chain, iter, gl);  // wave-uniform
-        const int base = ((int)(threadIdx.x & 63) - gl + pos * BPI) * 4;
-        const int src = base + 4 * (q >> 1);  // block (2q) / 4 of this iteration
+        advance_to(seed, chain, iter, gl);
+        const int gbase = (int)(threadIdx.x & 63) - gl;  // first lane of the group
+        const int src = (gbase + posn * NBn + (q >> 1)) * 4;  // block (2q) / 4 of this iteration
         const T e0 = fetch(mine[0], src), e1 = fetch(mine[1], src), e2 = fetch(mine[2], src), e3 = fetch(mine[3], src);
         zx = (q & 1) ? e2 : e0;
         zy = (q & 1) ? e3 : e1;
-        logu = fetch(lu, base + 4 * NBn);
-        ++pos;
+        logu = fetch(lu, (gbase + posu) * 4);
+        ++posn;
+        ++posu;
     }
-    // z[0..P) and log(u) of iteration `iter` (iterations must be requested consecutively)
+    // z[0..P) and log(u) of iteration `iter`
     __device__ __forceinline__ void next(uint64_t seed, uint64_t chain, uint64_t iter, int gl, T (&z)[P], T& logu) {
-        if (pos >= NB) refill(seed, chain, iter, gl);  // wave-uniform
-        const int base = ((int)(threadIdx.x & 63) - gl + pos * BPI) * 4;  // byte address of lane (group base + pos * BPI)
+        advance_to(seed, chain, iter, gl);
+        const int gbase = (int)(threadIdx.x & 63) - gl;
+        const int base = (gbase + posn * NBn) * 4;  // byte address of the lane that holds block 0 of this iteration
 #pragma unroll
         for (int j = 0; j < P; ++j) z[j] = fetch(mine[j & 3], base + 4 * (j >> 2));
-        logu = fetch(lu, base + 4 * NBn);
-        ++pos;
+        logu = fetch(lu, (gbase + posu) * 4);
+        ++posn;
+        ++posu;
     }
 };
 

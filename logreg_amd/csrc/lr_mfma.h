@@ -712,7 +712,7 @@ __global__ void __launch_bounds__((S == 1 ? 256 : 64 * S)) k_chain_mfma(ModelArg
                     float nrm[4];
                     box_muller(w4.x, w4.y, nrm[0], nrm[1]);
                     box_muller(w4.z, w4.w, nrm[2], nrm[3]);
-                    if constexpr (NC < 4) logu_f = from(c + 32, logf(u01<float>(w4.x)));
+                    if constexpr (NC < 4) logu_f = from(c + 32, log_u01(w4.x));
 #pragma unroll
                     for (int hh = 0; hh < 4; ++hh) {
                         const int h = 4 * r + hh;
@@ -723,7 +723,7 @@ __global__ void __launch_bounds__((S == 1 ? 256 : 64 * S)) k_chain_mfma(ModelArg
                         }
                     }
                 }
-                if constexpr (NC >= 4) logu_f = logf(u01<float>(block(TAG_UNIFORM).x));
+                if constexpr (NC >= 4) logu_f = log_u01(block(TAG_UNIFORM).x);
             }
             if constexpr (KIND == KIND_UL) {
 #pragma unroll

@@ -368,6 +368,25 @@ def test_wide_models_run_on_the_matrix_cores(la, p, n, C, engine, monkeypatch):
             assert np.array_equal(mixed, la.mcmc(b, k, thin=1, iters=2, verb=False, seed=6, chunk=1))
 
 
+@pytest.mark.parametrize("mode,group", [("reg", 16), ("reg", 64), ("lds", 8), ("mfma", 4), ("stepwise", 0)])
+def test_device_normals_against_the_oracle(la, models, mode, group):
+    """The device's Gaussian draws themselves: RWMH from x = 0 with unit proposal scale and ll = -inf accepts its first proposal,
+    which IS the normal vector of (seed, chain, iteration).  float32 kernels compute Box-Muller on the hardware transcendentals
+    (v_log / v_sqrt / v_sin / v_cos): within 4e-6 of the float64 oracle's normals on the same Philox words, in every engine (they
+    share one function), at iterations across a generator refill and with the high counter word set."""
+    from oracle import oracle as orc_mod
+    m = models["float32"]
+    C = 96
+    k = la.mhKernel(m.lpost, la.rwProposal(np.ones(8)))
+    for it in (0, 7, 8, 15, 16, 2**33 + 3):
+        cs = la.ChainSet(k, np.zeros((C, 8)), seed=99, mode=mode, group=group)
+        cs.iter_offset = it
+        z_dev = cs.advance(1, 1).to_host()[0].astype(np.float64)
+        assert np.all(cs.get_accepts() == 1)
+        z_ref = np.array([orc_mod.draws(99, c, it, 8)[0] for c in range(C)])
+        assert np.max(np.abs(z_dev - z_ref)) < 4e-6, (mode, group, it, np.max(np.abs(z_dev - z_ref)))
+
+
 def test_first_proposal_accepted_when_ll_is_minus_inf(la, models, map_beta):
     """mcmc() starts RWMH/MALA with ll = -inf (fit-np-mala.py:82): first proposal always accepted."""
     q0 = np.tile(map_beta, (256, 1))
