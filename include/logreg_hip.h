@@ -238,13 +238,19 @@ LR_API int lr_plan_run(const lr_model* m, int32_t kind, const lr_run_opts* opts,
  * head; chains [split, n) on (tail_group, tail_rows), wider lane groups that finish the remainder in one short launch.
  * The remainder's launch runs beside the head's on a stream owned by the model handle, forked from opts->stream (after everything
  * enqueued there so far) and joined back into it before the call returns: to the caller the call is still "enqueued on opts->stream".
+ * The same holds for HMC on the fused matrix-core kernel under LR_PREC_AUTO when the remainder is at most a quarter of an exactly-
+ * filling chain count (5120 chains: 4096 on the matrix cores + 1024 on 64 lanes per chain, 0.538 -> 0.440 ms per 20 iterations).
  * split = 0: one part (every field of the tail is 0).  A chain's variant is a function of its position in the planned run
  * (lr_run_opts.plan_chains / plan_first), so chunked and sharded runs reproduce the one-launch-sequence run bit for bit.
  */
 typedef struct lr_plan_info {
     int32_t mode, group, rows;     /* as lr_plan_run */
-    int32_t tail_group, tail_rows; /* the remainder's variant (mode is the same) */
+    int32_t tail_group, tail_rows; /* the remainder's variant ... */
     int64_t split;                 /* chains of the planned run in the first part; 0 = no second part */
+    int32_t tail_mode;             /* ... and its mode: LR_MODE_REG (also behind a matrix-core head: HMC under LR_PREC_AUTO, where the
+                                    * remainder's chains then run with exact interior gradients -- the policy permits reduced precision,
+                                    * it does not require it) */
+    int32_t reserved;
 } lr_plan_info;
 LR_API int lr_plan_run_info(const lr_model* m, int32_t kind, const lr_run_opts* opts, lr_plan_info* out);
 

@@ -34,7 +34,7 @@ class RunOpts(C.Structure):
 
 class PlanInfo(C.Structure):
     _fields_ = [("mode", C.c_int32), ("group", C.c_int32), ("rows", C.c_int32), ("tail_group", C.c_int32), ("tail_rows", C.c_int32),
-                ("split", C.c_int64)]
+                ("split", C.c_int64), ("tail_mode", C.c_int32), ("reserved", C.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/logreg_hip.h declares

@@ -78,7 +78,8 @@ int run_common(lr_model* m, const RunSpec& rs, const lr_run_opts* o, void* state
     if (threaded && !lp_state) return fail(LR_ERR_INVALID, "lp_state is required for RWMH/MALA");
     LR_HIP(hipSetDevice(m->device));
     Plan pl;
-    rc = make_plan(m, plan_count(o), o->group, o->mode, &pl, false, rs.kind == lr::KIND_HMC && o->precision != LR_PREC_FULL, rs.kind);
+    rc = make_plan(m, plan_count(o), o->group, o->mode, &pl, false, rs.kind == lr::KIND_HMC && o->precision != LR_PREC_FULL, rs.kind,
+                   o->precision == LR_PREC_AUTO);
     if (rc) return rc;
     if (o->iters == 0) return LR_OK;
     if (o->on_device) return do_chain(m, pl, (hipStream_t)o->stream, rs, o, state, threaded ? lp_state : nullptr, out, accepts);
@@ -358,9 +359,10 @@ int lr_plan_run_info(const lr_model* m, int32_t kind, const lr_run_opts* o, lr_p
     if (rc) return rc;
     if (kind < LR_KIND_RWMH || kind > LR_KIND_UL) return fail(LR_ERR_INVALID, "kind must be one of LR_KIND_*");
     Plan pl;
-    rc = make_plan(m, plan_count(o), o->group, o->mode, &pl, false, kind == LR_KIND_HMC && o->precision != LR_PREC_FULL, kind);
+    rc = make_plan(m, plan_count(o), o->group, o->mode, &pl, false, kind == LR_KIND_HMC && o->precision != LR_PREC_FULL, kind,
+                   o->precision == LR_PREC_AUTO);
     if (rc) return rc;
-    *out = lr_plan_info{pl.mode, pl.G, pl.R, pl.G2, pl.R2, pl.split};
+    *out = lr_plan_info{pl.mode, pl.G, pl.R, pl.G2, pl.R2, pl.split, pl.mode2, 0};
     return LR_OK;
 }
 
@@ -369,7 +371,8 @@ int lr_plan_run(const lr_model* m, int32_t kind, const lr_run_opts* o, int32_t* 
     if (rc) return rc;
     if (kind < LR_KIND_RWMH || kind > LR_KIND_UL) return fail(LR_ERR_INVALID, "kind must be one of LR_KIND_*");
     Plan pl;
-    rc = make_plan(m, plan_count(o), o->group, o->mode, &pl, false, kind == LR_KIND_HMC && o->precision != LR_PREC_FULL, kind);
+    rc = make_plan(m, plan_count(o), o->group, o->mode, &pl, false, kind == LR_KIND_HMC && o->precision != LR_PREC_FULL, kind,
+                   o->precision == LR_PREC_AUTO);
     if (rc) return rc;
     if (mode_out) *mode_out = pl.mode;
     if (group_out) *group_out = pl.G;

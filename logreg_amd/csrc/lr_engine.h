@@ -87,7 +87,9 @@ int do_chain_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs, c
     // 1.32 ms back to back, 1.47 co-resident, 1.40 as one launch; profiles/r4_chain_grid_corun_all.txt) -- then the parts run in turn
     const bool two = head > 0 && head < C;
     // (the threaded-ll kernels gain from the overlap at three waves as well: MALA +6 %, RWMH +10 % co-resident against -2 % / -1 % in turn)
-    const bool both = two && (rs.kind != lr::KIND_HMC || head * pl.G / 64 <= 2LL * 4 * m->cus);
+    // (a matrix-core head: workgroups per CU instead -- 16 chains per workgroup at S >= 4, 64 at S = 1)
+    const int64_t head_rounds = pl.mode == lr::MODE_MFMA ? head / ((pl.G == 1 ? 64 : 16) * (int64_t)m->cus) : head * pl.G / 64 / (4LL * m->cus);
+    const bool both = two && (rs.kind != lr::KIND_HMC || head_rounds <= 2);
     if (both && !m->side_stream) {
         if (hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -103,8 +105,8 @@ int do_chain_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs, c
         ca.count = part == 0 ? head : C - head;
         if (ca.count <= 0) continue;
         const bool side = both && part == 1;
-        lr::LaunchCfg cfg{pl.mode, part == 0 ? pl.G : pl.G2, part == 0 ? pl.R : pl.R2, rs.kind, side ? m->side_stream : st, pl.lds_bytes,
-                          m->dbg.residency_cap && !side ? m->cus : 0};
+        lr::LaunchCfg cfg{part == 0 ? pl.mode : pl.mode2, part == 0 ? pl.G : pl.G2, part == 0 ? pl.R : pl.R2, rs.kind, side ? m->side_stream : st,
+                          part == 0 ? pl.lds_bytes : 0, m->dbg.residency_cap && !side ? m->cus : 0};
         const int rc = m->table->launch_chain(&cfg, ca.count, &ma, &ca);
         if (rc != 0) return fail(rc == -3 ? LR_ERR_UNSUPPORTED : LR_ERR_HIP, "chain launch failed (%d): %s", rc,
                                  hipGetErrorString(hipGetLastError()));

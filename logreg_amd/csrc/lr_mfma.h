@@ -575,9 +575,9 @@ __global__ void __launch_bounds__((S == 1 ? 256 : 64 * S)) k_chain_mfma(ModelArg
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // (scalar: loop bounds, addresses)
     const int c = lane & 15, k = lane >> 4;
     const int64_t tile0 = S == 1 ? ((int64_t)blockIdx.x * 4 + wave) * 16 : (int64_t)blockIdx.x * 16;
-    int64_t chain = tile0 + c;
-    const bool live = chain < a.C;
-    if (!live) chain = a.C - 1;
+    int64_t chain = a.first + tile0 + c;  // (a launch advances chains [first, first + count) of the call's arrays: lr_kernels.h)
+    const bool live = chain < a.first + a.count;
+    if (!live) chain = a.first + a.count - 1;
     const bool writer = live && (S == 1 || wave == 0);
     const uint64_t gchain = (uint64_t)(a.chain_offset + chain);
 

@@ -16,7 +16,7 @@ struct Plan {
     size_t lds_bytes;
     // two-part plans (register family): chains [0, split) of the planned run on (G, R), [split, n) on (G2, R2); split = 0: one part
     int64_t split = 0;
-    int G2 = 0, R2 = 0;
+    int mode2 = 0, G2 = 0, R2 = 0;
 };
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -347,18 +347,51 @@ void plan_second_part(const PlanReq& q, const lr::Variant& whole, Plan* out) {
             best_total = total;
             *out = Plan{a.mode, a.G, a.R, 0};
             out->split = head;
+            out->mode2 = lr::MODE_REG;
             out->G2 = t->variants[bi].G;
             out->R2 = t->variants[bi].R;
         }
     }
 }
 
+// (6b) ... and of the fused matrix-core kernel with its operands in registers (HMC under LR_PREC_AUTO; S = 4: 16 chains per workgroup,
+// S = 1: 64): a remainder of at most a quarter of the exactly-filling count goes to the register kernel the model prefers for it and
+// runs beside the head (profiles/r4_two_part_auto_probe.txt, n = 200, ms per 20 iterations, one launch | two parts: 5120 chains
+// 0.538 | 0.440, 9216: 0.758 | 0.645, 20 480: 1.391 | 1.074; not for half a count: 6144: 0.539 | 0.666, 10 240: 0.697 | 0.701).  Its
+// chains then run with exact interior gradients, which LR_PREC_AUTO permits (LR_PREC_BF16 asks for the matrix pipe: no second part).
+void plan_second_part_mfma(const PlanReq& q, Plan* out) {
+    const lr_model* m = q.m;
+    const lr::InstTable* t = m->table;
+    if (out->mode != lr::MODE_MFMA || out->R <= 0) return;
+    const int64_t quantum = (int64_t)(out->G == 1 ? 64 : 16) * m->cus;
+    const int64_t head = q.C / quantum * quantum, rem = q.C - head;
+    if (head == 0 || rem == 0 || 4 * rem > quantum) return;
+    int bi = -1;
+    double cost = 0;
+    for (int i = 0; i < t->nvariants; ++i) {
+        const lr::Variant& u = t->variants[i];
+        if (u.mode != lr::MODE_REG || (int64_t)u.G * u.R < m->n) continue;
+        const double c = reg_cost(m, u, rem) + 1e-3 * u.R;
+        if (bi < 0 || c < cost) { bi = i; cost = c; }
+    }
+    if (bi < 0) return;
+    out->split = head;
+    out->mode2 = lr::MODE_REG;
+    out->G2 = t->variants[bi].G;
+    out->R2 = t->variants[bi].R;
+}
+
 // `hmc_bf16`: the run is HMC and its interior leapfrog gradients may use the bf16 matrix pipe (LR_PREC_AUTO / BF16)
+// `exact_tail_ok`: ... and need not (LR_PREC_AUTO): a remainder may run on the all-fp32 register kernels
 // `kind`: LR_KIND_* of the run, -1 = not a run of a known family (lr_plan, lr_eval)
-int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool for_eval = false, bool hmc_bf16 = false, int kind = -1) {
+int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool for_eval = false, bool hmc_bf16 = false, int kind = -1,
+              bool exact_tail_ok = false) {
     if (for_eval && (mode == LR_MODE_MFMA || mode == LR_MODE_STEPWISE) && m->P <= 32) { mode = LR_MODE_AUTO; group = 0; }
     const PlanReq q{m, C, group, mode, for_eval, kind};
-    if (hmc_bf16 && q.automatic() && plan_mfma_hmc(m, C, out)) return LR_OK;
+    if (hmc_bf16 && q.automatic() && plan_mfma_hmc(m, C, out)) {
+        if (exact_tail_ok && kind >= 0) plan_second_part_mfma(q, out);
+        return LR_OK;
+    }
     if (m->P > 32) return plan_wide(q, out);
     const size_t row_bytes = (size_t)m->n * m->P * m->esize();
     const bool prefer_stepwise = row_bytes > kLdsBudget ||

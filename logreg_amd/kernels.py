@@ -307,7 +307,8 @@ class ChainSet:
         check(self.model._L.lr_plan_run_info(self.model.handle, _lib.KIND_BY_NAME[self.kernel.kind], C.byref(opts), C.byref(info)))
         plan = {"mode": _lib.MODE_NAMES[info.mode], "group": info.group, "rows_per_lane": info.rows}
         if info.split > 0:  # a run planned in two parts: chains [split, n) of the planned run on wider lane groups
-            plan["tail"] = {"from": int(info.split), "group": info.tail_group, "rows_per_lane": info.tail_rows}
+            plan["tail"] = {"from": int(info.split), "mode": _lib.MODE_NAMES[info.tail_mode], "group": info.tail_group,
+                            "rows_per_lane": info.tail_rows}
         return plan
 
     def enable_stats(self, batch: int, slots: int, pivot=None):

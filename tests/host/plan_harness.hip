@@ -3,7 +3,7 @@
 // variant tables are the real ones): the host-side logic that picks kernels and sizes their LDS can then be exercised in the
 // GPU-less build container instead of with metered GPU minutes.
 //   stdin:  one request per line   dtype(0|1) p n chains kind(0 rwmh,1 mala,2 hmc,3 ul) precision(0 auto,1 full,2 bf16) group mode cus
-//   stdout: one line per request   "<mode> <group> <rows_per_lane> <lds_bytes> <RS_i> <slice_len_i> <waves_i> <split> <tail_group> <tail_rows>"   or   "ERR <status> <message>"
+//   stdout: one line per request   "<mode> <group> <rows_per_lane> <lds_bytes> <RS_i> <slice_len_i> <waves_i> <split> <tail_group> <tail_rows> <tail_mode>"   or   "ERR <status> <message>"
 //           (the last three: lr_plan.h plan_interior -- row slices of the reduced-precision interior leapfrog steps of the stepwise
 //            engine for this model and chain count; RS_i = 0: none)
 #include "lr_model.h"
@@ -38,12 +38,12 @@ int main() {
         m.d_xblk = m.d_xblk1 = im.wide ? yes : nullptr;
         Plan pl{};
         int rc = check_group_for(&m, group, mode);
-        if (rc == LR_OK) rc = make_plan(&m, chains, group, mode, &pl, false, kind == LR_KIND_HMC && prec != LR_PREC_FULL, kind);
+        if (rc == LR_OK) rc = make_plan(&m, chains, group, mode, &pl, false, kind == LR_KIND_HMC && prec != LR_PREC_FULL, kind, prec == LR_PREC_AUTO);
         if (rc != LR_OK) std::printf("ERR %d %s\n", rc, g_err);
         else {
             const InteriorPlan ip = plan_interior(&m, chains);
-            std::printf("%d %d %d %zu %d %lld %d %lld %d %d\n", pl.mode, pl.G, pl.R, pl.lds_bytes, ip.RS_i, (long long)ip.slice_len_i, ip.waves,
-                        (long long)pl.split, pl.G2, pl.R2);
+            std::printf("%d %d %d %zu %d %lld %d %lld %d %d %d\n", pl.mode, pl.G, pl.R, pl.lds_bytes, ip.RS_i, (long long)ip.slice_len_i, ip.waves,
+                        (long long)pl.split, pl.G2, pl.R2, pl.mode2);
         }
     }
     return 0;

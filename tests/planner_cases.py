@@ -23,10 +23,10 @@ CASES = [
     (200, 8, 5120, "mala", "auto", REG(16, 13)), (200, 8, 64, "mala", "auto", {"mode": "reg", "group": 64}),
     # ... and beyond an exactly-filled count the run is planned in two parts: the filled head on 16 lanes per chain, the remainder
     # on the group width the model prefers for it (one short wave per SIMD); no second part where the model sees no gain
-    (200, 8, 5120, "mala", "auto", {**REG(16, 13), "tail": {"from": 4096, "group": 64, "rows_per_lane": 4}}),
-    (200, 8, 6144, "hmc", "full", {**REG(16, 13), "tail": {"from": 4096, "group": 32, "rows_per_lane": 7}}),
-    (200, 8, 9216, "mala", "auto", {**REG(16, 13), "tail": {"from": 8192, "group": 64, "rows_per_lane": 4}}),
-    (200, 8, 10240, "hmc", "full", {**REG(16, 13), "tail": {"from": 8192, "group": 32, "rows_per_lane": 7}}),
+    (200, 8, 5120, "mala", "auto", {**REG(16, 13), "tail": {"from": 4096, "mode": "reg", "group": 64, "rows_per_lane": 4}}),
+    (200, 8, 6144, "hmc", "full", {**REG(16, 13), "tail": {"from": 4096, "mode": "reg", "group": 32, "rows_per_lane": 7}}),
+    (200, 8, 9216, "mala", "auto", {**REG(16, 13), "tail": {"from": 8192, "mode": "reg", "group": 64, "rows_per_lane": 4}}),
+    (200, 8, 10240, "hmc", "full", {**REG(16, 13), "tail": {"from": 8192, "mode": "reg", "group": 32, "rows_per_lane": 7}}),
     (200, 8, 12288, "mala", "auto", {"no_tail": True}),
     (200, 8, 4096, "mala", "auto", {"no_tail": True}), (200, 8, 8192, "mala", "auto", {"no_tail": True}),
     (200, 8, 7168, "mala", "auto", {"no_tail": True}), (200, 8, 2560, "mala", "auto", {"no_tail": True}),
@@ -43,6 +43,11 @@ CASES = [
     # ---- chains; "full" precision never does
     (200, 8, 2048, "hmc", "auto", {"mode": "reg"}), (200, 8, 4096, "hmc", "auto", MFMA(4, 4)), (200, 8, 4096, "hmc", "full", REG(16, 13)),
     (200, 8, 8192, "hmc", "auto", MFMA(4, 4)), (200, 8, 16384, "hmc", "auto", MFMA(1, 13)), (200, 8, 16384, "hmc", "full", REG(16, 13)),
+    # a remainder of at most a quarter of the exactly-filling count runs on a register kernel beside the matrix-core head (round 4)
+    (200, 8, 5120, "hmc", "auto", {**MFMA(4, 4), "tail": {"from": 4096, "mode": "reg", "group": 64, "rows_per_lane": 4}}),
+    (200, 8, 9216, "hmc", "auto", {**MFMA(4, 4), "tail": {"from": 8192, "mode": "reg", "group": 64, "rows_per_lane": 4}}),
+    (200, 8, 20480, "hmc", "auto", {**MFMA(1, 13), "tail": {"from": 16384, "mode": "reg", "group": 16, "rows_per_lane": 13}}),
+    (200, 8, 6144, "hmc", "auto", {**MFMA(4, 4), "no_tail": True}), (200, 8, 5120, "hmc", "bf16", {**MFMA(4, 4), "no_tail": True}),
     (200, 8, 16384, "mala", "auto", REG(16, 13)),
     # mid-size data: rows split over the 4 waves of a workgroup, 8 or 16 tiles per wave, from one workgroup per CU
     (700, 8, 4096, "hmc", "auto", MFMA(4, 16)), (700, 8, 2048, "hmc", "auto", {"mode": "reg"}),

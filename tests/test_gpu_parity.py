@@ -460,7 +460,7 @@ def test_two_part_plans_between_exactly_filled_chain_counts(la, models, oracle_m
     ll0 = oracle_model.lpost(q0) if kind in ("mala", "rwmh") else None
     kw = dict(thin=2, iters=3, verb=False, seed=8, precision="full")
     full, info = la.mcmc(q0, k, return_info=True, ll=ll0, **kw)
-    assert info["plan"] == {"mode": "reg", "group": 16, "rows_per_lane": 13, "tail": {"from": split, "group": 64, "rows_per_lane": 4}}
+    assert info["plan"] == {"mode": "reg", "group": 16, "rows_per_lane": 13, "tail": {"from": split, "mode": "reg", "group": 64, "rows_per_lane": 4}}
     head = la.mcmc(q0[:split], k, ll=None if ll0 is None else ll0[:split], mode="reg", group=16, **kw)
     tail = la.mcmc(q0[split:], k, ll=None if ll0 is None else ll0[split:], mode="reg", group=64, chain_offset=split, **kw)
     assert np.array_equal(full[:, :split], head) and np.array_equal(full[:, split:], tail)
@@ -483,6 +483,32 @@ def test_two_part_plans_between_exactly_filled_chain_counts(la, models, oracle_m
         ok = r["margin"] > 2e-3
         assert ok.mean() > 0.8
         assert np.max(np.abs(full[0, sl][ok] - r["out"][0][ok]) / POST_SD) < (5e-2 if kind == "mala" else 5e-3)
+
+
+@pytest.mark.parametrize("C,split,ways,tail", [(5120, 4096, 4, (64, 4)), (20480, 16384, 1, (16, 13))])
+def test_two_part_plans_behind_a_matrix_core_head(la, models, oracle_model, map_beta, C, split, ways, tail):
+    """HMC under the default precision policy between exactly-filled chain counts: the filled head on the fused matrix-core kernel
+    (bf16 interior gradients), a remainder of at most a quarter of a full count on a register kernel beside it -- exact interior
+    gradients there, which LR_PREC_AUTO permits.  Each part bit-equal to its forced variant, chunks and a shard straddling the
+    split bit-equal to the whole run, LR_PREC_BF16 keeps one part, the remainder's chains step for step with the oracle."""
+    m = models["float32"]
+    q0 = (map_beta + 0.5 * POST_SD * np.random.default_rng(6).standard_normal((C, 8))).astype(np.float32).astype(np.float64)
+    k = make_kernel(la, m, "hmc")
+    kw = dict(thin=2, iters=2, verb=False, seed=12)
+    full, info = la.mcmc(q0, k, return_info=True, **kw)
+    assert info["plan"]["mode"] == "mfma" and info["plan"]["group"] == ways
+    assert info["plan"]["tail"] == {"from": split, "mode": "reg", "group": tail[0], "rows_per_lane": tail[1]}
+    head = la.mcmc(q0[:split], k, mode="mfma", group=ways, **kw)
+    rest = la.mcmc(q0[split:], k, mode="reg", group=tail[0], chain_offset=split, precision="full", **kw)
+    assert np.array_equal(full[:, :split], head) and np.array_equal(full[:, split:], rest)
+    assert np.array_equal(full, la.mcmc(q0, k, chunk=1, **kw))
+    lo, hi = split - 100, split + 100
+    assert np.array_equal(la.mcmc(q0[lo:hi], k, chain_offset=lo, plan_chains=C, plan_first=0, **kw), full[:, lo:hi])
+    cs = la.ChainSet(k, q0, seed=12, precision="bf16")
+    assert "tail" not in cs.plan()
+    ref = oracle_model.run("hmc", q0[split:split + 64], thin=2, iters=1, seed=12, chain_offset=split, threads=0, **KW["hmc"])
+    ok = ref["margin"] > 2e-3
+    assert ok.mean() > 0.8 and np.max(np.abs(full[0, split:split + 64][ok] - ref["out"][0][ok]) / POST_SD) < 5e-3
 
 
 def test_groups_agree_statistically_not_bitwise(la, models, map_beta):

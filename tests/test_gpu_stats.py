@@ -174,7 +174,7 @@ def test_device_statistics_of_a_run_planned_in_two_parts(la, pima, map_beta, kin
     Cn, iters, thin, batch = 4608, 12, 2, 3
     q0 = map_beta + 0.01 * np.random.default_rng(2).standard_normal((Cn, 8))
     cs = la.ChainSet(k, q0, seed=6, precision="full")
-    assert cs.plan()["tail"] == {"from": 4096, "group": 64, "rows_per_lane": 4}
+    assert cs.plan()["tail"] == {"from": 4096, "mode": "reg", "group": 64, "rows_per_lane": 4}
     cs.enable_stats(batch, iters // batch)
     first = cs.advance(5, thin)
     path = cs.save(tmp_path / "two_part")

@@ -45,7 +45,7 @@ def harness(tmp_path_factory):
                 continue
             plan = {"mode": MODES[int(f[0])], "group": int(f[1]), "rows_per_lane": int(f[2]), "lds_bytes": int(f[3]), "interior": (int(f[4]), int(f[5]), int(f[6]))}
             if int(f[7]) > 0:
-                plan["tail"] = {"from": int(f[7]), "group": int(f[8]), "rows_per_lane": int(f[9])}
+                plan["tail"] = {"from": int(f[7]), "mode": MODES[int(f[10])], "group": int(f[8]), "rows_per_lane": int(f[9])}
             res.append(plan)
         return res
     return ask

@@ -29,6 +29,6 @@ for C in [int(a) for a in sys.argv[1:]] or [1024, 2048, 2560, 3072, 4096, 5120, 
             cs.sync()
             best = min(best, (time.perf_counter() - t0) / 10)
         pl = cs.plan()
-        tail = f"+{pl['tail']['group']}/{pl['tail']['rows_per_lane']}@{pl['tail']['from']}" if "tail" in pl else ""
+        tail = f"+{pl['tail']['mode']}{pl['tail']['group']}/{pl['tail']['rows_per_lane']}@{pl['tail']['from']}" if "tail" in pl else ""
         row += f"   {prec}: {pl['mode']}{pl['group']}/{pl['rows_per_lane']}{tail:<12s} {best * 1e3:7.3f} ms {C * thin / best:9.3e}"
     print(row, flush=True)

@@ -35,5 +35,5 @@ for kind, (k, thin) in kernels.items():
         ra, ta = rate(a, C, thin)
         rf, tf = rate(f, C, thin)
         pl = a.plan()
-        print(f"{kind:5s} {C:6d}: AUTO {pl['group']}/{pl['rows_per_lane']}{'+' + str(pl['tail']['group']) + '@' + str(pl['tail']['from']) if 'tail' in pl else '':10s} "
+        print(f"{kind:5s} {C:6d}: AUTO {pl['group']}/{pl['rows_per_lane']}{'+' + pl['tail']['mode'] + str(pl['tail']['group']) + '@' + str(pl['tail']['from']) if 'tail' in pl else '':13s} "
               f"{ra:.3e} ({ta * 1e3:.3f} ms) | reg16 {rf:.3e} ({tf * 1e3:.3f} ms)  ratio {ra / rf:.3f}", flush=True)
