@@ -485,7 +485,7 @@ def test_two_part_plans_between_exactly_filled_chain_counts(la, models, oracle_m
         assert np.max(np.abs(full[0, sl][ok] - r["out"][0][ok]) / POST_SD) < (5e-2 if kind == "mala" else 5e-3)
 
 
-@pytest.mark.parametrize("C,split,ways,tail", [(5120, 4096, 4, (64, 4)), (20480, 16384, 1, (16, 13))])
+@pytest.mark.parametrize("C,split,ways,tail", [(5120, 4096, 4, (64, 4)), (18432, 16384, 1, (32, 7))])
 def test_two_part_plans_behind_a_matrix_core_head(la, models, oracle_model, map_beta, C, split, ways, tail):
     """HMC under the default precision policy between exactly-filled chain counts: the filled head on the fused matrix-core kernel
     (bf16 interior gradients), a remainder of at most a quarter of a full count on a register kernel beside it -- exact interior
