@@ -89,7 +89,7 @@ int do_chain_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs, c
     // (the threaded-ll kernels gain from the overlap at three waves as well: MALA +6 %, RWMH +10 % co-resident against -2 % / -1 % in turn)
     // (a matrix-core head: workgroups per CU instead -- 16 chains per workgroup at S >= 4, 64 at S = 1)
     const int64_t head_rounds = pl.mode == lr::MODE_MFMA ? head / ((pl.G == 1 ? 64 : 16) * (int64_t)m->cus) : head * pl.G / 64 / (4LL * m->cus);
-    const bool both = two && (rs.kind != lr::KIND_HMC || head_rounds <= 2);
+    const bool both = two && pl.corun && (rs.kind != lr::KIND_HMC || head_rounds <= 2);
     if (both && !m->side_stream) {
         if (hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess ||

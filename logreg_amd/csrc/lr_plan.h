@@ -17,6 +17,7 @@ struct Plan {
     // two-part plans (register family): chains [0, split) of the planned run on (G, R), [split, n) on (G2, R2); split = 0: one part
     int64_t split = 0;
     int mode2 = 0, G2 = 0, R2 = 0;
+    bool corun = true;  // the remainder's launch beside the head's (false: after it)
 };
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -365,9 +366,11 @@ void plan_second_part_mfma(const PlanReq& q, Plan* out) {
     if (out->mode != lr::MODE_MFMA || out->R <= 0) return;
     const int64_t quantum = (int64_t)(out->G == 1 ? 64 : 16) * m->cus;
     const int64_t head = q.C / quantum * quantum, rem = q.C - head;
-    // (... and small enough for lane groups of 32 or 64: a remainder of 4096 chains on 16 lanes per chain beside a 16 384-chain head
-    //  measured 1.43 ms against 1.39 for the single launch -- its 256 uncapped workgroups double up on CUs)
-    if (head == 0 || rem == 0 || 4 * rem > quantum || rem > 8LL * m->cus) return;
+    if (head == 0 || rem == 0 || 4 * rem > quantum) return;
+    // beside the head only while it fits lane groups of 32 or 64: a remainder of 4096 chains on 16 lanes per chain beside a 16 384-chain
+    // head measured 1.43 ms against 1.39 for the single launch (its 256 uncapped workgroups double up on CUs) -- such a remainder runs
+    // AFTER the head (0.70 + 0.38 ms)
+    out->corun = rem <= 8LL * m->cus;
     int bi = -1;
     double cost = 0;
     for (int i = 0; i < t->nvariants; ++i) {

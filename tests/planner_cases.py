@@ -47,7 +47,7 @@ CASES = [
     (200, 8, 5120, "hmc", "auto", {**MFMA(4, 4), "tail": {"from": 4096, "mode": "reg", "group": 64, "rows_per_lane": 4}}),
     (200, 8, 9216, "hmc", "auto", {**MFMA(4, 4), "tail": {"from": 8192, "mode": "reg", "group": 64, "rows_per_lane": 4}}),
     (200, 8, 18432, "hmc", "auto", {**MFMA(1, 13), "tail": {"from": 16384, "mode": "reg", "group": 32, "rows_per_lane": 7}}),
-    (200, 8, 20480, "hmc", "auto", {**MFMA(1, 13), "no_tail": True}),
+    (200, 8, 20480, "hmc", "auto", {**MFMA(1, 13), "tail": {"from": 16384, "mode": "reg", "group": 16, "rows_per_lane": 13}}),  # (runs after the head)
     (200, 8, 6144, "hmc", "auto", {**MFMA(4, 4), "no_tail": True}), (200, 8, 5120, "hmc", "bf16", {**MFMA(4, 4), "no_tail": True}),
     (200, 8, 16384, "mala", "auto", REG(16, 13)),
     # mid-size data: rows split over the 4 waves of a workgroup, 8 or 16 tiles per wave, from one workgroup per CU

@@ -485,11 +485,11 @@ def test_two_part_plans_between_exactly_filled_chain_counts(la, models, oracle_m
         assert np.max(np.abs(full[0, sl][ok] - r["out"][0][ok]) / POST_SD) < (5e-2 if kind == "mala" else 5e-3)
 
 
-@pytest.mark.parametrize("C,split,ways,tail", [(5120, 4096, 4, (64, 4)), (18432, 16384, 1, (32, 7))])
+@pytest.mark.parametrize("C,split,ways,tail", [(5120, 4096, 4, (64, 4)), (18432, 16384, 1, (32, 7)), (20480, 16384, 1, (16, 13))])
 def test_two_part_plans_behind_a_matrix_core_head(la, models, oracle_model, map_beta, C, split, ways, tail):
     """HMC under the default precision policy between exactly-filled chain counts: the filled head on the fused matrix-core kernel
-    (bf16 interior gradients), a remainder of at most a quarter of a full count on a register kernel beside it -- exact interior
-    gradients there, which LR_PREC_AUTO permits.  Each part bit-equal to its forced variant, chunks and a shard straddling the
+    (bf16 interior gradients), a remainder of at most a quarter of a full count on a register kernel beside it (after it when it needs
+    16 lanes per chain: the 20 480 case) -- exact interior gradients there, which LR_PREC_AUTO permits.  Each part bit-equal to its forced variant, chunks and a shard straddling the
     split bit-equal to the whole run, LR_PREC_BF16 keeps one part, the remainder's chains step for step with the oracle."""
     m = models["float32"]
     q0 = (map_beta + 0.5 * POST_SD * np.random.default_rng(6).standard_normal((C, 8))).astype(np.float32).astype(np.float64)
