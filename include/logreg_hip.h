@@ -58,8 +58,10 @@ enum { LR_F32 = 0, LR_F64 = 1 };
  * reports the slice count as group_out and the slice length as rows_out).  Slice partials are summed in slice
  * order, so launches of different chain counts are bit-identical only under the same slicing: a sharded run
  * that wants bit-exact agreement with the one-GPU run sets lr_run_opts.plan_chains to the whole run's chain count
- * (which pins the interior kernels' own slicing as well; an explicit group > 0 pins the end-point slicing only) */
-enum { LR_MODE_AUTO = -1, LR_MODE_REG = 0, LR_MODE_LDS = 1, LR_MODE_GLOBAL = 2, LR_MODE_MFMA = 3, LR_MODE_STEPWISE = 4 };
+ * (which pins the interior kernels' own slicing as well; an explicit group > 0 pins the end-point slicing only).
+ * MIXED (float64 models, HMC only, 5 <= p <= 8, n <= 256): float64 rows in LDS for the end points of a trajectory, the same rows
+ * rounded to float32 in VGPRs for its interior gradients (see LR_PREC_*); 16 lanes per chain. */
+enum { LR_MODE_AUTO = -1, LR_MODE_REG = 0, LR_MODE_LDS = 1, LR_MODE_GLOBAL = 2, LR_MODE_MFMA = 3, LR_MODE_STEPWISE = 4, LR_MODE_MIXED = 5 };
 
 typedef struct lr_model lr_model;
 
@@ -105,7 +107,11 @@ typedef struct lr_run_opts {
  *                      (p > 8) / 16 per CU (p <= 8) upward, i.e. 1024 - 4096 chains on MI355X;
  *                    tall models on the stepwise engine (the same scheme with the rows streamed: lr_tall_mx.h);
  *                    wide models, 32 < p <= 128 (rows in one bf16 piece, beta in two: lr_wide_bf16.h);
- *                  elsewhere (float64 models, p < 5, few chains on register/LDS-resident data) it is LR_PREC_FULL.
+ *                  ... and for a float64 model with 5 <= p <= 8, n <= 256 (LR_MODE_MIXED): float32 interior gradients -- the
+ *                    trajectory's position and momentum, both end-point evaluations, the half kicks, the kinetic energies and
+ *                    the Metropolis test stay float64; only the force applied inside the trajectory is computed from the
+ *                    position and the rows rounded to float32 (4 - 5 x the all-float64 rate);
+ *                  elsewhere (other float64 models, p < 5, few chains on register/LDS-resident data) it is LR_PREC_FULL.
  *                  A default HMC run is therefore NOT step-for-step comparable with a float64 reference run (the
  *                  posterior is the same; acceptance rates measured within 0.001 - 0.01 of the exact-gradient run);
  *   LR_PREC_FULL   every evaluation in the model's dtype (comparable with the float64 oracle step by step)

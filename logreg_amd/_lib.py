@@ -15,9 +15,9 @@ LR_F32, LR_F64 = 0, 1
 STATS_ROWS = 7  # LR_STATS_ROWS
 PREC_BY_NAME = {"auto": 0, "full": 1, "bf16": 2}  # LR_PREC_*
 KIND_BY_NAME = {"rwmh": 0, "mala": 1, "hmc": 2, "ul": 3}  # LR_KIND_*
-MODE_AUTO, MODE_REG, MODE_LDS, MODE_GLOBAL, MODE_MFMA, MODE_STEPWISE = -1, 0, 1, 2, 3, 4
-MODE_NAMES = {MODE_REG: "reg", MODE_LDS: "lds", MODE_GLOBAL: "global", MODE_MFMA: "mfma", MODE_STEPWISE: "stepwise"}
-MODE_BY_NAME = {"auto": MODE_AUTO, "reg": MODE_REG, "lds": MODE_LDS, "global": MODE_GLOBAL, "mfma": MODE_MFMA, "stepwise": MODE_STEPWISE}
+MODE_AUTO, MODE_REG, MODE_LDS, MODE_GLOBAL, MODE_MFMA, MODE_STEPWISE, MODE_MIXED = -1, 0, 1, 2, 3, 4, 5
+MODE_NAMES = {MODE_REG: "reg", MODE_LDS: "lds", MODE_GLOBAL: "global", MODE_MFMA: "mfma", MODE_STEPWISE: "stepwise", MODE_MIXED: "mixed"}
+MODE_BY_NAME = {"auto": MODE_AUTO, "reg": MODE_REG, "lds": MODE_LDS, "global": MODE_GLOBAL, "mfma": MODE_MFMA, "stepwise": MODE_STEPWISE, "mixed": MODE_MIXED}
 
 
 class LogregHipError(RuntimeError):

@@ -719,11 +719,12 @@ template <int P, int R, int G> struct RegRowPairs {
     f2 q[RP > 0 ? RP : 1][P];
     f2 s[P / 2];  // the unpaired last row (ODD)
     int pad_rows;
-    __device__ __forceinline__ void load(const float* __restrict__ rows, int64_t n, int gl) {
+    // (S = double: a float64 model's rows rounded to float32 -- the interior leapfrog gradients of k_chain_mixed)
+    template <typename S> __device__ __forceinline__ void load(const S* __restrict__ rows, int64_t n, int gl) {
         pad_rows = 0;
         auto at = [&](int k, int j) {  // element j of the lane's k-th row (zero beyond n); branch-free: clamped load, then mask
             const int64_t i = gl + (int64_t)k * G;
-            const float v = rows[(i < n ? i : n - 1) * P + j];
+            const float v = (float)rows[(i < n ? i : n - 1) * P + j];
             return i < n ? v : 0.0f;
         };
 #pragma unroll
@@ -849,6 +850,59 @@ __device__ __forceinline__ void row_pairs_eval(const RegRowPairs<P, R, G>& rows,
 #pragma unroll
         for (int j = 0; j < P / 2; ++j) gp[j] += __builtin_shufflevector(hp[j], hp[j], 1, 0);
     }
+}
+
+// The gradient-only row pass written BREADTH-FIRST: all dot products step by step across the row pairs, then all exponentials,
+// all reciprocals, then the gradient accumulations.  Same arithmetic per row pair as pair_term (bit-identical sums: the order inside
+// every accumulator chain is unchanged).  For kernels where the machine scheduler keeps the source order of the loop (k_chain_mixed:
+// its max-ILP schedule of the leapfrog loop is discarded -- the float64 end-point code beside it puts the function over the register
+// budget the scheduler reverts on -- and pair-by-pair source order costs 44 hazard no-ops and every dependent-issue stall per step).
+template <int P, int R, int G>
+__device__ __forceinline__ void row_pairs_grad_bf(const RegRowPairs<P, R, G>& rows, const f32x2 (&bb)[P / 2], f32x2 (&gp)[P / 2]) {
+    typedef f32x2 f2;
+    constexpr int RP = RegRowPairs<P, R, G>::RP;
+    constexpr bool ODD = RegRowPairs<P, R, G>::ODD;
+    f2 bs[P / 2];
+#pragma unroll
+    for (int j = 0; j < P / 2; ++j) bs[j] = __builtin_shufflevector(bb[j], bb[j], 1, 0);
+    f2 ts[RP > 0 ? RP : 1], to = {0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k < RP; ++k) ts[k] = rows.q[k][0] * bb[0];
+    if constexpr (ODD) to = rows.s[0] * bb[0];
+#pragma unroll
+    for (int k = 0; k < RP; ++k) ts[k] = __builtin_elementwise_fma(rows.q[k][1], bs[0], ts[k]);
+#pragma unroll
+    for (int j = 2; j < P; j += 2) {
+#pragma unroll
+        for (int k = 0; k < RP; ++k) ts[k] = __builtin_elementwise_fma(rows.q[k][j], bb[j / 2], ts[k]);
+        if constexpr (ODD) to = __builtin_elementwise_fma(rows.s[j / 2], bb[j / 2], to);
+#pragma unroll
+        for (int k = 0; k < RP; ++k) ts[k] = __builtin_elementwise_fma(rows.q[k][j + 1], bs[j / 2], ts[k]);
+    }
+    f2 d[RP > 0 ? RP : 1];
+#pragma unroll
+    for (int k = 0; k < RP; ++k) d[k] = f2{ExpScale<float>::exp_scaled(ts[k].x), ExpScale<float>::exp_scaled(ts[k].y)} + f2{1.0f, 1.0f};
+    float wo = 0.0f;
+    if constexpr (ODD) wo = fast_rcp(1.0f + ExpScale<float>::exp_scaled(to.x + to.y));
+    f2 w[RP > 0 ? RP : 1];
+#pragma unroll
+    for (int k = 0; k < RP; ++k) w[k] = f2{fast_rcp(d[k].x), fast_rcp(d[k].y)};
+    f2 hp[P / 2];
+#pragma unroll
+    for (int j = 0; j < P / 2; ++j) gp[j] = hp[j] = f2{0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k < RP; ++k)
+#pragma unroll
+        for (int j = 0; j < P; j += 2) {
+            gp[j / 2] = __builtin_elementwise_fma(rows.q[k][j], w[k], gp[j / 2]);
+            hp[j / 2] = __builtin_elementwise_fma(rows.q[k][j + 1], w[k], hp[j / 2]);
+        }
+    if constexpr (ODD) {
+#pragma unroll
+        for (int j = 0; j < P / 2; ++j) gp[j] = __builtin_elementwise_fma(f2{wo, wo}, rows.s[j], gp[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < P / 2; ++j) gp[j] += __builtin_shufflevector(hp[j], hp[j], 1, 0);
 }
 
 template <typename T, int P, int G> struct StridedRows {  // LDS or global: same access code

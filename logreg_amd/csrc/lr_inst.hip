@@ -63,9 +63,17 @@ constexpr int P = LR_P;
 #define LR_MFMA_VARIANTS(X)
 #endif
 
+// float64, padded p = 8: HMC with float32 interior gradients (k_chain_mixed): X(rows per lane of the 16 lanes of a chain)
+#if LR_DTYPE == 1 && LR_P == 8
+#define LR_MIXED_VARIANTS(X) X(13) X(16)
+#else
+#define LR_MIXED_VARIANTS(X)
+#endif
+
 #define LR_VARIANT_ROW(M_, G_, R_) {M_, G_, R_},
+#define LR_MIXED_ROW(R_) {MODE_MIXED, 16, R_},
 #define LR_MFMA_ROW(S_, N_) {MODE_MFMA, S_, N_},
-const Variant kVariants[] = {LR_VARIANTS(LR_VARIANT_ROW) LR_MFMA_VARIANTS(LR_MFMA_ROW)};
+const Variant kVariants[] = {LR_VARIANTS(LR_VARIANT_ROW) LR_MFMA_VARIANTS(LR_MFMA_ROW) LR_MIXED_VARIANTS(LR_MIXED_ROW)};
 
 inline int check(hipError_t e) { return e == hipSuccess ? 0 : -2; }
 
@@ -161,6 +169,10 @@ int launch_chain(const LaunchCfg* cfg, int64_t C, const void* model_args, const 
 #define LR_DISPATCH_MFMA(S_, N_) \
     if (cfg->mode == MODE_MFMA && cfg->G == S_ && cfg->R == N_) return launch_mfma_v<S_, N_>(cfg, C, m, a);
     LR_MFMA_VARIANTS(LR_DISPATCH_MFMA)
+#define LR_DISPATCH_MIXED(R_)                                                                  \
+    if (cfg->mode == MODE_MIXED && cfg->G == 16 && cfg->R == R_ && cfg->kind == KIND_HMC) \
+        return launch_capped<&k_chain_mixed<R_>>(cfg, grid_for(C, 16), dim3(256), cfg->lds_bytes, m, a);
+    LR_MIXED_VARIANTS(LR_DISPATCH_MIXED)
     return -3;
 }
 

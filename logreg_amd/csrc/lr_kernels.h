@@ -10,7 +10,7 @@
 namespace lr {
 
 enum Kind { KIND_RWMH = 0, KIND_MALA = 1, KIND_HMC = 2, KIND_UL = 3 };
-enum Mode { MODE_REG = 0, MODE_LDS = 1, MODE_GLOBAL = 2, MODE_MFMA = 3, MODE_STEPWISE = 4 };
+enum Mode { MODE_REG = 0, MODE_LDS = 1, MODE_GLOBAL = 2, MODE_MFMA = 3, MODE_STEPWISE = 4, MODE_MIXED = 5 };
 
 template <typename T, int P> struct ModelArgs {
     const T* rows;  // [n][P] signed rows (2y-1)*x, zero-padded to P columns (device)
@@ -305,6 +305,157 @@ __global__ void __launch_bounds__(256) k_chain_rs16(ModelArgs<float, 8> m, Chain
         }
     }
     LR_RS16_PHASES_REPORT(KIND, a.iters * a.thin)
+}
+
+// --------------------------------------------------------------------------------------------
+// HMC on a FLOAT64 model (padded p = 8, n <= 16 R) with the l - 1 INTERIOR leapfrog gradients in float32 (LR_MODE_MIXED; the
+// float64 model's form of the interior-precision policy, include/logreg_hip.h LR_PREC_*).  The reference computes in float64
+// (fit-np-hmc.py:65-87): here the Metropolis test, both end-point evaluations of log-posterior and gradient, the half kicks,
+// the kinetic energies AND the trajectory's position and momentum are float64 -- rows in LDS, as the float64 LDS variant has
+// them -- while the force inside the trajectory is the float32 register kernel's row pass (hmc_interior_rs16's: twisted row
+// pairs of the rows rounded to float32, v_pk_fma_f32, reduce-scatter) applied to the float64 position rounded to float32.  A
+// force that is a deterministic function of the position keeps drift and kick shears of (q, p) in float64 arithmetic, exactly as
+// reversible and volume-preserving as the reference's own leapfrog; only the trajectory's energy error sees the rounding.
+// One float64 evaluation (~5.5 float32 ones) + l - 1 float32 ones per iteration instead of l float64 ones.
+constexpr int kMixedStashDoubles = 16;
+template <int R>
+__global__ void __launch_bounds__(256) k_chain_mixed(ModelArgs<double, 8> m, ChainArgs<double, 8> a) {
+    constexpr int P = 8, G = 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int gl = threadIdx.x % G;
+    int64_t chain = a.first + ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const bool live = chain < a.first + a.count;
+    if (!live) chain = a.first + a.count - 1;
+    const bool writer = live && gl == 0;
+    const auto rows = make_rows<double, P, G, MODE_LDS, 0>(m, gl, reinterpret_cast<double*>(smem_raw));  // float64 rows: end points
+    RegRowPairs<P, R, G> rows32;                                                                          // float32 rows: interior
+    rows32.load(m.rows, m.n, gl);
+    // (dynamic LDS: the float64 rows, then kMixedStashDoubles doubles per lane -- lr_plan.h plan_mixed_hmc sizes it)
+    double* const stash = reinterpret_cast<double*>(smem_raw) + m.n * P + threadIdx.x;
+    const uint64_t gchain = (uint64_t)(a.chain_offset + chain);
+
+    // The chain's state is DISTRIBUTED over its 16 lanes for the whole launch, as in k_chain_rs16: quad qd owns coordinates 2 qd,
+    // 2 qd + 1 of position, gradient and momentum (float64 pairs); only the end-point evaluation sees all 8 coordinates.
+    const int qd = (threadIdx.x >> 2) & 3;
+    auto pick = [&](const double (&v)[8], double& lo, double& hi) {
+        const double x01 = qd & 1 ? v[2] : v[0], x23 = qd & 1 ? v[6] : v[4];
+        const double y01 = qd & 1 ? v[3] : v[1], y23 = qd & 1 ? v[7] : v[5];
+        lo = qd & 2 ? x23 : x01;
+        hi = qd & 2 ? y23 : y01;
+    };
+    auto gather = [&](double lo, double hi, double (&v)[8]) {  // lane 4 j of the 16-lane row holds coordinates 2 j, 2 j + 1
+        v[0] = dpp_mov<0x150>(lo); v[1] = dpp_mov<0x150>(hi); v[2] = dpp_mov<0x154>(lo); v[3] = dpp_mov<0x154>(hi);
+        v[4] = dpp_mov<0x158>(lo); v[5] = dpp_mov<0x158>(hi); v[6] = dpp_mov<0x15C>(lo); v[7] = dpp_mov<0x15C>(hi);
+    };
+    auto quad_sum = [&](double v) {  // over the four quads of a value identical inside each quad; bit-identical in all 16 lanes
+        v += dpp_mov<0x141>(v);
+        v += dpp_mov<0x140>(v);
+        return v;
+    };
+    double a0, a1, b0, b1, c0, c1, e0, e1, x0, x1, g0, g1;
+    pick(a.a, a0, a1);  // sqrt(dmm)
+    pick(a.b, b0, b1);  // eps / dmm
+    pick(a.c, c0, c1);  // 1 / dmm
+    pick(m.prior.inv_var, e0, e1);
+    double lp;
+    uint32_t nacc = 0;
+    {
+        double x8[P], g8[P], ll0 = 0, lpr0 = 0;
+#pragma unroll
+        for (int j = 0; j < P; ++j) x8[j] = j < a.p ? a.state[chain * a.p + j] : 0.0;
+        eval_lpost<double, P, G, true, true>(rows, m.prior, x8, g8, ll0, lpr0);
+        lp = ll0 + lpr0;
+        pick(x8, x0, x1);
+        pick(g8, g0, g1);
+    }
+    const double heps = 0.5 * a.step, step = a.step;
+    constexpr float kf = ExpScale<float>::k;
+    DrawBatch<double, P, G> draws;
+    draws.reset();
+    for (int64_t it = 0; it < a.iters; ++it) {
+        for (int64_t jt = 0; jt < a.thin; ++jt) {
+            const uint64_t iter = (uint64_t)(a.iter_offset + it * a.thin + jt);
+            double zx, zy, logu;
+            draws.next_pair(a.seed, gchain, iter, gl, qd, zx, zy, logu);
+            // p ~ N(0, dmm); leapfrog l steps; a = alpi(prop) - alpi(x)     fit-np-hmc.py:65-87
+            double p0 = zx * a0, p1 = zy * a1;
+            const double k0_ = quad_sum(__builtin_fma(c0 * p0, p0, c1 * p1 * p1));
+            p0 = __builtin_fma(heps, g0, p0);
+            p1 = __builtin_fma(heps, g1, p1);
+            double xp0 = x0, xp1 = x1;
+            // Everything the trajectory does not touch waits in LDS (16 doubles per lane): with it in registers the interior loop
+            // enters with 62 VGPRs it never uses (tools/isa_liveness.py) and its breadth-first row pass wants ~180 of the 256.
+            stash[0 * 256] = x0, stash[1 * 256] = x1, stash[2 * 256] = g0, stash[3 * 256] = g1, stash[4 * 256] = lp, stash[5 * 256] = k0_;
+            stash[6 * 256] = logu, stash[7 * 256] = a0, stash[8 * 256] = a1, stash[9 * 256] = c0, stash[10 * 256] = c1;
+            stash[11 * 256] = draws.mine[0], stash[12 * 256] = draws.mine[1], stash[13 * 256] = draws.mine[2], stash[14 * 256] = draws.mine[3];
+            stash[15 * 256] = draws.lu;
+            asm volatile("" ::: "memory");  // (no store-to-load forwarding across the loop)
+            for (int i = 0; i < a.l - 1; ++i) {
+                xp0 = __builtin_fma(b0, p0, xp0);  // drift (float64)
+                xp1 = __builtin_fma(b1, p1, xp1);
+                f32x2 bb[4];
+                group16_allgather_pairs(f32x2{(float)xp0, (float)xp1} * f32x2{kf, kf}, bb);
+                f32x2 gpp[4];
+                row_pairs_grad_bf<P, R, G>(rows32, bb, gpp);
+                const float gv[8] = {gpp[0].x, gpp[0].y, gpp[1].x, gpp[1].y, gpp[2].x, gpp[2].y, gpp[3].x, gpp[3].y};
+                float u0, u1;
+                group16_reduce_scatter8(gv, u0, u1);
+                p0 = __builtin_fma(step, __builtin_fma(-xp0, e0, (double)u0), p0);  // kick (float64): float32 likelihood force + prior
+                p1 = __builtin_fma(step, __builtin_fma(-xp1, e1, (double)u1), p1);
+            }
+            asm volatile("" ::: "memory");
+            x0 = stash[0 * 256], x1 = stash[1 * 256], g0 = stash[2 * 256], g1 = stash[3 * 256], lp = stash[4 * 256];
+            const double k0 = stash[5 * 256];
+            logu = stash[6 * 256], a0 = stash[7 * 256], a1 = stash[8 * 256], c0 = stash[9 * 256], c1 = stash[10 * 256];
+            draws.mine[0] = stash[11 * 256], draws.mine[1] = stash[12 * 256], draws.mine[2] = stash[13 * 256], draws.mine[3] = stash[14 * 256];
+            draws.lu = stash[15 * 256];
+            xp0 = __builtin_fma(b0, p0, xp0);  // the last drift: its gradient is the end-point evaluation, in float64
+            xp1 = __builtin_fma(b1, p1, xp1);
+            double gp0, gp1, llp = 0, lprp = 0;
+            {
+                double xp8[P], gp8[P];
+                gather(xp0, xp1, xp8);
+                eval_lpost<double, P, G, true, true>(rows, m.prior, xp8, gp8, llp, lprp);
+                pick(gp8, gp0, gp1);
+            }
+            p0 = __builtin_fma(heps, gp0, p0);
+            p1 = __builtin_fma(heps, gp1, p1);
+            const double k1 = quad_sum(__builtin_fma(c0 * p0, p0, c1 * p1 * p1));
+            const double logr = ((llp + lprp) - lp) - 0.5 * (k1 - k0);
+            const bool acc = logu < logr;  // NaN -> reject, as `np.log(np.random.rand()) < a`
+            if (acc) {
+                ++nacc;
+                lp = llp + lprp;
+            }
+            x0 = acc ? xp0 : x0;
+            x1 = acc ? xp1 : x1;
+            g0 = acc ? gp0 : g0;
+            g1 = acc ? gp1 : g1;
+        }
+        if ((a.out || a.stats.buf) && live) {  // group-uniform: the kept sample, gathered back into the writer lane
+            double xs[P];
+            gather(x0, x1, xs);
+            if (writer) {
+                if (a.out) {
+                    double* o = a.out + (it * a.C + chain) * a.p;
+#pragma unroll
+                    for (int j = 0; j < P; ++j)
+                        if (j < a.p) o[j] = xs[j];
+                }
+                if (a.stats.buf) stats_update<double, P>(a.stats, it, a.C, chain, a.p, xs);
+            }
+        }
+    }
+    {
+        double xs[P];
+        gather(x0, x1, xs);
+        if (writer) {
+#pragma unroll
+            for (int j = 0; j < P; ++j)
+                if (j < a.p) a.state[chain * a.p + j] = xs[j];
+            if (a.accepts) a.accepts[chain] += nacc;
+        }
+    }
 }
 
 // --------------------------------------------------------------------------------------------

@@ -52,6 +52,8 @@ struct PlanConst {
     // f64 reduction (30 % of its leapfrog loop); rows in LDS with 16 lanes per chain from one wave per SIMD, 8 lanes per chain
     // (8 x 25 = 200 exactly) from two (round 4, HMC L=20 n=200, it/s, reg 32x7 | lds 16 | lds 8: 2048 chains 7.6 | 4.4 | 2.8e7,
     // 4096: 7.7 | 8.7 | 5.6, 8192: 7.7 | 8.7 | 11.2, 16 384: 7.7 | 8.8 | 11.3; MALA 8192: 5.3 | 7.2 | 7.2e8)
+    // float64 HMC under LR_PREC_AUTO, p <= 8, n <= 256: k_chain_mixed from this many chains per CU
+    int mixed_chains_per_cu = 0;
     int f64_lds16_chains_per_cu = 16;
     int f64_lds8_chains_per_cu = 32;
     int mfma_fp32_chains_per_cu = 16;
@@ -183,6 +185,25 @@ bool plan_mfma_hmc(const lr_model* m, int64_t C, Plan* out) {
     return false;
 }
 
+// HMC on a float64 model whose interior leapfrog gradients may be cheaper (LR_PREC_AUTO / LR_PREC_BF16), padded p = 8, rows within
+// 16 lanes x the instantiated rows per lane and within the LDS: k_chain_mixed (LR_MODE_MIXED) -- float64 end points, Metropolis test,
+// position and momentum; float32 force inside the trajectory.
+// dynamic LDS of k_chain_mixed: the float64 rows + its per-lane stash (lr_kernels.h)
+size_t mixed_lds_bytes(const lr_model* m) { return (size_t)m->n * m->P * m->esize() + (size_t)lr::kMixedStashDoubles * 8 * 256; }
+bool plan_mixed_hmc(const lr_model* m, int64_t C, Plan* out) {
+    if (m->dtype != LR_F64 || m->P != 8) return false;
+    const size_t row_bytes = mixed_lds_bytes(m);
+    if (row_bytes > kLdsBudget || C < (int64_t)kPlanConst.mixed_chains_per_cu * m->cus) return false;
+    const lr::InstTable* t = m->table;
+    for (int i = 0; i < t->nvariants; ++i) {  // (ascending rows per lane: the smallest that holds the rows)
+        const lr::Variant& v = t->variants[i];
+        if (v.mode != lr::MODE_MIXED || (int64_t)v.G * v.R < m->n) continue;
+        *out = Plan{v.mode, v.G, v.R, row_bytes};
+        return true;
+    }
+    return false;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------
 // make_plan and its steps.  Order: (1) HMC with reduced-precision interior steps -> kMfmaRules; (2) wide models -> stepwise;
 // (3) rows off chip (or forced) -> stepwise; (4) the best variant by residency tier and the register family's launch-time model;
@@ -261,6 +282,14 @@ int pick_variant(const PlanReq& q) {
             const bool filled = q.C >= 16LL * want_waves;
             // operands in LDS / device memory: only when no register variant fits
             const long score = v.R <= 0 ? 0 : ((filled ? (v.G == 1) : (v.G == 4)) ? 2 : 1);
+            if (score > best_score) { best_score = score; best = i; }
+            continue;
+        }
+        if (v.mode == lr::MODE_MIXED) {
+            // float64 HMC with float32 interior gradients (k_chain_mixed): here only on request; the planner's own use is plan_mixed_hmc
+            if (q.for_eval || q.mode != LR_MODE_MIXED || q.kind != LR_KIND_HMC || (q.group != 0 && v.G != q.group)) continue;
+            if ((int64_t)v.G * v.R < m->n || mixed_lds_bytes(m) > kLdsBudget) continue;
+            const long score = 1000 - v.R;  // the fewest padded rows
             if (score > best_score) { best_score = score; best = i; }
             continue;
         }
@@ -397,6 +426,7 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
         if (exact_tail_ok && kind >= 0) plan_second_part_mfma(q, out);
         return LR_OK;
     }
+    if (hmc_bf16 && q.automatic() && plan_mixed_hmc(m, C, out)) return LR_OK;
     if (m->P > 32) return plan_wide(q, out);
     const size_t row_bytes = (size_t)m->n * m->P * m->esize();
     const bool prefer_stepwise = row_bytes > kLdsBudget ||
@@ -411,7 +441,7 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
                     m->dtype, m->p, m->P, (long long)m->n, group, mode);
     if (q.automatic() && measured_overrides(q, &best, out)) return LR_OK;
     const lr::Variant& v = m->table->variants[best];
-    *out = Plan{v.mode, v.G, v.R, v.mode == lr::MODE_LDS ? row_bytes : (v.mode == lr::MODE_MFMA && v.R == 0 ? mfma_lds_bytes(m, v.G) : 0)};
+    *out = Plan{v.mode, v.G, v.R, v.mode == lr::MODE_MIXED ? mixed_lds_bytes(m) : v.mode == lr::MODE_LDS ? row_bytes : (v.mode == lr::MODE_MFMA && v.R == 0 ? mfma_lds_bytes(m, v.G) : 0)};
     if (v.mode == lr::MODE_REG && q.automatic() && kind >= 0) plan_second_part(q, v, out);
     return LR_OK;
 }

@@ -130,7 +130,7 @@ static int check_opts(const lr_model *m, const lr_run_opts *o, int run) {
     if (o->n_chains <= 0) return fail(LR_ERR_INVALID, "n_chains must be positive (got %lld)", (long long)o->n_chains);
     if (o->plan_chains < 0) return fail(LR_ERR_INVALID, "plan_chains must be 0 (= n_chains) or positive (got %d)", o->plan_chains);
     if (o->group < 0) return fail(LR_ERR_INVALID, "group must be >= 0");
-    if (o->mode < LR_MODE_AUTO || o->mode > LR_MODE_STEPWISE) return fail(LR_ERR_INVALID, "unknown mode %d", o->mode);
+    if (o->mode < LR_MODE_AUTO || o->mode > LR_MODE_MIXED) return fail(LR_ERR_INVALID, "unknown mode %d", o->mode);
     if (run) {
         if (o->thin <= 0 || o->iters < 0) return fail(LR_ERR_INVALID, "thin must be > 0 and iters >= 0");
         if (o->chain_offset < 0 || o->iter_offset < 0) return fail(LR_ERR_INVALID, "offsets must be >= 0");

@@ -404,11 +404,55 @@ def test_float64_free_running_matches_oracle(la, models, oracle_model, map_beta)
     for kind, iters, thin in (("hmc", 10, 2), ("rwmh", 100, 3), ("ul", 20, 2), ("mala", 6, 1)):
         ref = oracle_model.run(kind, q0, thin=thin, iters=iters, seed=9, threads=0, **KW[kind])
         out, info = la.mcmc(q0, make_kernel(la, models["float64"], kind), thin=thin, iters=iters, verb=False, seed=9,
-                            return_info=True)
+                            return_info=True, precision="full")
         ok = ref["margin"] > 1e-7
         assert ok.mean() > 0.9
         np.testing.assert_allclose(out[:, ok, :], ref["out"][:, ok, :], rtol=1e-6 if kind == "mala" else 1e-8, atol=1e-10)
         assert np.array_equal(info["accepts"][ok], ref["accepts"][ok].astype(np.uint32))
+
+
+def test_float64_hmc_with_float32_interior_gradients(la, models, oracle_model, map_beta):
+    """The float64 model under the default precision policy (LR_MODE_MIXED, k_chain_mixed): float64 end points, Metropolis test,
+    position and momentum; float32 force inside the trajectory.
+    * l = 1 has no interior gradient: bit-equal to the all-float64 LDS kernel on 16 lanes per chain (same drift, same end-point code);
+    * l = 50: a trajectory within 1e-3 posterior sd of the float64 oracle's (5e-3 is the float32 kernels' bound), identical decisions
+      away from near-ties; but NOT within float64 rounding of it (the interior force is float32: the test would notice a planner that
+      quietly kept the all-float64 kernel);
+    * chunks and shards bit-equal to the whole run; precision="full" keeps the all-float64 kernels;
+    * acceptance within 0.005 of the all-float64 run's on the same chains."""
+    m = models["float64"]
+    C = 4096
+    q0 = map_beta + 0.5 * POST_SD * np.random.default_rng(16).standard_normal((C, 8))
+    k = make_kernel(la, m, "hmc")
+    cs = la.ChainSet(k, q0, seed=3)
+    assert cs.plan() == {"mode": "mixed", "group": 16, "rows_per_lane": 13}
+    assert la.ChainSet(k, q0, seed=3, precision="full").plan()["mode"] in ("lds", "reg")
+    assert la.ChainSet(k, q0[:64], seed=3).plan()["mode"] == "mixed"
+    k1 = la.hmcKernel(m.lpost, m.glp, eps=1e-3, l=1, dmm=1 / PRE)
+    a = la.mcmc(q0[:512], k1, thin=3, iters=2, verb=False, seed=4, mode="mixed")
+    b = la.mcmc(q0[:512], k1, thin=3, iters=2, verb=False, seed=4, mode="lds", group=16, precision="full")
+    assert np.array_equal(a, b)
+    kw = dict(thin=2, iters=2, verb=False, seed=12)
+    full, info = la.mcmc(q0, k, return_info=True, **kw)
+    assert info["plan"]["mode"] == "mixed"
+    ref = oracle_model.run("hmc", q0[:256], thin=2, iters=1, seed=12, threads=0, **KW["hmc"])
+    ok = ref["margin"] > 2e-3
+    err = np.abs(full[0, :256][ok] - ref["out"][0][ok]) / POST_SD
+    assert ok.mean() > 0.8 and err.max() < 1e-3
+    assert err.max() > 1e-9  # float32 force: not the all-float64 trajectory
+    assert np.array_equal(full, la.mcmc(q0, k, chunk=1, **kw))
+    assert np.array_equal(la.mcmc(q0[1000:1300], k, chain_offset=1000, plan_chains=C, **kw), full[:, 1000:1300])
+    exact = la.mcmc(q0[:256], k, precision="full", **kw)
+    ref2 = oracle_model.run("hmc", q0[:256], thin=2, iters=2, seed=12, threads=0, **KW["hmc"])
+    ok2 = ref2["margin"] > 1e-7
+    np.testing.assert_allclose(exact[:, ok2], ref2["out"][:, ok2], rtol=1e-8, atol=1e-10)
+    acc = {}
+    for prec in ("auto", "full"):
+        c2 = la.ChainSet(k, q0, seed=77, precision=prec)
+        c2.advance(1, 40, keep=False)
+        acc[prec] = c2.get_accepts().sum() / (C * 40)
+    print("float64 HMC acceptance: float32 interior", acc["auto"], "all float64", acc["full"])
+    assert abs(acc["auto"] - acc["full"]) < 0.005
 
 
 def test_float32_short_run_tracks_oracle(la, models, oracle_model, map_beta):
@@ -534,13 +578,13 @@ def z_scores(summ, ref):
 @pytest.mark.parametrize("mode,group,C,burn,keep,precision", [
     ("reg", 16, 4096, 1000, 60, "full"), ("auto", 0, 4096, 1000, 60, "full"), ("auto", 0, 4096, 1000, 60, "auto"),
     ("mfma", 1, 4096, 1000, 60, "auto"), ("mfma", 4, 2048, 1000, 60, "auto"), ("global", 1, 4096, 1000, 60, "auto"),
-    ("lds", 8, 2048, 1000, 60, "auto"), ("stepwise", 0, 1024, 400, 40, "auto")])
+    ("lds", 8, 2048, 1000, 60, "auto"), ("stepwise", 0, 1024, 400, 40, "auto"), ("mixed", 16, 4096, 1000, 60, "auto")])
 def test_hmc_posterior_matches_reference_within_3_mcse(la, models, map_beta, mode, group, C, burn, keep, precision):
     """F7, the north_star criterion, for every engine: pooled posterior mean and sd of the 8-vector
     within 3 Monte-Carlo SEs of the seeded full reference runs, acceptance rate as the reference's."""
     ref = load_golden("posterior_hmc.json")["pooled"]
     q0 = np.tile(map_beta, (C, 1))
-    k = make_kernel(la, models["float32"], "hmc")
+    k = make_kernel(la, models["float64" if mode == "mixed" else "float32"], "hmc")  # ("mixed": the float64 model's default policy)
     cs = la.ChainSet(k, q0, seed=2024, mode=mode, group=group, precision=precision)
     assert mode == "auto" or cs.plan()["mode"] == mode
     if C == 4096 and precision == "full":  # the headline workload in all-fp32 arithmetic: the variant bench.py reports

@@ -8,10 +8,14 @@ import logreg_amd as la
 
 n, p, L, thin = 200, 8, 50, 20
 X, y, _ = la.synthetic_logreg(n, p, seed=20240001)
-m = la.LogReg(X, y, np.array([10.0] + [1.0] * 7))
+dtype = "float32"
+if sys.argv[1:2] == ["f64"]:  # python tools/chain_grid.py f64 [chain counts]: the float64 model
+    dtype = "float64"
+    del sys.argv[1]
+m = la.LogReg(X, y, np.array([10.0] + [1.0] * 7), dtype=dtype)
 init = np.array([-0.65920504, -0.18123564, -0.64985465, -0.19187958, -0.11223836, -0.51230749, -0.10401207, -0.8432688])
 k = la.hmcKernel(m.lpost, m.glp, eps=0.1, l=L, dmm=np.ones(p))
-print("# tools/chain_grid.py on one MI355X: chains, per policy the planned variant, ms per launch of 20 iterations, chain-iterations/s")
+print(f"# tools/chain_grid.py on one MI355X, {dtype} model: chains, per policy the planned variant, ms per launch of 20 iterations, chain-iterations/s")
 for C in [int(a) for a in sys.argv[1:]] or [1024, 2048, 2560, 3072, 4096, 5120, 6144, 8192, 10240, 12288, 16384, 24576, 32768, 65536]:
     q0 = init + 0.017 * np.random.default_rng(1).standard_normal((C, p))
     row = f"{C:6d}"
