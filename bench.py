@@ -298,28 +298,32 @@ def f64_run(la, L, check, dev, stream, X, y, pscale, q0, steps):
     timer = Timer(L, check, dev, stream)
     m64 = la.LogReg(X, y, pscale, dtype="float64", device=dev)
     k64 = la.hmcKernel(m64.lpost, m64.glp, eps=EPS, l=LEAP, dmm=np.ones(N_PAR))
-    cs = la.ChainSet(k64, q0, seed=SEED, stream=stream, precision="full")
-    cs.advance(2, THIN, keep=False)
-    cs.sync()
-    a0 = cs.get_accepts().astype(np.int64).sum()
-    n = max(2, min(steps, 20))
-    timer.start()
-    for _ in range(n):
-        cs.advance(1, THIN, keep=False)
-    ms = timer.stop_ms()
     C = q0.shape[0]
-    its = C * n * THIN / (ms * 1e-3)
-    tf = its * LEAP * flops_per_grad_eval(N_ROWS, N_PAR) / 1e12
-    return {"dtype": "f64", "kernel_variant": cs.plan(), "chain_iterations_per_s": its, "ms_per_step": ms / n,
-            "accept_rate": float((cs.get_accepts().astype(np.int64).sum() - a0) / (C * n * THIN)),
-            "algorithmic_TFLOPs": tf, "peak": PEAK_FP64_TFLOPS, "frac_of_fp64_vector_peak": tf / PEAK_FP64_TFLOPS,
-            "note": f"same workload, {C} chains, {n} launches of {THIN} iterations, HIP-event timed, not part of `value`"}
+    n = max(2, min(steps, 20))
+    res = {}
+    for prec in ("full", "auto"):
+        cs = la.ChainSet(k64, q0, seed=SEED, stream=stream, precision=prec)
+        cs.advance(2, THIN, keep=False)
+        cs.sync()
+        a0 = cs.get_accepts().astype(np.int64).sum()
+        timer.start()
+        for _ in range(n):
+            cs.advance(1, THIN, keep=False)
+        ms = timer.stop_ms()
+        its = C * n * THIN / (ms * 1e-3)
+        res[prec] = {"kernel_variant": cs.plan(), "chain_iterations_per_s": its, "ms_per_step": ms / n,
+                     "accept_rate": float((cs.get_accepts().astype(np.int64).sum() - a0) / (C * n * THIN))}
+    tf = res["full"]["chain_iterations_per_s"] * LEAP * flops_per_grad_eval(N_ROWS, N_PAR) / 1e12
+    return {"dtype": "f64", **res["full"], "algorithmic_TFLOPs": tf, "peak": PEAK_FP64_TFLOPS, "frac_of_fp64_vector_peak": tf / PEAK_FP64_TFLOPS,
+            "default_policy": {**res["auto"], "note": "precision='auto' on the float64 model (LR_MODE_MIXED): float64 end points, Metropolis "
+                               "test, position and momentum; float32 force inside the trajectory"},
+            "note": f"same workload, {C} chains, {n} launches of {THIN} iterations, HIP-event timed, not part of `value`; top level = precision='full'"}
 
 
 def f64_wide_run(la, L, check, dev, stream):
     """BASELINE config 5 (n = 4096, p = 128, HMC L = 50, 1024 chains) on LogReg(dtype="float64"): the reference's own arithmetic at
-    the wide shape, on the f64 matrix pipe (lr_wide_f64.h).  Every evaluation exact (there is no reduced-precision policy for
-    float64 models); 2 iterations = 100 evaluations, HIP-event timed."""
+    the wide shape, on the f64 matrix pipe (lr_wide_f64.h), every evaluation exact (precision="full") and under the default policy;
+    2 iterations = 100 evaluations, HIP-event timed."""
     timer = Timer(L, check, dev, stream)
     fix = json.load(open(os.path.join(REPO, "tests", "golden", "fullsize_cfg5.json")))
     n, p, C = fix["n"], fix["p"], 1024
@@ -328,17 +332,20 @@ def f64_wide_run(la, L, check, dev, stream):
     k = la.hmcKernel(m.lpost, m.glp, eps=fix["eps"], l=fix["l"], dmm=np.array(fix["dmm"]))
     rng = np.random.Generator(np.random.Philox(4005))
     q0 = np.array(fix["map"]) + np.array(fix["laplace_sd"]) * rng.standard_normal((C, p))
-    cs = la.ChainSet(k, q0, seed=5, stream=stream)
     iters = 2
-    ms = _timed_chainset(la, timer, cs, iters, 1, repeats=2)
-    evals = iters * (fix["l"] + 1)  # end points included: all evaluations run the same kernel
-    per_eval_s = ms * 1e-3 / evals
-    tf = C * flops_per_grad_eval(n, p) / per_eval_s / 1e12
-    return {"dtype": "f64", "workload": f"HMC L={fix['l']} eps={fix['eps']}, synthetic n={n} p={p}, {C} chains, float64 model", "kernel_variant": cs.plan(),
-            "chain_iterations_per_s": C * iters / (ms * 1e-3), "us_per_evaluation_all_chains": per_eval_s * 1e6,
-            "accept_rate": float(cs.get_accepts().sum() / (C * (2 * iters + 1))), "algorithmic_TFLOPs": tf, "peak": PEAK_FP64_TFLOPS,
-            "frac_of_fp64_matrix_peak": tf / PEAK_FP64_TFLOPS,
-            "note": "v_mfma_f64_16x16x4_f64; not part of `value`"}
+    evals = iters * (fix["l"] + 1)  # end points included
+    res = {}
+    for prec in ("full", "auto"):
+        cs = la.ChainSet(k, q0, seed=5, stream=stream, precision=prec)
+        ms = _timed_chainset(la, timer, cs, iters, 1, repeats=2)
+        res[prec] = {"kernel_variant": cs.plan(), "chain_iterations_per_s": C * iters / (ms * 1e-3), "us_per_evaluation_all_chains": ms * 1e3 / evals,
+                     "accept_rate": float(cs.get_accepts().sum() / (C * (2 * iters + 1)))}
+    tf = C * flops_per_grad_eval(n, p) / (res["full"]["us_per_evaluation_all_chains"] * 1e-6) / 1e12
+    return {"dtype": "f64", "workload": f"HMC L={fix['l']} eps={fix['eps']}, synthetic n={n} p={p}, {C} chains, float64 model", **res["full"],
+            "algorithmic_TFLOPs": tf, "peak": PEAK_FP64_TFLOPS, "frac_of_fp64_matrix_peak": tf / PEAK_FP64_TFLOPS,
+            "default_policy": {**res["auto"], "note": "precision='auto': interior gradients on the bf16 pipe (chain-split kernel, position and "
+                               "momentum float64), end points on the f64 pipe"},
+            "note": "top level = precision='full': every evaluation on v_mfma_f64_16x16x4_f64; not part of `value`"}
 
 
 def ess_per_draw(la, model, kern, q0, dev, plan, precision):

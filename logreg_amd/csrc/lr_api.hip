@@ -289,6 +289,15 @@ int lr_model_create(const double* X, const double* y, int64_t n, int32_t p, cons
             lr_model_destroy(m);
             return fail(LR_ERR_NOMEM, "allocating the bf16 block images (%zu bytes) failed", img.size() * 2);
         }
+    }
+    if (images.wide1) {  // ... and the one-piece image (float64 models: from the rows rounded to float32)
+        std::vector<float> rounded;
+        if (dtype != LR_F32) {
+            rounded.resize(elems);
+            for (size_t i = 0; i < elems; ++i) rounded[i] = (float)reinterpret_cast<const double*>(host.data())[i];
+        }
+        const float* hrows = dtype == LR_F32 ? reinterpret_cast<const float*>(host.data()) : rounded.data();
+        const int64_t nblk = (n + 31) / 32;
         const size_t elems_blk1 = m->P == 64 ? (size_t)lr::WideBf16Geom<64>::BUF1 : (size_t)lr::WideBf16Geom<128>::BUF1;
         std::vector<uint16_t> img1((size_t)nblk * elems_blk1);
         if (m->P == 64) lr::wide_bf16_prepare_rne<64>(hrows, n, img1.data());

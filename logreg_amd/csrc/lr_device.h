@@ -440,7 +440,27 @@ __device__ __forceinline__ double fast_rcp(double x) {
 }
 // log(1 + e) for e in [0, 1]
 __device__ __forceinline__ float log1p_unit(float e) { return __builtin_amdgcn_logf(1.0f + e) * 0.693147180559945309f; }
-__device__ __forceinline__ double log1p_unit(double e) { return log1p(e); }
+// float64: the fdlibm log kernel (e_log.c: log(1 + f) = f - (f^2/2 - s (f^2/2 + R(s^2))), s = f / (2 + f), |f| < 0.4143) on 1 + e split
+// as 2^k (1 + f), k in {0, 1}, with the rounding error of 1 + e carried as c / (1 + e).  ~45 instructions where the general-domain
+// library log1p takes ~140; 0.84 ulp against 80-bit arithmetic over 4e6 points of (0, 1] (e = 0 and subnormal e included).
+__device__ __forceinline__ double log1p_unit(double e) {
+    const double s = 1.0 + e, c = e - (s - 1.0);  // s - 1 is exact (Sterbenz), so c is the rounding error of s exactly
+    const bool big = s > 1.4142135623730951;
+    const double m = big ? 0.5 * s : s, k = big ? 1.0 : 0.0;
+    const double f = m - 1.0, hfsq = 0.5 * f * f, d = 2.0 + f;
+    double r = __builtin_amdgcn_rcp(d);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    double q = f * r;
+    q = __builtin_fma(__builtin_fma(-d, q, f), r, q);
+    const double z = q * q, w = z * z;
+    const double t1 = w * __builtin_fma(w, __builtin_fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+    const double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01),
+                                        6.666666666666735130e-01);
+    const double R = t2 + t1;
+    const double lo = __builtin_fma(k, 1.90821492927058770002e-10, c * __builtin_amdgcn_rcp(s));
+    return k * 6.93147180369123816490e-01 - ((hfsq - __builtin_fma(q, hfsq + R, lo)) - f);
+}
 
 // elementwise helpers written on explicit 2-vectors (v_pk_fma_f32 / v_pk_mul_f32) for float: the
 // library is built with -fno-slp-vectorize so that the DPP reduction adds stay fused
@@ -649,6 +669,27 @@ __device__ __forceinline__ void row_term(const T (&xs)[P], const T (&bs)[P], T (
         ts = xs[0] * bs[0];
 #pragma unroll
         for (int j = 1; j < P; ++j) ts = fma_t(xs[j], bs[j], ts);
+    }
+    if constexpr (sizeof(T) == 8) {
+        // float64: ONE exponential, e = exp(-|t|) in (0, 1], serves value and gradient -- sigma(-t) = e / (1 + e) for t > 0, 1 / (1 + e)
+        // otherwise; log sigma(t) = min(t, 0) - log1p(e) -- and 1 + e in (1, 2] needs no overflow guard in the reciprocal (was: exp(t),
+        // exp(-|t|), a clamped reciprocal and the library log1p per row: 220 instructions per row with value and gradient, 114 now).
+        // The gradient-only form uses the SAME weights (3 instructions more than rcp(1 + exp(t)) there): a chunked MALA run starts
+        // each launch with a gradient-only evaluation of a state whose gradient the previous launch took from a value + gradient one.
+        const T e = exp(-__builtin_fabs(ts));
+        if constexpr (GRAD) {
+            const T s1 = T(1) + e;
+            T r = __builtin_amdgcn_rcp(s1);
+            T err = __builtin_fma(-s1, r, T(1));
+            r = __builtin_fma(r, err, r);
+            err = __builtin_fma(-s1, r, T(1));
+            r = __builtin_fma(r, err, r);
+            const T w = ts > T(0) ? e * r : r;
+#pragma unroll
+            for (int j = 0; j < P; ++j) g[j] = fma_t(w, xs[j], g[j]);
+        }
+        if constexpr (VALUE) v += (ts < T(0) ? ts : T(0)) - log1p_unit(e);
+        return;
     }
     if constexpr (GRAD) {
         const T w = fast_rcp(T(1) + ExpScale<T>::exp_scaled(ts));  // sigma(-t); exp overflow -> rcp(inf) = 0

@@ -1,11 +1,10 @@
 // lr_inst_wide.hip -- kernels for WIDE models (padded p = 64 or 128): only the stepwise engine exists at these widths.
 //   float32 (LR_DTYPE=0): the exact-split / chain-split / row-split / trajectory kernels on the bf16 matrix pipe (lr_wide_bf16.h)
-//   float64 (LR_DTYPE=1): one partial kernel on the float64 matrix pipe (lr_wide_f64.h)
+//   float64 (LR_DTYPE=1): one exact partial kernel on the float64 matrix pipe (lr_wide_f64.h) + the chain-split bf16 interior kernel
 // Compiled four times:  hipcc -DLR_P=64|128 -DLR_DTYPE=0|1 -DLR_SFX=f32_p64 ...
 #include "lr_inst.h"
-#if LR_DTYPE == 0
 #include "lr_wide_bf16.h"
-#else
+#if LR_DTYPE == 1
 #include "lr_wide_f64.h"
 #endif
 
@@ -57,6 +56,10 @@ int launch_tall_traj(hipStream_t st, const void* tall_args) {
 int launch_tall_partial(hipStream_t st, int want_value, int /*want_grad*/, const void* tall_args) {
     const auto& a = *static_cast<const TallArgs<double, P>*>(tall_args);
     const dim3 grid((unsigned)((a.C + 63) / 64), (unsigned)a.RS), block(256);
+    if (a.interior && !want_value && a.xblk1) {  // interior leapfrog step of the default precision policy: the bf16 pipe, same slices
+        hipLaunchKernelGGL((k_wide_partial_bf16i<P, 4, double>), grid, block, 0, st, a);
+        return check(hipGetLastError());
+    }
     if (want_value) hipLaunchKernelGGL((k_wide_partial_f64<P, true>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((k_wide_partial_f64<P, false>), grid, block, 0, st, a);
     return check(hipGetLastError());

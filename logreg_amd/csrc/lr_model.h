@@ -151,13 +151,15 @@ namespace {
 //   wide      three-piece and one-piece bf16 block images (32 < p <= 128)
 // (the device-memory operand images of the matrix-core chain kernel, d_xms, additionally need "beyond the LDS variant", which
 //  only lr_plan.h's mfma_lds_bytes can say: see model_wants_xms there)
-struct ModelImages { bool tall_mx, mf_end, wide; };
+//   wide1     the one-piece image alone: wide float64 models too (interior leapfrog gradients of the default precision policy)
+struct ModelImages { bool tall_mx, mf_end, wide, wide1; };
 inline ModelImages model_images(int64_t n, int P, int dtype) {
     constexpr int64_t kMfmaStreamMaxRows = 8192;  // rows the matrix-core chain kernel still takes with its operands streamed from device memory
     ModelImages im{};
     im.tall_mx = P >= 8 && P <= 32 && dtype == LR_F32 && (size_t)n * P * 4 > 64 * 1024;
     im.mf_end = P >= 8 && P <= 32 && dtype == LR_F32 && n > (P == 32 ? 16 * 4 * 8 : (P == 8 ? 16 * 13 : 16 * 4 * 16)) && n <= kMfmaStreamMaxRows;
     im.wide = P > 32 && dtype == LR_F32;
+    im.wide1 = P > 32;
     return im;
 }
 inline int padded_width(int p) { return p <= 4 ? 4 : p <= 8 ? 8 : p <= 16 ? 16 : p <= 32 ? 32 : p <= 64 ? 64 : 128; }

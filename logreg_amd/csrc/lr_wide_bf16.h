@@ -262,8 +262,10 @@ __global__ void __launch_bounds__((64 * NW)) k_wide_partial_bf16(TallArgs<float,
 // P = 128) at a time into one of two buffers: the DMA of pass g + 1 runs under the arithmetic of pass g, and there
 // is ONE barrier per pass instead of one per 32-row block (config 5's slices of 8 blocks: 2 barriers, was 8 --
 // with the per-block barrier the loop paid the global-load latency of every block: 11.3 us per launch).
-template <int P, int NW>
-__global__ void __launch_bounds__((64 * NW)) k_wide_partial_bf16i(TallArgs<float, P> a) {
+// S = double: the same kernel on a FLOAT64 model (the default precision policy there: lr_wide_f64.h runs the end points) -- the
+// position is read as float64 and rounded, the slice partials are written as float64 for k_tall_update<double> to sum.
+template <int P, int NW, typename S = float>
+__global__ void __launch_bounds__((64 * NW)) k_wide_partial_bf16i(TallArgs<S, P> a) {
     using G = WideBf16Geom<P>;
     constexpr int NT = 64 * NW, CPB = 16 * NW;
     constexpr int kPassBytes = 32768, BLK_BYTES = G::BUF1 * 2;
@@ -300,9 +302,16 @@ __global__ void __launch_bounds__((64 * NW)) k_wide_partial_bf16i(TallArgs<float
     u32x4 bq[G::M32][2];
 #pragma unroll
     for (int m = 0; m < G::M32; ++m) {
-        const f32x4* src = reinterpret_cast<const f32x4*>(a.q1 + chain * P + 32 * m + 8 * kg);
-        const f32x4 v0 = src[0], v1 = src[1];
-        float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        float x[8];
+        if constexpr (sizeof(S) == 4) {
+            const f32x4* src = reinterpret_cast<const f32x4*>(a.q1 + chain * P + 32 * m + 8 * kg);
+            const f32x4 v0 = src[0], v1 = src[1];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) x[i] = v0[i], x[4 + i] = v1[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[i] = (float)a.q1[chain * P + 32 * m + 8 * kg + i];
+        }
         uint32_t hi[4], lo[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -376,9 +385,18 @@ __global__ void __launch_bounds__((64 * NW)) k_wide_partial_bf16i(TallArgs<float
     {
         const int64_t chain0 = (int64_t)blockIdx.x * CPB;
         const int64_t nlive = a.C - chain0 < CPB ? a.C - chain0 : CPB;
-        f32x4* dst = reinterpret_cast<f32x4*>(a.part_g + ((int64_t)rs * a.C + chain0) * P);
-        for (int i = tid; i < (int)(nlive * P / 4); i += NT)
-            __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(otile + (i / (P / 4)) * OT + (i % (P / 4)) * 4), &dst[i]);
+        if constexpr (sizeof(S) == 4) {
+            f32x4* dst = reinterpret_cast<f32x4*>(a.part_g + ((int64_t)rs * a.C + chain0) * P);
+            for (int i = tid; i < (int)(nlive * P / 4); i += NT)
+                __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(otile + (i / (P / 4)) * OT + (i % (P / 4)) * 4), &dst[i]);
+        } else {
+            typedef double f64x2 __attribute__((ext_vector_type(2)));
+            f64x2* dst = reinterpret_cast<f64x2*>(a.part_g + ((int64_t)rs * a.C + chain0) * P);
+            for (int i = tid; i < (int)(nlive * P / 2); i += NT) {
+                const float* o = otile + (i / (P / 2)) * OT + (i % (P / 2)) * 2;
+                __builtin_nontemporal_store(f64x2{(double)o[0], (double)o[1]}, &dst[i]);
+            }
+        }
     }
 }
 

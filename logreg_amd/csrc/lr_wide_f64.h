@@ -89,11 +89,16 @@ __global__ void __launch_bounds__(256) k_wide_partial_f64(TallArgs<double, P> a)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const double ts = e0[r] + e1[r];
-            w[r] = 1.0 / (1.0 + exp(ts));  // sigma(-t); exp overflow -> 1 / inf = 0
+            // one exponential for both (lr_device.h row_term, float64): e = exp(-|t|); sigma(-t) = e / (1 + e) for t > 0, 1 / (1 + e) otherwise
+            // (was exp(t) and an IEEE division, plus exp(-|t|) and the library log1p with the value)
+            const double e = exp(-__builtin_fabs(ts)), d1 = 1.0 + e;
+            double rc = __builtin_amdgcn_rcp(d1);
+            rc = __builtin_fma(__builtin_fma(-d1, rc, 1.0), rc, rc);
+            rc = __builtin_fma(__builtin_fma(-d1, rc, 1.0), rc, rc);
+            w[r] = ts > 0.0 ? e * rc : rc;
             if constexpr (VALUE) {
                 const int64_t row = s0 + 16 * t + 4 * r + k;
-                const double ats = ts < 0.0 ? -ts : ts;
-                const double lv = (ts < 0.0 ? ts : 0.0) - log1p(exp(-ats));  // log sigma(t), stable for both signs
+                const double lv = (ts < 0.0 ? ts : 0.0) - log1p_unit(e);  // log sigma(t), stable for both signs
                 if (row < s1) vsum += lv;
             }
         }

@@ -35,7 +35,8 @@ int main() {
         m.d_xmx = im.tall_mx ? yes : nullptr;
         m.d_xmf = im.mf_end ? yes : nullptr;
         m.d_xms = im.mf_end && model_wants_xms(&m) && m.table->mfma_image_bytes ? yes : nullptr;
-        m.d_xblk = m.d_xblk1 = im.wide ? yes : nullptr;
+        m.d_xblk = im.wide ? yes : nullptr;
+        m.d_xblk1 = im.wide1 ? yes : nullptr;
         Plan pl{};
         int rc = check_group_for(&m, group, mode);
         if (rc == LR_OK) rc = make_plan(&m, chains, group, mode, &pl, false, kind == LR_KIND_HMC && prec != LR_PREC_FULL, kind, prec == LR_PREC_AUTO);

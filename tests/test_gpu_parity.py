@@ -1180,7 +1180,9 @@ def test_float64_wide_models_run_on_the_f64_matrix_pipe(la, p, n, C):
     """LogReg(dtype="float64") at 32 < p <= 128 -- the arithmetic the reference computes in (fit-np-hmc.py:17-19) at config 5's
     width -- runs the stepwise engine with its partial kernel on v_mfma_f64_16x16x4_f64 (lr_wide_f64.h): closures at float64
     tolerances, two iterations of every kernel step for step with the float64 oracle on the shared Philox stream (free-running:
-    same decisions, states to 1e-9), reruns / chunks / shards bit-identical.  No precision policy applies to float64 models."""
+    same decisions, states to 1e-9), reruns / chunks / shards bit-identical.  Under the default precision policy HMC's interior
+    gradients run on the bf16 pipe (the chain-split kernel of the float32 engine on the rows rounded to one bf16 piece, position and
+    momentum kept in float64, end points on the f64 pipe): trajectories within 2e-2 of the exact ones, as for float32 models."""
     from oracle.oracle import OracleModel
     X, y, _ = la.synthetic_logreg(n, p, seed=20240005 + p, beta_sd=0.1)
     ps = np.full(p, 1.5)
@@ -1202,13 +1204,22 @@ def test_float64_wide_models_run_on_the_f64_matrix_pipe(la, p, n, C):
              "ul": lambda: la.ulKernel(m.glp, dt=1e-3, pre=np.ones(p))}[kind]()
         ll0 = orc.lpost(b) if kind in ("mala", "rwmh") else None
         ref = orc.run(kind, b, thin=1, iters=2, seed=6, ll_state=ll0, threads=0, **kw)
-        out, info = la.mcmc(b, k, thin=1, iters=2, verb=False, seed=6, ll=ll0, return_info=True)
+        out, info = la.mcmc(b, k, thin=1, iters=2, verb=False, seed=6, ll=ll0, return_info=True, precision="full")
         ok = ref["margin"] > 1e-8
         assert ok.all(), kind
         assert np.array_equal(info["accepts"], ref["accepts"].astype(np.uint32)), kind
         assert np.max(np.abs(out - ref["out"])) < 1e-9, kind
-        assert np.array_equal(out, la.mcmc(b, k, thin=1, iters=2, verb=False, seed=6, ll=ll0, chunk=1))
+        assert np.array_equal(out, la.mcmc(b, k, thin=1, iters=2, verb=False, seed=6, ll=ll0, chunk=1, precision="full"))
         lo, hi = 16, 48
         sub = la.mcmc(b[lo:hi], k, thin=1, iters=2, verb=False, seed=6, ll=None if ll0 is None else ll0[lo:hi], chain_offset=lo,
-                      mode="stepwise", group=info["plan"]["group"])
+                      mode="stepwise", group=info["plan"]["group"], precision="full")
         assert np.array_equal(sub, out[:, lo:hi]), kind
+        if kind == "hmc":  # the default policy
+            mixed, minfo = la.mcmc(b, k, thin=1, iters=2, verb=False, seed=6, return_info=True)
+            wide_ok = ref["margin"] > 0.2
+            assert np.array_equal(minfo["accepts"][wide_ok], ref["accepts"][wide_ok].astype(np.uint32))
+            assert not np.array_equal(mixed, out)
+            assert np.max(np.abs(mixed[:, wide_ok] - ref["out"][:, wide_ok])) < 2e-2
+            assert np.array_equal(mixed, la.mcmc(b, k, thin=1, iters=2, verb=False, seed=6, chunk=1))
+            sub = la.mcmc(b[lo:hi], k, thin=1, iters=2, verb=False, seed=6, chain_offset=lo, mode="stepwise", group=info["plan"]["group"])
+            assert np.array_equal(sub, mixed[:, lo:hi])
