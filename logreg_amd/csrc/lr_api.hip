@@ -243,7 +243,12 @@ int lr_model_create(const double* X, const double* y, int64_t n, int32_t p, cons
     // for the interior HMC steps on the matrix pipe.  Smaller models run the engine only when forced (mode = STEPWISE), then in
     // fp32 throughout, and carry no image.
     if (images.tall_mx) {
-        const float* hrows = reinterpret_cast<const float*>(host.data());
+        std::vector<float> rounded;
+        if (dtype != LR_F32) {
+            rounded.resize(elems);
+            for (size_t i = 0; i < elems; ++i) rounded[i] = (float)reinterpret_cast<const double*>(host.data())[i];
+        }
+        const float* hrows = dtype == LR_F32 ? reinterpret_cast<const float*>(host.data()) : rounded.data();
         const int64_t ntile = (n + 31) / 32 * 2;
         std::vector<uint16_t> img((size_t)ntile * (m->P / 8) * lr::kMxSetElems);
         if (m->P == 8) lr::tall_mx_prepare<8>(hrows, n, img.data());

@@ -145,7 +145,7 @@ namespace {
 
 // Which operand images a model of this shape carries besides its rows (one rule for lr_model_create, which builds them, and for
 // the CPU planner harness, which only needs to know they would exist):
-//   tall_mx   two-piece bf16 tile images for the interior steps of the stepwise engine (narrow float32 models the planner would
+//   tall_mx   two-piece bf16 tile images for the interior steps of the stepwise engine (narrow models the planner would
 //             ever send there by itself: rows beyond 64 KB)
 //   mf_end    fp32 MFMA operand images for the end points of the matrix-core chain kernel, beyond its register variants
 //   wide      three-piece and one-piece bf16 block images (32 < p <= 128)
@@ -156,7 +156,7 @@ struct ModelImages { bool tall_mx, mf_end, wide, wide1; };
 inline ModelImages model_images(int64_t n, int P, int dtype) {
     constexpr int64_t kMfmaStreamMaxRows = 8192;  // rows the matrix-core chain kernel still takes with its operands streamed from device memory
     ModelImages im{};
-    im.tall_mx = P >= 8 && P <= 32 && dtype == LR_F32 && (size_t)n * P * 4 > 64 * 1024;
+    im.tall_mx = P >= 8 && P <= 32 && (size_t)n * P * (dtype == LR_F32 ? 4 : 8) > 64 * 1024;  // (float64 models: from the rows rounded to float32)
     im.mf_end = P >= 8 && P <= 32 && dtype == LR_F32 && n > (P == 32 ? 16 * 4 * 8 : (P == 8 ? 16 * 13 : 16 * 4 * 16)) && n <= kMfmaStreamMaxRows;
     im.wide = P > 32 && dtype == LR_F32;
     im.wide1 = P > 32;

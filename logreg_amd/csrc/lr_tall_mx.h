@@ -161,8 +161,10 @@ __device__ __forceinline__ mx_u32x4 mx_beta_operand(float qa_, float qb_) {
     return mx_u32x4{ha, hb, mx_pack_rne(la, la), mx_pack_rne(lb, lb)};
 }
 
-template <int P, int NW>
-__global__ void __launch_bounds__((64 * NW)) k_tall_partial_mx(TallArgs<float, P> a) {
+// S = double: the same kernel on a FLOAT64 model (its default precision policy: lr_tall.h's float64 kernel runs the end points) --
+// the position is read as float64 and rounded, the slice partials are written as float64 for k_tall_update<double> to sum.
+template <int P, int NW, typename S = float>
+__global__ void __launch_bounds__((64 * NW)) k_tall_partial_mx(TallArgs<S, P> a) {
     using G = MxGeom<P>;
     constexpr int NS = G::NS, kMxTileElems = G::TILE, kMxChunkTiles = G::CHUNK_TILES;
     constexpr int CHUNK_BYTES = kMxChunkBytes;
@@ -203,7 +205,7 @@ __global__ void __launch_bounds__((64 * NW)) k_tall_partial_mx(TallArgs<float, P
 
     mx_u32x4 b32[NS];
 #pragma unroll
-    for (int st = 0; st < NS; ++st) b32[st] = mx_beta_operand(a.q1[chain * P + 8 * st + kg], a.q1[chain * P + 8 * st + kg + 4]);
+    for (int st = 0; st < NS; ++st) b32[st] = mx_beta_operand((float)a.q1[chain * P + 8 * st + kg], (float)a.q1[chain * P + 8 * st + kg + 4]);
 
     const int eta_off = mx_elem(kg, c);                                            // lane (row c, kg): its 4 elements
     const int tr_off = mx_elem(lane & 3, 4 * kg + ((lane & 15) >> 2));             // lane (kg, ri, ci): chunk ci, row 4 kg + ri
@@ -226,11 +228,11 @@ __global__ void __launch_bounds__((64 * NW)) k_tall_partial_mx(TallArgs<float, P
         for (; t < nt; t += 2, eta_lds += 2 * kMxTileElems * 2, tr_lds += 2 * kMxTileElems * 2) mx_pairs<P, 1>(eta_lds, tr_lds, b32, gacc);
     }
     if (live) {
-        float* dst = a.part_g + ((int64_t)rs * a.C + chain) * P;
+        S* dst = a.part_g + ((int64_t)rs * a.C + chain) * P;
 #pragma unroll
         for (int st = 0; st < NS; ++st) {
-            dst[8 * st + kg] = gacc[st][0] + gacc[st][1];
-            dst[8 * st + kg + 4] = gacc[st][2] + gacc[st][3];
+            dst[8 * st + kg] = (S)(gacc[st][0] + gacc[st][1]);
+            dst[8 * st + kg + 4] = (S)(gacc[st][2] + gacc[st][3]);
         }
     }
 }

@@ -293,6 +293,16 @@ def test_tall_data_uses_stepwise_engine_and_matches_oracle(la):
         assert ok.mean() > 0.9
         assert np.array_equal(info["accepts"][ok], ref["accepts"][ok].astype(np.uint32))
         assert np.max(np.abs(out[:, ok] - ref["out"][:, ok])) < tol
+        # the default policy: interior gradients on the bf16 matrix pipe (lr_tall_mx.h) for both dtypes -- float64 models keep
+        # position, momentum and end points in float64 -- the same trajectory to 1e-3, decisions away from near-ties, chunks and
+        # shards bit-equal
+        k = la.hmcKernel(m.lpost, m.glp, eps=2e-4, l=6, dmm=dmm)
+        dflt = la.mcmc(q0, k, thin=1, iters=2, verb=False, seed=12)
+        assert not np.array_equal(dflt, out)
+        ok2 = ref["margin"] > 5e-2
+        assert ok2.mean() > 0.8 and np.max(np.abs(dflt[:, ok2] - ref["out"][:, ok2])) < 1e-3
+        assert np.array_equal(dflt, la.mcmc(q0, k, thin=1, iters=2, verb=False, seed=12, chunk=1))
+        assert np.array_equal(dflt[:, 32:64], la.mcmc(q0[32:64], k, thin=1, iters=2, verb=False, seed=12, chain_offset=32, plan_chains=C))
 
 
 def test_planner_engine_choice_by_size(la):
