@@ -320,7 +320,9 @@ int do_stepwise_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs
                 for (int i = 0; i < rs.l - 1; ++i) {
                     KI();
                     a.RS = RS_mid;  // the update sums as many slice partials as the partial kernel just wrote
+                    a.part_f32 = sizeof(T) == 8 && bf16_interior;  // (float64 models: those partials are float32)
                     U(lr::PH_MID, 0, -1, 0);
+                    a.part_f32 = 0;
                     a.RS = RS_exact;
                 }
             }

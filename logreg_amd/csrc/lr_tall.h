@@ -15,6 +15,7 @@
 // boundaries per evaluation (~1.5 us each) cost a few percent.  Same Philox stream, same
 // arithmetic per row, same accept rule as the fused kernels (lr_kernels.h).
 #pragma once
+#include <type_traits>
 #include "lr_kernels.h"
 
 namespace lr {
@@ -77,6 +78,7 @@ template <typename T, int P> struct TallArgs {
     const uint16_t* xblk1;  // wide bf16: single-piece (round-to-nearest) images for interior leapfrog steps
     const uint16_t* xmx;    // narrow models (P = 8, float32): two-piece bf16 tile images (lr_tall_mx.h), else null
     int interior;  // this launch is an interior HMC gradient evaluation that may run in reduced precision
+    int part_f32;  // float64 models: part_g holds FLOAT32 partials [RS][C][P] (written by a reduced-precision interior kernel)
     // fused interior step (k_wide_partial_bf16r, fuse_mid = 1): the kernel first finishes the PREVIOUS leapfrog step
     // itself -- kick with the slice partials in part_in, drift -- from the state in (q1_in, pm_in), stores the new state
     // to (q1, pm) (slice 0 only; ping-pong buffers, so nobody reads what is being written) and then evaluates there
@@ -256,27 +258,32 @@ __global__ void __launch_bounds__(256) k_tall_update(TallArgs<T, P> a, int phase
     const T aj = a.a[j], bj = a.b[j], cj = a.c[j], ivj = a.prior.inv_var[j];
 
     auto reduced_grad = [&]() {  // likelihood partials in slice order + prior
-        double s = 0.0;
         // slice order, 16 loads in flight (a plain loop issues them one L2 round trip at a time: this kernel is
         // nothing but that latency)
-        const T* pg = a.part_g + chain * P + j;
-        const int64_t stride = a.C * P;
-        int r = 0;
-        for (; r + 16 <= a.RS; r += 16) {
-            T t[16];
+        auto slices = [&](auto* pg) {
+            using E = std::remove_cv_t<std::remove_pointer_t<decltype(pg)>>;
+            double s = 0.0;
+            const int64_t stride = a.C * P;
+            int r = 0;
+            for (; r + 16 <= a.RS; r += 16) {
+                E t[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) t[u] = pg[(r + u) * stride];
+                for (int u = 0; u < 16; ++u) t[u] = pg[(r + u) * stride];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) s += (double)t[u];
-        }
-        for (; r + 4 <= a.RS; r += 4) {
-            T t[4];
+                for (int u = 0; u < 16; ++u) s += (double)t[u];
+            }
+            for (; r + 4 <= a.RS; r += 4) {
+                E t[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) t[u] = pg[(r + u) * stride];
+                for (int u = 0; u < 4; ++u) t[u] = pg[(r + u) * stride];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) s += (double)t[u];
-        }
-        for (; r < a.RS; ++r) s += (double)pg[r * stride];
+                for (int u = 0; u < 4; ++u) s += (double)t[u];
+            }
+            for (; r < a.RS; ++r) s += (double)pg[r * stride];
+            return s;
+        };
+        // (float64 models after a reduced-precision interior kernel: that kernel's partials are float32 values, written as such)
+        const double s = sizeof(T) == 8 && a.part_f32 ? slices(reinterpret_cast<const float*>(a.part_g) + chain * P + j) : slices(a.part_g + chain * P + j);
         return (T)s - a.q1[ix] * ivj;
     };
     auto reduced_value = [&]() {  // lpost(q1) = sum of slice values + lprior(q1)

@@ -162,7 +162,7 @@ __device__ __forceinline__ mx_u32x4 mx_beta_operand(float qa_, float qb_) {
 }
 
 // S = double: the same kernel on a FLOAT64 model (its default precision policy: lr_tall.h's float64 kernel runs the end points) --
-// the position is read as float64 and rounded, the slice partials are written as float64 for k_tall_update<double> to sum.
+// the position is read as float64 and rounded, the slice partials stay float32 (TallArgs::part_f32) for k_tall_update<double> to sum.
 template <int P, int NW, typename S = float>
 __global__ void __launch_bounds__((64 * NW)) k_tall_partial_mx(TallArgs<S, P> a) {
     using G = MxGeom<P>;
@@ -228,11 +228,11 @@ __global__ void __launch_bounds__((64 * NW)) k_tall_partial_mx(TallArgs<S, P> a)
         for (; t < nt; t += 2, eta_lds += 2 * kMxTileElems * 2, tr_lds += 2 * kMxTileElems * 2) mx_pairs<P, 1>(eta_lds, tr_lds, b32, gacc);
     }
     if (live) {
-        S* dst = a.part_g + ((int64_t)rs * a.C + chain) * P;
+        float* dst = reinterpret_cast<float*>(a.part_g) + ((int64_t)rs * a.C + chain) * P;  // (float64 models: TallArgs::part_f32)
 #pragma unroll
         for (int st = 0; st < NS; ++st) {
-            dst[8 * st + kg] = (S)(gacc[st][0] + gacc[st][1]);
-            dst[8 * st + kg + 4] = (S)(gacc[st][2] + gacc[st][3]);
+            dst[8 * st + kg] = gacc[st][0] + gacc[st][1];
+            dst[8 * st + kg + 4] = gacc[st][2] + gacc[st][3];
         }
     }
 }

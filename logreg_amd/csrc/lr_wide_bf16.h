@@ -263,7 +263,7 @@ __global__ void __launch_bounds__((64 * NW)) k_wide_partial_bf16(TallArgs<float,
 // is ONE barrier per pass instead of one per 32-row block (config 5's slices of 8 blocks: 2 barriers, was 8 --
 // with the per-block barrier the loop paid the global-load latency of every block: 11.3 us per launch).
 // S = double: the same kernel on a FLOAT64 model (the default precision policy there: lr_wide_f64.h runs the end points) -- the
-// position is read as float64 and rounded, the slice partials are written as float64 for k_tall_update<double> to sum.
+// position is read as float64 and rounded, the slice partials stay float32 (TallArgs::part_f32) for k_tall_update<double> to sum.
 template <int P, int NW, typename S = float>
 __global__ void __launch_bounds__((64 * NW)) k_wide_partial_bf16i(TallArgs<S, P> a) {
     using G = WideBf16Geom<P>;
@@ -385,18 +385,10 @@ __global__ void __launch_bounds__((64 * NW)) k_wide_partial_bf16i(TallArgs<S, P>
     {
         const int64_t chain0 = (int64_t)blockIdx.x * CPB;
         const int64_t nlive = a.C - chain0 < CPB ? a.C - chain0 : CPB;
-        if constexpr (sizeof(S) == 4) {
-            f32x4* dst = reinterpret_cast<f32x4*>(a.part_g + ((int64_t)rs * a.C + chain0) * P);
-            for (int i = tid; i < (int)(nlive * P / 4); i += NT)
-                __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(otile + (i / (P / 4)) * OT + (i % (P / 4)) * 4), &dst[i]);
-        } else {
-            typedef double f64x2 __attribute__((ext_vector_type(2)));
-            f64x2* dst = reinterpret_cast<f64x2*>(a.part_g + ((int64_t)rs * a.C + chain0) * P);
-            for (int i = tid; i < (int)(nlive * P / 2); i += NT) {
-                const float* o = otile + (i / (P / 2)) * OT + (i % (P / 2)) * 2;
-                __builtin_nontemporal_store(f64x2{(double)o[0], (double)o[1]}, &dst[i]);
-            }
-        }
+        // (float64 models: float32 partials all the same -- TallArgs::part_f32 tells k_tall_update<double>)
+        f32x4* dst = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.part_g) + ((int64_t)rs * a.C + chain0) * P);
+        for (int i = tid; i < (int)(nlive * P / 4); i += NT)
+            __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(otile + (i / (P / 4)) * OT + (i % (P / 4)) * 4), &dst[i]);
     }
 }
 

@@ -74,6 +74,14 @@ CASES = [
     (200, 8, 4096, "hmc", "full", {"dtype": "float64", "mode": "lds", "group": 16}),
     (200, 8, 8192, "mala", "auto", {"dtype": "float64", "mode": "lds", "group": 8}),
     (200, 12, 4096, "hmc", "full", {"dtype": "float64", "mode": "lds"}),
+    # float64 HMC under the default precision policy, 5 <= p <= 8, n <= 256: float32 interior gradients (k_chain_mixed)
+    (200, 8, 4096, "hmc", "auto", {"dtype": "float64", "mode": "mixed", "group": 16, "rows_per_lane": 13}),
+    (200, 8, 64, "hmc", "auto", {"dtype": "float64", "mode": "mixed", "group": 16, "rows_per_lane": 13}),
+    (250, 6, 8192, "hmc", "auto", {"dtype": "float64", "mode": "mixed", "group": 16, "rows_per_lane": 16, "no_tail": True}),
+    (300, 8, 4096, "hmc", "auto", {"dtype": "float64", "not_mode": "mixed"}),
+    (200, 4, 4096, "hmc", "auto", {"dtype": "float64", "not_mode": "mixed"}),
+    (200, 12, 4096, "hmc", "auto", {"dtype": "float64", "not_mode": "mixed"}),
+    (200, 8, 4096, "mala", "auto", {"dtype": "float64", "not_mode": "mixed"}),
     # float64 wide models: the stepwise engine on the f64 matrix pipe (lr_wide_f64.h), 64 chains per workgroup
     (4096, 128, 1024, "hmc", "auto", {"dtype": "float64", "mode": "stepwise", "group": 16}),
     (300, 100, 64, "mala", "auto", {"dtype": "float64", "mode": "stepwise"}),

@@ -39,10 +39,11 @@ def _check(la, cs, samples, batch):
 
 
 @pytest.mark.parametrize("kind,mode,group", [("hmc", "auto", 0), ("mala", "reg", 64), ("mala", "reg", 16), ("rwmh", "reg", 16), ("rwmh", "lds", 8), ("ul", "global", 1),
-                                             ("hmc", "mfma", 1), ("hmc", "mfma", 4), ("hmc", "stepwise", 0), ("mala", "stepwise", 0)])
+                                             ("hmc", "mfma", 1), ("hmc", "mfma", 4), ("hmc", "stepwise", 0), ("mala", "stepwise", 0),
+                                             ("hmc", "mixed", 16)])  # ("mixed": a float64 model under the default precision policy)
 def test_device_statistics_equal_numpy_on_the_gathered_samples(la, pima, map_beta, kind, mode, group):
     X, y = pima
-    m = la.LogReg(X, y, PSCALE)
+    m = la.LogReg(X, y, PSCALE, dtype="float64" if mode == "mixed" else "float32")
     k = {"hmc": lambda: la.hmcKernel(m.lpost, m.glp, eps=1e-3, l=20, dmm=1 / PRE),
          "mala": lambda: la.malaKernel(m.lpost, m.glp, dt=1e-5, pre=PRE),
          "ul": lambda: la.ulKernel(m.glp, dt=1e-6, pre=PRE),

@@ -11,7 +11,7 @@ import pytest
 from conftest import REPO
 from planner_cases import CASES, matches
 
-MODES = {0: "reg", 1: "lds", 2: "global", 3: "mfma", 4: "stepwise"}
+MODES = {0: "reg", 1: "lds", 2: "global", 3: "mfma", 4: "stepwise", 5: "mixed"}
 KIND = {"rwmh": 0, "mala": 1, "hmc": 2, "ul": 3}
 PREC = {"auto": 0, "full": 1, "bf16": 2}
 
