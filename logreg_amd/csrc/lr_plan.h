@@ -227,6 +227,9 @@ int plan_wide(const PlanReq& q, Plan* out) {
     const int64_t cpb = wide_chains_per_block(m, q.C);
     const int64_t blocks = (q.C + cpb - 1) / cpb;
     int64_t RS = (m->cus + blocks - 1) / blocks;
+    // (the float64 kernel, 64 KB of LDS: from 64 chain blocks two workgroups per CU -- 4096 chains, config 5's design, us per evaluation
+    //  by slice count 4 | 8 | 16: 207 | 182 | 198; at 1024 chains 16 | 32 slices: 64.6 | 65.1 -- tools/f64_wide_slices_probe.py)
+    if (m->dtype == LR_F64 && blocks >= 64) RS = (2 * m->cus + blocks - 1) / blocks;
     if (q.group > 0) RS = q.group;  // explicit slice count: pins the summation order whatever the chain count
     int64_t slice_len = (m->n + RS - 1) / RS;
     slice_len = (slice_len + 31) / 32 * 32;  // whole 32-row blocks (the bf16 kernel's K = 32)

@@ -3,8 +3,9 @@
 //
 // X.beta over a block of chains is a dense GEMM; here it runs on the float64 matrix pipe (v_mfma_f64_16x16x4_f64:
 // D[16x16] += A[16x4] . B[4x16], an fma chain per output element in K order, so results are in the float64 rounding class
-// of the oracle).  Every evaluation of a float64 wide model -- end points and interior leapfrog steps alike -- goes through
-// this kernel: there is no reduced-precision policy for float64 models.
+// of the oracle).  Every evaluation of a float64 wide model goes through this kernel under LR_PREC_FULL; under the default policy
+// the interior leapfrog gradients of HMC run on the bf16 pipe instead (k_wide_partial_bf16i<P, 4, double>: float64 position and
+// momentum, float32 slice partials) and this kernel evaluates the end points.
 //
 // Workgroup = 4 waves = 64 chains; wave w owns chains 16w .. 16w+15 of the block.  Lane l = (c, k): c = l & 15 the chain
 // (and, for the A operands, the row / the coordinate inside a 16-block), k = l >> 4 the K slot.  The block walks its row

@@ -465,6 +465,35 @@ def test_float64_hmc_with_float32_interior_gradients(la, models, oracle_model, m
     assert abs(acc["auto"] - acc["full"]) < 0.005
 
 
+@pytest.mark.parametrize("n,p,C,l", [(256, 8, 17, 7), (5, 5, 1, 2), (97, 6, 333, 3), (16, 7, 64, 1), (241, 8, 1025, 4), (33, 5, 5000, 2)])
+def test_float64_mixed_kernel_over_shapes(la, n, p, C, l):
+    """k_chain_mixed at the edges of what it takes (5 <= p <= 8, n <= 256, any chain count, any trajectory length): planned by
+    default, two iterations against the float64 oracle -- decisions away from near-ties, states to 1e-4 (float32 force, float64
+    everything else) --, rerun / chunk / shard bit-equal, and precision="full" on the same chains to 1e-9."""
+    from oracle.oracle import OracleModel
+    X, y, _ = la.synthetic_logreg(n, p, seed=77 + n)
+    ps = np.full(p, 2.0)
+    orc = OracleModel(X, y, ps)
+    m = la.LogReg(X, y, ps, dtype="float64")
+    k = la.hmcKernel(m.lpost, m.glp, eps=0.05, l=l, dmm=np.linspace(0.5, 2.0, p))
+    q0 = 0.3 * np.random.default_rng(n + p).standard_normal((C, p))
+    kw = dict(thin=1, iters=2, verb=False, seed=31)
+    out, info = la.mcmc(q0, k, return_info=True, **kw)
+    assert info["plan"]["mode"] == "mixed" and info["plan"]["rows_per_lane"] == (13 if n <= 208 else 16)
+    sub = slice(0, min(C, 200))
+    ref = orc.run("hmc", q0[sub], step=0.05, l=l, scale=np.linspace(0.5, 2.0, p), thin=1, iters=2, seed=31, threads=0)
+    ok = ref["margin"] > 1e-2
+    assert ok.mean() > 0.7
+    assert np.array_equal(info["accepts"][sub][ok], ref["accepts"][ok].astype(np.uint32))
+    assert np.max(np.abs(out[:, sub][:, ok] - ref["out"][:, ok])) < 1e-4
+    assert np.array_equal(out, la.mcmc(q0, k, chunk=1, **kw))
+    if C > 40:
+        assert np.array_equal(out[:, 20:40], la.mcmc(q0[20:40], k, chain_offset=20, plan_chains=C, **kw))
+    exact = la.mcmc(q0[sub], k, precision="full", **kw)
+    tight = ref["margin"] > 1e-7
+    assert np.max(np.abs(exact[:, tight] - ref["out"][:, tight])) < 1e-9
+
+
 def test_float32_short_run_tracks_oracle(la, models, oracle_model, map_beta):
     """float32 HMC for 20 iterations: the large majority of chains never hit a near-tie and must
     stay within 1e-3 posterior-sd of the float64 oracle with identical accept counts."""
