@@ -56,8 +56,11 @@ int launch_tall_traj(hipStream_t st, const void* tall_args) {
 int launch_tall_partial(hipStream_t st, int want_value, int /*want_grad*/, const void* tall_args) {
     const auto& a = *static_cast<const TallArgs<double, P>*>(tall_args);
     const dim3 grid((unsigned)((a.C + 63) / 64), (unsigned)a.RS), block(256);
-    if (a.interior && !want_value && a.xblk1) {  // interior leapfrog step of the default precision policy: the bf16 pipe, same slices
-        hipLaunchKernelGGL((k_wide_partial_bf16i<P, 4, double>), grid, block, 0, st, a);
+    if (a.interior && !want_value && a.xblk1) {  // interior leapfrog step of the default precision policy: the bf16 pipe
+        if (a.RS_i > 0)  // few chains: the row-split kernel (one chain tile per workgroup), its update a launch of its own
+            hipLaunchKernelGGL((k_wide_partial_bf16r<P, 8, double>), dim3((unsigned)((a.C + 15) / 16), (unsigned)a.RS_i), dim3(512), 0, st, a);
+        else
+            hipLaunchKernelGGL((k_wide_partial_bf16i<P, 4, double>), grid, block, 0, st, a);
         return check(hipGetLastError());
     }
     if (want_value) hipLaunchKernelGGL((k_wide_partial_f64<P, true>), grid, block, 0, st, a);

@@ -479,7 +479,7 @@ InteriorPlan plan_interior(const lr_model* m, int64_t Cp) {
     int64_t slice_len_i = 0;
     // wide models, interior leapfrog steps with few chains: the row-split kernel (lr_wide_bf16.h) wants one chain
     // tile of 16 per workgroup and as many row slices as fill the chip; each slice a multiple of 128 rows
-    if (m->P > 32 && m->d_xblk1 && m->dtype == LR_F32) {  // (float64 models: the chain-split interior kernel on the exact slices)
+    if (m->P > 32 && m->d_xblk1) {
         const int64_t tiles = (Cp + 15) / 16;
         if (tiles <= (int64_t)m->cus) {
             int64_t want = m->cus / tiles;

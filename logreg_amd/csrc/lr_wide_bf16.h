@@ -415,8 +415,11 @@ template <int BYTES> __device__ __forceinline__ void wait_vm_blocks(int younger)
     else __builtin_amdgcn_s_waitcnt(0x0F70);
 }
 
-template <int P, int NW>
-__global__ void __launch_bounds__((64 * NW)) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4))) k_wide_partial_bf16r(TallArgs<float, P> a) {
+// S = double: a FLOAT64 model's interior steps (never fused: k_tall_update<double> finishes every step in float64 from this
+// kernel's float32 partials -- TallArgs::part_f32); the position is read as float64 and rounded.
+template <int P, int NW, typename S = float>
+__global__ void __launch_bounds__((64 * NW)) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4))) k_wide_partial_bf16r(TallArgs<S, P> a) {
+    constexpr bool kFusable = sizeof(S) == 4;
     using G = WideBf16Geom<P>;
     // NW = 4: one wave per SIMD, ring of 4 block images per wave; NW = 8: two waves per SIMD (each hides the other's
     // LDS -> MFMA latency, which is what a block costs at one wave per SIMD), ring of 2
@@ -480,7 +483,10 @@ __global__ void __launch_bounds__((64 * NW)) __attribute__((amdgpu_waves_per_eu(
     // 16 lanes of a service group (8 of one kg, 8 of the next: 512 bytes apart) then cover 16 distinct 16-byte bank slots.  As
     // [16][P] (round 2) the chains were 512 bytes = 0 banks apart: every access a 16-way conflict, 41 % of the kernel's LDS cycles.
     __shared__ __attribute__((aligned(16))) float qnew[P / 8][2][16][4];
-    if (a.fuse_mid) {
+    bool fused = false;
+    if constexpr (kFusable) fused = a.fuse_mid != 0;
+    if (fused) {
+      if constexpr (kFusable) {  // (float32 state only)
         if (wave < G::M32) {
             const int m = wave;
             const int64_t at = chain * P + 32 * m + 8 * kg;
@@ -542,6 +548,7 @@ __global__ void __launch_bounds__((64 * NW)) __attribute__((amdgpu_waves_per_eu(
         }
         LR_STAMP(a, 1);
         __syncthreads();
+      }
     } else {
 #pragma unroll
         for (int b = 0; b < NBUF - 1; ++b)
@@ -554,7 +561,7 @@ __global__ void __launch_bounds__((64 * NW)) __attribute__((amdgpu_waves_per_eu(
     for (int m = 0; m < G::M32; ++m) {
         const int64_t at = chain * P + 32 * m + 8 * kg;
         float x[8];
-        if (a.fuse_mid) {
+        if (fused) {
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(&qnew[4 * m + kg][0][c][0]);
             const f32x4 v1 = *reinterpret_cast<const f32x4*>(&qnew[4 * m + kg][1][c][0]);
 #pragma unroll
@@ -562,7 +569,7 @@ __global__ void __launch_bounds__((64 * NW)) __attribute__((amdgpu_waves_per_eu(
                 x[e] = v0[e];
                 x[4 + e] = v1[e];
             }
-        } else {
+        } else if constexpr (kFusable) {
             const f32x4* src = reinterpret_cast<const f32x4*>(a.q1 + at);
             const f32x4 v0 = src[0], v1 = src[1];
 #pragma unroll
@@ -570,6 +577,9 @@ __global__ void __launch_bounds__((64 * NW)) __attribute__((amdgpu_waves_per_eu(
                 x[e] = v0[e];
                 x[4 + e] = v1[e];
             }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = (float)a.q1[at + e];
         }
         uint32_t hi[4], lo[4];
 #pragma unroll
@@ -650,7 +660,7 @@ __global__ void __launch_bounds__((64 * NW)) __attribute__((amdgpu_waves_per_eu(
     LR_STAMP(a, 5);
     {
         const int64_t nlive = a.C - chain0 < 16 ? a.C - chain0 : 16;
-        f32x4* dst = reinterpret_cast<f32x4*>(a.part_g + ((int64_t)rs * a.C + chain0) * P);
+        f32x4* dst = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.part_g) + ((int64_t)rs * a.C + chain0) * P);  // (float32 whatever S)
         for (int i = tid; i < (int)(nlive * P / 4); i += 64 * NW) {
             const int off = (i / (P / 4)) * OT + (i % (P / 4)) * 4;
             f32x4 acc = *reinterpret_cast<const f32x4*>(smem + off * 4);
