@@ -275,7 +275,7 @@ int do_stepwise_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs
                        // (us per evaluation, launch per step | trajectory kernel: n=500 p=64: 5.5 | 2.8 at 1024 chains; n=300 p=100:
                        //  7.0 | 4.7; n=1000 p=128: 7.5 | 6.5; n=2000 p=50: 6.2 | 5.3; n=2000 p=128 (512 KB): 8.4 | 9.3)
                        (traj_tiles < m->cus && (int64_t)m->n * m->P * 2 <= 256 * 1024));
-    const bool fuse = sizeof(T) == 4 && bf16_interior && a.RS_i > 0 &&  // (float64 models: every step finished by k_tall_update<double>)
+    const bool fuse = bf16_interior && a.RS_i > 0 &&
                       ((P > 32 && a.RS_i <= 4) ||                                            // kFuseSlices (lr_wide_bf16.h)
                        (P <= 32 && a.rowsplit_waves == 16 && a.RS_i <= 16 && m->d_xmx));   // kMx16FuseSlices (lr_tall_mx.h)
     T* qb[2] = {a.q1, const_cast<T*>(a.q1_in)};
@@ -313,7 +313,9 @@ int do_stepwise_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs
                 }
                 if (rs.l > 1) {
                     a.RS = RS_mid;
+                    a.part_f32 = sizeof(T) == 8;  // (float64 models: the interior kernel's partials are float32)
                     U(lr::PH_MID, 0, -1, 0);
+                    a.part_f32 = 0;
                     a.RS = RS_exact;
                 }
             } else {

@@ -415,8 +415,8 @@ template <int BYTES> __device__ __forceinline__ void wait_vm_blocks(int younger)
     else __builtin_amdgcn_s_waitcnt(0x0F70);
 }
 
-// S = double: a FLOAT64 model's interior steps (never fused: k_tall_update<double> finishes every step in float64 from this
-// kernel's float32 partials -- TallArgs::part_f32); the position is read as float64 and rounded.
+// S = double: a FLOAT64 model's interior steps -- position, momentum and the fused update (kick, drift) are float64, the position
+// enters the GEMM rounded to two bf16 pieces, the slice partials are float32 as for float32 models (TallArgs::part_f32).
 template <int P, int NW, typename S = float>
 __global__ void __launch_bounds__((64 * NW)) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4))) k_wide_partial_bf16r(TallArgs<S, P> a) {
     constexpr bool kFusable = sizeof(S) == 4;
@@ -483,14 +483,39 @@ __global__ void __launch_bounds__((64 * NW)) __attribute__((amdgpu_waves_per_eu(
     // 16 lanes of a service group (8 of one kg, 8 of the next: 512 bytes apart) then cover 16 distinct 16-byte bank slots.  As
     // [16][P] (round 2) the chains were 512 bytes = 0 banks apart: every access a 16-way conflict, 41 % of the kernel's LDS cycles.
     __shared__ __attribute__((aligned(16))) float qnew[P / 8][2][16][4];
-    bool fused = false;
-    if constexpr (kFusable) fused = a.fuse_mid != 0;
+    const bool fused = a.fuse_mid != 0;
     if (fused) {
-      if constexpr (kFusable) {  // (float32 state only)
         if (wave < G::M32) {
             const int m = wave;
             const int64_t at = chain * P + 32 * m + 8 * kg;
-            f32x4 pg[kFuseSlices][2], vq[2], vp[2], vb[2], vi[2];
+            // (the slice partials are float32 whatever the state's type S; state and constants in S: 16-byte loads)
+            auto load8 = [](const S* src, S (&v)[8]) {
+                if constexpr (sizeof(S) == 4) {
+                    const f32x4 v0 = reinterpret_cast<const f32x4*>(src)[0], v1 = reinterpret_cast<const f32x4*>(src)[1];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v0[e], v[4 + e] = v1[e];
+                } else {
+                    typedef double f64x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const f64x2 t = reinterpret_cast<const f64x2*>(src)[e];
+                        v[2 * e] = t[0], v[2 * e + 1] = t[1];
+                    }
+                }
+            };
+            auto store8 = [](S* dst, const S (&v)[8]) {
+                if constexpr (sizeof(S) == 4) {
+                    reinterpret_cast<f32x4*>(dst)[0] = f32x4{v[0], v[1], v[2], v[3]};
+                    reinterpret_cast<f32x4*>(dst)[1] = f32x4{v[4], v[5], v[6], v[7]};
+                } else {
+                    typedef double f64x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) reinterpret_cast<f64x2*>(dst)[e] = f64x2{v[2 * e], v[2 * e + 1]};
+                }
+            };
+            const float* part_f = reinterpret_cast<const float*>(a.part_in);
+            f32x4 pg[kFuseSlices][2];
+            S vq[8], vp[8], vb[8], vi[8];
 #ifdef LR_STAMPS
             if (a.stamps && lane == 0) LR_STAMP_AT(a, 10) = __builtin_amdgcn_s_memrealtime();
             asm volatile("" ::: "memory");
@@ -499,17 +524,21 @@ __global__ void __launch_bounds__((64 * NW)) __attribute__((amdgpu_waves_per_eu(
             //  instead of RS_i, bit 3 none and no momentum either -- is the prologue fetch bound by volume or by latency?)
             const int nread = LR_DBG(a, 3) ? 0 : (LR_DBG(a, 2) ? 1 : a.RS_i);
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int r = 0; r < kFuseSlices; ++r) {
                     pg[r][h] = f32x4{0, 0, 0, 0};
-                    if (r < nread) pg[r][h] = *reinterpret_cast<const f32x4*>(a.part_in + ((int64_t)r * a.C) * P + at + 4 * h);
+                    if (r < nread) pg[r][h] = *reinterpret_cast<const f32x4*>(part_f + ((int64_t)r * a.C) * P + at + 4 * h);
                 }
-                vq[h] = *reinterpret_cast<const f32x4*>(a.q1_in + at + 4 * h);
-                vp[h] = LR_DBG(a, 3) ? vq[h] : *reinterpret_cast<const f32x4*>(a.pm_in + at + 4 * h);
-                vb[h] = *reinterpret_cast<const f32x4*>(a.cvec + 32 * m + 8 * kg + 4 * h);
-                vi[h] = *reinterpret_cast<const f32x4*>(a.cvec + P + 32 * m + 8 * kg + 4 * h);
+            load8(a.q1_in + at, vq);
+            if (LR_DBG(a, 3)) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) vp[e] = vq[e];
+            } else {
+                load8(a.pm_in + at, vp);
             }
+            load8(a.cvec + 32 * m + 8 * kg, vb);
+            load8(a.cvec + P + 32 * m + 8 * kg, vi);
 #ifdef LR_STAMPS
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (a.stamps && lane == 0) LR_STAMP_AT(a, 11) = __builtin_amdgcn_s_memrealtime();
@@ -521,25 +550,25 @@ __global__ void __launch_bounds__((64 * NW)) __attribute__((amdgpu_waves_per_eu(
 #ifdef LR_STAMPS
             if (a.stamps && lane == 0) LR_STAMP_AT(a, 12) = __builtin_amdgcn_s_memrealtime();
 #endif
-            f32x4 xn[2], pn[2];
+            S xn[8], pn[8];
+            f32x4 xf[2];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 double gs = 0.0;
 #pragma unroll
                 for (int r = 0; r < kFuseSlices; ++r)
                     if (r < a.RS_i) gs += (double)pg[r][e >> 2][e & 3];
-                const float g1 = (float)gs - vq[e >> 2][e & 3] * vi[e >> 2][e & 3];
-                const float pmn = fma_t(a.step, g1, vp[e >> 2][e & 3]);
-                pn[e >> 2][e & 3] = pmn;
-                xn[e >> 2][e & 3] = fma_t(vb[e >> 2][e & 3], pmn, vq[e >> 2][e & 3]);
+                const S g1 = (S)gs - vq[e] * vi[e];
+                const S pmn = fma_t(a.step, g1, vp[e]);
+                pn[e] = pmn;
+                xn[e] = fma_t(vb[e], pmn, vq[e]);
+                xf[e >> 2][e & 3] = (float)xn[e];
             }
-            *reinterpret_cast<f32x4*>(&qnew[4 * m + kg][0][c][0]) = xn[0];
-            *reinterpret_cast<f32x4*>(&qnew[4 * m + kg][1][c][0]) = xn[1];
+            *reinterpret_cast<f32x4*>(&qnew[4 * m + kg][0][c][0]) = xf[0];
+            *reinterpret_cast<f32x4*>(&qnew[4 * m + kg][1][c][0]) = xf[1];
             if (rs == 0 && chain0 + c < a.C) {
-                *reinterpret_cast<f32x4*>(a.q1 + at) = xn[0];
-                *reinterpret_cast<f32x4*>(a.q1 + at + 4) = xn[1];
-                *reinterpret_cast<f32x4*>(a.pm + at) = pn[0];
-                *reinterpret_cast<f32x4*>(a.pm + at + 4) = pn[1];
+                store8(a.q1 + at, xn);
+                store8(a.pm + at, pn);
             }
         } else {
 #pragma unroll
@@ -548,7 +577,6 @@ __global__ void __launch_bounds__((64 * NW)) __attribute__((amdgpu_waves_per_eu(
         }
         LR_STAMP(a, 1);
         __syncthreads();
-      }
     } else {
 #pragma unroll
         for (int b = 0; b < NBUF - 1; ++b)
