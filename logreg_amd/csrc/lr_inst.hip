@@ -187,9 +187,10 @@ int launch_tall_partial(hipStream_t st, int want_value, int want_grad, const voi
         return check(hipGetLastError());
     }
 #elif LR_P >= 8
-    if (a.interior && !want_value && a.xmx && a.RS_i > 0) {  // float64 models: the 4-wave interior kernel, position rounded on the way in
+    if (a.interior && !want_value && a.xmx && a.RS_i > 0) {  // float64 models: the same interior kernels, position rounded on the way in
         const dim3 gridm((unsigned)a.RS_i, (unsigned)((a.C + 63) / 64));
-        hipLaunchKernelGGL((k_tall_partial_mx<P, 4, double>), gridm, dim3(256), 0, st, a);
+        if (a.rowsplit_waves == 16) hipLaunchKernelGGL((k_tall_partial_mx16<P, double>), gridm, dim3(1024), 0, st, a);
+        else hipLaunchKernelGGL((k_tall_partial_mx<P, 4, double>), gridm, dim3(256), 0, st, a);
         return check(hipGetLastError());
     }
 #endif

@@ -510,7 +510,7 @@ InteriorPlan plan_interior(const lr_model* m, int64_t Cp) {
         // (and only when those slices still fill the chip: n=5000 p=30 at 1024 chains would get 5 slices x 16 blocks = 80
         //  workgroups and ran 13.5 -> 17.9 us per step; n=20 000 p=12: 17.8 -> 13.8, config 4: 29.7 -> 27.5)
         //  at 4096 chains the steps are long enough that the saved launch no longer shows: -3 .. +5 %, so up to 2048 chains)
-        if (m->dtype == LR_F32 && m->dbg.tall_mx16 && rs16 >= 1 && rs16 <= 16 && RS_i > rs16 && 4 * rs16 * blocks >= 3LL * m->cus && blocks <= 32) {
+        if (m->dbg.tall_mx16 && rs16 >= 1 && rs16 <= 16 && RS_i > rs16 && 4 * rs16 * blocks >= 3LL * m->cus && blocks <= 32) {
             RS_i = (int)rs16;
             slice_len_i = len16;
             rs_waves = 16;

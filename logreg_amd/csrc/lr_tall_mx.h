@@ -247,8 +247,9 @@ __global__ void __launch_bounds__((64 * NW)) k_tall_partial_mx(TallArgs<S, P> a)
 // (2 chain groups x 8 row groups -- 32 chains per workgroup, two workgroups per CU, eight waves per SIMD -- was measured:
 // config 4 unchanged (29.3 us), p = 12 / 24 / 32 slower (13.5 -> 16.1, 22.9 -> 27.9, 43.3 -> 45.6 us per step).)
 constexpr int kMx16FuseSlices = 16;  // the host fuses only when RS_i <= this
-template <int P>
-__global__ void __launch_bounds__(1024) k_tall_partial_mx16(TallArgs<float, P> a) {
+// S = double: a FLOAT64 model's interior steps (position, momentum and the fused update float64; float32 slice partials).
+template <int P, typename S = float>
+__global__ void __launch_bounds__(1024) k_tall_partial_mx16(TallArgs<S, P> a) {
     using G = MxGeom<P>;
     constexpr int CHUNK_BYTES = 2 * kMxChunkBytes;  // 32 KB chunks: half the barriers of the 4-wave kernel (config 4: 30.2 -> 28.9 us per step; 48 KB: 29.5)
     constexpr int NS = G::NS, kMxTileElems = G::TILE, kMxChunkTiles = CHUNK_BYTES / (G::TILE * 2), NW = 16;
@@ -292,17 +293,18 @@ __global__ void __launch_bounds__(1024) k_tall_partial_mx16(TallArgs<float, P> a
         const bool live = chain < a.C;
         if (!live) chain = a.C - 1;
         const int64_t ix = chain * P + j;
-        float q;
+        S q;
         if (a.fuse_mid) {
-            float t[kMx16FuseSlices];
+            float t[kMx16FuseSlices];  // (the partials are float32 whatever S)
+            const float* part_f = reinterpret_cast<const float*>(a.part_in);
 #pragma unroll
-            for (int r = 0; r < kMx16FuseSlices; ++r) t[r] = a.part_in[((int64_t)(r < a.RS_i ? r : a.RS_i - 1) * a.C) * P + ix];
-            const float q0 = a.q1_in[ix], p0 = a.pm_in[ix], bj = a.cvec[j], ivj = a.cvec[P + j];
+            for (int r = 0; r < kMx16FuseSlices; ++r) t[r] = part_f[((int64_t)(r < a.RS_i ? r : a.RS_i - 1) * a.C) * P + ix];
+            const S q0 = a.q1_in[ix], p0 = a.pm_in[ix], bj = a.cvec[j], ivj = a.cvec[P + j];
             double sum = 0.0;
 #pragma unroll
             for (int r = 0; r < kMx16FuseSlices; ++r) sum += r < a.RS_i ? (double)t[r] : 0.0;
-            const float g1 = (float)sum - q0 * ivj;
-            const float pn = fma_t(a.step, g1, p0);
+            const S g1 = (S)sum - q0 * ivj;
+            const S pn = fma_t(a.step, g1, p0);
             q = fma_t(bj, pn, q0);
             if (rs == 0 && live) {
                 a.q1[ix] = q;
@@ -311,7 +313,7 @@ __global__ void __launch_bounds__(1024) k_tall_partial_mx16(TallArgs<float, P> a
         } else {
             q = a.q1[ix];
         }
-        qnew[cc][j] = q;
+        qnew[cc][j] = (float)q;
     }
     LR_STAMP(a, 1);
     __builtin_amdgcn_s_waitcnt(0x0F70);  // (the loads above and this wave's share of chunk 0)
@@ -388,7 +390,7 @@ __global__ void __launch_bounds__(1024) k_tall_partial_mx16(TallArgs<float, P> a
     for (int e = tid; e < 64 * P; e += 64 * NW) {
         const int cc = e / P, j = e % P;
         if (chain0 + cc < a.C)
-            a.part_g[((int64_t)rs * a.C + chain0 + cc) * P + j] = (red[0][cc][j] + red[1][cc][j]) + (red[2][cc][j] + red[3][cc][j]);
+            reinterpret_cast<float*>(a.part_g)[((int64_t)rs * a.C + chain0 + cc) * P + j] = (red[0][cc][j] + red[1][cc][j]) + (red[2][cc][j] + red[3][cc][j]);
     }
     LR_STAMP(a, 6);
 }
