@@ -813,8 +813,9 @@ def test_other_parameter_counts_use_padded_kernels(la, oracle_model):
             assert np.max(np.abs(r["glp"] - orc.glp(b))) < (2e-2 if dtype == "float32" else 1e-8)
             q0 = 0.1 * rng.standard_normal((64, p))
             ref = orc.run("hmc", q0, step=0.02, l=7, scale=np.ones(p), thin=1, iters=1, seed=4, threads=0)
+            # (float64: every evaluation float64 -- under the default policy the tall p = 20 model's interior gradients are bf16-class)
             out, info = la.mcmc(q0, la.hmcKernel(m.lpost, m.glp, eps=0.02, l=7, dmm=np.ones(p)), thin=1, iters=1,
-                                verb=False, seed=4, return_info=True)
+                                verb=False, seed=4, return_info=True, precision="auto" if dtype == "float32" else "full")
             ok = ref["margin"] > 1e-3
             assert np.array_equal(info["accepts"][ok], ref["accepts"][ok].astype(np.uint32))
             assert np.max(np.abs(out[0, ok] - ref["out"][0, ok])) < (2e-3 if dtype == "float32" else 1e-9)
