@@ -110,7 +110,9 @@ typedef struct lr_run_opts {
  *                  ... and for a float64 model with 5 <= p <= 8, n <= 256 (LR_MODE_MIXED): float32 interior gradients -- the
  *                    trajectory's position and momentum, both end-point evaluations, the half kicks, the kinetic energies and
  *                    the Metropolis test stay float64; only the force applied inside the trajectory is computed from the
- *                    position and the rows rounded to float32 (4 - 5 x the all-float64 rate);
+ *                    position and the rows rounded to float32 (4 - 5 x the all-float64 rate); from 40 chains per CU (n <= 208) the
+ *                    fused matrix-core kernel takes over (LR_MODE_MFMA, bf16 interior force, the same float64 everything else);
+ *                    tall and wide float64 models run the stepwise engine's bf16 interior kernels on a float64 state;
  *                  elsewhere (other float64 models, p < 5, few chains on register/LDS-resident data) it is LR_PREC_FULL.
  *                  A default HMC run is therefore NOT step-for-step comparable with a float64 reference run (the
  *                  posterior is the same; acceptance rates measured within 0.001 - 0.01 of the exact-gradient run);

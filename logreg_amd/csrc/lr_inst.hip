@@ -6,6 +6,9 @@
 #if LR_DTYPE == 0 && LR_P >= 8
 #include "lr_mfma.h"
 #endif
+#if LR_DTYPE == 1 && LR_P == 8
+#include "lr_mfma_f64.h"
+#endif
 #if LR_P >= 8
 #include "lr_tall_mx.h"
 #endif
@@ -70,10 +73,18 @@ constexpr int P = LR_P;
 #define LR_MIXED_VARIANTS(X)
 #endif
 
+// float64, padded p = 8: HMC on the fused matrix-core kernel, 16 chains per wave (k_chain_mfma_f64): X(16-row tiles per wave)
+#if LR_DTYPE == 1 && LR_P == 8
+#define LR_MFMA64_VARIANTS(X) X(13)
+#else
+#define LR_MFMA64_VARIANTS(X)
+#endif
+
 #define LR_VARIANT_ROW(M_, G_, R_) {M_, G_, R_},
 #define LR_MIXED_ROW(R_) {MODE_MIXED, 16, R_},
+#define LR_MFMA64_ROW(N_) {MODE_MFMA, 1, N_},
 #define LR_MFMA_ROW(S_, N_) {MODE_MFMA, S_, N_},
-const Variant kVariants[] = {LR_VARIANTS(LR_VARIANT_ROW) LR_MFMA_VARIANTS(LR_MFMA_ROW) LR_MIXED_VARIANTS(LR_MIXED_ROW)};
+const Variant kVariants[] = {LR_VARIANTS(LR_VARIANT_ROW) LR_MFMA_VARIANTS(LR_MFMA_ROW) LR_MIXED_VARIANTS(LR_MIXED_ROW) LR_MFMA64_VARIANTS(LR_MFMA64_ROW)};
 
 inline int check(hipError_t e) { return e == hipSuccess ? 0 : -2; }
 
@@ -173,6 +184,10 @@ int launch_chain(const LaunchCfg* cfg, int64_t C, const void* model_args, const 
     if (cfg->mode == MODE_MIXED && cfg->G == 16 && cfg->R == R_ && cfg->kind == KIND_HMC) \
         return launch_capped<&k_chain_mixed<R_>>(cfg, grid_for(C, 16), dim3(256), cfg->lds_bytes, m, a);
     LR_MIXED_VARIANTS(LR_DISPATCH_MIXED)
+#define LR_DISPATCH_MFMA64(N_)                                                                 \
+    if (cfg->mode == MODE_MFMA && cfg->G == 1 && cfg->R == N_ && cfg->kind == KIND_HMC)   \
+        return launch_capped<&k_chain_mfma_f64<N_>>(cfg, dim3((unsigned)((C + 63) / 64)), dim3(256), cfg->lds_bytes, m, a);
+    LR_MFMA64_VARIANTS(LR_DISPATCH_MFMA64)
     return -3;
 }
 

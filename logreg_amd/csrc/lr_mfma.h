@@ -47,8 +47,9 @@ __device__ __forceinline__ float mf_hi_f32(uint32_t packed) { return __builtin_b
 // rows[row][coord] for row < n, else 0 -- without a branch: a guarded load is a basic block of its own with its own
 // vmcnt(0), and the operand builds below issue hundreds of them per launch (measured on the LDS variant at n = 2000:
 // 190 serial L2 round trips = 25 us per launch of 10 iterations)
-template <int P> __device__ __forceinline__ float mf_row_or_zero(const float* __restrict__ rows, int64_t n, int64_t row, int coord) {
-    const float v = rows[(row < n ? row : n - 1) * P + coord];
+// (Src = double: a float64 model's rows rounded to float32 -- the bf16 interior operands of k_chain_mfma_f64)
+template <int P, typename Src> __device__ __forceinline__ float mf_row_or_zero(const Src* __restrict__ rows, int64_t n, int64_t row, int coord) {
+    const float v = (float)rows[(row < n ? row : n - 1) * P + coord];
     return row < n ? v : 0.0f;
 }
 
@@ -76,7 +77,7 @@ template <int P, int NTW, int S> struct MfmaRows {
     mf_u32x4 xq[NPAIR][NU];
     int ntile_live;  // this wave's tiles that contain at least one real row (all-padding tiles are skipped)
 
-    __device__ __forceinline__ void load(const float* __restrict__ rows, int64_t n, int wave, int lane) {
+    template <typename Src> __device__ __forceinline__ void load(const Src* __restrict__ rows, int64_t n, int wave, int lane) {
         const int c = lane & 15, k = lane >> 4;
         const int rp = c & 3, kp = c >> 2;  // slot m = c = 4*kp + rp -> parameter kp + 4 rp (+ 16 per set) of the gradient A operand
         pad_rows = 0;

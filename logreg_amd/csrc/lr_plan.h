@@ -174,13 +174,19 @@ bool mfma_variant_fits(const lr_model* m, int S, Store st, Plan* out) {
 }
 
 bool plan_mfma_hmc(const lr_model* m, int64_t C, Plan* out) {
-    if (m->dtype != LR_F32 || m->P < 8 || m->P > 32) return false;
+    if (m->P < 8 || m->P > 32) return false;
+    // float64 models: k_chain_mfma_f64 (lr_mfma_f64.h) -- p = 8, rows as register operands, 16 chains per wave: the table's first row
+    // (its other variants are not instantiated for float64, so the rows that ask for them fit nothing); float64 rows in LDS
+    if (m->dtype != LR_F32 && m->P != 8) return false;
     for (const MfmaRule& r : kMfmaRules) {
         if (r.P != m->P || m->n <= r.n_lo || m->n > r.n_hi) continue;
         if (C < (int64_t)r.cpc_lo * m->cus || (r.cpc_hi && C >= (int64_t)r.cpc_hi * m->cus)) continue;
-        if (r.s8 && mfma_variant_fits(m, 8, r.store, out)) return true;
-        if (r.s8 && r.store == ST_LDS && r.cpc_lo < 16 && m->P == 8) continue;  // (the 8-chains-per-CU row is the 8-wave split's own)
-        if (mfma_variant_fits(m, r.S, r.store, out)) return true;
+        bool hit = r.s8 && mfma_variant_fits(m, 8, r.store, out);
+        if (!hit && r.s8 && r.store == ST_LDS && r.cpc_lo < 16 && m->P == 8) continue;  // (the 8-chains-per-CU row is the 8-wave split's own)
+        if (!hit) hit = mfma_variant_fits(m, r.S, r.store, out);
+        if (!hit) continue;
+        if (m->dtype != LR_F32) out->lds_bytes = (size_t)m->n * m->P * m->esize();
+        return true;
     }
     return false;
 }
@@ -279,6 +285,7 @@ int pick_variant(const PlanReq& q) {
             // fp32 matrix-core variants; G = row-split ways S, R = tiles per wave.  Here only on request (mode = LR_MODE_MFMA); the
             // planner's own uses are plan_mfma_hmc and measured_overrides.
             if (q.for_eval || q.mode != LR_MODE_MFMA) continue;
+            if (m->dtype != LR_F32 && q.kind != LR_KIND_HMC) continue;  // (float64: k_chain_mfma_f64 is an HMC kernel)
             if (v.R < 0 ? m->d_xms == nullptr
                         : (v.R == 0 ? mfma_lds_bytes(m, v.G) > mfma_lds_budget(m, v.G) : (int64_t)16 * v.G * v.R < m->n)) continue;
             if (q.group != 0 && v.G != q.group) continue;
@@ -426,7 +433,7 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
     if (for_eval && (mode == LR_MODE_MFMA || mode == LR_MODE_STEPWISE) && m->P <= 32) { mode = LR_MODE_AUTO; group = 0; }
     const PlanReq q{m, C, group, mode, for_eval, kind};
     if (hmc_bf16 && q.automatic() && plan_mfma_hmc(m, C, out)) {
-        if (exact_tail_ok && kind >= 0) plan_second_part_mfma(q, out);
+        if (exact_tail_ok && kind >= 0 && m->dtype == LR_F32) plan_second_part_mfma(q, out);
         return LR_OK;
     }
     if (hmc_bf16 && q.automatic() && plan_mixed_hmc(m, C, out)) return LR_OK;
@@ -444,7 +451,7 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
                     m->dtype, m->p, m->P, (long long)m->n, group, mode);
     if (q.automatic() && measured_overrides(q, &best, out)) return LR_OK;
     const lr::Variant& v = m->table->variants[best];
-    *out = Plan{v.mode, v.G, v.R, v.mode == lr::MODE_MIXED ? mixed_lds_bytes(m) : v.mode == lr::MODE_LDS ? row_bytes : (v.mode == lr::MODE_MFMA && v.R == 0 ? mfma_lds_bytes(m, v.G) : 0)};
+    *out = Plan{v.mode, v.G, v.R, v.mode == lr::MODE_MIXED ? mixed_lds_bytes(m) : v.mode == lr::MODE_LDS || (v.mode == lr::MODE_MFMA && m->dtype != LR_F32) ? row_bytes : (v.mode == lr::MODE_MFMA && v.R == 0 ? mfma_lds_bytes(m, v.G) : 0)};
     if (v.mode == lr::MODE_REG && q.automatic() && kind >= 0) plan_second_part(q, v, out);
     return LR_OK;
 }

@@ -78,6 +78,10 @@ CASES = [
     (200, 8, 4096, "hmc", "auto", {"dtype": "float64", "mode": "mixed", "group": 16, "rows_per_lane": 13}),
     (200, 8, 64, "hmc", "auto", {"dtype": "float64", "mode": "mixed", "group": 16, "rows_per_lane": 13}),
     (250, 6, 8192, "hmc", "auto", {"dtype": "float64", "mode": "mixed", "group": 16, "rows_per_lane": 16, "no_tail": True}),
+    (200, 8, 10240, "hmc", "auto", {"dtype": "float64", "mode": "mfma", "group": 1, "rows_per_lane": 13, "no_tail": True}),  # k_chain_mfma_f64
+    (200, 8, 18432, "hmc", "auto", {"dtype": "float64", "mode": "mfma", "group": 1, "rows_per_lane": 13, "no_tail": True}),
+    (200, 8, 10239, "hmc", "auto", {"dtype": "float64", "mode": "mixed"}),
+    (250, 8, 1 << 16, "hmc", "auto", {"dtype": "float64", "mode": "mixed"}),  # 250 rows: beyond the 13 register tiles
     (300, 8, 4096, "hmc", "auto", {"dtype": "float64", "not_mode": "mixed"}),
     (200, 4, 4096, "hmc", "auto", {"dtype": "float64", "not_mode": "mixed"}),
     (200, 12, 4096, "hmc", "auto", {"dtype": "float64", "not_mode": "mixed"}),

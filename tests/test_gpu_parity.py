@@ -234,6 +234,52 @@ def test_matrix_core_variant_invariances_and_short_run(la, models, oracle_model,
     assert np.max(np.abs(mixed[:, wide_ok, :] - ref["out"][:, wide_ok, :]) / POST_SD) < 5e-2
 
 
+def test_matrix_core_kernel_of_the_float64_model(la, models, oracle_model, map_beta):
+    """k_chain_mfma_f64 (lr_mfma_f64.h): float64 state, end points and Metropolis test, bf16 force inside the trajectory, 16 chains per
+    wave.  Forced with precision="full" every evaluation is its float64 one: step for step with the oracle (1e-8); under the default
+    policy (planned from 40 chains per CU) trajectories within 5e-2 sd of the exact ones, decisions away from near-ties; rerun, chunks
+    and shards bit-equal; l = 1 (no interior gradient) equal to the all-float64 run to rounding; acceptance as the all-float64 run's."""
+    m = models["float64"]
+    C = 200
+    q0 = map_beta + 0.3 * POST_SD * np.random.default_rng(2).standard_normal((C, 8))
+    k = make_kernel(la, m, "hmc")
+    kw = dict(thin=3, iters=4, verb=False, seed=99, group=1, mode="mfma")
+    ref = oracle_model.run("hmc", q0, thin=3, iters=4, seed=99, threads=0, **KW["hmc"])
+    full, info = la.mcmc(q0, k, precision="full", return_info=True, **kw)
+    assert info["plan"] == {"mode": "mfma", "group": 1, "rows_per_lane": 13}
+    ok = ref["margin"] > 1e-7
+    assert ok.mean() > 0.95 and np.array_equal(info["accepts"][ok], ref["accepts"][ok].astype(np.uint32))
+    np.testing.assert_allclose(full[:, ok], ref["out"][:, ok], rtol=1e-8, atol=1e-10)
+    mixed = la.mcmc(q0, k, **kw)
+    assert not np.array_equal(mixed, full)
+    assert np.array_equal(mixed, la.mcmc(q0, k, chunk=3, **kw))
+    a = la.mcmc(q0[:50], k, **kw)
+    b = la.mcmc(q0[50:], k, chain_offset=50, **kw)
+    assert np.array_equal(mixed, np.concatenate([a, b], axis=1))
+    wide_ok = ref["margin"] > 0.1
+    err = np.max(np.abs(mixed[:, wide_ok, :] - ref["out"][:, wide_ok, :]) / POST_SD)
+    print("float64 mfma bf16-interior vs oracle:", err, "sd")
+    assert err < 5e-2
+    k1 = la.hmcKernel(m.lpost, m.glp, eps=1e-3, l=1, dmm=1 / PRE)
+    one = la.mcmc(q0, k1, **kw)
+    np.testing.assert_allclose(one, la.mcmc(q0, k1, thin=3, iters=4, verb=False, seed=99, precision="full"), rtol=1e-12, atol=1e-13)
+    with pytest.raises(la.LogregHipError):
+        la.mcmc(q0, make_kernel(la, m, "mala"), thin=1, iters=1, verb=False, mode="mfma", group=1)
+    # planned by itself from 40 chains per CU
+    Cb = 16384
+    qb = map_beta + 0.5 * POST_SD * np.random.default_rng(3).standard_normal((Cb, 8))
+    acc = {}
+    for prec in ("auto", "full"):
+        cs = la.ChainSet(k, qb, seed=7, precision=prec)
+        if prec == "auto":
+            assert cs.plan() == {"mode": "mfma", "group": 1, "rows_per_lane": 13}
+            assert la.ChainSet(k, qb[:8192], seed=7).plan()["mode"] == "mixed"
+        cs.advance(1, 20, keep=False)
+        acc[prec] = cs.get_accepts().sum() / (Cb * 20)
+    print("float64 HMC acceptance at 16384 chains: bf16 interior", acc["auto"], "all float64", acc["full"])
+    assert abs(acc["auto"] - acc["full"]) < 0.01
+
+
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
 @pytest.mark.parametrize("kind", ["hmc", "mala", "rwmh", "ul"])
 def test_stepwise_engine_matches_oracle(la, models, oracle_model, map_beta, kind, dtype):
