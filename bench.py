@@ -313,8 +313,20 @@ def f64_run(la, L, check, dev, stream, X, y, pscale, q0, steps):
         its = C * n * THIN / (ms * 1e-3)
         res[prec] = {"kernel_variant": cs.plan(), "chain_iterations_per_s": its, "ms_per_step": ms / n,
                      "accept_rate": float((cs.get_accepts().astype(np.int64).sum() - a0) / (C * n * THIN))}
+    # ... and with many chains, where the default policy moves to the matrix-core kernel with a float64 state (lr_mfma_f64.h)
+    Cm = 4 * C
+    qm = np.tile(q0, (4, 1))
+    cs = la.ChainSet(k64, qm, seed=SEED, stream=stream)
+    cs.advance(2, THIN, keep=False)
+    cs.sync()
+    nm = max(2, n // 4)
+    timer.start()
+    for _ in range(nm):
+        cs.advance(1, THIN, keep=False)
+    ms = timer.stop_ms()
+    many = {"chains": Cm, "kernel_variant": cs.plan(), "chain_iterations_per_s": Cm * nm * THIN / (ms * 1e-3), "ms_per_step": ms / nm}
     tf = res["full"]["chain_iterations_per_s"] * LEAP * flops_per_grad_eval(N_ROWS, N_PAR) / 1e12
-    return {"dtype": "f64", **res["full"], "algorithmic_TFLOPs": tf, "peak": PEAK_FP64_TFLOPS, "frac_of_fp64_vector_peak": tf / PEAK_FP64_TFLOPS,
+    return {"dtype": "f64", **res["full"], "default_policy_many_chains": many, "algorithmic_TFLOPs": tf, "peak": PEAK_FP64_TFLOPS, "frac_of_fp64_vector_peak": tf / PEAK_FP64_TFLOPS,
             "default_policy": {**res["auto"], "note": "precision='auto' on the float64 model (LR_MODE_MIXED): float64 end points, Metropolis "
                                "test, position and momentum; float32 force inside the trajectory"},
             "note": f"same workload, {C} chains, {n} launches of {THIN} iterations, HIP-event timed, not part of `value`; top level = precision='full'"}

@@ -59,6 +59,7 @@ enum { LR_F32 = 0, LR_F64 = 1 };
  * order, so launches of different chain counts are bit-identical only under the same slicing: a sharded run
  * that wants bit-exact agreement with the one-GPU run sets lr_run_opts.plan_chains to the whole run's chain count
  * (which pins the interior kernels' own slicing as well; an explicit group > 0 pins the end-point slicing only).
+ * (float64 models: MFMA exists for HMC at 5 <= p <= 8, n <= 208, group = 1 -- lr_mfma_f64.h.)
  * MIXED (float64 models, HMC only, 5 <= p <= 8, n <= 256): float64 rows in LDS for the end points of a trajectory, the same rows
  * rounded to float32 in VGPRs for its interior gradients (see LR_PREC_*); 16 lanes per chain. */
 enum { LR_MODE_AUTO = -1, LR_MODE_REG = 0, LR_MODE_LDS = 1, LR_MODE_GLOBAL = 2, LR_MODE_MFMA = 3, LR_MODE_STEPWISE = 4, LR_MODE_MIXED = 5 };

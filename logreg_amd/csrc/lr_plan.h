@@ -211,7 +211,8 @@ bool plan_mixed_hmc(const lr_model* m, int64_t C, Plan* out) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// make_plan and its steps.  Order: (1) HMC with reduced-precision interior steps -> kMfmaRules; (2) wide models -> stepwise;
+// make_plan and its steps.  Order: (1) HMC with reduced-precision interior steps -> kMfmaRules, then (float64, p = 8) k_chain_mixed;
+// (2) wide models -> stepwise;
 // (3) rows off chip (or forced) -> stepwise; (4) the best variant by residency tier and the register family's launch-time model;
 // (5) measured overrides of vector-ALU plans; (6) a second part for the remainder between exactly-filled chain counts.
 struct PlanReq {
