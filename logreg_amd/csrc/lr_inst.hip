@@ -66,9 +66,9 @@ constexpr int P = LR_P;
 #define LR_MFMA_VARIANTS(X)
 #endif
 
-// float64, padded p = 8: HMC with float32 interior gradients (k_chain_mixed): X(rows per lane of the 16 lanes of a chain)
+// float64, padded p = 8: HMC with float32 interior gradients (k_chain_mixed / k_chain_mixed_rep): X(lanes per chain, rows per lane)
 #if LR_DTYPE == 1 && LR_P == 8
-#define LR_MIXED_VARIANTS(X) X(13) X(16)
+#define LR_MIXED_VARIANTS(X) X(16, 13) X(16, 16) X(64, 4) X(32, 7) X(32, 8)
 #else
 #define LR_MIXED_VARIANTS(X)
 #endif
@@ -81,7 +81,7 @@ constexpr int P = LR_P;
 #endif
 
 #define LR_VARIANT_ROW(M_, G_, R_) {M_, G_, R_},
-#define LR_MIXED_ROW(R_) {MODE_MIXED, 16, R_},
+#define LR_MIXED_ROW(G_, R_) {MODE_MIXED, G_, R_},
 #define LR_MFMA64_ROW(N_) {MODE_MFMA, 1, N_},
 #define LR_MFMA_ROW(S_, N_) {MODE_MFMA, S_, N_},
 const Variant kVariants[] = {LR_VARIANTS(LR_VARIANT_ROW) LR_MFMA_VARIANTS(LR_MFMA_ROW) LR_MIXED_VARIANTS(LR_MIXED_ROW) LR_MFMA64_VARIANTS(LR_MFMA64_ROW)};
@@ -162,6 +162,13 @@ int launch_mfma_image(hipStream_t st, const void* rows, int64_t n, void* store) 
 #define LR_MFMA_IMAGE_HOOKS nullptr, nullptr
 #endif
 
+#if LR_DTYPE == 1 && LR_P == 8
+template <int G, int R> int launch_mixed_v(const LaunchCfg* cfg, int64_t C, const ModelArgs<T, P>& m, const ChainArgs<T, P>& a) {
+    if constexpr (G == 16) return launch_capped<&k_chain_mixed<R>>(cfg, grid_for(C, G), dim3(256), cfg->lds_bytes, m, a);
+    else return launch_capped<&k_chain_mixed_rep<G, R>>(cfg, grid_for(C, G), dim3(256), cfg->lds_bytes, m, a);
+}
+#endif
+
 int launch_eval(const LaunchCfg* cfg, int64_t C, const void* model_args, const void* eval_args) {
     const auto& m = *static_cast<const ModelArgs<T, P>*>(model_args);
     const auto& a = *static_cast<const EvalArgs<T>*>(eval_args);
@@ -180,9 +187,9 @@ int launch_chain(const LaunchCfg* cfg, int64_t C, const void* model_args, const 
 #define LR_DISPATCH_MFMA(S_, N_) \
     if (cfg->mode == MODE_MFMA && cfg->G == S_ && cfg->R == N_) return launch_mfma_v<S_, N_>(cfg, C, m, a);
     LR_MFMA_VARIANTS(LR_DISPATCH_MFMA)
-#define LR_DISPATCH_MIXED(R_)                                                                  \
-    if (cfg->mode == MODE_MIXED && cfg->G == 16 && cfg->R == R_ && cfg->kind == KIND_HMC) \
-        return launch_capped<&k_chain_mixed<R_>>(cfg, grid_for(C, 16), dim3(256), cfg->lds_bytes, m, a);
+#define LR_DISPATCH_MIXED(G_, R_)                                                              \
+    if (cfg->mode == MODE_MIXED && cfg->G == G_ && cfg->R == R_ && cfg->kind == KIND_HMC) \
+        return launch_mixed_v<G_, R_>(cfg, C, m, a);
     LR_MIXED_VARIANTS(LR_DISPATCH_MIXED)
 #define LR_DISPATCH_MFMA64(N_)                                                                 \
     if (cfg->mode == MODE_MFMA && cfg->G == 1 && cfg->R == N_ && cfg->kind == KIND_HMC)   \

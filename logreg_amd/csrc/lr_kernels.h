@@ -458,6 +458,96 @@ __global__ void __launch_bounds__(256) k_chain_mixed(ModelArgs<double, 8> m, Cha
     }
 }
 
+// The same policy on 32 / 64 lanes per chain (few chains: a wave alone on its SIMD runs 7 / 4 rows per lane instead of 13), with
+// the float64 state REPLICATED in the group's lanes as k_chain has it: all-reduce of the float32 gradient, drift and kick on all 8
+// coordinates in every lane.
+template <int G, int R>
+__global__ void __launch_bounds__(256) k_chain_mixed_rep(ModelArgs<double, 8> m, ChainArgs<double, 8> a) {
+    constexpr int P = 8;
+    static_assert(G == 32 || G == 64, "16 lanes per chain: k_chain_mixed");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int gl = threadIdx.x % G;
+    int64_t chain = a.first + ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const bool live = chain < a.first + a.count;
+    if (!live) chain = a.first + a.count - 1;
+    const bool writer = live && gl == 0;
+    const auto rows = make_rows<double, P, G, MODE_LDS, 0>(m, gl, reinterpret_cast<double*>(smem_raw));
+    RegRowPairs<P, R, G> rows32;
+    rows32.load(m.rows, m.n, gl);
+    const uint64_t gchain = (uint64_t)(a.chain_offset + chain);
+    double x[P], g[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) x[j] = j < a.p ? a.state[chain * a.p + j] : 0.0;
+    double lp;
+    uint32_t nacc = 0;
+    {
+        double ll0 = 0, lpr0 = 0;
+        eval_lpost<double, P, G, true, true>(rows, m.prior, x, g, ll0, lpr0);
+        lp = ll0 + lpr0;
+    }
+    const double heps = 0.5 * a.step;
+    constexpr float kf = ExpScale<float>::k;
+    DrawBatch<double, P, G> draws;
+    draws.reset();
+    for (int64_t it = 0; it < a.iters; ++it) {
+        for (int64_t jt = 0; jt < a.thin; ++jt) {
+            const uint64_t iter = (uint64_t)(a.iter_offset + it * a.thin + jt);
+            double z[P], logu;
+            draws.next(a.seed, gchain, iter, gl, z, logu);
+            double pm[P], xp[P], gp[P];
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                pm[j] = z[j] * a.a[j];
+                xp[j] = x[j];
+            }
+            const double k0 = vquad<double, P>(a.c, pm);
+            vfma_s<double, P>(heps, g, pm);
+            for (int i = 0; i < a.l - 1; ++i) {
+                vfma_v<double, P>(a.b, pm, xp);  // drift (float64)
+                f32x2 bb[P / 2], gpp[P / 2];
+#pragma unroll
+                for (int j = 0; j < P / 2; ++j) bb[j] = f32x2{(float)xp[2 * j], (float)xp[2 * j + 1]} * f32x2{kf, kf};
+                row_pairs_grad_bf<P, R, G>(rows32, bb, gpp);
+                float gv[P];
+#pragma unroll
+                for (int j = 0; j < P / 2; ++j) gv[2 * j] = gpp[j].x, gv[2 * j + 1] = gpp[j].y;
+                group_sum_levels<G, P>(gv);
+#pragma unroll
+                for (int j = 0; j < P; ++j) pm[j] = __builtin_fma(a.step, __builtin_fma(-xp[j], m.prior.inv_var[j], (double)gv[j]), pm[j]);  // kick
+            }
+            vfma_v<double, P>(a.b, pm, xp);  // the last drift: its gradient is the end-point evaluation, in float64
+            double llp = 0, lprp = 0;
+            eval_lpost<double, P, G, true, true>(rows, m.prior, xp, gp, llp, lprp);
+            vfma_s<double, P>(heps, gp, pm);
+            const double k1 = vquad<double, P>(a.c, pm);
+            const double logr = ((llp + lprp) - lp) - 0.5 * (k1 - k0);
+            const bool acc = logu < logr;  // NaN -> reject
+            if (acc) {
+                ++nacc;
+                lp = llp + lprp;
+            }
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                x[j] = acc ? xp[j] : x[j];
+                g[j] = acc ? gp[j] : g[j];
+            }
+        }
+        if (a.out && writer) {
+            double* o = a.out + (it * a.C + chain) * a.p;
+#pragma unroll
+            for (int j = 0; j < P; ++j)
+                if (j < a.p) o[j] = x[j];
+        }
+        if (a.stats.buf && writer) stats_update<double, P>(a.stats, it, a.C, chain, a.p, x);
+    }
+    if (writer) {
+#pragma unroll
+        for (int j = 0; j < P; ++j)
+            if (j < a.p) a.state[chain * a.p + j] = x[j];
+        if (a.accepts) a.accepts[chain] += nacc;
+    }
+}
+
 // --------------------------------------------------------------------------------------------
 // the chain kernel
 template <typename T, int P, int G, int MODE, int R, int KIND>

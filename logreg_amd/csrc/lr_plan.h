@@ -194,6 +194,7 @@ bool plan_mfma_hmc(const lr_model* m, int64_t C, Plan* out) {
 // HMC on a float64 model whose interior leapfrog gradients may be cheaper (LR_PREC_AUTO / LR_PREC_BF16), padded p = 8, rows within
 // 16 lanes x the instantiated rows per lane and within the LDS: k_chain_mixed (LR_MODE_MIXED) -- float64 end points, Metropolis test,
 // position and momentum; float32 force inside the trajectory.
+double reg_cost(const lr_model* m, const lr::Variant& u, int64_t chains);
 // dynamic LDS of k_chain_mixed: the float64 rows + its per-lane stash (lr_kernels.h)
 size_t mixed_lds_bytes(const lr_model* m) { return (size_t)m->n * m->P * m->esize() + (size_t)lr::kMixedStashDoubles * 8 * 256; }
 bool plan_mixed_hmc(const lr_model* m, int64_t C, Plan* out) {
@@ -201,13 +202,17 @@ bool plan_mixed_hmc(const lr_model* m, int64_t C, Plan* out) {
     const size_t row_bytes = mixed_lds_bytes(m);
     if (row_bytes > kLdsBudget || C < (int64_t)kPlanConst.mixed_chains_per_cu * m->cus) return false;
     const lr::InstTable* t = m->table;
-    for (int i = 0; i < t->nvariants; ++i) {  // (ascending rows per lane: the smallest that holds the rows)
+    int bi = -1;
+    double cost = 0;
+    for (int i = 0; i < t->nvariants; ++i) {  // lanes per chain by the register family's launch-time model (few chains: wide groups)
         const lr::Variant& v = t->variants[i];
         if (v.mode != lr::MODE_MIXED || (int64_t)v.G * v.R < m->n) continue;
-        *out = Plan{v.mode, v.G, v.R, row_bytes};
-        return true;
+        const double c = reg_cost(m, v, C) + 1e-3 * v.R;
+        if (bi < 0 || c < cost) { bi = i; cost = c; }
     }
-    return false;
+    if (bi < 0) return false;
+    *out = Plan{t->variants[bi].mode, t->variants[bi].G, t->variants[bi].R, row_bytes};
+    return true;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------

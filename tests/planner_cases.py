@@ -76,7 +76,9 @@ CASES = [
     (200, 12, 4096, "hmc", "full", {"dtype": "float64", "mode": "lds"}),
     # float64 HMC under the default precision policy, 5 <= p <= 8, n <= 256: float32 interior gradients (k_chain_mixed)
     (200, 8, 4096, "hmc", "auto", {"dtype": "float64", "mode": "mixed", "group": 16, "rows_per_lane": 13}),
-    (200, 8, 64, "hmc", "auto", {"dtype": "float64", "mode": "mixed", "group": 16, "rows_per_lane": 13}),
+    (200, 8, 64, "hmc", "auto", {"dtype": "float64", "mode": "mixed", "group": 64, "rows_per_lane": 4}),  # few chains: wide lane groups
+    (200, 8, 2048, "hmc", "auto", {"dtype": "float64", "mode": "mixed", "group": 32, "rows_per_lane": 7}),
+    (256, 8, 512, "hmc", "auto", {"dtype": "float64", "mode": "mixed", "group": 64, "rows_per_lane": 4}),
     (250, 6, 8192, "hmc", "auto", {"dtype": "float64", "mode": "mixed", "group": 16, "rows_per_lane": 16, "no_tail": True}),
     (200, 8, 10240, "hmc", "auto", {"dtype": "float64", "mode": "mfma", "group": 1, "rows_per_lane": 13, "no_tail": True}),  # k_chain_mfma_f64
     (200, 8, 18432, "hmc", "auto", {"dtype": "float64", "mode": "mfma", "group": 1, "rows_per_lane": 13, "no_tail": True}),

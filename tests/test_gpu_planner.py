@@ -40,3 +40,18 @@ def test_auto_is_within_ten_percent_of_the_best_alternative(n, p, C, kind, preci
           + " | ".join(f"{pb.fmt(pl)} {r:.2e}" for _, pl, r in res[1:]))
     assert len(res) >= 3  # alternatives were actually timed
     assert auto[2] >= 0.9 * best[2], (pb.fmt(auto[1]), pb.fmt(best[1]))
+
+
+@pytest.mark.parametrize("C,expect", [(1024, "mixed"), (4096, "mixed"), (8192, "mixed"), (16384, "mfma")])
+def test_float64_default_policy_is_within_ten_percent_of_the_best_alternative(C, expect):
+    """float64 model, HMC under the default policy (n = 200, p = 8): float32-interior kernel on 16 lanes per chain, from 40 chains per
+    CU the matrix-core kernel with a float64 state -- against each other and against the all-float64 variants."""
+    import planner_bench as pb
+    res = pb.candidates(200, 8, C, "hmc", "auto", L=20, dtype="float64")
+    auto, best = res[0], max(res, key=lambda r: r[2])
+    if auto[2] < 0.9 * best[2]:
+        res = pb.candidates(200, 8, C, "hmc", "auto", L=20, dtype="float64")
+        auto, best = res[0], max(res, key=lambda r: r[2])
+    print(f"float64 C={C}: AUTO {pb.fmt(auto[1])} {auto[2]:.3e}, best {pb.fmt(best[1])} {best[2]:.3e}; " + " | ".join(f"{pb.fmt(pl)} {r:.2e}" for _, pl, r in res[1:]))
+    assert auto[1]["mode"] == expect and len(res) >= 4
+    assert auto[2] >= 0.9 * best[2], (pb.fmt(auto[1]), pb.fmt(best[1]))

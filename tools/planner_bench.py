@@ -28,7 +28,7 @@ SHAPES = [
 ]
 # forced alternatives tried for every shape (those the library rejects for the shape are skipped)
 ALTERNATIVES = [("reg", 16), ("reg", 32), ("reg", 64), ("lds", 1), ("lds", 8), ("lds", 16), ("lds", 64), ("global", 1), ("mfma", 1), ("mfma", 4), ("mfma", 8),
-                ("stepwise", 0)]
+                ("mixed", 16), ("stepwise", 0)]
 
 
 def rate(cs, C, thin, seconds=0.08):
@@ -51,9 +51,9 @@ def rate(cs, C, thin, seconds=0.08):
     return C * thin / best
 
 
-def candidates(n, p, C, kind, precision, L=20):
+def candidates(n, p, C, kind, precision, L=20, dtype=None):
     X, y, _ = la.synthetic_logreg(n, p, seed=n + p, beta_sd=0.5 / np.sqrt(p))
-    m = la.LogReg(X, y, np.ones(p), dtype=os.environ.get("PLANNER_BENCH_DTYPE", "float32"))  # (the tool's own switch, not the library's)
+    m = la.LogReg(X, y, np.ones(p), dtype=dtype or os.environ.get("PLANNER_BENCH_DTYPE", "float32"))  # (the tool's own switch, not the library's)
     bmap, info = la.find_map(m)
     eps = 0.9 / np.sqrt(np.max(np.linalg.eigvalsh(info["hessian"]))) / p ** 0.25
     if kind == "hmc":
