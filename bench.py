@@ -355,8 +355,8 @@ def f64_wide_run(la, L, check, dev, stream):
     tf = C * flops_per_grad_eval(n, p) / (res["full"]["us_per_evaluation_all_chains"] * 1e-6) / 1e12
     return {"dtype": "f64", "workload": f"HMC L={fix['l']} eps={fix['eps']}, synthetic n={n} p={p}, {C} chains, float64 model", **res["full"],
             "algorithmic_TFLOPs": tf, "peak": PEAK_FP64_TFLOPS, "frac_of_fp64_matrix_peak": tf / PEAK_FP64_TFLOPS,
-            "default_policy": {**res["auto"], "note": "precision='auto': interior gradients on the bf16 pipe (chain-split kernel, position and "
-                               "momentum float64), end points on the f64 pipe"},
+            "default_policy": {**res["auto"], "note": "precision='auto': interior gradients on the bf16 pipe (the float32 engine's row-split kernel on a float64 state: position, "
+                               "momentum and the fused update float64), end points on the f64 pipe"},
             "note": "top level = precision='full': every evaluation on v_mfma_f64_16x16x4_f64; not part of `value`"}
 
 
