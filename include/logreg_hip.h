@@ -60,8 +60,9 @@ enum { LR_F32 = 0, LR_F64 = 1 };
  * that wants bit-exact agreement with the one-GPU run sets lr_run_opts.plan_chains to the whole run's chain count
  * (which pins the interior kernels' own slicing as well; an explicit group > 0 pins the end-point slicing only).
  * (float64 models: MFMA exists for HMC at 5 <= p <= 8, n <= 208, group = 1 -- lr_mfma_f64.h.)
- * MIXED (float64 models, HMC only, 5 <= p <= 8, n <= 256): float64 rows in LDS for the end points of a trajectory, the same rows
- * rounded to float32 in VGPRs for its interior gradients (see LR_PREC_*); 16 lanes per chain. */
+ * MIXED (float64 models, HMC only, p <= 16, rows within the float32 register variants: n <= 1024 at p <= 8, 512 at p <= 16): float64
+ * rows in LDS for the end points of a trajectory, the same rows rounded to float32 in VGPRs for its interior gradients (see
+ * LR_PREC_*); `group` = lanes per chain (16 / 32 / 64). */
 enum { LR_MODE_AUTO = -1, LR_MODE_REG = 0, LR_MODE_LDS = 1, LR_MODE_GLOBAL = 2, LR_MODE_MFMA = 3, LR_MODE_STEPWISE = 4, LR_MODE_MIXED = 5 };
 
 typedef struct lr_model lr_model;
@@ -108,7 +109,7 @@ typedef struct lr_run_opts {
  *                      (p > 8) / 16 per CU (p <= 8) upward, i.e. 1024 - 4096 chains on MI355X;
  *                    tall models on the stepwise engine (the same scheme with the rows streamed: lr_tall_mx.h);
  *                    wide models, 32 < p <= 128 (rows in one bf16 piece, beta in two: lr_wide_bf16.h);
- *                  ... and for a float64 model with 5 <= p <= 8, n <= 256 (LR_MODE_MIXED): float32 interior gradients -- the
+ *                  ... and for a float64 model with p <= 16 and rows within the register variants (LR_MODE_MIXED): float32 interior gradients -- the
  *                    trajectory's position and momentum, both end-point evaluations, the half kicks, the kinetic energies and
  *                    the Metropolis test stay float64; only the force applied inside the trajectory is computed from the
  *                    position and the rows rounded to float32 (4 - 5 x the all-float64 rate); from 40 chains per CU (n <= 208) the

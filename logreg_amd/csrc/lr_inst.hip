@@ -67,9 +67,14 @@ constexpr int P = LR_P;
 #endif
 
 // float64, padded p = 8: HMC with float32 interior gradients (k_chain_mixed / k_chain_mixed_rep): X(lanes per chain, rows per lane)
+// (p = 8 on 16 lanes: the distributed-state kernel; every other row: the replicated-state one -- the float32 register variants' shapes)
 #if LR_DTYPE == 1 && LR_P == 8
-#define LR_MIXED_VARIANTS(X) X(16, 13) X(16, 16) X(64, 4) X(32, 7) X(32, 8)
-#else
+#define LR_MIXED_VARIANTS(X) X(16, 13) X(16, 16) X(64, 4) X(32, 7) X(32, 8) X(32, 16) X(64, 8) X(64, 12) X(64, 16)
+#elif LR_DTYPE == 1 && LR_P == 4
+#define LR_MIXED_VARIANTS(X) X(64, 8) X(16, 16) X(16, 32) X(32, 32) X(64, 32)
+#elif LR_DTYPE == 1 && LR_P == 16
+#define LR_MIXED_VARIANTS(X) X(64, 8) X(32, 7) X(32, 8)
+#else  // (p > 16: the replicated float64 state of 32 coordinates does not fit the register file beside the rows -- 410 spills)
 #define LR_MIXED_VARIANTS(X)
 #endif
 
@@ -162,10 +167,10 @@ int launch_mfma_image(hipStream_t st, const void* rows, int64_t n, void* store) 
 #define LR_MFMA_IMAGE_HOOKS nullptr, nullptr
 #endif
 
-#if LR_DTYPE == 1 && LR_P == 8
+#if LR_DTYPE == 1
 template <int G, int R> int launch_mixed_v(const LaunchCfg* cfg, int64_t C, const ModelArgs<T, P>& m, const ChainArgs<T, P>& a) {
-    if constexpr (G == 16) return launch_capped<&k_chain_mixed<R>>(cfg, grid_for(C, G), dim3(256), cfg->lds_bytes, m, a);
-    else return launch_capped<&k_chain_mixed_rep<G, R>>(cfg, grid_for(C, G), dim3(256), cfg->lds_bytes, m, a);
+    if constexpr (G == 16 && P == 8) return launch_capped<&k_chain_mixed<R>>(cfg, grid_for(C, G), dim3(256), cfg->lds_bytes, m, a);
+    else return launch_capped<&k_chain_mixed_rep<P, G, R>>(cfg, grid_for(C, G), dim3(256), cfg->lds_bytes, m, a);
 }
 #endif
 

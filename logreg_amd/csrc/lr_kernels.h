@@ -461,10 +461,10 @@ __global__ void __launch_bounds__(256) k_chain_mixed(ModelArgs<double, 8> m, Cha
 // The same policy on 32 / 64 lanes per chain (few chains: a wave alone on its SIMD runs 7 / 4 rows per lane instead of 13), with
 // the float64 state REPLICATED in the group's lanes as k_chain has it: all-reduce of the float32 gradient, drift and kick on all 8
 // coordinates in every lane.
-template <int G, int R>
-__global__ void __launch_bounds__(256) k_chain_mixed_rep(ModelArgs<double, 8> m, ChainArgs<double, 8> a) {
-    constexpr int P = 8;
-    static_assert(G == 32 || G == 64, "16 lanes per chain: k_chain_mixed");
+// Also the form for the other padded widths (p <= 4, 9 <= p <= 32) and for p <= 8 beyond 256 rows, at any lanes per chain.
+template <int P, int G, int R>
+__global__ void __launch_bounds__(256) k_chain_mixed_rep(ModelArgs<double, P> m, ChainArgs<double, P> a) {
+    static_assert(G == 16 || G == 32 || G == 64, "lanes per chain");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int gl = threadIdx.x % G;
     int64_t chain = a.first + ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
@@ -493,7 +493,8 @@ __global__ void __launch_bounds__(256) k_chain_mixed_rep(ModelArgs<double, 8> m,
         for (int64_t jt = 0; jt < a.thin; ++jt) {
             const uint64_t iter = (uint64_t)(a.iter_offset + it * a.thin + jt);
             double z[P], logu;
-            draws.next(a.seed, gchain, iter, gl, z, logu);
+            if constexpr (DrawBatch<double, P, G>::kEnabled) draws.next(a.seed, gchain, iter, gl, z, logu);
+            else draw_group<double, P, G>(a.seed, gchain, iter, gl, z, logu);
             double pm[P], xp[P], gp[P];
 #pragma unroll
             for (int j = 0; j < P; ++j) {

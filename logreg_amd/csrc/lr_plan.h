@@ -191,14 +191,14 @@ bool plan_mfma_hmc(const lr_model* m, int64_t C, Plan* out) {
     return false;
 }
 
-// HMC on a float64 model whose interior leapfrog gradients may be cheaper (LR_PREC_AUTO / LR_PREC_BF16), padded p = 8, rows within
-// 16 lanes x the instantiated rows per lane and within the LDS: k_chain_mixed (LR_MODE_MIXED) -- float64 end points, Metropolis test,
-// position and momentum; float32 force inside the trajectory.
+// HMC on a float64 model whose interior leapfrog gradients may be cheaper (LR_PREC_AUTO / LR_PREC_BF16), p <= 16, rows within the
+// instantiated (lanes per chain x rows per lane) shapes and within the LDS: k_chain_mixed / k_chain_mixed_rep (LR_MODE_MIXED) --
+// float64 end points, Metropolis test, position and momentum; float32 force inside the trajectory.
 double reg_cost(const lr_model* m, const lr::Variant& u, int64_t chains);
 // dynamic LDS of k_chain_mixed: the float64 rows + its per-lane stash (lr_kernels.h)
 size_t mixed_lds_bytes(const lr_model* m) { return (size_t)m->n * m->P * m->esize() + (size_t)lr::kMixedStashDoubles * 8 * 256; }
 bool plan_mixed_hmc(const lr_model* m, int64_t C, Plan* out) {
-    if (m->dtype != LR_F64 || m->P != 8) return false;
+    if (m->dtype != LR_F64 || m->P > 32) return false;
     const size_t row_bytes = mixed_lds_bytes(m);
     if (row_bytes > kLdsBudget || C < (int64_t)kPlanConst.mixed_chains_per_cu * m->cus) return false;
     const lr::InstTable* t = m->table;

@@ -84,9 +84,12 @@ CASES = [
     (200, 8, 18432, "hmc", "auto", {"dtype": "float64", "mode": "mfma", "group": 1, "rows_per_lane": 13, "no_tail": True}),
     (200, 8, 10239, "hmc", "auto", {"dtype": "float64", "mode": "mixed"}),
     (250, 8, 1 << 16, "hmc", "auto", {"dtype": "float64", "mode": "mixed"}),  # 250 rows: beyond the 13 register tiles
-    (300, 8, 4096, "hmc", "auto", {"dtype": "float64", "not_mode": "mixed"}),
-    (200, 4, 4096, "hmc", "auto", {"dtype": "float64", "not_mode": "mixed"}),
-    (200, 12, 4096, "hmc", "auto", {"dtype": "float64", "not_mode": "mixed"}),
+    (300, 8, 4096, "hmc", "auto", {"dtype": "float64", "mode": "mixed", "group": 32, "rows_per_lane": 16}),  # (replicated-state form)
+    (1000, 8, 4096, "hmc", "auto", {"dtype": "float64", "mode": "mixed", "group": 64, "rows_per_lane": 16}),
+    (1100, 8, 4096, "hmc", "auto", {"dtype": "float64", "not_mode": "mixed"}),
+    (200, 4, 4096, "hmc", "auto", {"dtype": "float64", "mode": "mixed", "group": 16, "rows_per_lane": 16}),
+    (200, 12, 4096, "hmc", "auto", {"dtype": "float64", "mode": "mixed", "group": 32, "rows_per_lane": 7}),
+    (200, 24, 4096, "hmc", "auto", {"dtype": "float64", "not_mode": "mixed"}),
     (200, 8, 4096, "mala", "auto", {"dtype": "float64", "not_mode": "mixed"}),
     # float64 wide models: the stepwise engine on the f64 matrix pipe (lr_wide_f64.h), 64 chains per workgroup
     (4096, 128, 1024, "hmc", "auto", {"dtype": "float64", "mode": "stepwise", "group": 16}),
