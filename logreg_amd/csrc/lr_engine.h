@@ -106,7 +106,7 @@ int do_chain_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs, c
         if (ca.count <= 0) continue;
         const bool side = both && part == 1;
         lr::LaunchCfg cfg{part == 0 ? pl.mode : pl.mode2, part == 0 ? pl.G : pl.G2, part == 0 ? pl.R : pl.R2, rs.kind, side ? m->side_stream : st,
-                          part == 0 ? pl.lds_bytes : 0, m->dbg.residency_cap && !side ? m->cus : 0};
+                          part == 0 || pl.mode2 == lr::MODE_MIXED ? pl.lds_bytes : 0, m->dbg.residency_cap && !side ? m->cus : 0};
         const int rc = m->table->launch_chain(&cfg, ca.count, &ma, &ca);
         if (rc != 0) return fail(rc == -3 ? LR_ERR_UNSUPPORTED : LR_ERR_HIP, "chain launch failed (%d): %s", rc,
                                  hipGetErrorString(hipGetLastError()));

@@ -54,6 +54,7 @@ struct PlanConst {
     // 4096: 7.7 | 8.7 | 5.6, 8192: 7.7 | 8.7 | 11.2, 16 384: 7.7 | 8.8 | 11.3; MALA 8192: 5.3 | 7.2 | 7.2e8)
     // float64 HMC under LR_PREC_AUTO, p <= 8, n <= 256: k_chain_mixed from this many chains per CU
     int mixed_chains_per_cu = 0;
+    int f64_mfma_chains_per_cu = 33;  // float64 HMC under LR_PREC_AUTO: k_chain_mfma_f64 beyond two rounds of k_chain_mixed (plan_mfma_hmc)
     int f64_lds16_chains_per_cu = 16;
     int f64_lds8_chains_per_cu = 32;
     int mfma_fp32_chains_per_cu = 16;
@@ -180,7 +181,10 @@ bool plan_mfma_hmc(const lr_model* m, int64_t C, Plan* out) {
     if (m->dtype != LR_F32 && m->P != 8) return false;
     for (const MfmaRule& r : kMfmaRules) {
         if (r.P != m->P || m->n <= r.n_lo || m->n > r.n_hi) continue;
-        if (C < (int64_t)r.cpc_lo * m->cus || (r.cpc_hi && C >= (int64_t)r.cpc_hi * m->cus)) continue;
+        // (float64: the alternative is the float32-interior kernel in rounds of 16 chains per CU -- beyond two rounds the one launch
+        //  of k_chain_mfma_f64 wins: 9216 chains 1.30 ms in two parts | 0.96 ms; at 8192 0.943 | 0.96)
+        const int cpc_lo = m->dtype != LR_F32 ? kPlanConst.f64_mfma_chains_per_cu : r.cpc_lo;
+        if (C < (int64_t)cpc_lo * m->cus || (r.cpc_hi && C >= (int64_t)r.cpc_hi * m->cus)) continue;
         bool hit = r.s8 && mfma_variant_fits(m, 8, r.store, out);
         if (!hit && r.s8 && r.store == ST_LDS && r.cpc_lo < 16 && m->P == 8) continue;  // (the 8-chains-per-CU row is the 8-wave split's own)
         if (!hit) hit = mfma_variant_fits(m, r.S, r.store, out);
@@ -197,7 +201,7 @@ bool plan_mfma_hmc(const lr_model* m, int64_t C, Plan* out) {
 double reg_cost(const lr_model* m, const lr::Variant& u, int64_t chains);
 // dynamic LDS of k_chain_mixed: the float64 rows + its per-lane stash (lr_kernels.h)
 size_t mixed_lds_bytes(const lr_model* m) { return (size_t)m->n * m->P * m->esize() + (size_t)lr::kMixedStashDoubles * 8 * 256; }
-bool plan_mixed_hmc(const lr_model* m, int64_t C, Plan* out) {
+bool plan_mixed_hmc(const lr_model* m, int64_t C, Plan* out, int* whole = nullptr) {
     if (m->dtype != LR_F64 || m->P > 32) return false;
     const size_t row_bytes = mixed_lds_bytes(m);
     if (row_bytes > kLdsBudget || C < (int64_t)kPlanConst.mixed_chains_per_cu * m->cus) return false;
@@ -212,6 +216,7 @@ bool plan_mixed_hmc(const lr_model* m, int64_t C, Plan* out) {
     }
     if (bi < 0) return false;
     *out = Plan{t->variants[bi].mode, t->variants[bi].G, t->variants[bi].R, row_bytes};
+    if (whole) *whole = bi;
     return true;
 }
 
@@ -364,11 +369,13 @@ bool measured_overrides(const PlanReq& q, int* best, Plan* out) {
 // planner is then planned in two parts: the largest exactly-filled head on the variant the model prefers for that count, the
 // remainder on whatever variant the model prefers for IT (usually a wider group that finishes in one short wave), when the model
 // prices the two launches kPlanConst.split_gain below the single one.  *out holds the one-part plan on entry.
-void plan_second_part(const PlanReq& q, const lr::Variant& whole, Plan* out) {
+// `family`: MODE_REG, or MODE_MIXED (float64 models under LR_PREC_AUTO: the same quantisation, the same model; its parts run in turn --
+// the head's waves hold 364 of a SIMD's 512 registers, nothing fits beside them)
+void plan_second_part(const PlanReq& q, const lr::Variant& whole, Plan* out, int family = lr::MODE_REG) {
     const lr_model* m = q.m;
     const lr::InstTable* t = m->table;
     const int64_t want_waves = 4LL * m->cus;
-    auto fits = [&](const lr::Variant& u) { return u.mode == lr::MODE_REG && (int64_t)u.G * u.R >= m->n; };
+    auto fits = [&](const lr::Variant& u) { return u.mode == family && (int64_t)u.G * u.R >= m->n; };
     auto best_reg = [&](int64_t chains, double* cost) {
         int bi = -1;
         for (int i = 0; i < t->nvariants; ++i) {
@@ -391,11 +398,12 @@ void plan_second_part(const PlanReq& q, const lr::Variant& whole, Plan* out) {
         const double total = reg_cost(m, a, head) + cb;
         if (total < best_total) {
             best_total = total;
-            *out = Plan{a.mode, a.G, a.R, 0};
+            *out = Plan{a.mode, a.G, a.R, family == lr::MODE_MIXED ? out->lds_bytes : 0};
             out->split = head;
-            out->mode2 = lr::MODE_REG;
+            out->mode2 = family;
             out->G2 = t->variants[bi].G;
             out->R2 = t->variants[bi].R;
+            out->corun = family == lr::MODE_REG;
         }
     }
 }
@@ -442,7 +450,11 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
         if (exact_tail_ok && kind >= 0 && m->dtype == LR_F32) plan_second_part_mfma(q, out);
         return LR_OK;
     }
-    if (hmc_bf16 && q.automatic() && plan_mixed_hmc(m, C, out)) return LR_OK;
+    int mixed_whole = -1;
+    if (hmc_bf16 && q.automatic() && plan_mixed_hmc(m, C, out, &mixed_whole)) {
+        if (kind >= 0) plan_second_part(q, m->table->variants[mixed_whole], out, lr::MODE_MIXED);
+        return LR_OK;
+    }
     if (m->P > 32) return plan_wide(q, out);
     const size_t row_bytes = (size_t)m->n * m->P * m->esize();
     const bool prefer_stepwise = row_bytes > kLdsBudget ||

@@ -82,7 +82,14 @@ CASES = [
     (250, 6, 8192, "hmc", "auto", {"dtype": "float64", "mode": "mixed", "group": 16, "rows_per_lane": 16, "no_tail": True}),
     (200, 8, 10240, "hmc", "auto", {"dtype": "float64", "mode": "mfma", "group": 1, "rows_per_lane": 13, "no_tail": True}),  # k_chain_mfma_f64
     (200, 8, 18432, "hmc", "auto", {"dtype": "float64", "mode": "mfma", "group": 1, "rows_per_lane": 13, "no_tail": True}),
-    (200, 8, 10239, "hmc", "auto", {"dtype": "float64", "mode": "mixed"}),
+    (200, 8, 8448, "hmc", "auto", {"dtype": "float64", "mode": "mfma", "group": 1}), (200, 8, 8447, "hmc", "auto", {"dtype": "float64", "mode": "mixed"}),
+    # ... planned in two parts between exactly-filled chain counts, as the register family is (the parts run in turn)
+    (200, 8, 5120, "hmc", "auto", {"dtype": "float64", "mode": "mixed", "group": 16, "rows_per_lane": 13,
+                                    "tail": {"from": 4096, "mode": "mixed", "group": 64, "rows_per_lane": 4}}),
+    (200, 8, 6144, "hmc", "auto", {"dtype": "float64", "mode": "mixed", "group": 16, "rows_per_lane": 13,
+                                    "tail": {"from": 4096, "mode": "mixed", "group": 32, "rows_per_lane": 7}}),
+    (200, 8, 7168, "hmc", "auto", {"dtype": "float64", "mode": "mixed", "no_tail": True}),
+    (200, 8, 4096, "hmc", "auto", {"dtype": "float64", "mode": "mixed", "no_tail": True}),
     (250, 8, 1 << 16, "hmc", "auto", {"dtype": "float64", "mode": "mixed"}),  # 250 rows: beyond the 13 register tiles
     (300, 8, 4096, "hmc", "auto", {"dtype": "float64", "mode": "mixed", "group": 32, "rows_per_lane": 16}),  # (replicated-state form)
     (1000, 8, 4096, "hmc", "auto", {"dtype": "float64", "mode": "mixed", "group": 64, "rows_per_lane": 16}),

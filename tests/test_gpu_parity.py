@@ -515,6 +515,28 @@ def test_float64_hmc_with_float32_interior_gradients(la, models, oracle_model, m
     assert abs(acc["auto"] - acc["full"]) < 0.005
 
 
+def test_float64_default_policy_planned_in_two_parts(la, models, oracle_model, map_beta):
+    """Between exactly-filled chain counts the float64 model's default-policy run is two launches too (5120 chains: 4096 on 16 lanes
+    per chain, 1024 on 64): each part bit-equal to its forced variant, chunks and a shard straddling the split bit-equal to the whole
+    run, the remainder's chains against the oracle."""
+    m = models["float64"]
+    C, split = 5120, 4096
+    q0 = map_beta + 0.5 * POST_SD * np.random.default_rng(26).standard_normal((C, 8))
+    k = make_kernel(la, m, "hmc")
+    kw = dict(thin=2, iters=2, verb=False, seed=14)
+    full, info = la.mcmc(q0, k, return_info=True, **kw)
+    assert info["plan"] == {"mode": "mixed", "group": 16, "rows_per_lane": 13, "tail": {"from": split, "mode": "mixed", "group": 64, "rows_per_lane": 4}}
+    head = la.mcmc(q0[:split], k, mode="mixed", group=16, **kw)
+    rest = la.mcmc(q0[split:], k, mode="mixed", group=64, chain_offset=split, **kw)
+    assert np.array_equal(full[:, :split], head) and np.array_equal(full[:, split:], rest)
+    assert np.array_equal(full, la.mcmc(q0, k, chunk=1, **kw))
+    lo, hi = split - 100, split + 100
+    assert np.array_equal(la.mcmc(q0[lo:hi], k, chain_offset=lo, plan_chains=C, plan_first=0, **kw), full[:, lo:hi])
+    ref = oracle_model.run("hmc", q0[split:split + 64], thin=2, iters=1, seed=14, chain_offset=split, threads=0, **KW["hmc"])
+    ok = ref["margin"] > 2e-3
+    assert ok.mean() > 0.8 and np.max(np.abs(full[0, split:split + 64][ok] - ref["out"][0][ok]) / POST_SD) < 1e-3
+
+
 @pytest.mark.parametrize("n,p,C,l", [(256, 8, 17, 7), (5, 5, 1, 2), (97, 6, 333, 3), (16, 7, 64, 1), (241, 8, 1025, 4), (33, 5, 5000, 2),
                                      # other padded widths and more rows: the replicated-state form
                                      (200, 3, 300, 3), (1000, 4, 4100, 2), (513, 2, 70, 3), (200, 12, 600, 3), (500, 16, 4096, 2), (1, 9, 33, 2),
