@@ -424,19 +424,25 @@ void plan_second_part_mfma(const PlanReq& q, Plan* out) {
     // head measured 1.43 ms against 1.39 for the single launch (its 256 uncapped workgroups double up on CUs) -- such a remainder runs
     // AFTER the head (0.70 + 0.38 ms)
     out->corun = rem <= 8LL * m->cus;
+    // (float64 models: the remainder on the float32-interior kernels, after the head -- 18 432 chains: 0.96 + 0.41 ms against 1.92)
+    const int family = m->dtype == LR_F32 ? lr::MODE_REG : lr::MODE_MIXED;
     int bi = -1;
     double cost = 0;
     for (int i = 0; i < t->nvariants; ++i) {
         const lr::Variant& u = t->variants[i];
-        if (u.mode != lr::MODE_REG || (int64_t)u.G * u.R < m->n) continue;
+        if (u.mode != family || (int64_t)u.G * u.R < m->n) continue;
         const double c = reg_cost(m, u, rem) + 1e-3 * u.R;
         if (bi < 0 || c < cost) { bi = i; cost = c; }
     }
     if (bi < 0) return;
     out->split = head;
-    out->mode2 = lr::MODE_REG;
+    out->mode2 = family;
     out->G2 = t->variants[bi].G;
     out->R2 = t->variants[bi].R;
+    if (family == lr::MODE_MIXED) {
+        out->corun = false;
+        if (mixed_lds_bytes(m) > out->lds_bytes) out->lds_bytes = mixed_lds_bytes(m);  // (one figure for both parts: lr_engine.h)
+    }
 }
 
 // `hmc_bf16`: the run is HMC and its interior leapfrog gradients may use the bf16 matrix pipe (LR_PREC_AUTO / BF16)
@@ -447,7 +453,7 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
     if (for_eval && (mode == LR_MODE_MFMA || mode == LR_MODE_STEPWISE) && m->P <= 32) { mode = LR_MODE_AUTO; group = 0; }
     const PlanReq q{m, C, group, mode, for_eval, kind};
     if (hmc_bf16 && q.automatic() && plan_mfma_hmc(m, C, out)) {
-        if (exact_tail_ok && kind >= 0 && m->dtype == LR_F32) plan_second_part_mfma(q, out);
+        if (kind >= 0 && (exact_tail_ok || m->dtype != LR_F32)) plan_second_part_mfma(q, out);  // (float64: the tail's interior is reduced too)
         return LR_OK;
     }
     int mixed_whole = -1;

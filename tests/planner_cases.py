@@ -81,7 +81,9 @@ CASES = [
     (256, 8, 512, "hmc", "auto", {"dtype": "float64", "mode": "mixed", "group": 64, "rows_per_lane": 4}),
     (250, 6, 8192, "hmc", "auto", {"dtype": "float64", "mode": "mixed", "group": 16, "rows_per_lane": 16, "no_tail": True}),
     (200, 8, 10240, "hmc", "auto", {"dtype": "float64", "mode": "mfma", "group": 1, "rows_per_lane": 13, "no_tail": True}),  # k_chain_mfma_f64
-    (200, 8, 18432, "hmc", "auto", {"dtype": "float64", "mode": "mfma", "group": 1, "rows_per_lane": 13, "no_tail": True}),
+    (200, 8, 18432, "hmc", "auto", {"dtype": "float64", "mode": "mfma", "group": 1, "rows_per_lane": 13,
+                                     "tail": {"from": 16384, "mode": "mixed", "group": 32, "rows_per_lane": 7}}),
+    (200, 8, 24576, "hmc", "auto", {"dtype": "float64", "mode": "mfma", "group": 1, "no_tail": True}),
     (200, 8, 8448, "hmc", "auto", {"dtype": "float64", "mode": "mfma", "group": 1}), (200, 8, 8447, "hmc", "auto", {"dtype": "float64", "mode": "mixed"}),
     # ... planned in two parts between exactly-filled chain counts, as the register family is (the parts run in turn)
     (200, 8, 5120, "hmc", "auto", {"dtype": "float64", "mode": "mixed", "group": 16, "rows_per_lane": 13,

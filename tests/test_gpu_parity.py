@@ -515,19 +515,20 @@ def test_float64_hmc_with_float32_interior_gradients(la, models, oracle_model, m
     assert abs(acc["auto"] - acc["full"]) < 0.005
 
 
-def test_float64_default_policy_planned_in_two_parts(la, models, oracle_model, map_beta):
+@pytest.mark.parametrize("C,split,head_v,tail_v", [(5120, 4096, ("mixed", 16, 13), ("mixed", 64, 4)), (18432, 16384, ("mfma", 1, 13), ("mixed", 32, 7))])
+def test_float64_default_policy_planned_in_two_parts(la, models, oracle_model, map_beta, C, split, head_v, tail_v):
     """Between exactly-filled chain counts the float64 model's default-policy run is two launches too (5120 chains: 4096 on 16 lanes
-    per chain, 1024 on 64): each part bit-equal to its forced variant, chunks and a shard straddling the split bit-equal to the whole
-    run, the remainder's chains against the oracle."""
+    per chain, 1024 on 64; 18 432: 16 384 on the matrix-core kernel, 2048 on 32 lanes per chain): each part bit-equal to its forced
+    variant, chunks and a shard straddling the split bit-equal to the whole run, the remainder's chains against the oracle."""
     m = models["float64"]
-    C, split = 5120, 4096
     q0 = map_beta + 0.5 * POST_SD * np.random.default_rng(26).standard_normal((C, 8))
     k = make_kernel(la, m, "hmc")
     kw = dict(thin=2, iters=2, verb=False, seed=14)
     full, info = la.mcmc(q0, k, return_info=True, **kw)
-    assert info["plan"] == {"mode": "mixed", "group": 16, "rows_per_lane": 13, "tail": {"from": split, "mode": "mixed", "group": 64, "rows_per_lane": 4}}
-    head = la.mcmc(q0[:split], k, mode="mixed", group=16, **kw)
-    rest = la.mcmc(q0[split:], k, mode="mixed", group=64, chain_offset=split, **kw)
+    assert info["plan"] == {"mode": head_v[0], "group": head_v[1], "rows_per_lane": head_v[2],
+                            "tail": {"from": split, "mode": tail_v[0], "group": tail_v[1], "rows_per_lane": tail_v[2]}}
+    head = la.mcmc(q0[:split], k, mode=head_v[0], group=head_v[1], **kw)
+    rest = la.mcmc(q0[split:], k, mode=tail_v[0], group=tail_v[1], chain_offset=split, **kw)
     assert np.array_equal(full[:, :split], head) and np.array_equal(full[:, split:], rest)
     assert np.array_equal(full, la.mcmc(q0, k, chunk=1, **kw))
     lo, hi = split - 100, split + 100
