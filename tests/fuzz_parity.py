@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised parity fuzz (GPU): random n, p, chain counts, kernels and engines against the CPU oracle.
-usage: fuzz_parity.py [cases] [seed]      -- prints failures and a summary; exit code 1 on any failure."""
+usage: fuzz_parity.py [cases] [seed] [full|auto] [float32|float64]   -- prints failures and a summary; exit code 1 on any failure."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -12,6 +12,9 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 # third argument "auto": HMC cases run with the default interior-gradient policy (bf16 matrix-pipe interior steps
 # where a kernel exists) and are compared with the oracle at the looser tolerances such trajectories allow
 PREC = sys.argv[3] if len(sys.argv) > 3 else "full"
+# fourth argument: the model's dtype ("float64": the all-float64 kernels, and with "auto" the float64 models' default policy --
+# float32 / bf16 force inside HMC trajectories under a float64 state)
+DTYPE = sys.argv[4] if len(sys.argv) > 4 else "float32"
 fails, done, skipped = [], 0, 0
 t0 = time.time()
 for case in range(cases):
@@ -25,8 +28,10 @@ for case in range(cases):
     X, y, _ = la.synthetic_logreg(n, p, seed=1000 + case, beta_sd=0.3 / np.sqrt(p))
     ps = rng.uniform(0.5, 3.0, p)
     orc = OracleModel(X, y, ps)
-    m = la.LogReg(X, y, ps)
+    m = la.LogReg(X, y, ps, dtype=DTYPE)
     modes = [("auto", 0)]
+    if DTYPE == "float64" and kind == "hmc" and p <= 16:
+        modes += [("mixed", g) for g in (16, 32, 64)]  # (rejected where the rows do not fit: skipped)
     if p <= 32:
         modes += [("lds", 8), ("lds", 64), ("global", 64), ("global", 1), ("stepwise", 0)]
         for g in (16, 32, 64):

@@ -516,6 +516,34 @@ def test_float64_hmc_with_float32_interior_gradients(la, models, oracle_model, m
 
 
 @pytest.mark.parametrize("C,split,head_v,tail_v", [(5120, 4096, ("mixed", 16, 13), ("mixed", 64, 4)), (18432, 16384, ("mfma", 1, 13), ("mixed", 32, 7))])
+@pytest.mark.parametrize("n,p,C", [(1, 17, 15), (16, 24, 64)])
+def test_float64_threaded_kernels_at_padded_width_32(la, n, p, C):
+    """float64 models at 17 <= p <= 32: the chain kernels spill both register files; the unit is built with its SGPR spills sent to
+    memory (logreg_amd/build.py UNIT_FLAGS: with the compiler's default MALA on 64 lanes per chain computed wrong states -- found by
+    tests/fuzz_parity.py in float64).  Every kernel family and lane-group width against the oracle at float64 tolerance."""
+    from oracle.oracle import OracleModel
+    X, y, _ = la.synthetic_logreg(n, p, seed=1071, beta_sd=0.3 / np.sqrt(p))
+    rng = np.random.default_rng(5)
+    ps = rng.uniform(0.5, 3.0, p)
+    orc = OracleModel(X, y, ps)
+    m = la.LogReg(X, y, ps, dtype="float64")
+    sc = 1.0 / np.sqrt(max(n, 4))
+    q0 = 0.3 * sc * rng.standard_normal((C, p))
+    scale = rng.uniform(0.5, 2.0, p)
+    dt = 0.05 * sc * sc
+    ll0 = orc.lpost(q0)
+    runs = {"mala": (la.malaKernel(m.lpost, m.glp, dt=dt, pre=scale), dict(step=dt, scale=scale), ll0),
+            "rwmh": (la.mhKernel(m.lpost, la.rwProposal(0.3 * sc * scale)), dict(scale=0.3 * sc * scale), ll0),
+            "hmc": (la.hmcKernel(m.lpost, m.glp, eps=0.3 * sc, l=3, dmm=scale), dict(step=0.3 * sc, l=3, scale=scale), None),
+            "ul": (la.ulKernel(m.glp, dt=dt, pre=scale), dict(step=dt, scale=scale), None)}
+    for kind, (kern, kw, ll) in runs.items():
+        ref = orc.run(kind, q0, thin=2, iters=2, seed=71, ll_state=ll, threads=0, **kw)
+        for mode, g in (("auto", 0), ("lds", 64), ("lds", 8), ("lds", 1), ("global", 64), ("global", 1)):
+            out, info = la.mcmc(q0, kern, thin=2, iters=2, verb=False, seed=71, ll=ll, mode=mode, group=g, return_info=True, precision="full")
+            assert np.array_equal(info["accepts"], ref["accepts"].astype(np.uint32)), (kind, mode, g)
+            assert np.max(np.abs(out - ref["out"])) < 1e-12, (kind, mode, g)
+
+
 def test_float64_default_policy_planned_in_two_parts(la, models, oracle_model, map_beta, C, split, head_v, tail_v):
     """Between exactly-filled chain counts the float64 model's default-policy run is two launches too (5120 chains: 4096 on 16 lanes
     per chain, 1024 on 64; 18 432: 16 384 on the matrix-core kernel, 2048 on 32 lanes per chain): each part bit-equal to its forced
