@@ -45,12 +45,7 @@ EXTRA_ENV = "LOGREG_HIPCC_FLAGS"
 
 INSTANCES = [(dt, dtype_id, ctype, p) for dt, dtype_id, ctype in (("f32", 0, "float"), ("f64", 1, "double"))
              for p in (4, 8, 16, 32)]
-# per-unit flags (part of the source hash).  float64, padded p = 32: the chain kernels hold up to seven 32-double vectors per lane and
-# 160 doubles of per-coordinate constants in scalar registers -- 400+ SGPR spills AND VGPR spills to scratch in one kernel.  With
-# ROCm 7.2's default (SGPR spills into VGPR lanes) k_chain<double, 32, 64, LDS, MALA> computed wrong states (every chain, all
-# launches: tools/f64_p32_repro.py, found by tests/fuzz_parity.py in float64); with the SGPR spills sent to memory it is exact.
-# A validation-grade path (no packed math, no matrix pipe at this width): the slower spills cost nothing that matters.
-UNIT_FLAGS = {"f64_p32": ["-mllvm", "-amdgpu-spill-sgpr-to-vgpr=0"]}
+
 
 
 def _hipcc() -> str:
@@ -90,7 +85,6 @@ def source_hash(extra: str | None = None) -> str:
             h.update(f.read())
     flags = [f for f in COMMON if not os.path.isabs(f)] + (built_extra() if extra is None else extra).split()
     h.update(" ".join(flags).encode())  # flags without the -I paths
-    h.update(repr(sorted(UNIT_FLAGS.items())).encode())
     return h.hexdigest()[:16]
 
 
@@ -145,7 +139,7 @@ def _build_locked(jobs: int | None, verbose: bool) -> str:
         sfx = f"{dt}_p{p}"
         obj = os.path.join(OBJDIR, f"lr_inst_{sfx}.o")
         objs.append(obj)
-        jobs_list.append([hipcc, *COMMON, *UNIT_FLAGS.get(sfx, []), f"-DLR_T={ctype}", f"-DLR_P={p}", f"-DLR_SFX={sfx}",
+        jobs_list.append([hipcc, *COMMON, f"-DLR_T={ctype}", f"-DLR_P={p}", f"-DLR_SFX={sfx}",
                           f"-DLR_DTYPE={dtype_id}", "-c", os.path.join(CSRC, "lr_inst.hip"), "-o", obj])
     for dt, dtype_id in (("f32", 0), ("f64", 1)):  # wide models: MFMA stepwise engine (bf16 pipe for float32, f64 pipe for float64)
         for p in (64, 128):

@@ -548,6 +548,36 @@ __device__ __forceinline__ T vdiffsq(const T (&c)[P], const T (&u)[P], const T (
         return acc;
     }
 }
+// MALA's proposal-density difference without keeping advance(x) and advance(prop) as arrays across the evaluation:
+//   sum_j c[j] * ((x[j] - advp_j)^2 - (xp[j] - advx_j)^2),  advx_j = a[j] g[j] + x[j],  advp_j = a[j] gp[j] + xp[j]
+// -- the same operations in the same order as vfma_o + vdiffsq on stored arrays (advx is recomputed from unchanged inputs: bit-
+// identical), two P-vectors fewer live across the evaluation (float64 at padded p = 32: 128 VGPRs, the difference between spilling
+// to scratch and not).
+template <typename T, int P>
+__device__ __forceinline__ T mala_dq(const T (&a)[P], const T (&c)[P], const T (&x)[P], const T (&g)[P], const T (&xp)[P], const T (&gp)[P]) {
+    if constexpr (sizeof(T) == 4 && P % 2 == 0) {
+        f32x2 acc = {0.0f, 0.0f};
+#pragma unroll
+        for (int j = 0; j < P; j += 2) {
+            const f32x2 a2 = {a[j], a[j + 1]}, x2 = {x[j], x[j + 1]}, xp2 = {xp[j], xp[j + 1]};
+            const f32x2 advx = __builtin_elementwise_fma(a2, f32x2{g[j], g[j + 1]}, x2);
+            const f32x2 advp = __builtin_elementwise_fma(a2, f32x2{gp[j], gp[j + 1]}, xp2);
+            const f32x2 d1 = x2 - advp, d2 = xp2 - advx;
+            const f32x2 t = __builtin_elementwise_fma(-d2, d2, d1 * d1);
+            acc = __builtin_elementwise_fma(f32x2{c[j], c[j + 1]}, t, acc);
+        }
+        return acc.x + acc.y;
+    } else {
+        T acc = T(0);
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const T advx = fma_t(a[j], g[j], x[j]), advp = fma_t(a[j], gp[j], xp[j]);
+            const T d1 = x[j] - advp, d2 = xp[j] - advx;
+            acc = fma_t(c[j], d1 * d1 - d2 * d2, acc);
+        }
+        return acc;
+    }
+}
 // sum_j a[j] * x[j]^2
 template <typename T, int P> __device__ __forceinline__ T vquad(const T (&a)[P], const T (&x)[P]) {
     if constexpr (sizeof(T) == 4 && P % 2 == 0) {

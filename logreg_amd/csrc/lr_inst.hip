@@ -115,6 +115,14 @@ int launch_capped(const LaunchCfg* cfg, dim3 grid, dim3 block, size_t lds_dynami
 
 template <int G, int MODE, int R>
 int launch_chain_v(const LaunchCfg* cfg, int64_t C, const ModelArgs<T, P>& m, const ChainArgs<T, P>& a) {
+#if LR_DTYPE == 1 && LR_P == 32
+    // float64 at 17 <= p <= 32: no fused chain kernels.  Replicated in every lane, the float64 state of such a chain (five to seven
+    // 32-vectors) takes the whole register file and more: the kernels spilled both files, and MALA on 64 lanes per chain -- with the
+    // compiler's other spill placement, on 8 -- computed wrong states (tests/fuzz_parity.py in float64, tools/f64_p32_repro.py).
+    // Runs of these models go to the stepwise engine (lr_plan.h), whose kernels hold one coordinate per lane.
+    (void)cfg; (void)C; (void)m; (void)a;
+    return -3;
+#else
     const dim3 grid = grid_for(C, G), block(256);
 #if LR_DTYPE == 0 && LR_P == 8
     if constexpr (G == 16 && MODE == MODE_REG) {  // state distributed over the 16 lanes of a chain (lr_kernels.h)
@@ -129,6 +137,7 @@ int launch_chain_v(const LaunchCfg* cfg, int64_t C, const ModelArgs<T, P>& m, co
     case KIND_UL: return launch_capped<&k_chain<T, P, G, MODE, R, KIND_UL>>(cfg, grid, block, cfg->lds_bytes, m, a);
     default: return -1;
     }
+#endif
 }
 
 #if LR_DTYPE == 0 && LR_P >= 8

@@ -620,13 +620,14 @@ __global__ void __launch_bounds__(256) k_chain(ModelArgs<T, P> m, ChainArgs<T, P
                 } else if constexpr (KIND == KIND_MALA) {
                     // prop = advance(x) + sqrt(pre*dt) z ; advance(x) = x + 0.5*pre*dt*glp(x)
                     // a = lp' - ll + dprop(x,prop) - dprop(prop,x)           fit-np-mala.py:61-78
-                    T advx[P], advp[P];
-                    vfma_o<T, P>(a.a, g, x, advx);
-                    vfma_o<T, P>(a.b, z, advx, xp);
+                    {
+                        T advx[P];
+                        vfma_o<T, P>(a.a, g, x, advx);
+                        vfma_o<T, P>(a.b, z, advx, xp);
+                    }
                     eval_lpost<T, P, G, true, true>(rows, m.prior, xp, gp, llp, lprp);
-                    vfma_o<T, P>(a.a, gp, xp, advp);
                     // dprop(x, prop) - dprop(prop, x): (x - advance(prop))^2 - (prop - advance(x))^2, weighted 1/(pre dt)
-                    const T dq = vdiffsq<T, P>(a.c, x, advp, xp, advx);
+                    const T dq = mala_dq<T, P>(a.a, a.c, x, g, xp, gp);
                     logr = (llp + lprp) - lp - 0.5 * (double)dq;
                 } else {  // HMC
                     // p ~ N(0, dmm); leapfrog l steps; a = alpi(prop) - alpi(x)     fit-np-hmc.py:65-87

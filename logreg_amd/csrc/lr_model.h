@@ -156,7 +156,8 @@ struct ModelImages { bool tall_mx, mf_end, wide, wide1; };
 inline ModelImages model_images(int64_t n, int P, int dtype) {
     constexpr int64_t kMfmaStreamMaxRows = 8192;  // rows the matrix-core chain kernel still takes with its operands streamed from device memory
     ModelImages im{};
-    im.tall_mx = P >= 8 && P <= 32 && (size_t)n * P * (dtype == LR_F32 ? 4 : 8) > 64 * 1024;  // (float64 models: from the rows rounded to float32)
+    // (float64 models: from the rows rounded to float32; float64 at padded p = 32 always runs the stepwise engine: lr_plan.h)
+    im.tall_mx = P >= 8 && P <= 32 && ((size_t)n * P * (dtype == LR_F32 ? 4 : 8) > 64 * 1024 || (dtype != LR_F32 && P == 32));
     im.mf_end = P >= 8 && P <= 32 && dtype == LR_F32 && n > (P == 32 ? 16 * 4 * 8 : (P == 8 ? 16 * 13 : 16 * 4 * 16)) && n <= kMfmaStreamMaxRows;
     im.wide = P > 32 && dtype == LR_F32;
     im.wide1 = P > 32;

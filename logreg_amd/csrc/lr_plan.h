@@ -463,6 +463,12 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
     }
     if (m->P > 32) return plan_wide(q, out);
     const size_t row_bytes = (size_t)m->n * m->P * m->esize();
+    if (!for_eval && m->dtype == LR_F64 && m->P == 32) {  // no fused chain kernels at this width in float64 (lr_inst.hip launch_chain_v)
+        if (mode != LR_MODE_AUTO && mode != LR_MODE_STEPWISE)
+            return fail(LR_ERR_UNSUPPORTED, "float64 models with 17 <= p <= 32 run on the stepwise engine only (mode=%d requested)", mode);
+        plan_tall(q, out);
+        return LR_OK;
+    }
     const bool prefer_stepwise = row_bytes > kLdsBudget ||
                                  (row_bytes > kPlanConst.lds_rows_prefer_stepwise_bytes && C >= kPlanConst.lds_rows_prefer_stepwise_chains);
     if (!for_eval && (mode == LR_MODE_STEPWISE || (mode == LR_MODE_AUTO && group == 0 && prefer_stepwise))) {

@@ -515,18 +515,20 @@ def test_float64_hmc_with_float32_interior_gradients(la, models, oracle_model, m
     assert abs(acc["auto"] - acc["full"]) < 0.005
 
 
-@pytest.mark.parametrize("C,split,head_v,tail_v", [(5120, 4096, ("mixed", 16, 13), ("mixed", 64, 4)), (18432, 16384, ("mfma", 1, 13), ("mixed", 32, 7))])
-@pytest.mark.parametrize("n,p,C", [(1, 17, 15), (16, 24, 64)])
-def test_float64_threaded_kernels_at_padded_width_32(la, n, p, C):
-    """float64 models at 17 <= p <= 32: the chain kernels spill both register files; the unit is built with its SGPR spills sent to
-    memory (logreg_amd/build.py UNIT_FLAGS: with the compiler's default MALA on 64 lanes per chain computed wrong states -- found by
-    tests/fuzz_parity.py in float64).  Every kernel family and lane-group width against the oracle at float64 tolerance."""
+@pytest.mark.parametrize("n,p,C", [(1, 17, 15), (16, 24, 64), (255, 32, 16), (100, 20, 130)])
+def test_float64_at_padded_width_32_runs_on_the_stepwise_engine(la, n, p, C):
+    """float64 models at 17 <= p <= 32 have no fused chain kernels: replicated per lane, such a chain's float64 state does not fit the
+    register file, the kernels spilled both files, and MALA on 64 (or, with the compiler's other spill placement, 8) lanes per chain
+    computed wrong states -- found by tests/fuzz_parity.py in float64 (tools/f64_p32_repro.py).  Runs go to the stepwise engine (one
+    coordinate per lane, no spills); a forced fused mode is refused.  Every kernel family against the oracle at float64 tolerance."""
     from oracle.oracle import OracleModel
     X, y, _ = la.synthetic_logreg(n, p, seed=1071, beta_sd=0.3 / np.sqrt(p))
     rng = np.random.default_rng(5)
     ps = rng.uniform(0.5, 3.0, p)
     orc = OracleModel(X, y, ps)
     m = la.LogReg(X, y, ps, dtype="float64")
+    r = m.eval(0.1 * rng.standard_normal((40, p)))  # (lr_eval keeps its kernels at this width)
+    assert np.all(np.isfinite(r["lpost"]))
     sc = 1.0 / np.sqrt(max(n, 4))
     q0 = 0.3 * sc * rng.standard_normal((C, p))
     scale = rng.uniform(0.5, 2.0, p)
@@ -538,12 +540,23 @@ def test_float64_threaded_kernels_at_padded_width_32(la, n, p, C):
             "ul": (la.ulKernel(m.glp, dt=dt, pre=scale), dict(step=dt, scale=scale), None)}
     for kind, (kern, kw, ll) in runs.items():
         ref = orc.run(kind, q0, thin=2, iters=2, seed=71, ll_state=ll, threads=0, **kw)
-        for mode, g in (("auto", 0), ("lds", 64), ("lds", 8), ("lds", 1), ("global", 64), ("global", 1)):
-            out, info = la.mcmc(q0, kern, thin=2, iters=2, verb=False, seed=71, ll=ll, mode=mode, group=g, return_info=True, precision="full")
-            assert np.array_equal(info["accepts"], ref["accepts"].astype(np.uint32)), (kind, mode, g)
-            assert np.max(np.abs(out - ref["out"])) < 1e-12, (kind, mode, g)
+        out, info = la.mcmc(q0, kern, thin=2, iters=2, verb=False, seed=71, ll=ll, return_info=True, precision="full")
+        assert info["plan"]["mode"] == "stepwise", kind
+        assert np.array_equal(info["accepts"], ref["accepts"].astype(np.uint32)), kind
+        assert np.max(np.abs(out - ref["out"])) < 1e-12, kind
+        assert np.array_equal(out, la.mcmc(q0, kern, thin=2, iters=2, verb=False, seed=71, ll=ll, chunk=1, precision="full")), kind
+        for mode, g in (("lds", 64), ("lds", 8), ("global", 1)):
+            with pytest.raises(la.LogregHipError, match="stepwise engine only"):
+                la.mcmc(q0, kern, thin=1, iters=1, verb=False, seed=71, ll=ll, mode=mode, group=g)
+    # the default policy: interior gradients on the bf16 matrix pipe under a float64 state here too
+    kern = runs["hmc"][0]
+    dflt = la.mcmc(q0, kern, thin=2, iters=2, verb=False, seed=71)
+    ref = orc.run("hmc", q0, thin=2, iters=2, seed=71, threads=0, **runs["hmc"][1])
+    ok = ref["margin"] > 0.1
+    assert np.max(np.abs(dflt[:, ok] - ref["out"][:, ok])) < 2e-2 * sc * 3
 
 
+@pytest.mark.parametrize("C,split,head_v,tail_v", [(5120, 4096, ("mixed", 16, 13), ("mixed", 64, 4)), (18432, 16384, ("mfma", 1, 13), ("mixed", 32, 7))])
 def test_float64_default_policy_planned_in_two_parts(la, models, oracle_model, map_beta, C, split, head_v, tail_v):
     """Between exactly-filled chain counts the float64 model's default-policy run is two launches too (5120 chains: 4096 on 16 lanes
     per chain, 1024 on 64; 18 432: 16 384 on the matrix-core kernel, 2048 on 32 lanes per chain): each part bit-equal to its forced

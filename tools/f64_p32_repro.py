@@ -2,7 +2,7 @@ import sys, numpy as np
 sys.path.insert(0, '.')
 import logreg_amd as la
 from oracle.oracle import OracleModel
-for (n, p, C) in ((1, 17, 15), (16, 24, 64), (16, 12, 64), (16, 8, 64), (200, 8, 64)):
+for (n, p, C) in ((1, 17, 15), (16, 24, 64), (255, 32, 16), (255, 32, 64), (100, 20, 16), (1000, 30, 130)):
     X, y, _ = la.synthetic_logreg(n, p, seed=1071, beta_sd=0.3 / np.sqrt(p))
     rng = np.random.default_rng(5)
     ps = rng.uniform(0.5, 3.0, p)

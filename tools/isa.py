@@ -13,7 +13,7 @@ if rest[:1] == ["-o"]:
 if p > 32:
     cmd = [B._hipcc(), *B.COMMON, f"-DLR_P={p}", f"-DLR_SFX={dt}_p{p}", f"-DLR_DTYPE={0 if dt == 'f32' else 1}", os.path.join(B.CSRC, "lr_inst_wide.hip")]
 else:
-    cmd = [B._hipcc(), *B.COMMON, *B.UNIT_FLAGS.get(f"{dt}_p{p}", []), f"-DLR_T={'float' if dt == 'f32' else 'double'}", f"-DLR_P={p}", f"-DLR_SFX={dt}_p{p}",
+    cmd = [B._hipcc(), *B.COMMON, f"-DLR_T={'float' if dt == 'f32' else 'double'}", f"-DLR_P={p}", f"-DLR_SFX={dt}_p{p}",
            f"-DLR_DTYPE={0 if dt == 'f32' else 1}", os.path.join(B.CSRC, "lr_inst.hip")]
 subprocess.run(cmd + ["-S", "--cuda-device-only", "-o", out] + rest, check=True)
 print(out)
