@@ -24,6 +24,10 @@ for case in range(cases):
     if p > 32:
         n = min(n, 1000)
     C = int(rng.choice([1, 2, 15, 16, 17, 63, 64, 65, 130, 300]))
+    big = rng.random() < 0.12 and p <= 32  # many chains (two-part plans, matrix-core kernels at full occupancy): few rows, the oracle
+    if big:                                  # replays the first 64 chains and 64 behind the largest exactly-filled count
+        C = int(rng.choice([1031, 4097, 5120, 9000, 10240, 17000]))
+        n = min(n, 256)
     kind = str(rng.choice(["hmc", "mala", "rwmh", "ul"]))
     X, y, _ = la.synthetic_logreg(n, p, seed=1000 + case, beta_sd=0.3 / np.sqrt(p))
     ps = rng.uniform(0.5, 3.0, p)
@@ -63,11 +67,24 @@ for case in range(cases):
     ll0 = orc.lpost(q0) if kind in ("mala", "rwmh") else None
     thin, iters = int(rng.integers(1, 3)), int(rng.integers(1, 3))
     tag = f"case {case}: n={n} p={p} C={C} {kind} {mode}/{group} thin={thin} iters={iters}"
+    sel = np.arange(C)
+    if big:
+        mode, group = "auto", 0
+        t0c = (C // 4096) * 4096 if C > 4096 else 0
+        sel = np.unique(np.concatenate([np.arange(64), np.arange(t0c, min(C, t0c + 64))]))
     try:
-        ref = orc.run(kind, q0, thin=thin, iters=iters, seed=case, ll_state=ll0, threads=0, **kw)
-        out, info = la.mcmc(q0, kern, thin=thin, iters=iters, verb=False, seed=case, ll=ll0, mode=mode, group=group,
-                            return_info=True, precision=PREC)
-        r = m.eval(q0, mode=mode if mode != "stepwise" else "auto", group=group if mode != "stepwise" else 0)
+        if big:  # two oracle runs with the global chain ids of the two blocks
+            blocks = [sel[sel < 64], sel[sel >= 64]]
+            parts = [orc.run(kind, q0[b], thin=thin, iters=iters, seed=case, ll_state=None if ll0 is None else ll0[b], threads=0, chain_offset=int(b[0]), **kw)
+                     for b in blocks if len(b)]
+            ref = {k2: np.concatenate([pp[k2] for pp in parts], axis=1 if k2 == "out" else 0) for k2 in ("out", "accepts", "margin")}
+        else:
+            ref = orc.run(kind, q0, thin=thin, iters=iters, seed=case, ll_state=ll0, threads=0, **kw)
+        out_all, info = la.mcmc(q0, kern, thin=thin, iters=iters, verb=False, seed=case, ll=ll0, mode=mode, group=group,
+                                return_info=True, precision=PREC)
+        out = out_all[:, sel]
+        info = dict(info, accepts=info["accepts"][sel])
+        r = m.eval(q0[sel], mode=mode if mode != "stepwise" else "auto", group=group if mode != "stepwise" else 0)
     except la.LogregHipError as e:
         skipped += 1
         print("SKIP", tag, "->", str(e)[:80]); continue
@@ -78,13 +95,13 @@ for case in range(cases):
     loose = PREC != "full" and kind == "hmc"
     if loose:
         ok = ref["margin"] > 0.25
-    lp_ref = orc.lpost(q0)
+    lp_ref = orc.lpost(q0[sel])
     errs = []
     if not np.allclose(r["lpost"], lp_ref, rtol=3e-5, atol=3e-5 * n ** 0.5):
         errs.append("lpost %.3g" % np.max(np.abs(r["lpost"] - lp_ref)))
     gtol = 2e-4 * np.sqrt(n) * max(1.0, np.abs(X).max())
-    if np.max(np.abs(r["glp"] - orc.glp(q0))) > gtol:
-        errs.append("glp %.3g" % np.max(np.abs(r["glp"] - orc.glp(q0))))
+    if np.max(np.abs(r["glp"] - orc.glp(q0[sel]))) > gtol:
+        errs.append("glp %.3g" % np.max(np.abs(r["glp"] - orc.glp(q0[sel]))))
     if ok.any():
         if not np.array_equal(info["accepts"][ok], ref["accepts"][ok].astype(np.uint32)):
             errs.append("accepts differ in %d chains" % int((info["accepts"][ok] != ref["accepts"][ok]).sum()))
@@ -96,10 +113,10 @@ for case in range(cases):
     if rng.random() < 0.4:  # chunk and shard invariance: bit-exact (global chain id and iteration in the Philox counter)
         again = la.mcmc(q0, kern, thin=thin, iters=iters, verb=False, seed=case, ll=ll0, mode=mode, group=group, chunk=1,
                         precision=PREC)
-        if not np.array_equal(again, out):
+        if not np.array_equal(again, out_all):
             errs.append("chunk=1 differs")
         pl = info["plan"]
-        if C > 1 and pl["mode"] != "stepwise":  # (stepwise slicing depends on the chain count by design)
+        if C > 1 and pl["mode"] != "stepwise" and not big:  # (stepwise slicing depends on the chain count by design)
             h = C // 2
             a = la.mcmc(q0[:h], kern, thin=thin, iters=iters, verb=False, seed=case, ll=None if ll0 is None else ll0[:h],
                         mode=pl["mode"], group=pl["group"], precision=PREC)
@@ -107,10 +124,16 @@ for case in range(cases):
                         mode=pl["mode"], group=pl["group"], chain_offset=h, precision=PREC)
             if not np.array_equal(np.concatenate([a, b], axis=1), out):
                 errs.append("shards differ")
+        if big:  # a shard of the planned run, straddling the split of a two-part plan if there is one
+            lo = max(0, t0c - 50)
+            sh = la.mcmc(q0[lo:lo + 120], kern, thin=thin, iters=iters, verb=False, seed=case, ll=None if ll0 is None else ll0[lo:lo + 120],
+                         chain_offset=lo, plan_chains=C, plan_first=0, precision=PREC)
+            if not np.array_equal(sh, out_all[:, lo:lo + 120]):
+                errs.append("planned shard differs")
     if errs:
         fails.append(tag + " :: " + "; ".join(errs)); print("FAIL", fails[-1], flush=True)
         # the same chains on every engine that takes the shape, and on the other dtype: which variants disagree with the oracle?
-        for dt2 in ("float64", "float32"):
+        for dt2 in (() if big else ("float64", "float32")):
             m2 = la.LogReg(X, y, ps, dtype=dt2)
             k2 = {"hmc": lambda: la.hmcKernel(m2.lpost, m2.glp, eps=kw.get("step"), l=kw.get("l", 1), dmm=scale),
                   "mala": lambda: la.malaKernel(m2.lpost, m2.glp, dt=kw.get("step"), pre=scale),
