@@ -470,7 +470,9 @@ def mcmc(init, kernel, thin=10, iters=10000, verb=True, *, seed=None, chunk=None
     `precision` (HMC): "auto" (DEFAULT) lets the L - 1 interior leapfrog gradients of a trajectory run on the bf16 matrix
     pipe where such a kernel exists (the end-point value + gradient and the Metropolis test stay in the model's dtype, so
     the sampler stays exact; the acceptance rate is the only thing that can move); "full" keeps every evaluation in the
-    model's dtype (step-for-step comparable with the float64 reference); see include/logreg_hip.h LR_PREC_*.
+    model's dtype (step-for-step comparable with the float64 reference); see include/logreg_hip.h LR_PREC_*.  float64 models
+    follow the same policy with more kept exact: position, momentum, end points, kinetic energies and the Metropolis test are
+    float64, only the force inside the trajectory comes from float32 / bf16 operands (4 - 6 x the all-float64 rate).
     `plan_chains`, `plan_first`: chain count to plan the kernel variant for and the global id of that run's first chain (a shard of
     a larger run passes the whole run's: its chains then run on the variants they have in the whole run, bit for bit).
     """

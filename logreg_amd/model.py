@@ -112,7 +112,8 @@ class LogReg:
 
     X [n,p] (intercept column included, as the reference builds it, fit-np-hmc.py:18-19),
     y [n] in {0,1}, pscale [p] or scalar (fit-np-hmc.py:31).  dtype = arithmetic type of the
-    device path ("float32" default; "float64" is a slower validation-grade path).
+    device path ("float32" default; "float64" = the reference's own arithmetic: every kernel family at every width up to p = 128,
+    HMC under the default precision policy with float64 state and end points and a cheaper force inside the trajectory).
     """
 
     def __init__(self, X, y, pscale, dtype="float32", device: int = 0):
