@@ -48,6 +48,8 @@ struct PlanConst {
     //    wave (MALA, 16 384 chains, reg | lds 8: n=600 p=8 1.64 | 1.89e9, n=800 p=8 1.43 | 1.47 (1.44 | 1.64 at 65 536), n=300 p=12
     //    0.89 | 2.25, n=400 p=16 0.89 | 1.82; not at 32 KB: n=1000 p=8 1.42 | 1.19, n=500 p=16 mfma 1.69 | lds 8 1.52; not at
     //    p > 16: n=200 p=24, 4096 chains, lds 8 0.41 | mfma 1.27e9)
+    //  * p <= 8 at 16 384 / 65 536 chains (several waves per SIMD), HMC all-fp32, reg 16x13 | mfma S=1: 5.44 | 3.72e8, 5.63 | 3.74e8 -- the
+    //    fp32-input MFMAs alone bound that kernel (profiles/r4_planner_bench_full_many.txt): never for p <= 8
     // float64, p <= 8, rows that fit the register variants (n <= 256): 32 lanes x 7 rows pads 200 rows to 224 and pays a 5-level
     // f64 reduction (30 % of its leapfrog loop); rows in LDS with 16 lanes per chain from one wave per SIMD, 8 lanes per chain
     // (8 x 25 = 200 exactly) from two (round 4, HMC L=20 n=200, it/s, reg 32x7 | lds 16 | lds 8: 2048 chains 7.6 | 4.4 | 2.8e7,
