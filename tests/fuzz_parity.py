@@ -130,6 +130,20 @@ for case in range(cases):
                          chain_offset=lo, plan_chains=C, plan_first=0, precision=PREC)
             if not np.array_equal(sh, out_all[:, lo:lo + 120]):
                 errs.append("planned shard differs")
+    if rng.random() < 0.3:  # on-device streaming statistics of the same engine against NumPy on its own kept samples
+        try:
+            cs = la.ChainSet(kern, q0, seed=case, ll=ll0, mode=mode, group=group, precision=PREC)
+            cs.enable_stats(2, 3)
+            smp = np.concatenate([cs.advance(k_, thin).to_host() for k_ in (1, 3, 2)]).astype(np.float64)
+            got = cs.stats_summary()
+            flat = smp.reshape(-1, p)
+            tol = 1e-9 if DTYPE == "float64" else 1e-6
+            if not np.allclose(got["mean"], flat.mean(0), rtol=tol, atol=tol * (np.abs(flat).max() + 1e-30)):
+                errs.append("stats mean %.3g" % np.max(np.abs(got["mean"] - flat.mean(0))))
+            if C * 6 > 1 and not np.allclose(got["sd"], flat.std(0, ddof=1), rtol=1e-5, atol=1e-7 * (np.abs(flat).max() + 1e-30)):
+                errs.append("stats sd %.3g" % np.max(np.abs(got["sd"] - flat.std(0, ddof=1))))
+        except la.LogregHipError as e:
+            errs.append("stats run: " + str(e)[:80])
     if errs:
         fails.append(tag + " :: " + "; ".join(errs)); print("FAIL", fails[-1], flush=True)
         # the same chains on every engine that takes the shape, and on the other dtype: which variants disagree with the oracle?
