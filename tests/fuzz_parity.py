@@ -92,6 +92,11 @@ for case in range(cases):
     # decisions are compared where the oracle's |a - log u| clears the fp32 resolution of the log-density
     # (|ll| ~ 0.7 n: ulp-level sums of n terms; 2e-3 up to n = 1000, growing with n)
     ok = ref["margin"] > 2e-3 * max(1.0, n / 1000.0)
+    if p == 1 and DTYPE == "float32":
+        # intercept-only design: every row is +-1, so the fp32 rounding errors of the n value terms and of their running sum are all
+        # the same error, not a random walk (n = 8193 on 1 - 8 lanes per chain: |lpost error| up to 0.033 where p = 3 has 0.0015;
+        # tools/f32_value_sum_probe.py) -- a forced narrow lane group there resolves decisions to ~0.1
+        ok = ref["margin"] > 1.5e-2 * max(1.0, n / 1000.0)
     loose = PREC != "full" and kind == "hmc"
     if loose:
         ok = ref["margin"] > 0.25
@@ -144,6 +149,20 @@ for case in range(cases):
                 errs.append("stats sd %.3g" % np.max(np.abs(got["sd"] - flat.std(0, ddof=1))))
         except la.LogregHipError as e:
             errs.append("stats run: " + str(e)[:80])
+    if rng.random() < 0.15:  # checkpoint in the middle of a run, resume in another object: bit-equal to the uninterrupted run
+        try:
+            one = la.ChainSet(kern, q0, seed=case, ll=ll0, mode=mode, group=group, precision=PREC)
+            whole = one.advance(4, thin).to_host()
+            two = la.ChainSet(kern, q0, seed=case, ll=ll0, mode=mode, group=group, precision=PREC)
+            first = two.advance(1, thin).to_host()
+            three = la.ChainSet.resume(kern, two.checkpoint(), group=group, mode=mode, precision=PREC)
+            rest = three.advance(3, thin).to_host()
+            if not np.array_equal(np.concatenate([first, rest]), whole):
+                errs.append("checkpoint / resume differs")
+            if not np.array_equal(one.get_accepts(), three.get_accepts()):
+                errs.append("accept counts after resume differ")
+        except la.LogregHipError as e:
+            errs.append("checkpoint run: " + str(e)[:80])
     if errs:
         fails.append(tag + " :: " + "; ".join(errs)); print("FAIL", fails[-1], flush=True)
         # the same chains on every engine that takes the shape, and on the other dtype: which variants disagree with the oracle?
