@@ -418,11 +418,15 @@ class Exchange:
             self.dist.barrier()
             self.sync()
 
-    def gather(self, t):
+    def gather(self, t, source=None):
         """Gather every rank's block `t` to rank 0 -> (this rank's wall seconds, the list of blocks on rank 0 / None);
-        complete on return.  The receive buffers are allocated once per block shape."""
+        complete on return.  The receive buffers are allocated once per block shape.  `source`: the buffer `t` was made from --
+        on the CPU exchange (gloo) a tensor of a GPU buffer is a snapshot, so it is taken again here (two gloo ranks sharing one GPU:
+        tests/test_gpu_distributed.py); the RCCL exchange views the buffer in place and ignores it."""
         if not self.active:
             return 0.0, None
+        if source is not None and self.dev == "cpu":
+            t = self.tensor(source)
         key = (tuple(t.shape), t.dtype)
         if self.rank == 0 and key not in self._bufs:
             self._bufs[key] = [self.torch.empty_like(t) for _ in range(self.world)]
@@ -544,7 +548,7 @@ def dist_configs(la, L, check, dev, stream, ex, rank, world, scale=1):
     cs.advance(1, THIN3, keep=False)
     cs.sync()
     ex.gather(t3)  # untimed first use of this block shape
-    wall, kmin, kmax, xs, bufs = timed(lambda: cs.advance(KEEP3, THIN3, keep=True, out=out3), lambda: ex.gather(t3))
+    wall, kmin, kmax, xs, bufs = timed(lambda: cs.advance(KEEP3, THIN3, keep=True, out=out3), lambda: ex.gather(t3, out3))
     its = world * C3 * KEEP3 * THIN3
     fg = flops_per_grad_eval(200, 8)
     # the same chains' on-device statistics instead of their samples: 7p + 1 doubles per rank, one all-reduce
@@ -590,7 +594,7 @@ def dist_configs(la, L, check, dev, stream, ex, rank, world, scale=1):
     cs.sync()
     ex.gather(t5)
     a0 = int(cs.get_accepts().astype(np.int64).sum())
-    wall, kmin, kmax, xs, bufs = timed(lambda: cs.advance(iters, 1, keep=True, out=out5), lambda: ex.gather(t5))
+    wall, kmin, kmax, xs, bufs = timed(lambda: cs.advance(iters, 1, keep=True, out=out5), lambda: ex.gather(t5, out5))
     acc = ex.reduce(int(cs.get_accepts().astype(np.int64).sum()) - a0, "sum")
     if rank == 0:
         evals = iters * fix["l"]
@@ -736,7 +740,7 @@ def main(argv=None):
         one_step(i, True)
     _lib.check(L.lr_event_record(dev, timer.e1, stream))
     cs.sync()
-    gather_s, gathered = ex.gather(tout)  # the ONE exchange of the path: RCCL gather of the thinned samples to rank 0
+    gather_s, gathered = ex.gather(tout, out)  # the ONE exchange of the path: RCCL gather of the thinned samples to rank 0
     ex.barrier()
     t1 = time.perf_counter()
     ms = Ct.c_float()

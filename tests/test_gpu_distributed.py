@@ -78,3 +78,26 @@ def test_bench_rccl_branch_runs_on_a_gpu_under_torchrun():
     assert c3["summary_only"]["chains_counted"] == 8192 and c3["roofline"]["frac"] > 0.15
     assert c5["chains_total"] == 1024 and c5["blocks_ok"] and 0.6 < c5["accept_rate"] < 0.9
     assert c5["us_per_evaluation_all_chains_of_a_gpu"] < 14 and c5["roofline"]["frac"] > 0.06
+
+
+def test_bench_with_two_ranks_sharing_the_gpu_over_gloo():
+    """The N = 2 flow of bench.py with real kernels in BOTH ranks: two processes under torch.distributed.run on the one GPU of a test
+    box, the exchange on gloo (RCCL refuses two ranks on one device).  Rank 1's chain block (chain_offset = C, its own pre-warm count),
+    the gather, and the line's self-check: rank 0 re-runs 64 chains of RANK 1's block and finds them bit-equal; the line says the two
+    ranks shared a device."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "6",
+           "--warmup", "2", "--no-ess", "--no-cpu-baseline", "--scale", "8"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    mg = d["multi_gpu"]
+    assert d["n_gpus"] == 2 and mg["ranks_seen"] == 2 and mg["devices_distinct"] is False
+    assert mg["gather_checked_rank"] == 1 and mg["gather_bitexact"] is True
+    assert d["config"]["kernel_variant"] == {"mode": "reg", "group": 16, "rows_per_lane": 13}
+    rows = {row["config"]: row for row in d["extra"]["configs"]}
+    assert rows[3]["n_gpus"] == 2 and rows[5]["n_gpus"] == 2 and rows[3]["scaled_down"] == 8
