@@ -42,6 +42,8 @@ def gather_samples(local, n_chains: int, dst: int = 0, group=None):
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     sizes = [shard_bounds(n_chains, world, r) for r in range(world)]
     cmax = max(hi - lo for lo, hi in sizes)
+    if local.is_cuda and dist.get_backend(group) != "nccl":  # a CPU exchange (gloo: tests, ranks sharing one GPU) moves host tensors
+        local = local.cpu()
     iters, c_local, p = local.shape
     assert c_local == sizes[rank][1] - sizes[rank][0], (c_local, sizes[rank])
     if c_local < cmax:  # pad ragged shards so one fixed-size gather serves all ranks

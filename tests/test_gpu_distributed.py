@@ -32,6 +32,17 @@ def test_mcmc_sharded_over_rccl_single_rank():
     assert "bit-exact vs single process" in r.stdout and "summary_only over 1000 chains" in r.stdout
 
 
+def test_mcmc_sharded_with_three_ranks_sharing_the_gpu_over_gloo():
+    """mcmc_sharded at world 3 with the HIP kernels in every rank (1000 chains: ragged shards of 334 / 333 / 333), the exchange on
+    gloo: gathered samples bit-equal to the single-process run (plan="global"), statistics all-reduce equal to NumPy on that run."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SHARDED_SMOKE_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                        os.path.join(REPO, "tools", "sharded_smoke.py")], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "world 3" in r.stdout and "bit-exact vs single process" in r.stdout and "summary_only over 1000 chains" in r.stdout
+
+
 def _bench(extra_env, *launcher, extra=False):
     import json
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)

@@ -8,8 +8,12 @@ import logreg_amd as la
 from logreg_amd.distributed import mcmc_sharded
 
 rank, world, lr = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
-torch.cuda.set_device(lr)
-dist.init_process_group("nccl", device_id=torch.device("cuda", lr))
+if os.environ.get("SHARDED_SMOKE_BACKEND") == "gloo":  # several ranks sharing GPU 0 (a one-GPU test box), the exchange on the CPU
+    lr = 0
+    dist.init_process_group("gloo")
+else:
+    torch.cuda.set_device(lr)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", lr))
 X, y = la.load_pima()
 pre = np.array([100., 1, 1, 1, 1, 1, 25, 1])
 init = np.tile([-9.19131622, 0.09705401, 0.03112265, -0.00564495, -0.00062272, 0.0814371, 1.26032561, 0.03939102], (1000, 1))
@@ -18,7 +22,7 @@ def make_kernel(dev):
     m = la.LogReg(X, y, [10, 1, 1, 1, 1, 1, 1, 1], device=dev)
     return la.malaKernel(m.lpost, m.glp, dt=1e-5, pre=pre)
 
-out = mcmc_sharded(init, make_kernel, thin=5, iters=7, seed=11)
+out = mcmc_sharded(init, make_kernel, thin=5, iters=7, seed=11, local_device=lr, plan="global")
 if rank == 0:
     ref = la.mcmc(init, make_kernel(lr), thin=5, iters=7, seed=11, verb=False)
     got = out.cpu().numpy()
@@ -26,7 +30,7 @@ if rank == 0:
     assert np.array_equal(got, ref), "sharded run differs from the single-process run"
     print("sharded_smoke ok: world", world, "gathered", got.shape, "bit-exact vs single process")
 # the no-samples path: on-device statistics of every rank's shard, one all-reduce of 7p + 1 doubles over RCCL
-summ = mcmc_sharded(init, make_kernel, thin=5, iters=8, seed=11, summary_only=True, max_batches=4, plan="global")
+summ = mcmc_sharded(init, make_kernel, thin=5, iters=8, seed=11, summary_only=True, max_batches=4, plan="global", local_device=lr)
 if rank == 0:
     ref = la.mcmc(init, make_kernel(lr), thin=5, iters=8, seed=11, verb=False).astype(np.float64)
     flat = ref.reshape(-1, 8)
