@@ -73,6 +73,31 @@ def test_planner_scales_with_the_cu_count_and_sizes_lds_within_the_chip(harness)
             assert pl["lds_bytes"] > 0 and pl["group"] in (1, 4, 8)
 
 
+def test_float64_default_policy_plans_size_their_lds_on_the_cpu(harness):
+    """float64 models, HMC under the default policy, over a sweep of rows, widths and chain counts: the float32-interior kernels ask for
+    their float64 rows + the per-lane stash, the matrix-core kernel for the rows (and for the stash as well when a remainder runs on
+    the float32-interior kernels behind it), everything within a CU's 160 KB; 17 <= p <= 32 is the stepwise engine's."""
+    reqs = [(1, p, n, C, "hmc", "auto", 0, -1) for p in (3, 8, 12, 16, 20) for n in (1, 100, 200, 208, 209, 256, 257, 512, 1000, 1024, 1025, 2000)
+            for C in (1, 1000, 4096, 5120, 8448, 16384, 18432, 65536)]
+    for rq, pl in zip(reqs, harness(reqs)):
+        assert not isinstance(pl, tuple), (rq, pl)
+        _, p, n, C = rq[:4]
+        P = 4 if p <= 4 else 8 if p <= 8 else 16 if p <= 16 else 32
+        rows = n * P * 8
+        if P == 32:
+            assert pl["mode"] == "stepwise", (rq, pl)
+        elif pl["mode"] == "mixed":
+            assert pl["group"] * pl["rows_per_lane"] >= n and pl["lds_bytes"] == rows + 16 * 8 * 256 <= 160 * 1024, (rq, pl)
+        elif pl["mode"] == "mfma":
+            assert P == 8 and n <= 208 and C >= 33 * 256 and pl["group"] == 1, (rq, pl)
+            assert pl["lds_bytes"] == (rows + 16 * 8 * 256 if "tail" in pl else rows), (rq, pl)
+            if "tail" in pl:
+                assert pl["tail"]["mode"] == "mixed", (rq, pl)
+        else:  # beyond the register shapes: the all-float64 kernels
+            assert n > 256 or P == 32 or (P == 16 and n > 512) or (P == 4 and n > 1024) or (P == 8 and n > 1024), (rq, pl)
+            assert pl["lds_bytes"] <= 160 * 1024, (rq, pl)
+
+
 def test_group_is_validated_per_mode_on_the_cpu(harness):
     res = harness([(0, 8, 200, 100, "mala", "auto", 48, -1), (0, 8, 200, 100, "hmc", "auto", 2, 3), (0, 8, 20000, 1024, "hmc", "auto", 63, 4),
                    (0, 8, 20000, 1024, "hmc", "auto", 10 ** 6, 4), (0, 100, 300, 64, "hmc", "auto", 5, -1)])
