@@ -976,10 +976,16 @@ __device__ __forceinline__ void row_pairs_grad_bf(const RegRowPairs<P, R, G>& ro
     for (int j = 0; j < P / 2; ++j) gp[j] += __builtin_shufflevector(hp[j], hp[j], 1, 0);
 }
 
+// Rows staged in LDS sit kLdsRowPad<T> elements apart beyond P.  float64: a lane's 16-byte reads of a 64-byte row, 16 lanes of a group on
+// 16 consecutive rows, hit the same 4 banks in every fourth lane (64 B = 16 banks: 4-way conflict; rocprofv3 on k_chain_mixed:
+// SQ_LDS_BANK_CONFLICT = 61 % of SQ_LDS_IDX_ACTIVE); two doubles of padding put the 16 rows on 16 disjoint 4-bank windows (P = 4, 8,
+// 16, 32: row pitch 12, 20, 36, 68 banks).
+template <typename T> constexpr int kLdsRowPad = sizeof(T) == 8 ? 2 : 0;
 template <typename T, int P, int G> struct StridedRows {  // LDS or global: same access code
-    const T* base;  // row-major [n][P]
+    const T* base;  // row-major [n][ld]
     int64_t n;
     int gl;
+    int ld = P;  // row pitch in elements (P in device memory, P + kLdsRowPad<T> in LDS)
     template <class F> __device__ __forceinline__ void for_each(F&& f) const { for_each_in(0, n, f); }
     // the lane's rows inside [lo, hi), lo a multiple of G
     template <class F> __device__ __forceinline__ void for_each_in(int64_t lo, int64_t hi, F&& f) const {
@@ -993,14 +999,14 @@ template <typename T, int P, int G> struct StridedRows {  // LDS or global: same
 #pragma unroll
             for (int u = 0; u < UB; ++u)
 #pragma unroll
-                for (int j = 0; j < P; ++j) xs[u][j] = base[(i + u * G) * P + j];
+                for (int j = 0; j < P; ++j) xs[u][j] = base[(i + u * G) * ld + j];
 #pragma unroll
             for (int u = 0; u < UB; ++u) f(xs[u]);
         }
         for (; i < n; i += G) {
             T xs[P];
 #pragma unroll
-            for (int j = 0; j < P; ++j) xs[j] = base[i * P + j];
+            for (int j = 0; j < P; ++j) xs[j] = base[i * ld + j];
             f(xs);
         }
     }

@@ -84,13 +84,15 @@ __device__ __forceinline__ typename RowsOf<T, P, G, MODE, R>::type make_rows(con
     if constexpr (MODE == MODE_REG) {
         rows.load(m.rows, m.n, gl);
     } else if constexpr (MODE == MODE_LDS) {
-        // stage all rows once; coalesced copy by the whole workgroup
+        // stage all rows once; coalesced copy by the whole workgroup (row pitch P + kLdsRowPad<T>: lr_device.h)
+        constexpr int LD = P + kLdsRowPad<T>;
         const int64_t tot = m.n * P;
-        for (int64_t i = threadIdx.x; i < tot; i += blockDim.x) smem[i] = m.rows[i];
+        for (int64_t i = threadIdx.x; i < tot; i += blockDim.x) smem[(i / P) * LD + (i % P)] = m.rows[i];
         __syncthreads();
         rows.base = smem;
         rows.n = m.n;
         rows.gl = gl;
+        rows.ld = LD;
     } else if constexpr (is_scalar_pairs<typename RowsOf<T, P, G, MODE, R>::type>::value) {
         rows.base = m.rows_tw;
         rows.k0 = 0;
@@ -331,7 +333,7 @@ __global__ void __launch_bounds__(256) k_chain_mixed(ModelArgs<double, 8> m, Cha
     RegRowPairs<P, R, G> rows32;                                                                          // float32 rows: interior
     rows32.load(m.rows, m.n, gl);
     // (dynamic LDS: the float64 rows, then kMixedStashDoubles doubles per lane -- lr_plan.h plan_mixed_hmc sizes it)
-    double* const stash = reinterpret_cast<double*>(smem_raw) + m.n * P + threadIdx.x;
+    double* const stash = reinterpret_cast<double*>(smem_raw) + m.n * (P + kLdsRowPad<double>) + threadIdx.x;
     const uint64_t gchain = (uint64_t)(a.chain_offset + chain);
 
     // The chain's state is DISTRIBUTED over its 16 lanes for the whole launch, as in k_chain_rs16: quad qd owns coordinates 2 qd,

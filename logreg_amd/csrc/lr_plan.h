@@ -202,7 +202,9 @@ bool plan_mfma_hmc(const lr_model* m, int64_t C, Plan* out) {
 // float64 end points, Metropolis test, position and momentum; float32 force inside the trajectory.
 double reg_cost(const lr_model* m, const lr::Variant& u, int64_t chains);
 // dynamic LDS of k_chain_mixed: the float64 rows + its per-lane stash (lr_kernels.h)
-size_t mixed_lds_bytes(const lr_model* m) { return (size_t)m->n * m->P * m->esize() + (size_t)lr::kMixedStashDoubles * 8 * 256; }
+// rows staged in LDS by the lane-group kernels: float64 rows are padded by two doubles (lr_device.h kLdsRowPad)
+size_t lds_rows_bytes(const lr_model* m) { return (size_t)m->n * (m->P + (m->dtype == LR_F32 ? 0 : 2)) * m->esize(); }
+size_t mixed_lds_bytes(const lr_model* m) { return lds_rows_bytes(m) + (size_t)lr::kMixedStashDoubles * 8 * 256; }
 bool plan_mixed_hmc(const lr_model* m, int64_t C, Plan* out, int* whole = nullptr) {
     if (m->dtype != LR_F64 || m->P > 32) return false;
     const size_t row_bytes = mixed_lds_bytes(m);
@@ -319,7 +321,7 @@ int pick_variant(const PlanReq& q) {
         if (q.mode != LR_MODE_AUTO && v.mode != q.mode) continue;
         if (q.group != 0 && v.G != q.group) continue;
         if (v.mode == lr::MODE_REG && (int64_t)v.G * v.R < m->n) continue;
-        if (v.mode == lr::MODE_LDS && row_bytes > kLdsBudget) continue;
+        if (v.mode == lr::MODE_LDS && lds_rows_bytes(m) > kLdsBudget) continue;
         const int64_t waves = (q.C * v.G + 63) / 64;
         long score = (2 - v.mode) * 1000000L;
         if (waves >= want_waves) score += 100000L - 1000L * v.G;  // filled: prefer small groups
@@ -363,6 +365,11 @@ bool measured_overrides(const PlanReq& q, int* best, Plan* out) {
         if (q.C >= (int64_t)kPlanConst.f64_lds8_chains_per_cu * m->cus) move_to_lds(8);
         else if (q.C >= (int64_t)kPlanConst.f64_lds16_chains_per_cu * m->cus) move_to_lds(16);
     }
+    // float64 at the other widths (LDS rows on 1 / 8 / 64 lanes per chain only): one chain per wave saturates at one wave per SIMD;
+    // 8 lanes per chain overtake from 16 chains per CU (round 4, PLANNER_BENCH_DTYPE=float64 tools/planner_bench.py, lds 64 | lds 8,
+    // it/s: MALA n=200 p=12: 2048 chains 2.61 | 2.58e8, 4096: 2.62 | 5.12e8; HMC all-float64 4096: 2.12 | 4.14e7; MALA p=3 4096: 6.1 | 8.5e8)
+    if (m->dtype == LR_F64 && m->P != 8 && b.mode == lr::MODE_LDS && b.G == 64 && q.C >= (int64_t)kPlanConst.f64_lds16_chains_per_cu * m->cus)
+        move_to_lds(8);
     return false;
 }
 
@@ -471,7 +478,7 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
         plan_tall(q, out);
         return LR_OK;
     }
-    const bool prefer_stepwise = row_bytes > kLdsBudget ||
+    const bool prefer_stepwise = lds_rows_bytes(m) > kLdsBudget ||
                                  (row_bytes > kPlanConst.lds_rows_prefer_stepwise_bytes && C >= kPlanConst.lds_rows_prefer_stepwise_chains);
     if (!for_eval && (mode == LR_MODE_STEPWISE || (mode == LR_MODE_AUTO && group == 0 && prefer_stepwise))) {
         plan_tall(q, out);
@@ -483,7 +490,7 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
                     m->dtype, m->p, m->P, (long long)m->n, group, mode);
     if (q.automatic() && measured_overrides(q, &best, out)) return LR_OK;
     const lr::Variant& v = m->table->variants[best];
-    *out = Plan{v.mode, v.G, v.R, v.mode == lr::MODE_MIXED ? mixed_lds_bytes(m) : v.mode == lr::MODE_LDS || (v.mode == lr::MODE_MFMA && m->dtype != LR_F32) ? row_bytes : (v.mode == lr::MODE_MFMA && v.R == 0 ? mfma_lds_bytes(m, v.G) : 0)};
+    *out = Plan{v.mode, v.G, v.R, v.mode == lr::MODE_MIXED ? mixed_lds_bytes(m) : v.mode == lr::MODE_LDS ? lds_rows_bytes(m) : (v.mode == lr::MODE_MFMA && m->dtype != LR_F32) ? row_bytes : (v.mode == lr::MODE_MFMA && v.R == 0 ? mfma_lds_bytes(m, v.G) : 0)};
     if (v.mode == lr::MODE_REG && q.automatic() && kind >= 0) plan_second_part(q, v, out);
     return LR_OK;
 }

@@ -73,7 +73,8 @@ CASES = [
     # ... from one wave per SIMD in LDS with 16 lanes per chain, from two with 8 (8 x 25 rows = 200 exactly; round 4)
     (200, 8, 4096, "hmc", "full", {"dtype": "float64", "mode": "lds", "group": 16}),
     (200, 8, 8192, "mala", "auto", {"dtype": "float64", "mode": "lds", "group": 8}),
-    (200, 12, 4096, "hmc", "full", {"dtype": "float64", "mode": "lds"}),
+    (200, 12, 4096, "hmc", "full", {"dtype": "float64", "mode": "lds", "group": 8}), (200, 12, 2048, "mala", "auto", {"dtype": "float64", "mode": "lds", "group": 64}),
+    (200, 3, 4096, "mala", "auto", {"dtype": "float64", "mode": "lds", "group": 8}),
     # float64 HMC under the default precision policy, 5 <= p <= 8, n <= 256: float32 interior gradients (k_chain_mixed)
     (200, 8, 4096, "hmc", "auto", {"dtype": "float64", "mode": "mixed", "group": 16, "rows_per_lane": 13}),
     (200, 8, 64, "hmc", "auto", {"dtype": "float64", "mode": "mixed", "group": 64, "rows_per_lane": 4}),  # few chains: wide lane groups
