@@ -79,25 +79,44 @@ def usable_cores() -> int:
     return n
 
 
-def cpu_baseline(X, y, pscale, init, target_s=12.0):
-    """Time the CPU oracle (float64 C restatement, OpenMP over chains) on a bounded sample of the
-    same workload.  The oracle is the checker, used here only as the reported CPU baseline."""
-    from oracle.oracle import OracleModel, max_threads
-    m = OracleModel(X, y, pscale)
-    threads = min(max_threads(), usable_cores())
-    chains = 8 * threads
-    st = np.tile(init, (chains, 1))
-    t0 = time.perf_counter()
-    m.run("hmc", st, step=EPS, l=LEAP, scale=np.ones(N_PAR), thin=1, iters=4, seed=SEED, keep=False, threads=threads)
-    probe = (time.perf_counter() - t0) / 4
-    iters = int(max(4, min(200000, target_s / max(probe, 1e-6))))
-    t0 = time.perf_counter()
-    m.run("hmc", st, step=EPS, l=LEAP, scale=np.ones(N_PAR), thin=1, iters=iters, seed=SEED, keep=False, threads=threads)
-    dt = time.perf_counter() - t0
-    return {"value": chains * iters / dt, "unit": "chain-iterations/s", "cores": threads, "kind": "port",
-            "sample": f"{chains} chains x {iters} HMC iterations (L={LEAP}) of the same n={N_ROWS},p={N_PAR} workload, "
-                      f"float64 C oracle, {dt:.1f} s",
-            "grad_evals_per_s": chains * iters * (LEAP + 1) / dt}
+def cpu_baseline(X, y, pscale, init, target_s=6.0):
+    """Time the CPU oracle on bounded samples of the same workload, as SURVEY.md section 8(d)(ii) asks: the float64 C
+    restatement (OpenMP over chains) at ALL usable cores and at ONE core, and the same C source compiled in IEEE float32
+    (oracle/Makefile `f32`) likewise -- four legs of ~`target_s`/2..`target_s` seconds each (~20 s in all).  `value` is the
+    float64 all-cores leg (the reference's arithmetic).  The oracle is the checker, used here only as the reported CPU
+    baseline; every leg is `kind: "port"`."""
+    from oracle import oracle as orc
+    m = orc.OracleModel(X, y, pscale)
+    # the thread count is passed explicitly (num_threads clause): torchrun exports OMP_NUM_THREADS=1 to its ranks
+    all_threads = usable_cores()
+    scale = np.ones(N_PAR)
+
+    def leg(real, threads, budget):
+        chains = 8 * threads
+        st = np.tile(init, (chains, 1))
+
+        def go(iters):
+            t0 = time.perf_counter()
+            if real == "f64":
+                m.run("hmc", st, step=EPS, l=LEAP, scale=scale, thin=1, iters=iters, seed=SEED, keep=False, threads=threads)
+            else:
+                orc.run_f32(X, y, pscale, "hmc", st, step=EPS, l=LEAP, scale=scale, thin=1, iters=iters, seed=SEED, threads=threads)
+            return time.perf_counter() - t0
+        go(2)  # thread pool and caches warm
+        probe = go(8) / 8
+        iters = int(max(8, min(200000, budget / max(probe, 1e-6))))
+        dt = go(iters)
+        return {"value": chains * iters / dt, "unit": "chain-iterations/s", "cores": threads, "kind": "port", "arithmetic": real,
+                "grad_evals_per_s": chains * iters * (LEAP + 1) / dt,
+                "sample": f"{chains} chains x {iters} HMC iterations (L={LEAP}) of the same n={N_ROWS},p={N_PAR} workload, "
+                          f"{'float64' if real == 'f64' else 'float32'} C oracle, {threads} thread(s), {dt:.1f} s"}
+    all64 = leg("f64", all_threads, target_s)
+    one64 = leg("f64", 1, target_s * 0.7)
+    all32 = leg("f32", all_threads, target_s * 0.7)
+    one32 = leg("f32", 1, target_s * 0.7)
+    return {**all64, "all_cores": all64, "one_core": one64, "fp32": {"all_cores": all32, "one_core": one32},
+            "note": "value = the float64 all-cores leg; one_core / fp32 rows: SURVEY.md section 8(d)(ii).  The reference's own "
+                    "NumPy script (1 core) is `reference_cpu`."}
 
 
 class Timer:
@@ -389,6 +408,13 @@ class Exchange:
             self.torch, self.dist = torch, dist
             if backend == "nccl":
                 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: the only kind this driver supports
+                # one rank per GPU or nothing: device_count() does not initialise the GPU, every rank sees the same count and
+                # leaves before the rendezvous, so a node with fewer GPUs than ranks ends the job at once with a non-zero code
+                have = torch.cuda.device_count()
+                if have < world:
+                    print(f"bench.py: {world} ranks but only {have} GPU(s) visible on this node -- refusing to share GPUs "
+                          f"between ranks (rank {rank})", file=sys.stderr, flush=True)
+                    sys.exit(3)
                 torch.cuda.set_device(local_rank)
                 self.dev = f"cuda:{local_rank}"
                 dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -660,6 +686,27 @@ def headline_init(rank, C):
     return INIT + 0.1 * 0.17 * rng.standard_normal((C, N_PAR))
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` as a PLAIN process (no WORLD_SIZE / RANK in the environment), N > 1: start the N ranks
+    ourselves -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>
+    <this script> <the same arguments>` as a CHILD process (never an exec), before this process has imported the package,
+    torch or touched a GPU -- and hand back its exit code.  Rank 0's JSON line reaches stdout through the inherited pipe.
+    The ranks themselves refuse to run when the node shows fewer than N GPUs (Exchange.__init__), so the code is non-zero
+    then.  The torchrun entry (`WORLD_SIZE` set by the launcher) is untouched."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(sys.argv[0]), *sys.argv[1:]]
+    print(f"bench.py: --gpus {n} without a launcher: starting {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -681,6 +728,8 @@ def main(argv=None):
     ap.add_argument("--prewarm", type=float, default=PREWARM_S, help="seconds of untimed load before the warm-up steps")
     a = ap.parse_args(argv)
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        return self_launch(a.gpus)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -856,8 +905,6 @@ def main(argv=None):
                            "not_comparable_with": "reference_cpu.min_ess_per_s (24.8): that is Pima at eps=1e-3, dmm=1/pre; this is the "
                                                   "synthetic headline design at eps=0.1, unit mass.  The like-for-like pair is "
                                                   "extra.configs[config=2_pima]"}
-        if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(X, y, pscale, init)
         if dist_rows is not None:
             # N > 1 (or the forced one-rank process group): BASELINE configs 3 and 5 as stated, across the ranks
             line["extra"] = {"configs": dist_rows}
@@ -866,9 +913,15 @@ def main(argv=None):
                              "default_policy": default_policy_runs(la, L, _lib.check, dev, stream, kern, init, a.steps),
                              "f64": f64_run(la, L, _lib.check, dev, stream, X, y, pscale, q0, a.steps),
                              "f64_wide": f64_wide_run(la, L, _lib.check, dev, stream)}
-        print(json.dumps(line), flush=True)
+    # the process group is closed first: at N > 1 the other ranks leave, and rank 0 times the CPU oracle on an otherwise idle
+    # host (they would spin in a barrier otherwise) before it prints the ONE line
     ex.close()
+    if rank == 0:
+        if not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(X, y, pscale, init)
+        print(json.dumps(line), flush=True)
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -22,7 +22,7 @@ KINDS = {"rwmh": RWMH, "mala": MALA, "hmc": HMC, "ul": UL}
 def build(force: bool = False) -> str:
     src = os.path.join(_HERE, "lr_oracle.c")
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
-        subprocess.run(["make", "-C", _HERE, "-s"], check=True)
+        subprocess.run(["make", "-C", _HERE, "-s"], check=True)  # builds the float32 timing build too
     return _LIB_PATH
 
 
@@ -187,3 +187,48 @@ class OracleModel:
 
 def max_threads() -> int:
     return int(lib().orc_max_threads())
+
+
+# ---- the same C source compiled in IEEE float32 (`make f32`): a TIMING build for bench.py's cpu_baseline fp32 row
+# (SURVEY.md section 8(d)(ii)); no test uses it as a checker -- the parity oracle is the float64 build above.
+_LIB32_PATH = os.path.join(_HERE, "_build", "liblr_oracle_f32.so")
+_lib32 = None
+
+
+class _Kernel32(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("step", C.c_float), ("l", C.c_int32), ("scale", C.c_void_p)]
+
+
+def lib32():
+    global _lib32
+    if _lib32 is None:
+        build()
+        if not os.path.exists(_LIB32_PATH):
+            subprocess.run(["make", "-C", _HERE, "-s", "f32"], check=True)
+        L = C.CDLL(_LIB32_PATH)
+        L.orc_sizeof_real.restype = C.c_int32
+        assert L.orc_sizeof_real() == 4
+        L.orc_run.restype = C.c_int
+        L.orc_run.argtypes = lib().orc_run.argtypes
+        _lib32 = L
+    return _lib32
+
+
+def run_f32(X, y, pscale, kind, state, *, step, l=0, scale=1.0, thin=1, iters=1, seed=0, threads=1):
+    """orc_run of the float32 build on C chains (no samples kept) -> dict(state[C,p] float32, accepts[C])."""
+    f32 = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+    X, y = f32(X), f32(y)
+    n, p = X.shape
+    ps = f32(np.broadcast_to(np.asarray(pscale, dtype=np.float32), (p,)))
+    m = _Model(n, p, X.ctypes.data, y.ctypes.data, ps.ctypes.data)
+    sc = f32(np.broadcast_to(np.asarray(scale, dtype=np.float32), (p,))).copy()
+    k = _Kernel32(KINDS[kind], float(step), int(l), sc.ctypes.data)
+    st = np.atleast_2d(f32(state)).copy()
+    Cn = st.shape[0]
+    ll = np.full(Cn, -np.inf, dtype=np.float32)
+    acc = np.zeros(Cn, dtype=np.uint64)
+    rc = lib32().orc_run(C.cast(C.pointer(m), C.c_void_p), C.cast(C.pointer(k), C.c_void_p), _ptr(st), _ptr(ll), Cn, 0,
+                         int(thin), int(iters), 0, int(seed), None, None, None, _ptr(acc), None, int(threads))
+    if rc != 0:
+        raise RuntimeError("orc_run (float32 build) failed")
+    return {"state": st, "accepts": acc}

@@ -32,4 +32,4 @@ def host_view(self, samples):
 
 
 bench.Exchange.tensor = host_view
-bench.main(sys.argv[1:] + ["--backend", "gloo", "--no-ess", "--no-cpu-baseline"])
+sys.exit(bench.main(sys.argv[1:] + ["--backend", "gloo", "--no-ess", "--no-cpu-baseline"]) or 0)

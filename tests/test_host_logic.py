@@ -240,6 +240,43 @@ def test_bench_multi_gpu_line_on_the_abi_test_double(world):
     assert c5["gathered_bytes_per_rank"] == 16 * 128 * 4
 
 
+def test_bench_gpus_n_without_a_launcher_starts_its_own_ranks():
+    """The driver's N > 1 invocation may be a PLAIN `python bench.py --gpus N ...` (BENCH_r04.json.cmd): with no WORLD_SIZE in
+    the environment bench.main() must start the N ranks itself (a torch.distributed.run child, before any GPU call) and relay
+    rank 0's one line and the exit code -- never measure one GPU silently.  Here: the real main() on the ABI test double over
+    gloo, world 2, launched as a plain process."""
+    import json
+    import os
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tests", "bench_on_twin.py"), "--gpus", "2", "--chains", "80", "--steps", "2",
+                        "--warmup", "1", "--prewarm", "0.02", "--scale", "64"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    assert "without a launcher: starting 2 ranks" in r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["multi_gpu"]["ranks_seen"] == 2 and d["multi_gpu"]["gather_bitexact"] is True
+    assert {row["config"] for row in d["extra"]["configs"]} == {3, 5}
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`--gpus 2` over RCCL on a node with fewer than 2 GPUs (this container has none): the ranks refuse before the rendezvous
+    and the plain invocation exits non-zero -- it does not fall back to one GPU."""
+    import os
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert r.returncode != 0
+        assert "refusing to share GPUs" in r.stderr
+        assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
 def test_bench_self_check_detects_a_wrong_block():
     """gather_bitexact is a real comparison: a re-run that differs in one element, or a gather that delivered the blocks in
     another order, reads false."""
