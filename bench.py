@@ -881,7 +881,7 @@ def main(argv=None):
             line["multi_gpu"] = check_block
         # HBM traffic of the same launch from the committed rocprofv3 PMC passes (profiles/), if they
         # were taken for this kernel variant and shape
-        for name in ("r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
+        for name in ("r5_traffic.json", "r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
             try:
                 tr = json.load(open(os.path.join(REPO, "profiles", name)))
                 if tr["kernel_variant"] == plan and tr["chains"] == C and tr["thin"] == THIN:

@@ -153,7 +153,7 @@ LR_API int lr_model_info(const lr_model* m, int64_t* n, int32_t* p, int32_t* dty
  * lr_model_create (an unknown key or value fails the creation); nothing else on the run path consults the environment:
  *   residency_cap=0   fused chain kernels launched without the LDS request that spreads a grid evenly over the CUs
  *   tall_mx16=0       tall models: 4-wave interior kernel with separate update launches instead of the fused 16-wave form
- *   wide_traj=0|1     wide models: forbid / force the one-launch trajectory kernel (default: by chain count)
+ *   wide_traj=0|1|2   wide models: forbid / force the one-launch trajectory kernel with 1 / 2 chain tiles per workgroup (default: by chain count)
  *   wide_waves=4|8    wide models: waves (x 16 chains) per workgroup of the exact-split / chain-split kernels (default: by chain count)
  * Writes "" to buf for a model on the defaults (what a benchmark must run with), else the four settings.  No reference counterpart. */
 LR_API int lr_model_debug_opts(const lr_model* m, char* buf, int len);

@@ -169,6 +169,60 @@ def _build_locked(jobs: int | None, verbose: bool) -> str:
     return LIB
 
 
+def _demangle(names):
+    for tool in ("/opt/rocm/lib/llvm/bin/llvm-cxxfilt", "c++filt"):
+        try:
+            r = subprocess.run([tool], input="\n".join(names), capture_output=True, text=True)
+            out = r.stdout.split("\n")
+            if r.returncode == 0 and len(out) >= len(names):
+                return out[:len(names)]
+        except OSError:
+            pass
+    return list(names)
+
+
+def kernel_resources(objdir: str = OBJDIR):
+    """-> one dict per kernel of every gfx950 code object under `objdir`: unit, name (demangled), scratch bytes
+    (.private_segment_fixed_size), sgpr_spills, vgpr_spills, vgprs, agprs, sgprs, lds (static bytes) -- read from the AMDGPU
+    metadata note of the device code bundled in each object file."""
+    import re
+    import tempfile
+    llvm = "/opt/rocm/lib/llvm/bin"
+    rows = []
+    with tempfile.TemporaryDirectory(prefix="lr_co_") as tmp:
+        for obj in sorted(os.listdir(objdir)):
+            if not obj.endswith(".o"):
+                continue
+            link = os.path.join(tmp, obj)
+            os.symlink(os.path.join(objdir, obj), link)
+            subprocess.run([os.path.join(llvm, "llvm-objdump"), "--offloading", link], capture_output=True, text=True)  # writes <link>.N.<target>
+            cos = [os.path.join(tmp, f) for f in os.listdir(tmp) if f.startswith(obj + ".") and f.endswith("gfx950")]
+            if not cos:
+                continue  # a host-only unit
+            co = cos[0]
+            notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", co], capture_output=True, text=True, check=True).stdout
+            cur = None
+            for ln in notes.split("\n"):
+                m = re.match(r"\s*(- )?\.(\w+):\s+(\S.*)$", ln)
+                if not m:
+                    continue
+                k, v = m.group(2), m.group(3).strip()
+                if k == "agpr_count":  # first per-kernel key (keys are sorted) of a new kernel entry
+                    cur = {"unit": obj[:-2], "agprs": int(v)}
+                    rows.append(cur)
+                elif cur is not None:
+                    if k == "name" and "name" not in cur:
+                        cur["name"] = v.strip("'")
+                    elif k in ("private_segment_fixed_size", "sgpr_spill_count", "vgpr_spill_count", "vgpr_count", "sgpr_count",
+                               "group_segment_fixed_size"):
+                        cur[{"private_segment_fixed_size": "scratch", "sgpr_spill_count": "sgpr_spills", "vgpr_spill_count": "vgpr_spills",
+                             "vgpr_count": "vgprs", "sgpr_count": "sgprs", "group_segment_fixed_size": "lds"}[k]] = int(v)
+    rows = [r for r in rows if "name" in r and "scratch" in r]
+    for r, d in zip(rows, _demangle([r["name"] for r in rows])):
+        r["name"] = d
+    return rows
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--force", action="store_true")

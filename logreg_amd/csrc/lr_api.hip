@@ -179,7 +179,7 @@ int lr_model_create(const double* X, const double* y, int64_t n, int32_t p, cons
         if (!parse_debug_opts(std::getenv("LOGREG_DEBUG_OPTS"), &m->dbg, bad, sizeof bad)) {
             delete m;
             return fail(LR_ERR_INVALID, "LOGREG_DEBUG_OPTS: unknown or out-of-range item '%s' (keys: residency_cap=0|1, tall_mx16=0|1, "
-                                        "wide_traj=0|1, wide_waves=4|8)", bad);
+                                        "wide_traj=0|1|2, wide_waves=4|8)", bad);
         }
     }
     m->device = device;

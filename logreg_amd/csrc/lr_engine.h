@@ -218,6 +218,9 @@ int do_eval_stepwise_t(lr_model* m, const Plan& pl, hipStream_t st, int64_t C, c
     return LR_OK;
 }
 
+// wide models: two chain tiles per workgroup of the trajectory kernel beyond this many tiles per CU (one tile per workgroup up to it)
+constexpr int kTraj2FromTilesPerCu = 1;
+
 template <typename T, int P>
 int do_stepwise_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs, const lr_run_opts* o, void* state,
                   double* lp_state, void* out, uint32_t* accepts) {
@@ -267,10 +270,16 @@ int do_stepwise_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs
     // until the 64-chain workgroups of the chain-split kernel amortise the stream better (config 5 design, us per
     // evaluation of all chains, trajectory kernel | launch per step: 1024 chains 15.7 | 11.5, 2048: 16.1 | 14.4,
     // 4096: 22.2 | 25.0, 8192: 39.5 | 44.9, 16 384: 73.4 | 72.5).  LOGREG_DEBUG_OPTS wide_traj=1 forces it on, wide_traj=0 off.
+    // Round 5: with two chain tiles per workgroup (below) it wins at every chain count from one tile per CU up (us per evaluation,
+    // launch per step | two-tile trajectory kernel: 12 288 chains 79.6 | 49.6, 16 384: 67.5 | 51.4, 32 768: 120.6 | 101.6, 65 536: 235.9 | 202.7;
+    // profiles/r5_cfg5_whole.txt), so the upper bound on the chain count is gone.
     const int64_t traj_tiles = (Cp + 15) / 16;
+    // Two chain tiles per workgroup (k_wide_traj2_bf16, round 5; the same trajectories bit for bit) from the chain count at which
+    // the one-tile kernel needs a second round of workgroups: measured rule below.  LOGREG_DEBUG_OPTS wide_traj=2 / 1 force either.
+    a.traj_tiles = m->dbg.wide_traj == 2 ? 2 : (m->dbg.wide_traj == 1 ? 1 : (traj_tiles > (int64_t)kTraj2FromTilesPerCu * m->cus ? 2 : 1));
     const bool traj = P > 32 && bf16_interior && m->d_xblk1 != nullptr && t->launch_tall_traj != nullptr && rs.l > 1 &&
                       m->dbg.wide_traj != 0 &&
-                      (m->dbg.wide_traj == 1 || (traj_tiles >= m->cus && traj_tiles < 4LL * m->cus) ||
+                      (m->dbg.wide_traj >= 1 || traj_tiles >= m->cus ||
                        // small designs (the one-piece image within 256 KB): the per-step stream is cheap, the launch per step is not
                        // (us per evaluation, launch per step | trajectory kernel: n=500 p=64: 5.5 | 2.8 at 1024 chains; n=300 p=100:
                        //  7.0 | 4.7; n=1000 p=128: 7.5 | 6.5; n=2000 p=50: 6.2 | 5.3; n=2000 p=128 (512 KB): 8.4 | 9.3)
@@ -291,7 +300,9 @@ int do_stepwise_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs
     for (int64_t tt = 0; tt < total && !rc; ++tt) {
         if (kind == lr::KIND_HMC) {
             if (traj) {
+                LR_STAMPS_ARM(a);
                 if (!rc) rc = t->launch_tall_traj(st, &a);
+                LR_STAMPS_DISARM(a);
             } else if (fuse) {
                 // row-split interior kernel: every launch but the first finishes the previous leapfrog step in its
                 // own prologue (state and partial buffers ping-pong), so the L - 1 interior steps are L - 1

@@ -64,7 +64,7 @@ struct DebugOpts {
     int residency_cap = 1;  // 0: fused chain kernels without the LDS request that spreads a grid evenly over the CUs (lr_inst.h)
     int tall_mx16 = 1;      // 0: tall models run their interior leapfrog steps on the 4-wave kernel with separate update launches
                             //    instead of the 16-wave kernel that finishes the previous step in its prologue (lr_tall_mx.h)
-    int wide_traj = -1;     // wide models: 1 forces / 0 forbids the one-launch trajectory kernel (-1: by chain count; lr_engine.h)
+    int wide_traj = -1;     // wide models: 1 / 2 force the one-launch trajectory kernel with 1 / 2 chain tiles per workgroup, 0 forbids it (-1: by chain count; lr_engine.h)
     int wide_waves = 0;     // wide models: 4 | 8 waves (64 | 128 chains) per workgroup of the exact and chain-split kernels (0: by chain count)
     bool is_default() const { return residency_cap == 1 && tall_mx16 == 1 && wide_traj == -1 && wide_waves == 0; }
 };
@@ -85,13 +85,13 @@ inline bool parse_debug_opts(const char* text, DebugOpts* out, char* bad, size_t
         char* rest = nullptr;
         const long v = eq == std::string::npos ? 0 : std::strtol(item.c_str() + eq + 1, &rest, 10);
         bool ok = eq != std::string::npos && rest && *rest == 0 && eq + 1 < item.size();
-        // key -> (field, the two values it accepts)
-        struct { const char* key; int* field; long a, b; } const table[] = {
-            {"residency_cap", &out->residency_cap, 0, 1}, {"tall_mx16", &out->tall_mx16, 0, 1},
-            {"wide_traj", &out->wide_traj, 0, 1}, {"wide_waves", &out->wide_waves, 4, 8}};
+        // key -> (field, the values it accepts)
+        struct { const char* key; int* field; long a, b, c; } const table[] = {
+            {"residency_cap", &out->residency_cap, 0, 1, 1}, {"tall_mx16", &out->tall_mx16, 0, 1, 1},
+            {"wide_traj", &out->wide_traj, 0, 1, 2}, {"wide_waves", &out->wide_waves, 4, 8, 8}};
         bool known = false;
         for (const auto& e : table)
-            if (ok && key == e.key && (v == e.a || v == e.b)) {
+            if (ok && key == e.key && (v == e.a || v == e.b || v == e.c)) {
                 *e.field = (int)v;
                 known = true;
             }

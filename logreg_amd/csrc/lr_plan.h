@@ -267,7 +267,7 @@ void plan_tall(const PlanReq& q, Plan* out) {
     const int64_t want_waves = 4LL * m->cus;
     // a workgroup = NW waves x 64 chains working on one slice (NW as lr::TallGeom: LDS-limited)
     const int raw = 2048 / (m->P * (int)m->esize());
-    const int64_t NW = raw >= 16 ? 16 : (raw >= 8 ? 8 : 4);
+    const int64_t NW = (raw >= 16 && m->P <= 16) ? 16 : (raw >= 8 ? 8 : 4);
     const int64_t waves_per_slice = NW * ((q.C + 63) / 64);
     int64_t RS = (4 * want_waves + waves_per_slice - 1) / waves_per_slice;
     if (q.mode == LR_MODE_STEPWISE && q.group > 0) RS = q.group;  // explicit slice count (see plan_wide)

@@ -30,8 +30,27 @@
     if (blockIdx.x == 0 && threadIdx.x == 0 && (its) >= 100)                                                                                   \
         printf("k_chain_rs16 kind %d, %lld iterations, shader cycles per iteration: draws %.1f, proposal + evaluation %.1f, accept %.1f, loop %.1f\n", \
                (kind), (long long)(its), (double)ph[0] / (its), (double)ph[1] / (its), (double)ph[2] / (its), (double)ph[3] / (its));
+// trajectory kernels: shader cycles of a wave per phase, summed over the steps of the launch -> stamp slots 8 + k (k < 5), slot 7 = total
+#define LR_TRAJ_PHASES_BEGIN unsigned long long tph[5] = {0, 0, 0, 0, 0}, ttp = __builtin_amdgcn_s_memtime(); const unsigned long long tt0 = ttp;
+#define LR_TRAJ_PHASE(k) do { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); tph[k] += tn_ - ttp; ttp = tn_; } while (0)
+#define LR_TRAJ_PHASES_REPORT(a)                                                                         \
+    if ((a).stamps && (threadIdx.x & 63) == 0) {                                                         \
+        for (int k_ = 0; k_ < 5; ++k_) LR_STAMP_AT(a, 8 + k_) = tph[k_];                                 \
+        LR_STAMP_AT(a, 7) = __builtin_amdgcn_s_memtime() - tt0;                                         \
+    }
+// timing experiments of the trajectory kernels, chosen at COMPILE time (-DLR_TRAJ2_EXP=<bit mask>; results knowingly wrong): bit 0 no
+// exp / rcp, 1 one gradient MFMA per tile instead of P / 16, 2 no lo-piece eta MFMAs, 3 no DMA (issue or wait), 5 no reduction phase
+#ifdef LR_TRAJ2_EXP
+#define LR_TRAJ_EXP(bit) (((LR_TRAJ2_EXP) >> (bit)) & 1)
+#else
+#define LR_TRAJ_EXP(bit) 0
+#endif
 #else
 #define LR_STAMP_FIELDS
+#define LR_TRAJ_EXP(bit) 0
+#define LR_TRAJ_PHASES_BEGIN
+#define LR_TRAJ_PHASE(k) do { } while (0)
+#define LR_TRAJ_PHASES_REPORT(a)
 #define LR_STAMP(a, k) do { } while (0)
 #define LR_STAMP_CLK(a, k) do { } while (0)
 #define LR_DBG(a, bit) 0

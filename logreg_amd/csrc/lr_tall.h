@@ -90,6 +90,7 @@ template <typename T, int P> struct TallArgs {
     int RS_i;               // row-split interior kernel (k_wide_partial_bf16r): slices, 0 = not used for this run
     int64_t slice_len_i;    //   and rows per slice (a multiple of 32 * rowsplit_waves: whole 32-row blocks per wave)
     int rowsplit_waves;     //   4 or 8 waves per workgroup (wide); 16: the 16-wave tall kernel k_tall_partial_mx16 is in use
+    int traj_tiles;         // wide models, trajectory kernel: chain tiles (16 chains) per workgroup -- 1: k_wide_traj_bf16, 2: k_wide_traj2_bf16
     int p, l;
     T step;
     T a[P], b[P], c[P];
@@ -104,7 +105,10 @@ template <typename T, int P> struct TallArgs {
 // per (chain, coordinate) reach memory.
 template <typename T, int P> struct TallGeom {
     static constexpr int kRaw = 2048 / (P * (int)sizeof(T));
-    static constexpr int NW = kRaw >= 16 ? 16 : (kRaw >= 8 ? 8 : 4);  // LDS = NW*64*P*sizeof(T) <= 128 KB
+    // LDS = NW*64*P*sizeof(T) <= 128 KB.  16 waves (1024 threads: 128 VGPRs per lane) only while the lane's three P-vectors (position,
+    // fp32 and fp64 gradient sums: 4 P registers) leave room for the row pass -- at P = 32 they are the whole budget and the kernel
+    // spilled 13-36 registers to scratch (round 5: tools/kernel_resources.py; no kernel of the library may use scratch)
+    static constexpr int NW = (kRaw >= 16 && P <= 16) ? 16 : (kRaw >= 8 ? 8 : 4);
 };
 
 template <typename T, int P, bool VALUE, bool GRAD>

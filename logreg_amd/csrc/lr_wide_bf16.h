@@ -818,16 +818,16 @@ __global__ void __launch_bounds__(512) k_wide_traj_bf16(TallArgs<float, P> a) {
             uint32_t wq[4];
 #pragma unroll
             for (int T = 0; T < 2; ++T) {
-                f32x4 e0 = {0, 0, 0, 0}, e1 = {0, 0, 0, 0};
+                f32x4 e0 = {0, 0, 0, 0};  // (hi and lo products into ONE accumulator: the order k_wide_traj2_bf16 uses)
 #pragma unroll
                 for (int m = 0; m < G::M32; ++m) {
                     const u32x4 xa = *reinterpret_cast<const u32x4*>(base + G::tile1(T, m) + eta_off);
                     e0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(xa), as_bf16x8(bq[m][0]), e0, 0, 0, 0);
-                    e1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(xa), as_bf16x8(bq[m][1]), e1, 0, 0, 0);
+                    e0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(xa), as_bf16x8(bq[m][1]), e0, 0, 0, 0);
                 }
                 float w[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) w[r] = fast_rcp(1.0f + __builtin_amdgcn_exp2f(e0[r] + e1[r]));
+                for (int r = 0; r < 4; ++r) w[r] = fast_rcp(1.0f + __builtin_amdgcn_exp2f(e0[r]));
                 wq[2 * T] = pack_rne(w[0], w[1]);
                 wq[2 * T + 1] = pack_rne(w[2], w[3]);
             }
@@ -866,6 +866,314 @@ __global__ void __launch_bounds__(512) k_wide_traj_bf16(TallArgs<float, P> a) {
         for (int r = 0; r < G::M32; ++r) {
             a.q1[ochain * P + 32 * r + oj] = sq[r];
             a.pm[ochain * P + 32 * r + oj] = sp[r];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// TRAJECTORY kernel, TWO chain tiles (32 chains) per workgroup (round 5): config 5 as a whole -- 8192 chains on one GPU -- is 512
+// chain tiles on 256 CUs.  With one tile per workgroup every CU streams the whole one-piece image twice per leapfrog step
+// (512 MB per step chip-wide from the L2s: 17 TB/s sustained at the 30 us per step measured, half the L2's aggregate peak; MFMA
+// busy 38 %, profiles/r5_cfg5_whole_baseline.txt).  Here every wave carries the beta operands and gradient accumulators of TWO
+// tiles and uses each block image it fetched -- and every LDS operand read of it -- for both: per chain, half the L2 -> LDS traffic,
+// half the LDS operand reads, the same MFMAs; 256 workgroups of 8 waves = one per CU at 8192 chains.  Row partition over the
+// waves, MFMA order per tile and the wave-order fp64 reduction are those of k_wide_traj_bf16: a chain's trajectory is bit-identical
+// under either kernel (tests/test_gpu_fullsize.py), so the choice between them is a matter of speed only.
+//  * Block body, software-pipelined by hand (sched_group_barrier): left to itself the scheduler issues the 32 eta MFMAs of both
+//    tiles, then ALL 75 vector instructions of the two sigmoids with the matrix pipe idle, then the 16 gradient MFMAs (measured:
+//    2200-2600 cycles per block and wave against 768 of MFMA).  Here tile 0's sigmoid issues between tile 1's eta MFMAs and tile 1's
+//    between tile 0's gradient MFMAs.
+//  * Reduction over the waves through the wave's OWN last ring slot, one tile (16 chains x P floats = one slot) at a time: 4
+//    barriers per step instead of 16, 16-byte accesses only; thread (chain oc, chunk oq) owns coordinates 4 oq .. 4 oq + 3.
+// LDS: 8 rings x 16 KB + the new positions (16 KB) = 144 KB.
+template <int P>
+__global__ void __launch_bounds__(512) k_wide_traj2_bf16(TallArgs<float, P> a) {
+    using G = WideBf16Geom<P>;
+    constexpr int NW = 8, NT2 = 2, BLK_BYTES = G::BUF1 * 2, NBUF = P >= 128 ? 2 : 4, RING_BYTES = NBUF * BLK_BYTES;
+    constexpr int NQ = P / 4;             // 16-byte chunks per chain
+    constexpr int EPT = 16 * NQ / 512;    // chunks a thread owns per tile (P = 128: 1, P = 64: half the threads own one)
+    static_assert(16 * P * 4 == BLK_BYTES, "a tile's gradients fill exactly one ring slot");
+    static_assert(P == 128 || P == 64, "chunk ownership below");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NW * RING_BYTES];
+    // coordinate j of chain c of tile t at [t][j / 8][(j / 4) & 1][c][j & 3]: the b128 reads of lanes (c, kg) are conflict-free
+    // (see k_wide_partial_bf16r)
+    __shared__ __attribute__((aligned(16))) float qnew[NT2][P / 8][2][16][4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, kg = lane >> 4;
+    const int nblk = (int)((a.n + 31) / 32);
+    const int per_wave = (nblk + NW - 1) / NW;
+    const int wb0 = wave * per_wave;
+    const int wnb = nblk - wb0 < 0 ? 0 : (nblk - wb0 < per_wave ? nblk - wb0 : per_wave);
+    unsigned char* ring = smem + wave * RING_BYTES;
+    const uint32_t ring_lds = (uint32_t)(uintptr_t)ring;
+
+    auto issue = [&](int b) {  // block b of this wave -> ring slot b % NBUF; one M0 set-up per block (see k_wide_partial_bf16r)
+        static_assert(BLK_BYTES == 8192 || BLK_BYTES == 4096, "pieces addressed around the middle of the block");
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(a.xblk1 + (wb0 + b) * (int64_t)G::BUF1) + lane * 16 + BLK_BYTES / 2;
+        const uint32_t dst = ring_lds + (uint32_t)((b & (NBUF - 1)) * BLK_BYTES) + BLK_BYTES / 2;
+        uint32_t keep;
+        if constexpr (BLK_BYTES == 8192)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                         "global_load_lds_dwordx4 %1, off offset:-4096\n\tglobal_load_lds_dwordx4 %1, off offset:-3072\n\t"
+                         "global_load_lds_dwordx4 %1, off offset:-2048\n\tglobal_load_lds_dwordx4 %1, off offset:-1024\n\t"
+                         "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
+                         "global_load_lds_dwordx4 %1, off offset:2048\n\tglobal_load_lds_dwordx4 %1, off offset:3072\n\t"
+                         "s_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+        else
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                         "global_load_lds_dwordx4 %1, off offset:-2048\n\tglobal_load_lds_dwordx4 %1, off offset:-1024\n\t"
+                         "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
+                         "s_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    };
+
+    // the thread's share of the state: chains 16 t + oc (t = 0, 1), coordinates 4 oq .. 4 oq + 3
+    const int oc = tid / NQ, oq = tid % NQ;
+    const bool owner = oc < 16;  // (P = 64: 256 of the 512 threads)
+    const int occ = owner ? oc : 15;
+    // (addresses are recomputed where they are used: kept live across the trajectory they spilled to scratch)
+    auto state_at = [&](int t, bool& live) {
+        int tix = threadIdx.x;
+        asm volatile("" : "+v"(tix));  // (opaque: otherwise the two uses are merged and the addresses stay live -- in scratch)
+        int64_t ch = (int64_t)blockIdx.x * (16 * NT2) + 16 * t + (tix / NQ < 16 ? tix / NQ : 15);
+        live = tix / NQ < 16 && ch < a.C;
+        if (ch >= a.C) ch = a.C - 1;
+        return ch * P + 4 * (tix % NQ);
+    };
+    // position and momentum of the thread's coordinates live in LDS between the reductions (qnew and pmom: the row loop needs the
+    // registers): 8 + 8 floats per thread
+    __shared__ __attribute__((aligned(16))) f32x4 pmom[NT2][512];
+    f32x4 sq[NT2];
+#pragma unroll
+    for (int t = 0; t < NT2; ++t) {
+        bool live;
+        const int64_t at = state_at(t, live);
+        sq[t] = *reinterpret_cast<const f32x4*>(a.q1 + at);
+        pmom[t][tid] = *reinterpret_cast<const f32x4*>(a.pm + at);
+    }
+    auto qslot = [&](int t) -> f32x4& { return *reinterpret_cast<f32x4*>(&qnew[t][oq >> 1][oq & 1][occ][0]); };
+    if (owner) {
+#pragma unroll
+        for (int t = 0; t < NT2; ++t) qslot(t) = sq[t];
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // nothing but the DMA ring counts on vmcnt from here on
+#pragma unroll
+    for (int b = 0; b < NBUF - 1; ++b)
+        if (b < wnb) issue(b);
+    __syncthreads();
+
+    const int eta_off = G::elem(kg, c, 0) & ~7;
+    const int ri = (lane & 15) >> 2, ci = lane & 3;
+    const int tr_off[2] = {G::elem(ci, 4 * kg + ri, 0), G::elem(ci, 4 * kg + ri, 4)};
+    // the exchange slot (the wave's last ring slot, which no step-start prefetch touches), as [16 chains][NQ chunks of 16 bytes],
+    // chunk index XOR-swizzled by the chain (8 consecutive chains write / 32 consecutive chunks read distinct bank groups)
+    float* const xslot = reinterpret_cast<float*>(ring + (NBUF - 1) * BLK_BYTES);
+    const int xw_row = c * P, xw_sw = c & 7;
+    const int xr_off = occ * P + ((oq ^ (occ & 7)) << 2);
+    const int nsteps = a.l - 1;
+    LR_TRAJ_PHASES_BEGIN  // development builds: shader cycles per phase of a step (lr_stamps.h)
+    for (int s = 0; s < nsteps; ++s) {
+        // beta = hi + lo (two round-to-nearest bf16 pieces) of the lane's coordinates 32 m + 8 kg + i, times log2(e), per tile
+        u32x4 bq[NT2][G::M32][2];
+#pragma unroll
+        for (int t = 0; t < NT2; ++t)
+#pragma unroll
+            for (int m = 0; m < G::M32; ++m) {
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(&qnew[t][4 * m + kg][0][c][0]);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(&qnew[t][4 * m + kg][1][c][0]);
+                const float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                uint32_t hi[4], lo[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float x0 = x[2 * i] * ExpScale<float>::k, x1 = x[2 * i + 1] * ExpScale<float>::k;
+                    hi[i] = pack_rne(x0, x1);
+                    const float h0 = __builtin_bit_cast(float, hi[i] << 16), h1 = __builtin_bit_cast(float, hi[i] & 0xFFFF0000u);
+                    lo[i] = pack_rne(x0 - h0, x1 - h1);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int j = (kg & 1) ? (i ^ 2) : i;  // odd kg: halves swapped, as the eta read delivers them
+                    bq[t][m][0][i] = hi[j];
+                    bq[t][m][1][i] = lo[j];
+                }
+            }
+        f32x4 gacc[NT2][G::MBP];
+#pragma unroll
+        for (int t = 0; t < NT2; ++t)
+#pragma unroll
+            for (int mb = 0; mb < G::MBP; ++mb) gacc[t][mb] = f32x4{0, 0, 0, 0};
+        LR_TRAJ_PHASE(0);
+        // The row loop runs the gradient half ONE BLOCK BEHIND the eta half: trip b issues the eta MFMAs of block b with the
+        // sigmoid of block b - 1 (independent work) in their shadow, then the gradient MFMAs of block b - 1 with the transposed
+        // operand reads of block b in theirs.  The two waves of a SIMD leave every barrier in lockstep and stay there -- with the
+        // matrix and the vector work of a trip depending on each other (eta -> sigmoid -> gradient of the SAME block) both waves
+        // did their MFMAs together and their sigmoids together, the matrix pipe idle meanwhile: every exp / rcp cost its full issue
+        // time (profiles/r5_traj2_marginal_costs.txt).
+        u32x2 xt[G::MBP][2];  // transposed (gradient) operands of the block whose gradient MFMAs are still to come
+        f32x4 e[NT2][2];      // its eta
+        auto read_xt = [&](const uint16_t* base) {
+#pragma unroll
+            for (int mb = 0; mb < G::MBP; ++mb) {
+                xt[mb][0] = lds_read_tr16(base + G::tile1(0, mb >> 1) + tr_off[mb & 1]);
+                xt[mb][1] = lds_read_tr16(base + G::tile1(1, mb >> 1) + tr_off[mb & 1]);
+            }
+        };
+        // One MFMA "slot" = the MFMA and the vector / LDS instructions that issue in its shadow; a scheduling barrier closes every slot, so
+        // the emitted order is the source order (the group-barrier form left the sigmoid in one run in front of the MFMAs).
+        constexpr int NE = 4 * G::M32, NG = G::MBP;  // eta / gradient MFMAs per tile
+        auto eta_mfma = [&](const u32x4 (&xa)[2][G::M32], int i, f32x4 (&en)[NT2][2]) {  // slot i of the 2 NE: tile i / NE, then (m, h, T)
+            const int t = i / NE, r = i % NE, m = r / 4, h = (r >> 1) & 1, T = r & 1;
+            if (LR_TRAJ_EXP(2) && h) return;
+            if (m == 0 && h == 0) en[t][T] = f32x4{0, 0, 0, 0};
+            en[t][T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(xa[T][m]), as_bf16x8(bq[t][m][h]), en[t][T], 0, 0, 0);
+        };
+        auto grad_mfma = [&](int t, int mb, const u32x4& wv) {
+            if (LR_TRAJ_EXP(1) && mb) return;
+            const u32x4 xg = {xt[mb][0][0], xt[mb][0][1], xt[mb][1][0], xt[mb][1][1]};
+            gacc[t][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(xg), as_bf16x8(wv), gacc[t][mb], 0, 0, 0);
+        };
+        // the sigmoid of both tiles of the pending block as four stages over 16 values (v = 8 t + 4 T + r), two values per slot
+        float sx[16];
+        uint32_t spk[8];
+        auto sig_stage = [&](int stage, int v) {
+            const int t = v >> 3, T = (v >> 2) & 1, r = v & 3;
+            if (stage == 0) sx[v] = LR_TRAJ_EXP(0) ? e[t][T][r] : __builtin_amdgcn_exp2f(e[t][T][r]);
+            else if (stage == 1) sx[v] = LR_TRAJ_EXP(0) ? sx[v] : 1.0f + sx[v];
+            else if (stage == 2) sx[v] = LR_TRAJ_EXP(0) ? sx[v] : fast_rcp(sx[v]);
+            else if ((v & 1) == 0) spk[v >> 1] = pack_rne(sx[v], sx[v + 1]);
+        };
+        auto trip = [&](int b, auto first_tag) {
+            constexpr bool FIRST = decltype(first_tag)::value;
+            LR_TRAJ_PHASE(4);
+            // (the transposed reads of block b - 1 have returned before the DMA may overwrite its slot)
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+            if (!LR_TRAJ_EXP(3) && b + NBUF - 1 < wnb) issue(b + NBUF - 1);
+            const int last = b + NBUF - 1 < wnb ? b + NBUF - 1 : wnb - 1;
+            LR_TRAJ_PHASE(1);
+            if (!LR_TRAJ_EXP(3)) wait_vm_blocks<BLK_BYTES>(last - b);
+            LR_TRAJ_PHASE(2);
+            const uint16_t* base = reinterpret_cast<const uint16_t*>(ring + (b & (NBUF - 1)) * BLK_BYTES);
+            __builtin_amdgcn_sched_barrier(0);
+            // the eta operands of the block, requested two 32-coordinate chunks ahead of their MFMAs (all eight at once are 32
+            // registers this kernel does not have); tile 1 reads them again
+            u32x4 xa[2][G::M32];
+            auto read_xa = [&](int m) {
+                xa[0][m] = *reinterpret_cast<const u32x4*>(base + G::tile1(0, m) + eta_off);
+                xa[1][m] = *reinterpret_cast<const u32x4*>(base + G::tile1(1, m) + eta_off);
+            };
+            auto xa_ahead = [&](int i) {  // in the shadow of eta slot i: the chunk two ahead in the (tile, chunk) order
+                if (i % 4 != 0) return;
+                const int seq = i / 4 + 2;  // chunk sequence number over both tiles
+                if (seq < 2 * G::M32) read_xa(seq % G::M32);
+            };
+            read_xa(0);
+            if (G::M32 > 1) read_xa(1);
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 en[NT2][2];
+            if constexpr (FIRST) {
+#pragma unroll
+                for (int i = 0; i < 2 * NE; ++i) {
+                    eta_mfma(xa, i, en);
+                    xa_ahead(i);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                read_xt(base);
+            } else {
+                constexpr int Q = 2 * NE / 4, VPS = 16 / Q;  // slots per sigmoid stage, values per slot (P = 128: 8 and 2, P = 64: 4 and 4)
+                static_assert(2 * NE % 4 == 0 && Q * VPS == 16, "sixteen sigmoid values over a quarter of the eta slots per stage");
+#pragma unroll
+                for (int i = 0; i < 2 * NE; ++i) {
+                    eta_mfma(xa, i, en);
+                    xa_ahead(i);
+                    const int stage = i / Q, k = i % Q;        // values VPS k .. VPS k + VPS - 1 of this stage
+#pragma unroll
+                    for (int v = 0; v < VPS; ++v) sig_stage(stage, VPS * k + v);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const u32x4 w0 = {spk[0], spk[1], spk[2], spk[3]}, w1 = {spk[4], spk[5], spk[6], spk[7]};
+#pragma unroll
+                for (int mb = 0; mb < NG; ++mb) {
+                    grad_mfma(0, mb, w0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int mb = 0; mb < NG; ++mb) {  // the last use of xt[mb]: block b's operand takes its place
+                    grad_mfma(1, mb, w1);
+                    xt[mb][0] = lds_read_tr16(base + G::tile1(0, mb >> 1) + tr_off[mb & 1]);
+                    xt[mb][1] = lds_read_tr16(base + G::tile1(1, mb >> 1) + tr_off[mb & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NT2; ++t) e[t][0] = en[t][0], e[t][1] = en[t][1];
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if (wnb > 0) trip(0, std::integral_constant<bool, true>{});
+        for (int b = 1; b < wnb; ++b) trip(b, std::integral_constant<bool, false>{});
+        if (wnb > 0) {  // drain: sigmoid and gradient of the last block
+#pragma unroll
+            for (int stage = 0; stage < 4; ++stage)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) sig_stage(stage, v);
+            const u32x4 w0 = {spk[0], spk[1], spk[2], spk[3]}, w1 = {spk[4], spk[5], spk[6], spk[7]};
+#pragma unroll
+            for (int mb = 0; mb < NG; ++mb) grad_mfma(0, mb, w0);
+#pragma unroll
+            for (int mb = 0; mb < NG; ++mb) grad_mfma(1, mb, w1);
+        }
+        // every ring slot has been read: the next step's first blocks travel while the step is finished
+        // (the step's constants -- drift factors, prior precisions of the thread's coordinates -- are fetched again every step, AHEAD of
+        //  the DMA requests so that a counted vmcnt wait reaches them: held in registers across the row loop they spilled to scratch)
+        const f32x4 sb = *reinterpret_cast<const f32x4*>(a.cvec + 4 * oq), si = *reinterpret_cast<const f32x4*>(a.cvec + P + 4 * oq);
+        asm volatile("" ::: "memory");
+        int dma_pending = 0;
+        if (!LR_TRAJ_EXP(3) && s + 1 < nsteps) {
+#pragma unroll
+            for (int b = 0; b < NBUF - 1; ++b)
+                if (b < wnb) issue(b), ++dma_pending;
+        }
+        LR_TRAJ_PHASE(4);
+        // the waves' gradients meet in every wave's own exchange slot, a tile at a time; wave-order fp64 sums, then the step's kick and drift
+#pragma unroll
+        for (int t = 0; t < (LR_TRAJ_EXP(5) ? 0 : NT2); ++t) {
+#pragma unroll
+            for (int mb = 0; mb < G::MBP; ++mb) {
+                const int q = 8 * (mb >> 1) + 2 * kg + (mb & 1);  // chunk of coordinates 32 (mb >> 1) + 8 kg + 4 (mb & 1) ..
+                *reinterpret_cast<f32x4*>(xslot + xw_row + ((q ^ xw_sw) << 2)) = gacc[t][mb];
+            }
+            __syncthreads();
+            if (t == 0) wait_vm_blocks<BLK_BYTES>(dma_pending);  // sb, si have arrived (the DMA requests behind them may still be in flight)
+            if (owner) {
+                f32x4 pw[NW];
+#pragma unroll
+                for (int w = 0; w < NW; ++w) pw[w] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(smem + w * RING_BYTES + (NBUF - 1) * BLK_BYTES) + xr_off);
+                f32x4 qn = qslot(t), pn = pmom[t][tid];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    double gs = 0.0;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) gs += (double)pw[w][i];  // wave order
+                    const float g1 = (float)gs - qn[i] * si[i];
+                    pn[i] = fma_t(a.step, g1, pn[i]);
+                    qn[i] = fma_t(sb[i], pn[i], qn[i]);
+                }
+                qslot(t) = qn;
+                pmom[t][tid] = pn;
+            }
+            __syncthreads();  // the exchange slots have been read (next tile / the next step's DMA may overwrite them); qnew is complete
+        }
+        LR_TRAJ_PHASE(3);
+    }
+    LR_TRAJ_PHASES_REPORT(a)
+#pragma unroll
+    for (int t = 0; t < NT2; ++t) {
+        bool live;
+        const int64_t at = state_at(t, live);
+        if (live) {
+            *reinterpret_cast<f32x4*>(a.q1 + at) = qslot(t);
+            *reinterpret_cast<f32x4*>(a.pm + at) = pmom[t][tid];
         }
     }
 }

@@ -1,40 +1,35 @@
 #!/usr/bin/env python3
-"""Copy the summaries of a tools/gpu_profile.sh run (gpurun_out/<dir>) into profiles/ (tracked).
-usage: refresh_profiles.py gpurun_out/prof_xxx gpurun_out/bench_xxx.json [cfg45_summary.txt]"""
-import json, os, shutil, sqlite3, subprocess, sys
+"""Copy the summaries of a tools/gpu_profile.sh run of bench.py (gpurun_out/<dir>) into profiles/ (tracked).
+usage: refresh_profiles.py <tag> gpurun_out/<dir>      e.g.  refresh_profiles.py r5 gpurun_out/prof_r5
+Writes profiles/<tag>_rocprof_summary.txt (kernel trace + PMC passes of `python3 bench.py --no-cpu-baseline --no-ess`),
+profiles/<tag>_traffic.json (HBM bytes per launch of the headline kernel, for bench.py's roofline.traffic) and
+profiles/<tag>_bench_line_profiled.json (the bench line of the traced run)."""
+import json, os, re, shutil, sys
 
-src, bench_json = sys.argv[1], sys.argv[2]
+tag, src = sys.argv[1], sys.argv[2]
 here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 prof = os.path.join(here, "profiles")
-subprocess.check_call([sys.executable, os.path.join(here, "tools", "summarize_prof.py"), src,
-                       os.path.join(prof, "r1_hmc_reg16x13_rocprof.txt")], stdout=subprocess.DEVNULL)
-lines = []
-for c in (3, 4, 5):
-    con = sqlite3.connect(f"{src}/trace_cfg{c}/cfg{c}_results.db")
-    lines.append(f"## config {c}: rocprofv3 --kernel-trace --stats -- python3 tools/bench_configs.py {c}   (durations in us)")
-    lines.append(f"{'calls':>6} {'total_us':>12} {'avg_us':>10} {'pct':>7}  kernel")
-    for name, calls, total, avg, pct in con.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
-        lines.append(f"{calls:6d} {total:12.1f} {avg:10.2f} {pct:7.2f}  {name}")
-    lines.append("")
-open(os.path.join(prof, "r1_configs_3_4_5_kernel_trace.txt"), "w").write("\n".join(lines) + "\n")
-shutil.copy(f"{src}/sweep.log", os.path.join(prof, "r1_variant_sweep.log"))
-shutil.copy(f"{src}/configs.jsonl", os.path.join(prof, "r1_configs_1_3_4_5.jsonl"))
+txt = open(os.path.join(src, "summary.txt")).read()
+open(os.path.join(prof, f"{tag}_rocprof_summary.txt"), "w").write(txt)
+line = open(os.path.join(src, "bench_line.json")).read().strip()
+d = json.loads(line)
+open(os.path.join(prof, f"{tag}_bench_line_profiled.json"), "w").write(line + "\n")
 
 
-def avg(db, ctr):
-    con = sqlite3.connect(db)
-    return con.execute("select avg(value) from counters_collection where counter_name=? and kernel_name like '%k_chain%'", (ctr,)).fetchone()[0]
+def counter(name, kernel_pat):
+    m = re.search(r"^\s*%s\s+([0-9.]+)\s+\(n=\d+\)\s+.*%s" % (name, kernel_pat), txt, re.M)
+    return float(m.group(1))
 
 
-f = avg(f"{src}/pmc_FETCH_SIZE/bench_results.db", "FETCH_SIZE")
-w = avg(f"{src}/pmc_WRITE_SIZE/bench_results.db", "WRITE_SIZE")
-tp = os.path.join(prof, "r1_traffic.json")
-t = json.load(open(tp))
-t["FETCH_SIZE_KB_per_launch"], t["WRITE_SIZE_KB_per_launch"], t["hbm_bytes_per_launch"] = f, w, (2 * f + w) * 1024
-json.dump(t, open(tp, "w"), indent=1)
-line = open(bench_json).read().strip().splitlines()[-1]
-json.loads(line)
-open(os.path.join(prof, "r1_bench_line.json"), "w").write(line + "\n")
-if len(sys.argv) > 3:
-    shutil.copy(sys.argv[3], os.path.join(prof, "r1_configs_4_5_pmc.txt"))
-print(line[:240])
+kpat = r"k_chain<float, 8, 16, 0, 13, 2>"
+f, w = counter("FETCH_SIZE", kpat), counter("WRITE_SIZE", kpat)
+t = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python3 bench.py --no-cpu-baseline --no-ess`, "
+               "" + f"{tag} (tools/gpu_profile.sh; profiles/{tag}_rocprof_summary.txt)",
+     "kernel": "lr::k_chain<float, 8, 16, 0, 13, 2>", "kernel_variant": d["config"]["kernel_variant"],
+     "chains": d["config"]["chains_per_gpu"], "thin": d["config"]["thin"],
+     "FETCH_SIZE_KB_per_launch": f, "WRITE_SIZE_KB_per_launch": w,
+     "correction": "MI355X_MICROARCH.md HBM section: hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024; FETCH_SIZE counts 128-B requests "
+                   "at 64 B on gfx950 -> doubled (an upper bound: calibrated for wide coalesced reads only)",
+     "hbm_bytes_per_launch": (2 * f + w) * 1024}
+json.dump(t, open(os.path.join(prof, f"{tag}_traffic.json"), "w"), indent=1)
+print(json.dumps(t)[:300])

@@ -7,9 +7,12 @@ import sqlite3
 import sys
 
 src, dst = sys.argv[1], sys.argv[2]
-lines = [f"# rocprofv3 summary of `python3 bench.py --no-cpu-baseline --no-ess` ({os.path.basename(src)})",
+cmd_file = os.path.join(src, "command.txt")
+cmd = open(cmd_file).read().strip() if os.path.exists(cmd_file) else "python3 bench.py --no-cpu-baseline --no-ess"
+lines = [f"# rocprofv3 summary of `{cmd}` ({os.path.basename(src)})",
          "# produced by tools/gpu_profile.sh on one MI355X; kernel-trace and each --pmc set are separate runs", ""]
-db = os.path.join(src, "trace", "bench_results.db")
+dbs = glob.glob(os.path.join(src, "trace", "**", "*_results.db"), recursive=True)
+db = dbs[0] if dbs else os.path.join(src, "trace", "bench_results.db")
 if os.path.exists(db):
     con = sqlite3.connect(db)
     lines.append("## --kernel-trace --stats (durations in us)")
@@ -27,9 +30,10 @@ if os.path.exists(db):
     except sqlite3.Error:
         pass
     lines.append("")
-for db in sorted(glob.glob(os.path.join(src, "pmc_*", "bench_results.db"))):
+for db in sorted(glob.glob(os.path.join(src, "pmc_*", "**", "*_results.db"), recursive=True)):
     con = sqlite3.connect(db)
-    lines.append(f"## --pmc pass {os.path.basename(os.path.dirname(db))} (per-dispatch average over all dispatches of the kernel)")
+    pass_name = os.path.relpath(db, src).split(os.sep)[0]
+    lines.append(f"## --pmc pass {pass_name} (per-dispatch average over all dispatches of the kernel)")
     for kname, cname, avg, n in con.execute("select kernel_name, counter_name, avg(value), count(*) from counters_collection "
                                             "group by kernel_name, counter_name order by kernel_name, counter_name"):
         if "lr::" in kname:
