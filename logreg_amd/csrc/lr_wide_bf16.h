@@ -895,9 +895,12 @@ __global__ void __launch_bounds__(512) k_wide_traj2_bf16(TallArgs<float, P> a) {
     static_assert(16 * P * 4 == BLK_BYTES, "a tile's gradients fill exactly one ring slot");
     static_assert(P == 128 || P == 64, "chunk ownership below");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[NW * RING_BYTES];
-    // coordinate j of chain c of tile t at [t][j / 8][(j / 4) & 1][c][j & 3]: the b128 reads of lanes (c, kg) are conflict-free
-    // (see k_wide_partial_bf16r)
-    __shared__ __attribute__((aligned(16))) float qnew[NT2][P / 8][2][16][4];
+    // The beta operands of the eta MFMAs, READY-MADE: piece h (hi, lo) of the 8 coordinates 32 m + 8 kg + .. of chain c of tile t as the
+    // 16 bytes lane (c, kg) feeds the MFMA (odd kg: halves swapped, as the eta read of the rows delivers them), at
+    // [t][m][kg][h][c ^ ((4 m + kg) & 15)] -- the XOR keeps the 16 chains of a reader's service group AND the 16 (m, kg) cells an owner
+    // thread's chain is spread over on distinct bank groups.  Written once per step by the thread that owns the coordinates (8 values
+    // per thread) instead of being rebuilt from fp32 positions by every lane of all 8 waves (64 values per lane: 3400 cycles per step).
+    __shared__ __attribute__((aligned(16))) uint32_t qop[NT2][G::M32][4][2][16][4];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, kg = lane >> 4;
@@ -942,21 +945,31 @@ __global__ void __launch_bounds__(512) k_wide_traj2_bf16(TallArgs<float, P> a) {
         if (ch >= a.C) ch = a.C - 1;
         return ch * P + 4 * (tix % NQ);
     };
-    // position and momentum of the thread's coordinates live in LDS between the reductions (qnew and pmom: the row loop needs the
-    // registers): 8 + 8 floats per thread
+    // Between the reductions the thread's momenta wait in LDS (pmom) and its positions in a.q1 itself -- the row loop needs every
+    // register, and the LDS is full: 8 + 8 floats per thread.
     __shared__ __attribute__((aligned(16))) f32x4 pmom[NT2][512];
-    f32x4 sq[NT2];
+    // the two bf16 pieces of k * position for the thread's four coordinates -> qop
+    auto put_ops = [&](int t, const f32x4& q) {
+        const int m = oq >> 3, okg = (oq >> 1) & 3, ip = ((oq & 1) << 1) ^ ((okg & 1) << 1);  // pair slot after the odd-kg half swap
+        uint32_t hi[2], lo[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float x0 = q[2 * i] * ExpScale<float>::k, x1 = q[2 * i + 1] * ExpScale<float>::k;
+            hi[i] = pack_rne(x0, x1);
+            const float h0 = __builtin_bit_cast(float, hi[i] << 16), h1 = __builtin_bit_cast(float, hi[i] & 0xFFFF0000u);
+            lo[i] = pack_rne(x0 - h0, x1 - h1);
+        }
+        const int cs = occ ^ ((4 * m + okg) & 15);
+        *reinterpret_cast<u32x2*>(&qop[t][m][okg][0][cs][ip]) = u32x2{hi[0], hi[1]};
+        *reinterpret_cast<u32x2*>(&qop[t][m][okg][1][cs][ip]) = u32x2{lo[0], lo[1]};
+    };
 #pragma unroll
     for (int t = 0; t < NT2; ++t) {
         bool live;
         const int64_t at = state_at(t, live);
-        sq[t] = *reinterpret_cast<const f32x4*>(a.q1 + at);
+        const f32x4 q0 = *reinterpret_cast<const f32x4*>(a.q1 + at);
         pmom[t][tid] = *reinterpret_cast<const f32x4*>(a.pm + at);
-    }
-    auto qslot = [&](int t) -> f32x4& { return *reinterpret_cast<f32x4*>(&qnew[t][oq >> 1][oq & 1][occ][0]); };
-    if (owner) {
-#pragma unroll
-        for (int t = 0; t < NT2; ++t) qslot(t) = sq[t];
+        if (owner) put_ops(t, q0);
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);  // nothing but the DMA ring counts on vmcnt from here on
 #pragma unroll
@@ -975,30 +988,14 @@ __global__ void __launch_bounds__(512) k_wide_traj2_bf16(TallArgs<float, P> a) {
     const int nsteps = a.l - 1;
     LR_TRAJ_PHASES_BEGIN  // development builds: shader cycles per phase of a step (lr_stamps.h)
     for (int s = 0; s < nsteps; ++s) {
-        // beta = hi + lo (two round-to-nearest bf16 pieces) of the lane's coordinates 32 m + 8 kg + i, times log2(e), per tile
+        // beta = hi + lo (two round-to-nearest bf16 pieces) of the lane's coordinates 32 m + 8 kg + i, times log2(e), per tile: ready in qop
         u32x4 bq[NT2][G::M32][2];
 #pragma unroll
         for (int t = 0; t < NT2; ++t)
 #pragma unroll
-            for (int m = 0; m < G::M32; ++m) {
-                const f32x4 v0 = *reinterpret_cast<const f32x4*>(&qnew[t][4 * m + kg][0][c][0]);
-                const f32x4 v1 = *reinterpret_cast<const f32x4*>(&qnew[t][4 * m + kg][1][c][0]);
-                const float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                uint32_t hi[4], lo[4];
+            for (int m = 0; m < G::M32; ++m)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float x0 = x[2 * i] * ExpScale<float>::k, x1 = x[2 * i + 1] * ExpScale<float>::k;
-                    hi[i] = pack_rne(x0, x1);
-                    const float h0 = __builtin_bit_cast(float, hi[i] << 16), h1 = __builtin_bit_cast(float, hi[i] & 0xFFFF0000u);
-                    lo[i] = pack_rne(x0 - h0, x1 - h1);
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int j = (kg & 1) ? (i ^ 2) : i;  // odd kg: halves swapped, as the eta read delivers them
-                    bq[t][m][0][i] = hi[j];
-                    bq[t][m][1][i] = lo[j];
-                }
-            }
+                for (int h = 0; h < 2; ++h) bq[t][m][h] = *reinterpret_cast<const u32x4*>(&qop[t][m][kg][h][c ^ ((4 * m + kg) & 15)][0]);
         f32x4 gacc[NT2][G::MBP];
 #pragma unroll
         for (int t = 0; t < NT2; ++t)
@@ -1049,6 +1046,8 @@ __global__ void __launch_bounds__(512) k_wide_traj2_bf16(TallArgs<float, P> a) {
             LR_TRAJ_PHASE(4);
             // (the transposed reads of block b - 1 have returned before the DMA may overwrite its slot)
             __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+            // (the requests stay in front of the wait: one per eta slot, in the MFMAs' shadow, cost 11 500 cycles more per step than the
+            //  2900 they take here -- profiles/r5_cfg5_whole.txt)
             if (!LR_TRAJ_EXP(3) && b + NBUF - 1 < wnb) issue(b + NBUF - 1);
             const int last = b + NBUF - 1 < wnb ? b + NBUF - 1 : wnb - 1;
             LR_TRAJ_PHASE(1);
@@ -1126,8 +1125,19 @@ __global__ void __launch_bounds__(512) k_wide_traj2_bf16(TallArgs<float, P> a) {
         // every ring slot has been read: the next step's first blocks travel while the step is finished
         // (the step's constants -- drift factors, prior precisions of the thread's coordinates -- are fetched again every step, AHEAD of
         //  the DMA requests so that a counted vmcnt wait reaches them: held in registers across the row loop they spilled to scratch)
-        const f32x4 sb = *reinterpret_cast<const f32x4*>(a.cvec + 4 * oq), si = *reinterpret_cast<const f32x4*>(a.cvec + P + 4 * oq);
-        asm volatile("" ::: "memory");
+        // ... and so are the thread's positions, which it stored itself a step ago (L1-bypassing loads: the stores went to L2).  The loads
+        // are inline asm: the compiler's own wait insertion knows nothing of the DMA requests queued behind them and would wait for
+        // vmcnt(0) -- the whole prefetch -- at their first use; the counted wait below is tied to the four registers instead.
+        f32x4 sb, si, qg[NT2];
+        bool qlive[NT2];
+        int64_t qat[NT2];
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sb) : "v"(a.cvec + 4 * oq) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(si) : "v"(a.cvec + P + 4 * oq) : "memory");
+#pragma unroll
+        for (int t = 0; t < NT2; ++t) {
+            qat[t] = state_at(t, qlive[t]);
+            asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(qg[t]) : "v"(a.q1 + qat[t]) : "memory");
+        }
         int dma_pending = 0;
         if (!LR_TRAJ_EXP(3) && s + 1 < nsteps) {
 #pragma unroll
@@ -1144,12 +1154,21 @@ __global__ void __launch_bounds__(512) k_wide_traj2_bf16(TallArgs<float, P> a) {
                 *reinterpret_cast<f32x4*>(xslot + xw_row + ((q ^ xw_sw) << 2)) = gacc[t][mb];
             }
             __syncthreads();
-            if (t == 0) wait_vm_blocks<BLK_BYTES>(dma_pending);  // sb, si have arrived (the DMA requests behind them may still be in flight)
+            if (t == 0) {  // constants and positions have arrived (the DMA requests behind them may still be in flight)
+                static_assert(NT2 == 2, "registers named in the waits");
+                constexpr int per = BLK_BYTES / 1024;
+#define LR_WAIT_VM4(N) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(sb), "+v"(si), "+v"(qg[0]), "+v"(qg[1]) : "n"(N) : "memory")
+                if (dma_pending >= 3) LR_WAIT_VM4(3 * per);
+                else if (dma_pending == 2) LR_WAIT_VM4(2 * per);
+                else if (dma_pending == 1) LR_WAIT_VM4(per);
+                else LR_WAIT_VM4(0);
+#undef LR_WAIT_VM4
+            }
             if (owner) {
                 f32x4 pw[NW];
 #pragma unroll
                 for (int w = 0; w < NW; ++w) pw[w] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(smem + w * RING_BYTES + (NBUF - 1) * BLK_BYTES) + xr_off);
-                f32x4 qn = qslot(t), pn = pmom[t][tid];
+                f32x4 qn = qg[t], pn = pmom[t][tid];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     double gs = 0.0;
@@ -1159,10 +1178,11 @@ __global__ void __launch_bounds__(512) k_wide_traj2_bf16(TallArgs<float, P> a) {
                     pn[i] = fma_t(a.step, g1, pn[i]);
                     qn[i] = fma_t(sb[i], pn[i], qn[i]);
                 }
-                qslot(t) = qn;
+                put_ops(t, qn);
                 pmom[t][tid] = pn;
+                if (qlive[t]) *reinterpret_cast<f32x4*>(a.q1 + qat[t]) = qn;
             }
-            __syncthreads();  // the exchange slots have been read (next tile / the next step's DMA may overwrite them); qnew is complete
+            __syncthreads();  // the exchange slots have been read (next tile / the next step's DMA may overwrite them); qop is complete
         }
         LR_TRAJ_PHASE(3);
     }
@@ -1171,10 +1191,7 @@ __global__ void __launch_bounds__(512) k_wide_traj2_bf16(TallArgs<float, P> a) {
     for (int t = 0; t < NT2; ++t) {
         bool live;
         const int64_t at = state_at(t, live);
-        if (live) {
-            *reinterpret_cast<f32x4*>(a.q1 + at) = qslot(t);
-            *reinterpret_cast<f32x4*>(a.pm + at) = pmom[t][tid];
-        }
+        if (live) *reinterpret_cast<f32x4*>(a.pm + at) = pmom[t][tid];  // (the position is in a.q1 already)
     }
 }
 

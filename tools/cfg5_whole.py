@@ -9,7 +9,7 @@ import numpy as np, logreg_amd as la
 from logreg_amd import _lib
 import bench
 
-args = [a for a in sys.argv[1:] if not a.startswith("--")]
+args = [a for i, a in enumerate(sys.argv[1:], 1) if not a.startswith("--") and not sys.argv[i - 1].startswith("--")]
 iters = int(sys.argv[sys.argv.index("--iters") + 1]) if "--iters" in sys.argv else 4
 prec = sys.argv[sys.argv.index("--prec") + 1] if "--prec" in sys.argv else "auto"
 fix = json.load(open(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "fullsize_cfg5.json")))
