@@ -226,9 +226,10 @@ def extra_configs(la, L, check, dev, stream):
                              "note": "1 fused value+gradient evaluation per iteration (F_g flops counted; the value's "
                                      "log and the Philox/Box-Muller work, ~60 % of the instructions, are not)"}})
     # ---- configs 4 and 5: stepwise engines at full size, tuned step sizes from the committed fixtures
-    for cfg in (4, 5):
+    # ("5_whole": config 5 AS A WHOLE -- all 8192 chains on this one GPU instead of one eighth of them: the matrix-pipe roofline point)
+    for cfg, C, label in ((4, 1024, 4), (5, 1024, 5), (5, 8192, "5_whole")):
         fix = json.load(open(os.path.join(REPO, "tests", "golden", f"fullsize_cfg{cfg}.json")))
-        n, p, C = fix["n"], fix["p"], 1024
+        n, p = fix["n"], fix["p"]
         X, y, _ = la.synthetic_logreg(n, p, seed=fix["data_seed"], beta_sd=fix["beta_sd"])
         m = la.LogReg(X, y, np.array(fix["pscale"]), device=dev)
         k = la.hmcKernel(m.lpost, m.glp, eps=fix["eps"], l=fix["l"], dmm=np.array(fix["dmm"]))
@@ -242,8 +243,9 @@ def extra_configs(la, L, check, dev, stream):
         fg = flops_per_grad_eval(n, p)
         ach = C * fg / per_eval_s / 1e12
         acc = float(cs.get_accepts().sum() / (C * (3 * iters + 1)))
-        row = {"config": cfg, "workload": f"HMC L={fix['l']} eps={fix['eps']} unit mass, synthetic n={n} p={p}, {C} chains"
-               + (" (one GPU's shard of 8192)" if cfg == 5 else ""), "kernel_variant": cs.plan(),
+        row = {"config": label, "workload": f"HMC L={fix['l']} eps={fix['eps']} unit mass, synthetic n={n} p={p}, {C} chains"
+               + (" (one GPU's shard of 8192)" if label == 5 else " (BASELINE.json configs[4] as a whole on ONE GPU)" if label == "5_whole" else ""),
+               "kernel_variant": cs.plan(),
                "interior_precision": "auto (bf16 matrix pipe for the L-1 interior gradients; end points exact)",
                "chain_iterations_per_s": C * iters / (ms * 1e-3), "grad_evals_per_s": C * evals / (ms * 1e-3),
                "accept_rate": acc, "us_per_evaluation_all_chains": per_eval_s * 1e6,
@@ -268,7 +270,10 @@ def extra_configs(la, L, check, dev, stream):
                                "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
                                "frac_of_fp32_peak": ach / PEAK_FP32_TFLOPS, "flops_per_grad_eval": fg,
                                "note": "algorithmic flops counted once (SURVEY 8(d)); at 1024 chains an evaluation is 2.15 GFLOP = "
-                                       "0.9 us of the bf16 pipe: launch, prologue and epilogue dominate (DESIGN.md section 5)"}
+                                       "0.9 us of the bf16 pipe: launch, prologue and epilogue dominate (DESIGN.md section 5)" if C == 1024 else
+                                       "algorithmic flops counted once (SURVEY 8(d)); 17.4 GFLOP per evaluation; the interior steps run as ONE "
+                                       "launch per trajectory (k_wide_traj2_bf16: 32 chains per workgroup, one workgroup per CU); the MFMAs issued "
+                                       "are 1.5x the algorithmic ones (beta in two bf16 pieces): MFMA-busy 52-57 % (profiles/r5_cfg5_whole*.txt)"}
         res.append(row)
     return res
 

@@ -89,6 +89,11 @@ typedef struct lr_run_opts {
                            * run's chain count, so that every choice that depends on the chain count (kernel variant, row
                            * slicing of the stepwise engine and of its interior kernels, trajectory kernels) is the one-GPU
                            * run's and the shard's output is bit-identical to the same chains of that run */
+    /* (layout history: `plan_first` was appended in round 4 -- lr_sizeof_run_opts() lets a binding check its struct against the
+     *  library's; a caller that zero-initialises an OLDER, shorter struct must not be linked against this library.  With
+     *  plan_chains > 0 the launched chains [chain_offset, chain_offset + n_chains) must lie inside the planned run
+     *  [plan_first, plan_first + plan_chains): LR_ERR_INVALID otherwise -- a chain_offset used only to decorrelate runs goes with
+     *  plan_chains = 0.) */
     int64_t plan_first;   /* read only when plan_chains > 0: global id (chain_offset units) of the FIRST chain of the run being
                            * planned for.  A run planned in two parts (lr_plan_info.split: an exactly-filled head on narrow lane
                            * groups, the remainder on wide ones) assigns a chain to its part by its position in the WHOLE run,
@@ -112,10 +117,11 @@ typedef struct lr_run_opts {
  *                  ... and for a float64 model with p <= 16 and rows within the register variants (LR_MODE_MIXED): float32 interior gradients -- the
  *                    trajectory's position and momentum, both end-point evaluations, the half kicks, the kinetic energies and
  *                    the Metropolis test stay float64; only the force applied inside the trajectory is computed from the
- *                    position and the rows rounded to float32 (4 - 5 x the all-float64 rate); from 40 chains per CU (n <= 208) the
+ *                    position and the rows rounded to float32 (4 - 5 x the all-float64 rate); from 33 chains per CU (n <= 208) the
  *                    fused matrix-core kernel takes over (LR_MODE_MFMA, bf16 interior force, the same float64 everything else);
  *                    tall and wide float64 models run the stepwise engine's bf16 interior kernels on a float64 state;
- *                  elsewhere (other float64 models, p < 5, few chains on register/LDS-resident data) it is LR_PREC_FULL.
+ *                  elsewhere (other float64 models -- 17 <= p <= 32 with rows in LDS run all-float64 on the distributed-state
+ *                    kernel --, p < 5, few chains on register/LDS-resident data) it is LR_PREC_FULL.
  *                  A default HMC run is therefore NOT step-for-step comparable with a float64 reference run (the
  *                  posterior is the same; acceptance rates measured within 0.001 - 0.01 of the exact-gradient run);
  *   LR_PREC_FULL   every evaluation in the model's dtype (comparable with the float64 oracle step by step)

@@ -159,6 +159,7 @@ def _build_locked(jobs: int | None, verbose: bool) -> str:
         for warn in ex.map(_run, jobs_list):
             if warn.strip() and verbose:
                 print(warn, file=sys.stderr)
+    resource_gate(strict=not extra, verbose=verbose)
     tmp = LIB + f".tmp{os.getpid()}"
     _run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", tmp, *objs])
     os.replace(tmp, LIB)
@@ -167,6 +168,25 @@ def _build_locked(jobs: int | None, verbose: bool) -> str:
     if verbose:
         print(f"[logreg_amd.build] wrote {LIB}", flush=True)
     return LIB
+
+
+def resource_gate(strict: bool = True, verbose: bool = True) -> None:
+    """No kernel of the library may use scratch memory (`.private_segment_fixed_size` of every gfx950 code object must be 0): a
+    register spill to scratch is a large, silent slowdown, and the one kernel family ever found computing wrong results (round 4,
+    float64 at padded p = 32) was one that spilled.  No whitelist.  Production builds fail here, before the library is linked;
+    development builds (LOGREG_HIPCC_FLAGS: instrumentation may cost registers) only report."""
+    rows = kernel_resources()
+    if not rows:
+        raise RuntimeError("resource gate: no kernel metadata found under " + OBJDIR)
+    bad = [r for r in rows if r["scratch"]]
+    if verbose:
+        print(f"[logreg_amd.build] resource gate: {len(rows)} kernels, {len(bad)} with scratch, "
+              f"{sum(1 for r in rows if r['vgpr_spills'])} with VGPR->AGPR spills, {sum(1 for r in rows if r['sgpr_spills'])} with SGPR->VGPR-lane spills", flush=True)
+    if bad:
+        text = "\n".join(f"  {r['unit']}: {r['scratch']} bytes of scratch ({r['vgpr_spills']} VGPR / {r['sgpr_spills']} SGPR spills)  {r['name']}" for r in bad)
+        if strict:
+            raise RuntimeError("kernels with scratch memory (logreg_amd/build.py resource_gate):\n" + text)
+        print("[logreg_amd.build] development build: kernels with scratch memory\n" + text, file=sys.stderr)
 
 
 def _demangle(names):

@@ -329,9 +329,11 @@ void lr_model_destroy(lr_model* m) {
     if (m->d_xmx) (void)hipFree(m->d_xmx);
     if (m->d_xmf) (void)hipFree(m->d_xmf);
     if (m->d_xms) (void)hipFree(m->d_xms);
-    if (m->side_stream) (void)hipStreamDestroy(m->side_stream);
-    if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
-    if (m->ev_join) (void)hipEventDestroy(m->ev_join);
+    for (auto& e : m->sides) {
+        (void)hipStreamDestroy(e.stream);
+        (void)hipEventDestroy(e.ev_fork);
+        (void)hipEventDestroy(e.ev_join);
+    }
     delete m;
 }
 

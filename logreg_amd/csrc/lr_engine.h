@@ -90,14 +90,26 @@ int do_chain_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs, c
     // (a matrix-core head: workgroups per CU instead -- 16 chains per workgroup at S >= 4, 64 at S = 1)
     const int64_t head_rounds = pl.mode == lr::MODE_MFMA ? head / ((pl.G == 1 ? 64 : 16) * (int64_t)m->cus) : head * pl.G / 64 / (4LL * m->cus);
     const bool both = two && pl.corun && (rs.kind != lr::KIND_HMC || head_rounds <= 2);
-    if (both && !m->side_stream) {
-        if (hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming) != hipSuccess)
-            return fail(LR_ERR_HIP, "creating the side stream of a two-part launch failed: %s", hipGetErrorString(hipGetLastError()));
-    }
+    lr_model::Side* side_slot = nullptr;
     if (both) {
-        if (hipEventRecord(m->ev_fork, st) != hipSuccess || hipStreamWaitEvent(m->side_stream, m->ev_fork, 0) != hipSuccess)
+        for (auto& e : m->sides)
+            if (e.caller == st) side_slot = &e;
+        if (!side_slot) {  // created all or nothing: a partly made slot is destroyed again, never kept
+            lr_model::Side e{st, nullptr, nullptr, nullptr};
+            const bool ok = hipStreamCreateWithFlags(&e.stream, hipStreamNonBlocking) == hipSuccess &&
+                            hipEventCreateWithFlags(&e.ev_fork, hipEventDisableTiming) == hipSuccess &&
+                            hipEventCreateWithFlags(&e.ev_join, hipEventDisableTiming) == hipSuccess;
+            if (!ok) {
+                const hipError_t err = hipGetLastError();
+                if (e.ev_join) (void)hipEventDestroy(e.ev_join);
+                if (e.ev_fork) (void)hipEventDestroy(e.ev_fork);
+                if (e.stream) (void)hipStreamDestroy(e.stream);
+                return fail(LR_ERR_HIP, "creating the side stream of a two-part launch failed: %s", hipGetErrorString(err));
+            }
+            m->sides.push_back(e);
+            side_slot = &m->sides.back();
+        }
+        if (hipEventRecord(side_slot->ev_fork, st) != hipSuccess || hipStreamWaitEvent(side_slot->stream, side_slot->ev_fork, 0) != hipSuccess)
             return fail(LR_ERR_HIP, "forking the two-part launch failed: %s", hipGetErrorString(hipGetLastError()));
     }
     for (int part = 0; part < 2; ++part) {
@@ -105,14 +117,14 @@ int do_chain_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs, c
         ca.count = part == 0 ? head : C - head;
         if (ca.count <= 0) continue;
         const bool side = both && part == 1;
-        lr::LaunchCfg cfg{part == 0 ? pl.mode : pl.mode2, part == 0 ? pl.G : pl.G2, part == 0 ? pl.R : pl.R2, rs.kind, side ? m->side_stream : st,
+        lr::LaunchCfg cfg{part == 0 ? pl.mode : pl.mode2, part == 0 ? pl.G : pl.G2, part == 0 ? pl.R : pl.R2, rs.kind, side ? side_slot->stream : st,
                           part == 0 || pl.mode2 == lr::MODE_MIXED ? pl.lds_bytes : 0, m->dbg.residency_cap && !side ? m->cus : 0};
         const int rc = m->table->launch_chain(&cfg, ca.count, &ma, &ca);
         if (rc != 0) return fail(rc == -3 ? LR_ERR_UNSUPPORTED : LR_ERR_HIP, "chain launch failed (%d): %s", rc,
                                  hipGetErrorString(hipGetLastError()));
     }
     if (both) {
-        if (hipEventRecord(m->ev_join, m->side_stream) != hipSuccess || hipStreamWaitEvent(st, m->ev_join, 0) != hipSuccess)
+        if (hipEventRecord(side_slot->ev_join, side_slot->stream) != hipSuccess || hipStreamWaitEvent(st, side_slot->ev_join, 0) != hipSuccess)
             return fail(LR_ERR_HIP, "joining the two-part launch failed: %s", hipGetErrorString(hipGetLastError()));
     }
     return LR_OK;

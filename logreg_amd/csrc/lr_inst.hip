@@ -44,6 +44,11 @@ constexpr int P = LR_P;
 // float64 at Pima's width: the rows in registers as well (7 rows x 8 doubles = 112 VGPRs at 32 lanes per chain; 16 lanes x 13 rows = 208 of the 256 addressable registers spills
 // the state), plain (unpacked) v_fma_f64 arithmetic -- the reference computes in float64, so its rate is reported (bench.py extra.f64)
 #define LR_VARIANTS(X) X(MODE_REG, 64, 4) X(MODE_REG, 32, 7) X(MODE_LDS, 1, 0) X(MODE_LDS, 8, 0) X(MODE_LDS, 16, 0) X(MODE_LDS, 64, 0) X(MODE_GLOBAL, 64, 0) X(MODE_GLOBAL, 1, 0)
+#elif LR_DTYPE == 1 && LR_P == 32
+// float64 at 17 <= p <= 32: chains on the distributed-state kernel (k_chain_dist: 16 lanes own the coordinates), so lane groups of 16 and
+// 64; lane groups below 16 serve lr_eval only.  (No lane-per-chain variant with rows from the scalar unit: a row is 64 SGPRs and
+// k_eval spilled to scratch.)
+#define LR_VARIANTS(X) X(MODE_LDS, 1, 0) X(MODE_LDS, 8, 0) X(MODE_LDS, 16, 0) X(MODE_LDS, 64, 0) X(MODE_GLOBAL, 16, 0) X(MODE_GLOBAL, 64, 0)
 #else  // float64: validation-grade path, no register-resident variants
 #define LR_VARIANTS(X) X(MODE_LDS, 1, 0) X(MODE_LDS, 8, 0) X(MODE_LDS, 64, 0) X(MODE_GLOBAL, 64, 0) X(MODE_GLOBAL, 1, 0)
 #endif
@@ -115,15 +120,30 @@ int launch_capped(const LaunchCfg* cfg, dim3 grid, dim3 block, size_t lds_dynami
 
 template <int G, int MODE, int R>
 int launch_chain_v(const LaunchCfg* cfg, int64_t C, const ModelArgs<T, P>& m, const ChainArgs<T, P>& a) {
-#if LR_DTYPE == 1 && LR_P == 32
-    // float64 at 17 <= p <= 32: no fused chain kernels.  Replicated in every lane, the float64 state of such a chain (five to seven
-    // 32-vectors) takes the whole register file and more: the kernels spilled both files, and MALA on 64 lanes per chain -- with the
-    // compiler's other spill placement, on 8 -- computed wrong states (tests/fuzz_parity.py in float64, tools/f64_p32_repro.py).
-    // Runs of these models go to the stepwise engine (lr_plan.h), whose kernels hold one coordinate per lane.
-    (void)cfg; (void)C; (void)m; (void)a;
-    return -3;
-#else
     const dim3 grid = grid_for(C, G), block(256);
+#if LR_P == 32
+    // Padded p = 32: replicated in every lane, the state of a chain (five to seven 32-vectors) takes the whole register file and
+    // more.  float64: every such kernel spilled, and MALA on 64 lanes per chain computed wrong states beside its spills (round 4:
+    // tests/fuzz_parity.py, tools/f64_p32_repro.py); float32: HMC with the rows in registers spilled to scratch.  Those run on
+    // k_chain_dist (lr_kernels.h: the state distributed over the 16 lanes of a DPP row); lane groups below 16 have no chain kernel
+    // in float64.
+    constexpr bool kDist = G >= 16 && (LR_DTYPE == 1 || MODE == MODE_REG);
+    if constexpr (LR_DTYPE == 1 && G < 16) {
+        (void)grid; (void)block; (void)m; (void)a;
+        return -3;
+    } else if constexpr (kDist) {
+        switch (cfg->kind) {
+        case KIND_RWMH: if constexpr (LR_DTYPE == 1) return launch_capped<&k_chain_dist<T, P, G, MODE, R, KIND_RWMH>>(cfg, grid, block, cfg->lds_bytes, m, a); else break;
+        case KIND_MALA: if constexpr (LR_DTYPE == 1) return launch_capped<&k_chain_dist<T, P, G, MODE, R, KIND_MALA>>(cfg, grid, block, cfg->lds_bytes, m, a); else break;
+        case KIND_UL: if constexpr (LR_DTYPE == 1) return launch_capped<&k_chain_dist<T, P, G, MODE, R, KIND_UL>>(cfg, grid, block, cfg->lds_bytes, m, a); else break;
+        case KIND_HMC: return launch_capped<&k_chain_dist<T, P, G, MODE, R, KIND_HMC>>(cfg, grid, block, cfg->lds_bytes, m, a);
+        default: return -1;
+        }
+    }
+#endif
+#if LR_DTYPE == 1 && LR_P == 32
+    return -1;  // (every float64 kind was dispatched above)
+#else
 #if LR_DTYPE == 0 && LR_P == 8
     if constexpr (G == 16 && MODE == MODE_REG) {  // state distributed over the 16 lanes of a chain (lr_kernels.h)
         if (cfg->kind == KIND_RWMH) return launch_capped<&k_chain_rs16<R, KIND_RWMH>>(cfg, grid, block, 0, m, a);
@@ -133,7 +153,12 @@ int launch_chain_v(const LaunchCfg* cfg, int64_t C, const ModelArgs<T, P>& m, co
     switch (cfg->kind) {
     case KIND_RWMH: return launch_capped<&k_chain<T, P, G, MODE, R, KIND_RWMH>>(cfg, grid, block, cfg->lds_bytes, m, a);
     case KIND_MALA: return launch_capped<&k_chain<T, P, G, MODE, R, KIND_MALA>>(cfg, grid, block, cfg->lds_bytes, m, a);
-    case KIND_HMC: return launch_capped<&k_chain<T, P, G, MODE, R, KIND_HMC>>(cfg, grid, block, cfg->lds_bytes, m, a);
+    case KIND_HMC:
+#if LR_P == 32 && LR_DTYPE == 0
+        if constexpr (G >= 16 && MODE == MODE_REG) return -1;  // (dispatched to k_chain_dist above)
+        else
+#endif
+        return launch_capped<&k_chain<T, P, G, MODE, R, KIND_HMC>>(cfg, grid, block, cfg->lds_bytes, m, a);
     case KIND_UL: return launch_capped<&k_chain<T, P, G, MODE, R, KIND_UL>>(cfg, grid, block, cfg->lds_bytes, m, a);
     default: return -1;
     }

@@ -53,13 +53,112 @@ template <int P, typename Src> __device__ __forceinline__ float mf_row_or_zero(c
     return row < n ? v : 0.0f;
 }
 
-template <int P, int NTW, int S> struct MfmaRows {
+template <int P> constexpr int mf_image_floats();
+// End-point evaluation (fp32-input MFMAs) with the operands STREAMED from device memory -- the tile image `image` (mf_image_prepare
+// layout; null: gathered from the row matrix) -- for this wave's tiles t S + wave, t < ntile_live.  Shared by the LDS / device-memory
+// variants of the bf16 operands and by the register variant whose end-point operands do not fit beside them (MfmaRows END_MEM).
+template <int P, int S, bool VALUE>
+__device__ __forceinline__ void mf_eval_stream(const float* __restrict__ rows, const float* __restrict__ image, int64_t n, int wave, int lane,
+                                               int ntile_live, const float (&q)[P / 4], float (&gl)[P / 4], float& vsum) {
+    constexpr int NC = P / 4, NG = (NC + 3) / 4, HG = NC < 4 ? NC : 4;
+    const int c = lane & 15, k = lane >> 4;
+    const int rp = c & 3, kp = c >> 2;
+    float bs[NC];
+#pragma unroll
+    for (int h = 0; h < NC; ++h) bs[h] = q[h] * ExpScale<float>::k;
+    f32x4 ga[NG], gb[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) ga[g] = gb[g] = f32x4{0, 0, 0, 0};
+    float v = 0.0f;
+    int pad = 0;
+    // the fp32 operands come from global memory (L2): blocks of TB tiles, the next block requested before the current
+    // one is worked on (one tile ahead left 2200 cycles per tile, mostly L2 latency; the operands-in-registers
+    // variant spends 730 on the same arithmetic)
+    constexpr int TB = P <= 8 ? 4 : 2;
+    float ca[TB][NC], cg[TB][NG][4];
+    auto fetch = [&](int t0, float (&fa)[TB][NC], float (&fg)[TB][NG][4]) {
+#pragma unroll
+        for (int i = 0; i < TB; ++i) {
+            const int64_t row0 = 16 * ((int64_t)(t0 + i) * S + wave);  // tiles past the wave's last one: rows >= n, masked to 0
+            if (image) {
+                const int64_t T = (t0 + i) * S + wave, tiles = (n + 15) / 16;
+                const float* o = image + ((size_t)(T < tiles ? T : tiles - 1) * 64 + lane) * mf_image_floats<P>();
+#pragma unroll
+                for (int h = 0; h < NC; ++h) fa[i][h] = T < tiles ? o[h] : 0.0f;
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) fg[i][g][s] = T < tiles ? o[NC + 4 * g + s] : 0.0f;
+                continue;
+            }
+#pragma unroll
+            for (int h = 0; h < NC; ++h) fa[i][h] = mf_row_or_zero<P>(rows, n, row0 + c, k + 4 * h);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+                    fg[i][g][s] = rp < HG ? mf_row_or_zero<P>(rows, n, row0 + 4 * k + s, kp + 4 * (rp < HG ? rp : 0) + 16 * g) : 0.0f;
+        }
+    };
+    fetch(0, ca, cg);
+    for (int t0 = 0; t0 < ntile_live; t0 += TB) {
+        float na[TB][NC], ng[TB][NG][4];
+        fetch(t0 + TB, na, ng);
+#pragma unroll
+        for (int i = 0; i < TB; ++i) {
+            if (t0 + i < ntile_live) {
+                const int64_t row0 = 16 * ((int64_t)(t0 + i) * S + wave);
+                f32x4 e = {0, 0, 0, 0};
+#pragma unroll
+                for (int h = 0; h < NC; ++h) e = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[i][h], bs[h], e, 0, 0, 0);
+                float w[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float tr = VALUE ? __builtin_fminf(e[r], 100.0f) : e[r];  // (see MfmaRows::eval)
+                    const float d = 1.0f + __builtin_amdgcn_exp2f(tr);
+                    w[r] = fast_rcp(d);
+                    if constexpr (VALUE) v += tr - __builtin_amdgcn_logf(d);
+                    if (row0 + 4 * k + r >= n) ++pad;
+                }
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    ga[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(cg[i][g][0], w[0], ga[g], 0, 0, 0);
+                    gb[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(cg[i][g][1], w[1], gb[g], 0, 0, 0);
+                    ga[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(cg[i][g][2], w[2], ga[g], 0, 0, 0);
+                    gb[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(cg[i][g][3], w[3], gb[g], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TB; ++i) {
+#pragma unroll
+            for (int h = 0; h < NC; ++h) ca[i][h] = na[i][h];
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) cg[i][g][s2] = ng[i][g][s2];
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < NC; ++h) gl[h] = ga[h >> 2][h & 3] + gb[h >> 2][h & 3];
+    if constexpr (VALUE) vsum = (v + (float)pad) * ExpScale<float>::inv;
+}
+
+// END_MEM (round 5): the fp32 end-point operands are NOT held -- an end-point evaluation streams them from device memory
+// (mf_eval_stream).  For HMC at the largest tile counts (p = 16: 16 tiles per wave, p = 32: 8): end-point and interior operands
+// together are 1.25 P registers per tile, 320 per lane there -- the kernels ran with 33 / 108 registers spilled to scratch.  One of an
+// iteration's l evaluations is an end point, so the stream costs little; the l - 1 interior ones keep their operands in registers.
+template <int P, int NTW, int S, bool END_MEM = false> struct MfmaRows {
     static constexpr int NC = P / 4;             // coordinates per lane: j_h = k + 4 h
     static constexpr int NU = NC / 2;            // coordinate pairs (h = 2u, 2u + 1): one bf16 MFMA each
     static constexpr int NG = (NC + 3) / 4;      // fp32 gradient MFMA sets of up to four h
     static constexpr int HG = NC < 4 ? NC : 4;   // h per set
-    float xa[NTW][NC];
-    float xg[NTW][NG][4];
+    float xa[END_MEM ? 1 : NTW][NC];
+    float xg[END_MEM ? 1 : NTW][NG][4];
+    const float* rows_ = nullptr;  // END_MEM: the row matrix, the fp32 operand image (or null) and this lane's place
+    const float* image = nullptr;
+    int64_t n_ = 0;
+    int wave_ = 0, lane_ = 0;
     int pad_rows;  // rows >= n among this lane's eta rows (each adds log sigma(0) = -log 2)
     // INTERIOR leapfrog steps on the bf16 matrix pipe (the scheme of lr_tall_mx.h with the rows in registers):
     //   xs = x log2 e = xh + xl, beta = bh + bl (two round-to-nearest bf16 pieces each); per pair u the lane's coordinates
@@ -81,18 +180,25 @@ template <int P, int NTW, int S> struct MfmaRows {
         const int c = lane & 15, k = lane >> 4;
         const int rp = c & 3, kp = c >> 2;  // slot m = c = 4*kp + rp -> parameter kp + 4 rp (+ 16 per set) of the gradient A operand
         pad_rows = 0;
+        if constexpr (END_MEM) {
+            if constexpr (std::is_same<Src, float>::value) rows_ = rows;
+            n_ = n;
+            wave_ = wave;
+            lane_ = lane;
+        } else {
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) {
-            const int64_t base = 16 * ((int64_t)t * S + wave);
-            const int64_t ra = base + c;
+            for (int t = 0; t < NTW; ++t) {
+                const int64_t base = 16 * ((int64_t)t * S + wave);
+                const int64_t ra = base + c;
 #pragma unroll
-            for (int h = 0; h < NC; ++h) xa[t][h] = mf_row_or_zero<P>(rows, n, ra, k + 4 * h);
+                for (int h = 0; h < NC; ++h) xa[t][h] = mf_row_or_zero<P>(rows, n, ra, k + 4 * h);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int64_t rg = base + 4 * k + s;
+                for (int s = 0; s < 4; ++s) {
+                    const int64_t rg = base + 4 * k + s;
 #pragma unroll
-                for (int g = 0; g < NG; ++g) xg[t][g][s] = rp < HG ? mf_row_or_zero<P>(rows, n, rg, kp + 4 * (rp < HG ? rp : 0) + 16 * g) : 0.0f;
-                if (rg >= n) ++pad_rows;
+                    for (int g = 0; g < NG; ++g) xg[t][g][s] = rp < HG ? mf_row_or_zero<P>(rows, n, rg, kp + 4 * (rp < HG ? rp : 0) + 16 * g) : 0.0f;
+                    if (rg >= n) ++pad_rows;
+                }
             }
         }
         // bf16 operands of the interior steps
@@ -205,6 +311,10 @@ template <int P, int NTW, int S> struct MfmaRows {
     //   gl[h] = sum_rows sigma(-t) * xs[row][k+4h],  vsum = sum over the lane's eta rows of log sigma(t)
     template <bool VALUE>
     __device__ __forceinline__ void eval(const float (&q)[NC], float (&gl)[NC], float& vsum) const {
+        if constexpr (END_MEM) {
+            mf_eval_stream<P, S, VALUE>(rows_, image, n_, wave_, lane_, ntile_live, q, gl, vsum);
+            return;
+        }
         float bs[NC];
 #pragma unroll
         for (int h = 0; h < NC; ++h) bs[h] = q[h] * ExpScale<float>::k;
@@ -462,87 +572,7 @@ template <int P, int S, bool GLOBAL = false> struct MfmaRowsLds {
 
     template <bool VALUE>
     __device__ __forceinline__ void eval(const float (&q)[NC], float (&gl)[NC], float& vsum) const {
-        const int c = lane & 15, k = lane >> 4;
-        const int rp = c & 3, kp = c >> 2;
-        float bs[NC];
-#pragma unroll
-        for (int h = 0; h < NC; ++h) bs[h] = q[h] * ExpScale<float>::k;
-        f32x4 ga[NG], gb[NG];
-#pragma unroll
-        for (int g = 0; g < NG; ++g) ga[g] = gb[g] = f32x4{0, 0, 0, 0};
-        float v = 0.0f;
-        int pad = 0;
-        // the fp32 operands come from global memory (L2): blocks of TB tiles, the next block requested before the current
-        // one is worked on (one tile ahead left 2200 cycles per tile, mostly L2 latency; the operands-in-registers
-        // variant spends 730 on the same arithmetic)
-        constexpr int TB = P <= 8 ? 4 : 2;
-        float ca[TB][NC], cg[TB][NG][4];
-        auto fetch = [&](int t0, float (&fa)[TB][NC], float (&fg)[TB][NG][4]) {
-#pragma unroll
-            for (int i = 0; i < TB; ++i) {
-                const int64_t row0 = 16 * ((int64_t)(t0 + i) * S + wave);  // tiles past the wave's last one: rows >= n, masked to 0
-                if (image) {
-                    const int64_t T = (t0 + i) * S + wave, tiles = (n + 15) / 16;
-                    const float* o = image + ((size_t)(T < tiles ? T : tiles - 1) * 64 + lane) * mf_image_floats<P>();
-#pragma unroll
-                    for (int h = 0; h < NC; ++h) fa[i][h] = T < tiles ? o[h] : 0.0f;
-#pragma unroll
-                    for (int g = 0; g < NG; ++g)
-#pragma unroll
-                        for (int s = 0; s < 4; ++s) fg[i][g][s] = T < tiles ? o[NC + 4 * g + s] : 0.0f;
-                    continue;
-                }
-#pragma unroll
-                for (int h = 0; h < NC; ++h) fa[i][h] = mf_row_or_zero<P>(rows, n, row0 + c, k + 4 * h);
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int g = 0; g < NG; ++g)
-                        fg[i][g][s] = rp < HG ? mf_row_or_zero<P>(rows, n, row0 + 4 * k + s, kp + 4 * (rp < HG ? rp : 0) + 16 * g) : 0.0f;
-            }
-        };
-        fetch(0, ca, cg);
-        for (int t0 = 0; t0 < ntile_live; t0 += TB) {
-            float na[TB][NC], ng[TB][NG][4];
-            fetch(t0 + TB, na, ng);
-#pragma unroll
-            for (int i = 0; i < TB; ++i) {
-                if (t0 + i < ntile_live) {
-                    const int64_t row0 = 16 * ((int64_t)(t0 + i) * S + wave);
-                    f32x4 e = {0, 0, 0, 0};
-#pragma unroll
-                    for (int h = 0; h < NC; ++h) e = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[i][h], bs[h], e, 0, 0, 0);
-                    float w[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float tr = VALUE ? __builtin_fminf(e[r], 100.0f) : e[r];  // (see MfmaRows::eval)
-                        const float d = 1.0f + __builtin_amdgcn_exp2f(tr);
-                        w[r] = fast_rcp(d);
-                        if constexpr (VALUE) v += tr - __builtin_amdgcn_logf(d);
-                        if (row0 + 4 * k + r >= n) ++pad;
-                    }
-#pragma unroll
-                    for (int g = 0; g < NG; ++g) {
-                        ga[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(cg[i][g][0], w[0], ga[g], 0, 0, 0);
-                        gb[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(cg[i][g][1], w[1], gb[g], 0, 0, 0);
-                        ga[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(cg[i][g][2], w[2], ga[g], 0, 0, 0);
-                        gb[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(cg[i][g][3], w[3], gb[g], 0, 0, 0);
-                    }
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < TB; ++i) {
-#pragma unroll
-                for (int h = 0; h < NC; ++h) ca[i][h] = na[i][h];
-#pragma unroll
-                for (int g = 0; g < NG; ++g)
-#pragma unroll
-                    for (int s2 = 0; s2 < 4; ++s2) cg[i][g][s2] = ng[i][g][s2];
-            }
-        }
-#pragma unroll
-        for (int h = 0; h < NC; ++h) gl[h] = ga[h >> 2][h & 3] + gb[h >> 2][h & 3];
-        if constexpr (VALUE) vsum = (v + (float)pad) * ExpScale<float>::inv;
+        mf_eval_stream<P, S, VALUE>(rows, image, n, wave, lane, ntile_live, q, gl, vsum);
     }
 };
 
@@ -583,15 +613,17 @@ __global__ void __launch_bounds__((S == 1 ? 256 : 64 * S)) k_chain_mfma(ModelArg
     const uint64_t gchain = (uint64_t)(a.chain_offset + chain);
 
     // NTW = 0: operands in LDS; NTW = -1: operands in device memory (built once per model)
+    // (HMC at the largest tile counts: the end-point operands streamed -- MfmaRows END_MEM)
+    constexpr bool kEndMem = KIND == KIND_HMC && NTW > 0 && NTW * P >= 256;
     using Rows = std::conditional_t<NTW == 0, MfmaRowsLds<P, S, false>,
-                                    std::conditional_t<NTW < 0, MfmaRowsLds<P, S, true>, MfmaRows<P, (NTW <= 0 ? 1 : NTW), S>>>;
+                                    std::conditional_t<NTW < 0, MfmaRowsLds<P, S, true>, MfmaRows<P, (NTW <= 0 ? 1 : NTW), S, kEndMem>>>;
     Rows rows;
     if constexpr (NTW < 0) {  // device images: the S = 4 one first, the S = 8 one behind it
         const size_t skip = S == 8 ? 4 * MfmaRowsLds<P, 4, true>::bytes_per_wave((int64_t)(((m.n + 15) / 16 + 3) / 4)) : 0;
         rows.attach(m.rows, m.n, wave, lane, const_cast<unsigned char*>(m.ops_mf) + skip);
     }
     else rows.load(m.rows, m.n, S == 1 ? 0 : wave, lane);
-    if constexpr (NTW <= 0) rows.image = m.rows_mf;
+    if constexpr (NTW <= 0 || kEndMem) rows.image = m.rows_mf;
 
     // the lane's coordinates: j_h = k + 4h
     auto pick = [&](const float (&v)[P], int h) {

@@ -133,8 +133,11 @@ struct lr_model {
     DebugOpts dbg;  // A/B switches, parsed once at creation (LOGREG_DEBUG_OPTS)
     // two-part plans (lr_plan.h): the remainder's launch runs beside the head's on a stream of the handle's own, forked from and
     // joined back into the caller's stream with these events (created on first use)
-    hipStream_t side_stream = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // One {side stream, fork event, join event} per CALLER stream (as the workspaces below): two ChainSets of one model on two streams
+    // each fork into a side stream of their own instead of serialising their remainders through one.  The handle is not thread-safe
+    // (include/logreg_hip.h): callers serialise per handle.
+    struct Side { hipStream_t caller; hipStream_t stream; hipEvent_t ev_fork, ev_join; };
+    std::vector<Side> sides;
     struct Ws { hipStream_t stream; void* p; size_t bytes; };
     std::vector<Ws> ws;
     size_t esize() const { return dtype == LR_F32 ? 4 : 8; }
@@ -158,7 +161,8 @@ inline ModelImages model_images(int64_t n, int P, int dtype) {
     ModelImages im{};
     // (float64 models: from the rows rounded to float32; float64 at padded p = 32 always runs the stepwise engine: lr_plan.h)
     im.tall_mx = P >= 8 && P <= 32 && ((size_t)n * P * (dtype == LR_F32 ? 4 : 8) > 64 * 1024 || (dtype != LR_F32 && P == 32));
-    im.mf_end = P >= 8 && P <= 32 && dtype == LR_F32 && n > (P == 32 ? 16 * 4 * 8 : (P == 8 ? 16 * 13 : 16 * 4 * 16)) && n <= kMfmaStreamMaxRows;
+    // (p = 16 / 32: from half the register variants' rows -- at the largest tile counts HMC streams its end-point operands: lr_mfma.h END_MEM)
+    im.mf_end = P >= 8 && P <= 32 && dtype == LR_F32 && n > (P == 32 ? 16 * 4 * 4 : (P == 8 ? 16 * 13 : 16 * 4 * 8)) && n <= kMfmaStreamMaxRows;
     im.wide = P > 32 && dtype == LR_F32;
     im.wide1 = P > 32;
     return im;

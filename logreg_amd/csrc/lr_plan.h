@@ -206,6 +206,8 @@ double reg_cost(const lr_model* m, const lr::Variant& u, int64_t chains);
 size_t lds_rows_bytes(const lr_model* m) { return (size_t)m->n * (m->P + (m->dtype == LR_F32 ? 0 : 2)) * m->esize(); }
 size_t mixed_lds_bytes(const lr_model* m) { return lds_rows_bytes(m) + (size_t)lr::kMixedStashDoubles * 8 * 256; }
 bool plan_mixed_hmc(const lr_model* m, int64_t C, Plan* out, int* whole = nullptr) {
+    // (MIXED variants are instantiated for padded p <= 16 only -- lr_inst.hip LR_MIXED_VARIANTS: at p = 32 the loop below finds none;
+    //  mixed_chains_per_cu = 0: from the first chain, i.e. the float64 model's DEFAULT policy is the float32 force at any chain count)
     if (m->dtype != LR_F64 || m->P > 32) return false;
     const size_t row_bytes = mixed_lds_bytes(m);
     if (row_bytes > kLdsBudget || C < (int64_t)kPlanConst.mixed_chains_per_cu * m->cus) return false;
@@ -320,6 +322,9 @@ int pick_variant(const PlanReq& q) {
         }
         if (q.mode != LR_MODE_AUTO && v.mode != q.mode) continue;
         if (q.group != 0 && v.G != q.group) continue;
+        // float64 at 17 <= p <= 32: chains run on the distributed-state kernel, whose state lives on the 16 lanes of a DPP row
+        // (lr_kernels.h k_chain_dist); narrower lane groups serve lr_eval only
+        if (!q.for_eval && m->dtype == LR_F64 && m->P == 32 && v.G < 16) continue;
         if (v.mode == lr::MODE_REG && (int64_t)v.G * v.R < m->n) continue;
         if (v.mode == lr::MODE_LDS && lds_rows_bytes(m) > kLdsBudget) continue;
         const int64_t waves = (q.C * v.G + 63) / 64;
@@ -369,7 +374,7 @@ bool measured_overrides(const PlanReq& q, int* best, Plan* out) {
     // 8 lanes per chain overtake from 16 chains per CU (round 4, PLANNER_BENCH_DTYPE=float64 tools/planner_bench.py, lds 64 | lds 8,
     // it/s: MALA n=200 p=12: 2048 chains 2.61 | 2.58e8, 4096: 2.62 | 5.12e8; HMC all-float64 4096: 2.12 | 4.14e7; MALA p=3 4096: 6.1 | 8.5e8)
     if (m->dtype == LR_F64 && m->P != 8 && b.mode == lr::MODE_LDS && b.G == 64 && q.C >= (int64_t)kPlanConst.f64_lds16_chains_per_cu * m->cus)
-        move_to_lds(8);
+        move_to_lds(m->P == 32 && !q.for_eval ? 16 : 8);  // (p > 16: the chain kernel needs 16 lanes per chain)
     return false;
 }
 
@@ -472,14 +477,11 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
     }
     if (m->P > 32) return plan_wide(q, out);
     const size_t row_bytes = (size_t)m->n * m->P * m->esize();
-    if (!for_eval && m->dtype == LR_F64 && m->P == 32) {  // no fused chain kernels at this width in float64 (lr_inst.hip launch_chain_v)
-        if (mode != LR_MODE_AUTO && mode != LR_MODE_STEPWISE)
-            return fail(LR_ERR_UNSUPPORTED, "float64 models with 17 <= p <= 32 run on the stepwise engine only (mode=%d requested)", mode);
-        plan_tall(q, out);
-        return LR_OK;
-    }
+    // (float64 at 17 <= p <= 32: the fused distributed-state kernel keeps its lead over the stepwise engine while the rows fit the LDS --
+    //  n=500 p=20, HMC L=20, it/s, lds 16 | stepwise: 4096 chains 1.53 | 0.98e7, 16 384: 1.54 | 1.47e7; profiles/r5_f64_p32.txt)
+    const bool f64_wide_fused = m->dtype == LR_F64 && m->P == 32;
     const bool prefer_stepwise = lds_rows_bytes(m) > kLdsBudget ||
-                                 (row_bytes > kPlanConst.lds_rows_prefer_stepwise_bytes && C >= kPlanConst.lds_rows_prefer_stepwise_chains);
+                                 (!f64_wide_fused && row_bytes > kPlanConst.lds_rows_prefer_stepwise_bytes && C >= kPlanConst.lds_rows_prefer_stepwise_chains);
     if (!for_eval && (mode == LR_MODE_STEPWISE || (mode == LR_MODE_AUTO && group == 0 && prefer_stepwise))) {
         plan_tall(q, out);
         return LR_OK;

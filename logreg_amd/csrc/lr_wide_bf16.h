@@ -891,7 +891,6 @@ __global__ void __launch_bounds__(512) k_wide_traj2_bf16(TallArgs<float, P> a) {
     using G = WideBf16Geom<P>;
     constexpr int NW = 8, NT2 = 2, BLK_BYTES = G::BUF1 * 2, NBUF = P >= 128 ? 2 : 4, RING_BYTES = NBUF * BLK_BYTES;
     constexpr int NQ = P / 4;             // 16-byte chunks per chain
-    constexpr int EPT = 16 * NQ / 512;    // chunks a thread owns per tile (P = 128: 1, P = 64: half the threads own one)
     static_assert(16 * P * 4 == BLK_BYTES, "a tile's gradients fill exactly one ring slot");
     static_assert(P == 128 || P == 64, "chunk ownership below");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[NW * RING_BYTES];
@@ -1109,6 +1108,7 @@ __global__ void __launch_bounds__(512) k_wide_traj2_bf16(TallArgs<float, P> a) {
             for (int t = 0; t < NT2; ++t) e[t][0] = en[t][0], e[t][1] = en[t][1];
             __builtin_amdgcn_sched_barrier(0);
         };
+        // (starting the second wave of every SIMD 256 .. 1024 cycles late, to break the lockstep of the pair: 24.4 .. 24.7 us against 24.5)
         if (wnb > 0) trip(0, std::integral_constant<bool, true>{});
         for (int b = 1; b < wnb; ++b) trip(b, std::integral_constant<bool, false>{});
         if (wnb > 0) {  // drain: sigmoid and gradient of the last block

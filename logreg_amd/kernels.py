@@ -50,6 +50,9 @@ def rwProposal(sd) -> RandomWalkProposal:
     return RandomWalkProposal(sd)
 
 
+_PROBE_LOCK = __import__("threading").Lock()
+
+
 def _model_of(fn, kind):
     return fn.model if isinstance(fn, ModelFn) and fn.kind == kind else None
 
@@ -67,6 +70,15 @@ def _recognise_random_walk(rprop, p):
         return rprop.sd
     if not callable(rprop):
         return None
+    with _PROBE_LOCK:  # np.random.randn is process-wide state while patched: one probe at a time
+        state = np.random.get_state()  # a proposal that draws through another np.random function must not move the caller's seeded stream
+        try:
+            return _probe_random_walk(rprop, p)
+        finally:
+            np.random.set_state(state)
+
+
+def _probe_random_walk(rprop, p):
     saved = np.random.randn
     calls = []
 
@@ -171,8 +183,13 @@ class FusedKernel:
 
 
 # ------------------------------------------------------------------------------------------------
-def mhKernel(lpost, rprop, dprop=_default_dprop):
+def mhKernel(lpost, rprop, dprop=_default_dprop, *, fuse=True):
     """Metropolis-Hastings kernel constructor.
+
+    `fuse=False` (an addition to the reference's signature) keeps the reference's generic composition whatever `rprop` is: the caller's
+    own Python proposal is then called every step and draws from NumPy's generator, instead of being recognised and replaced by the
+    device kernel's Philox draws.  A fused kernel says how its proposal was recognised in `kernel.proposal` ("rwProposal" | "probed"),
+    which `mcmc(..., return_info=True)` reports as `info["proposal"]`.
 
     Fused when `lpost` is a LogReg's lpost and `rprop` is a random-walk proposal `beta + sd * N(0, I)` -- a
     `rwProposal(sd)`, or the script's own Python function `rprop` (fit-numpy.py:81-84), recognised by probing it
@@ -181,10 +198,12 @@ def mhKernel(lpost, rprop, dprop=_default_dprop):
     `kernel(x, ll)` threads the current log-density (fit-numpy.py:54-61); called as `kernel(x)`
     it re-evaluates both ends like the HMC script's variant (fit-np-hmc.py:56-63)."""
     model = _model_of(lpost, "lpost")
-    if model is not None and dprop is _default_dprop:
+    if fuse and model is not None and dprop is _default_dprop:
         sd = _recognise_random_walk(rprop, model.p)  # a rwProposal, or the script's own `rprop` recognised by probing it
         if sd is not None:
-            return FusedKernel("rwmh", model, prop_sd=sd)
+            k = FusedKernel("rwmh", model, prop_sd=sd)
+            k.proposal = "rwProposal" if isinstance(rprop, RandomWalkProposal) else "probed"
+            return k
 
     def kernel(x, ll=None):
         prop = rprop(x)
@@ -463,6 +482,11 @@ def mcmc(init, kernel, thin=10, iters=10000, verb=True, *, seed=None, chunk=None
     `ll=` is given.  `seed=None` draws the Philox key from NumPy's global RNG, so
     `np.random.seed(s)` before the call makes a run reproducible, like the reference.
 
+    `precision="auto"` (the DEFAULT) lets HMC's l - 1 gradient evaluations strictly inside a trajectory run in reduced precision where such
+    a kernel exists -- on a float64 model too (float64 state, end points and Metropolis test; float32 / bf16 force inside the
+    trajectory, at any chain count): such a run is NOT step-for-step comparable with the reference; `precision="full"` is (every
+    evaluation in the model's dtype).  INTEGRATION.md section 3b has the numbers.
+
     `summary_only=True` (fused kernels): no sample matrix at all -- the kept samples are folded into on-device
     running statistics and the call returns a dict (mean, sd, rhat, ess, mcse, accept_rate, ...): what the
     reference computes from the full matrix afterwards (fit-np-hmc.py:113-117, analyse.R:17-19).
@@ -526,6 +550,8 @@ def mcmc(init, kernel, thin=10, iters=10000, verb=True, *, seed=None, chunk=None
     if return_info:
         info = {"accepts": cs.get_accepts(), "state": cs.get_state(), "ll": cs.get_ll(), "seed": seed,
                 "plan": cs.plan(), "iterations": iters * thin}
+        if getattr(kernel, "proposal", None):  # RWMH: how the proposal was recognised ("rwProposal" | "probed": mhKernel)
+            info["proposal"] = kernel.proposal
         return res, info
     return res
 

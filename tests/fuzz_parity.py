@@ -18,7 +18,9 @@ DTYPE = sys.argv[4] if len(sys.argv) > 4 else "float32"
 fails, done, skipped = [], 0, 0
 t0 = time.time()
 for case in range(cases):
-    p = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 12, 16, 17, 24, 32, 33, 40, 64, 100, 128]))
+    # (FUZZ_P="9,12,16,17,20,24,31,32": a campaign on chosen widths)
+    p = int(rng.choice([int(v) for v in os.environ["FUZZ_P"].split(",")] if os.environ.get("FUZZ_P") else
+                       [1, 2, 3, 4, 5, 7, 8, 9, 12, 16, 17, 24, 32, 33, 40, 64, 100, 128]))
     n = int(rng.choice([1, 2, 3, 7, 16, 33, 64, 100, 199, 200, 201, 208, 209, 255, 256, 257, 400, 513, 1000, 1024, 1025, 1450, 2390, 2401, 2500,
                       5001, 8191, 8193, 9001]))
     if p > 32:
@@ -36,7 +38,9 @@ for case in range(cases):
     modes = [("auto", 0)]
     if DTYPE == "float64" and kind == "hmc" and p <= 16:
         modes += [("mixed", g) for g in (16, 32, 64)]  # (rejected where the rows do not fit: skipped)
-    if p <= 32 and not (DTYPE == "float64" and p > 16):  # (float64 at 17 <= p <= 32: the stepwise engine only)
+    if DTYPE == "float64" and 16 < p <= 32:  # (float64 at 17 <= p <= 32: the distributed-state kernel, 16 or 64 lanes per chain)
+        modes += [("lds", 16), ("lds", 64), ("global", 16), ("global", 64), ("stepwise", 0)]
+    if p <= 32 and not (DTYPE == "float64" and p > 16):
         modes += [("lds", 8), ("lds", 64), ("global", 64), ("global", 1), ("stepwise", 0)]
         for g in (16, 32, 64):
             try:

@@ -68,3 +68,17 @@ def test_plain_c_client_compiles_against_the_header(tmp_path):
                     os.path.join(REPO, "examples", "fit_bayes.c"), "-L", lib_dir, "-llogreg_hip",
                     "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)], check=True)
     assert exe.exists()
+
+
+def test_no_kernel_of_the_library_uses_scratch_memory():
+    """The build gate (logreg_amd/build.py resource_gate) on the objects the library was linked from: every gfx950 code object's
+    `.private_segment_fixed_size` is 0 -- no whitelist.  A register spill to scratch is a large silent slowdown, and the one kernel
+    family ever found computing wrong results (round 4, float64 at padded p = 32) was one that spilled."""
+    from logreg_amd import build as b
+    b.build(verbose=False)
+    rows = b.kernel_resources()
+    assert len(rows) > 400 and all(r["name"] for r in rows)
+    assert {r["unit"] for r in rows} >= {f"lr_inst_{dt}_p{p}" for dt in ("f32", "f64") for p in (4, 8, 16, 32, 64, 128)}
+    bad = [(r["unit"], r["name"], r["scratch"]) for r in rows if r["scratch"]]
+    assert not bad, bad
+    b.resource_gate(strict=True, verbose=False)

@@ -46,7 +46,7 @@ def test_mcmc_sharded_with_three_ranks_sharing_the_gpu_over_gloo():
 def _bench(extra_env, *launcher, extra=False):
     import json
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
-    cmd = [sys.executable, *launcher, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "1",
+    cmd = [sys.executable, *launcher, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "40", "--warmup", "1",
            "--no-ess", "--no-cpu-baseline"] + ([] if extra else ["--no-extra"])
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
@@ -65,14 +65,15 @@ def test_bench_rccl_branch_runs_on_a_gpu_under_torchrun():
     dist = _bench({"LOGREG_BENCH_FORCE_DIST": "1"}, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
                   "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), extra=True)
     for d in (plain, dist):
-        assert d["n_gpus"] == 1 and d["steps"] == 5 and d["scaling"] == "weak" and d["dtype"] == "f32"
+        assert d["n_gpus"] == 1 and d["steps"] == 40 and d["scaling"] == "weak" and d["dtype"] == "f32"
         assert d["config"]["kernel_variant"] == {"mode": "reg", "group": 16, "rows_per_lane": 13}
         assert np.isfinite(d["value"]) and d["value"] > 1e8  # north_star: >= 1e8 gradient evaluations/s is 2e6 of these
         assert d["roofline"]["frac"] > 0.3 and d["roofline"]["kernel_ms"] > 0
     assert dist["config"]["parallelism"] == "chains sharded x1" and dist["gather_ms"] > 0 and plain["gather_ms"] == 0
     assert dist["accept_rate"] == plain["accept_rate"]
-    # 5 timed steps = 2 ms: the gather (0.66 MB device-to-device at N = 1) is inside the timed region of the distributed run
-    assert dist["value"] > 0.85 * plain["value"] * (1 - dist["gather_ms"] / (5 * dist["ms_per_step"])), (plain["value"], dist["value"])
+    # 40 timed steps = 15 ms (round 5; with 5 steps = 2 ms the closing RCCL barrier alone, inside the timed region, decided the
+    # comparison): the gather (5 MB device-to-device at N = 1) is inside the timed region of the distributed run
+    assert dist["value"] > 0.85 * plain["value"] * (1 - dist["gather_ms"] / (40 * dist["ms_per_step"])), (plain["value"], dist["value"])
     # the self-check block of a multi-process line, produced on the hardware of this very run
     mg = dist["multi_gpu"]
     assert mg["ranks_seen"] == 1 and len(mg["devices"]) == 1 and mg["devices"][0].startswith("pci=") and "uuid=" in mg["devices"][0]

@@ -156,6 +156,55 @@ def test_config5_wide_model_full_size(la):
     assert res["auto"][2] > res["full"][2] - 0.03
 
 
+def test_config5_whole_8192_chains_on_one_gpu(la, monkeypatch):
+    """BASELINE config 5 AS A WHOLE on one GPU (8192 chains, n = 4096, p = 128): the interior of every trajectory runs on the two-tile
+    trajectory kernel (k_wide_traj2_bf16, 32 chains per workgroup).  (a) It computes the SAME trajectories, bit for bit, as the one-tile
+    kernel -- ragged chain counts included -- so which of the two runs is a matter of speed only; (b) a shard of the run launched on its
+    own reproduces its chains of the whole run bit for bit; (c) the pooled posterior of all 8192 chains agrees with the long float64
+    oracle run under both interior-gradient policies."""
+    fix = load_golden("fullsize_cfg5.json")
+    n, p, C = fix["n"], fix["p"], 8192
+    X, y, _ = la.synthetic_logreg(n, p, seed=fix["data_seed"], beta_sd=fix["beta_sd"])
+    ps = np.array(fix["pscale"])
+    rng = np.random.Generator(np.random.Philox(4005))
+    q0 = (np.array(fix["map"]) + np.array(fix["laplace_sd"]) * rng.standard_normal((C, p))).astype(np.float32).astype(np.float64)
+    kw = dict(eps=fix["eps"], l=fix["l"], dmm=np.array(fix["dmm"]))
+    # (a) one tile per workgroup against two, forced (the switch is read at model creation)
+    outs = {}
+    for opt in ("wide_traj=1", "wide_traj=2"):
+        monkeypatch.setenv("LOGREG_DEBUG_OPTS", opt)
+        mm = la.LogReg(X, y, ps)
+        assert opt in mm.debug_opts()
+        kk = la.hmcKernel(mm.lpost, mm.glp, **kw)
+        outs[opt] = [la.mcmc(q0[:cc], kk, thin=1, iters=2, verb=False, seed=5, return_info=True) for cc in (100, 1000)]
+    for (o1, i1), (o2, i2) in zip(outs["wide_traj=1"], outs["wide_traj=2"]):
+        assert np.array_equal(o1, o2) and np.array_equal(i1["accepts"], i2["accepts"])
+        assert 0 < i1["accepts"].sum() < 2 * o1.shape[1]
+    monkeypatch.delenv("LOGREG_DEBUG_OPTS")
+    m = la.LogReg(X, y, ps)
+    assert m.debug_opts() == ""
+    k = la.hmcKernel(m.lpost, m.glp, **kw)
+    # (b) + (c)
+    res = {}
+    for prec in ("auto", "full"):
+        cs = la.ChainSet(k, q0, seed=2025, precision=prec)
+        first = cs.advance(1, 1).to_host()
+        if prec == "auto":
+            sub = la.mcmc(q0[4000:4100], k, thin=1, iters=1, verb=False, seed=2025, chain_offset=4000, plan_chains=C, precision=prec)
+            assert np.array_equal(sub, first[:, 4000:4100])
+        cs.advance(1, 49, keep=False)
+        samples = cs.advance(20, 2).to_host()
+        acc = cs.get_accepts().sum() / (C * 90)
+        zm, zs = _z(la, samples, fix)
+        print(f"cfg5 whole precision={prec}: accept {acc:.4f} (oracle {fix['accept']:.4f}), max|z| mean {np.max(np.abs(zm)):.2f} sd "
+              f"{np.max(np.abs(zs)):.2f}, rms z mean {np.sqrt(np.mean(zm ** 2)):.2f} sd {np.sqrt(np.mean(zs ** 2)):.2f}")
+        assert abs(acc - fix["accept"]) < 4 * fix["accept_se"] + (0.01 if prec == "full" else 0.03)
+        assert np.max(np.abs(zm)) < 4.2 and np.max(np.abs(zs)) < 4.2, prec
+        assert 0.5 < np.sqrt(np.mean(zm ** 2)) < 1.3 and 0.5 < np.sqrt(np.mean(zs ** 2)) < 1.3, prec
+        res[prec] = acc
+    assert res["auto"] > res["full"] - 0.03
+
+
 def test_config1_rwmh_single_chain_thin_1000(la, pima, oracle_model, map_beta):
     """fit-numpy.py's run shape: ONE chain (a single 64-lane group on the whole chip), thin 1000."""
     X, y = pima

@@ -389,3 +389,14 @@ def test_the_scripts_own_rprop_is_recognised_and_fused(la, models, map_beta):
         assert not isinstance(la.mhKernel(m.lpost, other), K.FusedKernel)
     # a custom dprop keeps the generic path too (the fused kernel is the symmetric random walk)
     assert not isinstance(la.mhKernel(m.lpost, rprop, lambda new, old: 0.0), K.FusedKernel)
+    # how the proposal was recognised is on the kernel and in the run's info; fuse=False opts out of the recognition altogether
+    assert k.proposal == "probed" and la.mhKernel(m.lpost, la.rwProposal(0.02 * pre)).proposal == "rwProposal"
+    _, info = la.mcmc(map_beta, k, thin=2, iters=2, verb=False, seed=3, return_info=True)
+    assert info["proposal"] == "probed"
+    assert not isinstance(la.mhKernel(m.lpost, rprop, fuse=False), K.FusedKernel)
+    # a proposal that draws through ANOTHER function of NumPy's global generator is not recognised -- and the probe leaves the caller's
+    # seeded stream where it was (the generator's state is saved and restored around the probe)
+    np.random.seed(11)
+    before = np.random.get_state()[1].copy()
+    assert not isinstance(la.mhKernel(m.lpost, lambda beta: beta + 0.02 * np.random.normal(size=p)), K.FusedKernel)
+    assert np.array_equal(np.random.get_state()[1], before)

@@ -406,22 +406,6 @@ template <typename T, int P, int G> struct DrawBatch {
         ++posn;
         ++posu;
     }
-    // the normals of coordinates r + 16 k (k < NK) and log(u) only: state distributed over the 16 lanes of a DPP row (k_chain_dist)
-    template <int NK>
-    __device__ __forceinline__ void next_own(uint64_t seed, uint64_t chain, uint64_t iter, int gl, int r, T (&z)[NK], T& logu) {
-        advance_to(seed, chain, iter, gl);
-        const int gbase = (int)(threadIdx.x & 63) - gl;
-#pragma unroll
-        for (int k = 0; k < NK; ++k) {
-            const int src = (gbase + posn * NBn + (r >> 2) + 4 * k) * 4;  // block (r + 16 k) / 4 of this iteration
-            const T e0 = fetch(mine[0], src), e1 = fetch(mine[1], src), e2 = fetch(mine[2], src), e3 = fetch(mine[3], src);
-            const T lo = (r & 1) ? e1 : e0, hi = (r & 1) ? e3 : e2;
-            z[k] = (r & 2) ? hi : lo;
-        }
-        logu = fetch(lu, (gbase + posu) * 4);
-        ++posn;
-        ++posu;
-    }
     // z[0..P) and log(u) of iteration `iter`
     __device__ __forceinline__ void next(uint64_t seed, uint64_t chain, uint64_t iter, int gl, T (&z)[P], T& logu) {
         advance_to(seed, chain, iter, gl);
@@ -559,36 +543,6 @@ __device__ __forceinline__ T vdiffsq(const T (&c)[P], const T (&u)[P], const T (
 #pragma unroll
         for (int j = 0; j < P; ++j) {
             const T d1 = u[j] - v[j], d2 = w[j] - z[j];
-            acc = fma_t(c[j], d1 * d1 - d2 * d2, acc);
-        }
-        return acc;
-    }
-}
-// MALA's proposal-density difference without keeping advance(x) and advance(prop) as arrays across the evaluation:
-//   sum_j c[j] * ((x[j] - advp_j)^2 - (xp[j] - advx_j)^2),  advx_j = a[j] g[j] + x[j],  advp_j = a[j] gp[j] + xp[j]
-// -- the same operations in the same order as vfma_o + vdiffsq on stored arrays (advx is recomputed from unchanged inputs: bit-
-// identical), two P-vectors fewer live across the evaluation (float64 at padded p = 32: 128 VGPRs, the difference between spilling
-// to scratch and not).
-template <typename T, int P>
-__device__ __forceinline__ T mala_dq(const T (&a)[P], const T (&c)[P], const T (&x)[P], const T (&g)[P], const T (&xp)[P], const T (&gp)[P]) {
-    if constexpr (sizeof(T) == 4 && P % 2 == 0) {
-        f32x2 acc = {0.0f, 0.0f};
-#pragma unroll
-        for (int j = 0; j < P; j += 2) {
-            const f32x2 a2 = {a[j], a[j + 1]}, x2 = {x[j], x[j + 1]}, xp2 = {xp[j], xp[j + 1]};
-            const f32x2 advx = __builtin_elementwise_fma(a2, f32x2{g[j], g[j + 1]}, x2);
-            const f32x2 advp = __builtin_elementwise_fma(a2, f32x2{gp[j], gp[j + 1]}, xp2);
-            const f32x2 d1 = x2 - advp, d2 = xp2 - advx;
-            const f32x2 t = __builtin_elementwise_fma(-d2, d2, d1 * d1);
-            acc = __builtin_elementwise_fma(f32x2{c[j], c[j + 1]}, t, acc);
-        }
-        return acc.x + acc.y;
-    } else {
-        T acc = T(0);
-#pragma unroll
-        for (int j = 0; j < P; ++j) {
-            const T advx = fma_t(a[j], g[j], x[j]), advp = fma_t(a[j], gp[j], xp[j]);
-            const T d1 = x[j] - advp, d2 = xp[j] - advx;
             acc = fma_t(c[j], d1 * d1 - d2 * d2, acc);
         }
         return acc;
@@ -992,24 +946,16 @@ __device__ __forceinline__ void row_pairs_grad_bf(const RegRowPairs<P, R, G>& ro
     for (int j = 0; j < P / 2; ++j) gp[j] += __builtin_shufflevector(hp[j], hp[j], 1, 0);
 }
 
-// Rows staged in LDS sit kLdsRowPad<T> elements apart beyond P.  float64: a lane's 16-byte reads of a 64-byte row, 16 lanes of a group on
-// 16 consecutive rows, hit the same 4 banks in every fourth lane (64 B = 16 banks: 4-way conflict; rocprofv3 on k_chain_mixed:
-// SQ_LDS_BANK_CONFLICT = 61 % of SQ_LDS_IDX_ACTIVE); two doubles of padding put the 16 rows on 16 disjoint 4-bank windows (P = 4, 8,
-// 16, 32: row pitch 12, 20, 36, 68 banks).
-template <typename T> constexpr int kLdsRowPad = sizeof(T) == 8 ? 2 : 0;
 template <typename T, int P, int G> struct StridedRows {  // LDS or global: same access code
-    const T* base;  // row-major [n][ld]
+    const T* base;  // row-major [n][P]
     int64_t n;
     int gl;
-    int ld = P;  // row pitch in elements (P in device memory, P + kLdsRowPad<T> in LDS)
     template <class F> __device__ __forceinline__ void for_each(F&& f) const { for_each_in(0, n, f); }
     // the lane's rows inside [lo, hi), lo a multiple of G
     template <class F> __device__ __forceinline__ void for_each_in(int64_t lo, int64_t hi, F&& f) const {
         // four rows are fetched before the first is used: with one load batch per row the loop is one LDS / L2
         // round trip per row, which nothing else in the wave covers
-        // (256-byte rows -- float64 at padded p = 32 --: one at a time; two are 128 registers, beside the position and gradient
-        //  32-vectors the whole file)
-        constexpr int UB = sizeof(T) * P <= 64 ? 4 : (sizeof(T) * P <= 128 ? 2 : 1);
+        constexpr int UB = sizeof(T) * P <= 64 ? 4 : 2;
         const int64_t n = hi;
         int64_t i = lo + gl;
         for (; i + (UB - 1) * G < n; i += UB * G) {
@@ -1017,14 +963,14 @@ template <typename T, int P, int G> struct StridedRows {  // LDS or global: same
 #pragma unroll
             for (int u = 0; u < UB; ++u)
 #pragma unroll
-                for (int j = 0; j < P; ++j) xs[u][j] = base[(i + u * G) * ld + j];
+                for (int j = 0; j < P; ++j) xs[u][j] = base[(i + u * G) * P + j];
 #pragma unroll
             for (int u = 0; u < UB; ++u) f(xs[u]);
         }
         for (; i < n; i += G) {
             T xs[P];
 #pragma unroll
-            for (int j = 0; j < P; ++j) xs[j] = base[i * ld + j];
+            for (int j = 0; j < P; ++j) xs[j] = base[i * P + j];
             f(xs);
         }
     }

@@ -84,15 +84,13 @@ __device__ __forceinline__ typename RowsOf<T, P, G, MODE, R>::type make_rows(con
     if constexpr (MODE == MODE_REG) {
         rows.load(m.rows, m.n, gl);
     } else if constexpr (MODE == MODE_LDS) {
-        // stage all rows once; coalesced copy by the whole workgroup (row pitch P + kLdsRowPad<T>: lr_device.h)
-        constexpr int LD = P + kLdsRowPad<T>;
+        // stage all rows once; coalesced copy by the whole workgroup
         const int64_t tot = m.n * P;
-        for (int64_t i = threadIdx.x; i < tot; i += blockDim.x) smem[(i / P) * LD + (i % P)] = m.rows[i];
+        for (int64_t i = threadIdx.x; i < tot; i += blockDim.x) smem[i] = m.rows[i];
         __syncthreads();
         rows.base = smem;
         rows.n = m.n;
         rows.gl = gl;
-        rows.ld = LD;
     } else if constexpr (is_scalar_pairs<typename RowsOf<T, P, G, MODE, R>::type>::value) {
         rows.base = m.rows_tw;
         rows.k0 = 0;
@@ -333,7 +331,7 @@ __global__ void __launch_bounds__(256) k_chain_mixed(ModelArgs<double, 8> m, Cha
     RegRowPairs<P, R, G> rows32;                                                                          // float32 rows: interior
     rows32.load(m.rows, m.n, gl);
     // (dynamic LDS: the float64 rows, then kMixedStashDoubles doubles per lane -- lr_plan.h plan_mixed_hmc sizes it)
-    double* const stash = reinterpret_cast<double*>(smem_raw) + m.n * (P + kLdsRowPad<double>) + threadIdx.x;
+    double* const stash = reinterpret_cast<double*>(smem_raw) + m.n * P + threadIdx.x;
     const uint64_t gchain = (uint64_t)(a.chain_offset + chain);
 
     // The chain's state is DISTRIBUTED over its 16 lanes for the whole launch, as in k_chain_rs16: quad qd owns coordinates 2 qd,
@@ -552,245 +550,6 @@ __global__ void __launch_bounds__(256) k_chain_mixed_rep(ModelArgs<double, P> m,
 }
 
 // --------------------------------------------------------------------------------------------
-// The chain kernel with the state DISTRIBUTED over the 16 lanes of a DPP row, for padded p = 16 / 32 on 16 / 32 / 64 lanes per chain
-// (round 5).  k_chain keeps every P-vector of a chain -- position, gradient, proposal, its gradient, momentum, scaled position --
-// replicated in all lanes of the group: at p = 32 that is 6 x 32 registers of state in float32 and 12 x 32 in float64, more than the
-// register file: the float32 HMC kernel with rows in registers and every float64 kernel spilled to scratch, and one float64 kernel
-// computed wrong states beside its spills (round 4: the float64 kernels were withdrawn).  Here lane r = lane & 15 of every 16-lane
-// row of the group OWNS coordinates r + 16 k (k < P / 16): between evaluations a lane holds P / 16 scalars per vector, all updates,
-// proposal densities and kinetic energies act on those (sums over the coordinates: a 4-level DPP sum over the row), and only an
-// evaluation sees whole vectors -- all-gather of the position (P row_share moves), eval_lpost as k_chain calls it, the lane's
-// coordinates picked out of the replicated gradient (select tree).  Rows of a wider group carry identical copies, so decisions never
-// diverge inside a group.  Same Philox stream, same accept rules (fit-numpy.py:53-62, fit-np-mala.py:61-78, fit-np-hmc.py:56-87,
-// fit-np-ul.py:61-68) as k_chain; the summation order over the coordinates differs, as between any two variants.
-template <typename T, int P, int S = 0> __device__ __forceinline__ void dist_gather16(T own, int k, T (&all)[P]) {
-    if constexpr (S < 16) {
-        all[16 * k + S] = dpp_mov<0x150 + S>(own);  // row_share:S
-        dist_gather16<T, P, S + 1>(own, k, all);
-    }
-}
-// element 16 K + r of a vector that is replicated in the lanes, r the lane's position in its row: a four-level select tree on SCALARS
-// that each passed through an empty asm -- written on array elements, the tree is folded into ONE load at a lane-dependent address of
-// an array that then has to live in scratch
-template <typename T> __device__ __forceinline__ T opaque(T v) {
-    asm volatile("" : "+v"(v));
-    return v;
-}
-template <typename T, int P, int K> __device__ __forceinline__ T dist_pick16(const T (&v)[P], int r) {
-    const bool b0 = (r & 1) != 0, b1 = (r & 2) != 0, b2 = (r & 4) != 0, b3 = (r & 8) != 0;
-    const T e0 = opaque(v[16 * K + 0]), e1 = opaque(v[16 * K + 1]), e2 = opaque(v[16 * K + 2]), e3 = opaque(v[16 * K + 3]);
-    const T e4 = opaque(v[16 * K + 4]), e5 = opaque(v[16 * K + 5]), e6 = opaque(v[16 * K + 6]), e7 = opaque(v[16 * K + 7]);
-    const T e8 = opaque(v[16 * K + 8]), e9 = opaque(v[16 * K + 9]), e10 = opaque(v[16 * K + 10]), e11 = opaque(v[16 * K + 11]);
-    const T e12 = opaque(v[16 * K + 12]), e13 = opaque(v[16 * K + 13]), e14 = opaque(v[16 * K + 14]), e15 = opaque(v[16 * K + 15]);
-    const T u0 = b0 ? e1 : e0, u1 = b0 ? e3 : e2, u2 = b0 ? e5 : e4, u3 = b0 ? e7 : e6;
-    const T u4 = b0 ? e9 : e8, u5 = b0 ? e11 : e10, u6 = b0 ? e13 : e12, u7 = b0 ? e15 : e14;
-    const T w0 = b1 ? u1 : u0, w1 = b1 ? u3 : u2, w2 = b1 ? u5 : u4, w3 = b1 ? u7 : u6;
-    const T y0 = b2 ? w1 : w0, y1 = b2 ? w3 : w2;
-    return b3 ? y1 : y0;
-}
-template <typename T, int P, int G, int MODE, int R, int KIND>
-__global__ void __launch_bounds__(256) k_chain_dist(ModelArgs<T, P> m, ChainArgs<T, P> a) {
-    static_assert(P % 16 == 0 && G >= 16, "one DPP row of 16 lanes per copy of the state");
-    constexpr int NK = P / 16;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int gl = threadIdx.x % G, r = threadIdx.x & 15;
-    int64_t chain = a.first + ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
-    const bool live = chain < a.first + a.count;
-    if (!live) chain = a.first + a.count - 1;  // whole waves stay converged for the DPP exchanges; stores are masked
-    const bool writer = live && gl < 16;       // the first row of the group stores its lanes' coordinates
-    const auto rows = make_rows<T, P, G, MODE, R>(m, gl, reinterpret_cast<T*>(smem_raw));
-    const uint64_t gchain = (uint64_t)(a.chain_offset + chain);
-
-    // the lane's coordinates of the state and of the kernel's constant vectors (kernel arguments, read per lane)
-    // (the prior's precisions too: the prior term of value and gradient is the OWNER's work -- P / 16 multiply-adds per lane instead of P
-    //  replicated ones, and no 32-vector of precisions in SGPRs: with both of HMC's (plain and prescaled) there the float64 kernels
-    //  carried 220-255 spilled SGPRs)
-    T x[NK], ca[NK], cb[NK], cc[NK], cd[NK], civ[NK], cek[NK];
-#pragma unroll
-    for (int k = 0; k < NK; ++k) {
-        const int j = r + 16 * k;
-        x[k] = j < a.p ? a.state[chain * a.p + j] : T(0);
-        ca[k] = a.a[j];
-        cb[k] = a.b[j];
-        cc[k] = a.c[j];
-        cd[k] = a.d[j];
-        civ[k] = m.prior.inv_var[j];
-        cek[k] = a.e[j];  // HMC: inv_var / ExpScale<T>::k, for positions carried as k * q
-    }
-    const double lprior_const = m.prior.lprior_const;
-    auto row_sum = [&](T v) { return group_sum<16>(v); };  // over the 16 owners of a row: bit-identical in all of them
-
-    // value (replicated) and / or the lane's coordinates of the gradient at the distributed point `xo`; `prescaled`: xo = k * position
-    // (gradient only).  eval_lpost gets a ZERO prior (folded away at compile time): likelihood only.
-    auto evaluate = [&](auto want_value, auto want_grad, auto prescaled, const T (&xo)[NK], T (&go)[NK], double& ll, double& lpr) {
-        constexpr bool VALUE = decltype(want_value)::value, GRAD = decltype(want_grad)::value, PRE = decltype(prescaled)::value;
-        T xb[P], gb[P];
-#pragma unroll
-        for (int k = 0; k < NK; ++k) dist_gather16<T, P>(xo[k], k, xb);
-        Prior<T, P> none;
-#pragma unroll
-        for (int j = 0; j < P; ++j) none.inv_var[j] = T(0);
-        none.lprior_const = 0.0;
-        double lpr_unused = 0;
-        eval_lpost<T, P, G, VALUE, GRAD, PRE>(rows, none, xb, gb, ll, lpr_unused);
-        if constexpr (GRAD) {
-            static_assert(NK <= 2, "picks spelled out");
-            go[0] = dist_pick16<T, P, 0>(gb, r);
-            if constexpr (NK > 1) go[NK - 1] = dist_pick16<T, P, NK - 1>(gb, r);
-#pragma unroll
-            for (int k = 0; k < NK; ++k) go[k] = fma_t(-xo[k], PRE ? cek[k] : civ[k], go[k]);  // + prior
-        }
-        if constexpr (VALUE) {
-            T qd = T(0);
-#pragma unroll
-            for (int k = 0; k < NK; ++k) qd = fma_t(xo[k] * xo[k], civ[k], qd);
-            lpr = lprior_const - 0.5 * (double)row_sum(qd);
-        }
-    };
-    using True = std::integral_constant<bool, true>;
-    using False = std::integral_constant<bool, false>;
-
-    T g[NK];    // gradient at x (MALA / HMC / UL)
-    double lp;  // log-density attached to x: threaded value (RWMH / MALA) or lpost(x) (HMC)
-    uint32_t nacc = 0;
-#pragma unroll
-    for (int k = 0; k < NK; ++k) g[k] = T(0);
-    {
-        double ll0 = 0, lpr0 = 0;
-        if constexpr (KIND == KIND_HMC) {
-            evaluate(True{}, True{}, False{}, x, g, ll0, lpr0);
-            lp = ll0 + lpr0;
-        } else if constexpr (KIND == KIND_MALA) {
-            evaluate(False{}, True{}, False{}, x, g, ll0, lpr0);
-            lp = a.lp_state[chain];
-        } else if constexpr (KIND == KIND_UL) {
-            evaluate(False{}, True{}, False{}, x, g, ll0, lpr0);
-            lp = 0;
-        } else {
-            lp = a.lp_state[chain];
-        }
-    }
-
-    DrawBatch<T, P, G> draws;
-    static_assert(DrawBatch<T, P, G>::kEnabled, "batched draws");
-    draws.reset();
-    for (int64_t it = 0; it < a.iters; ++it) {
-        for (int64_t jt = 0; jt < a.thin; ++jt) {
-            const uint64_t iter = (uint64_t)(a.iter_offset + it * a.thin + jt);
-            T z[NK], logu_t;
-            draws.template next_own<NK>(a.seed, gchain, iter, gl, r, z, logu_t);
-            if constexpr (KIND == KIND_UL) {
-                // x <- x + 0.5*pre*dt*glp(x) + sqrt(pre*dt)*z            fit-np-ul.py:65-67
-#pragma unroll
-                for (int k = 0; k < NK; ++k) x[k] = fma_t(cb[k], z[k], fma_t(ca[k], g[k], x[k]));
-                double d0, d1;
-                evaluate(False{}, True{}, False{}, x, g, d0, d1);
-                ++nacc;
-            } else {
-                const double logu = (double)logu_t;
-                T xp[NK], gp[NK];
-#pragma unroll
-                for (int k = 0; k < NK; ++k) gp[k] = T(0);
-                double llp = 0, lprp = 0, logr;
-                if constexpr (KIND == KIND_RWMH) {
-                    // prop = x + sd*z; a = lpost(prop) - ll                  fit-numpy.py:53-62,83-84
-#pragma unroll
-                    for (int k = 0; k < NK; ++k) xp[k] = fma_t(ca[k], z[k], x[k]);
-                    evaluate(True{}, False{}, False{}, xp, gp, llp, lprp);
-                    logr = (llp + lprp) - lp;
-                } else if constexpr (KIND == KIND_MALA) {
-                    // prop = advance(x) + sqrt(pre*dt) z ; advance(x) = x + 0.5*pre*dt*glp(x)
-                    // a = lp' - ll + dprop(x,prop) - dprop(prop,x)           fit-np-mala.py:61-78
-                    T advx[NK];
-#pragma unroll
-                    for (int k = 0; k < NK; ++k) {
-                        advx[k] = fma_t(ca[k], g[k], x[k]);
-                        xp[k] = fma_t(cb[k], z[k], advx[k]);
-                    }
-                    evaluate(True{}, True{}, False{}, xp, gp, llp, lprp);
-                    T dq = T(0);
-#pragma unroll
-                    for (int k = 0; k < NK; ++k) {
-                        const T advp = fma_t(ca[k], gp[k], xp[k]);
-                        const T d1 = x[k] - advp, d2 = xp[k] - advx[k];
-                        dq = fma_t(cc[k], d1 * d1 - d2 * d2, dq);
-                    }
-                    logr = (llp + lprp) - lp - 0.5 * (double)row_sum(dq);
-                } else {  // HMC
-                    // p ~ N(0, dmm); leapfrog l steps; a = alpi(prop) - alpi(x)     fit-np-hmc.py:65-87
-                    T pm[NK], xk[NK];
-                    T k0p = T(0);
-                    const T heps = T(0.5) * a.step;
-#pragma unroll
-                    for (int k = 0; k < NK; ++k) {
-                        pm[k] = z[k] * ca[k];
-                        k0p = fma_t(pm[k] * pm[k], cc[k], k0p);
-                        pm[k] = fma_t(heps, g[k], pm[k]);
-                        xk[k] = ExpScale<T>::k * x[k];  // k * position
-                    }
-                    const T k0 = row_sum(k0p);
-                    for (int i = 0; i < a.l - 1; ++i) {
-#pragma unroll
-                        for (int k = 0; k < NK; ++k) xk[k] = fma_t(cd[k], pm[k], xk[k]);  // drift
-                        double d0, d1;
-                        evaluate(False{}, True{}, True{}, xk, gp, d0, d1);
-#pragma unroll
-                        for (int k = 0; k < NK; ++k) pm[k] = fma_t(a.step, gp[k], pm[k]);  // kick
-                    }
-#pragma unroll
-                    for (int k = 0; k < NK; ++k) {
-                        xk[k] = fma_t(cd[k], pm[k], xk[k]);
-                        xp[k] = ExpScale<T>::inv * xk[k];
-                    }
-                    evaluate(True{}, True{}, False{}, xp, gp, llp, lprp);
-                    T k1p = T(0);
-#pragma unroll
-                    for (int k = 0; k < NK; ++k) {
-                        pm[k] = fma_t(heps, gp[k], pm[k]);
-                        k1p = fma_t(pm[k] * pm[k], cc[k], k1p);
-                    }
-                    const T k1 = row_sum(k1p);
-                    logr = ((llp + lprp) - lp) - 0.5 * ((double)k1 - (double)k0);
-                }
-                const bool acc = logu < logr;  // NaN -> reject, as `np.log(np.random.rand()) < a`
-                if (acc) {
-                    ++nacc;
-                    lp = llp + lprp;
-                }
-#pragma unroll
-                for (int k = 0; k < NK; ++k) {
-                    x[k] = acc ? xp[k] : x[k];
-                    if constexpr (KIND != KIND_RWMH) g[k] = acc ? gp[k] : g[k];
-                }
-            }
-        }
-        if (writer) {
-#pragma unroll
-            for (int k = 0; k < NK; ++k) {
-                const int j = r + 16 * k;
-                if (j < a.p) {
-                    if (a.out) a.out[(it * a.C + chain) * a.p + j] = x[k];
-                    if (a.stats.buf) {  // (stats_update of lr_device.h for one coordinate)
-                        const int64_t idx = a.stats.first + it, b = idx / a.stats.batch, kk = idx - b * a.stats.batch;
-                        double* sbuf = a.stats.buf + ((b * a.C + chain) * 2) * a.p;
-                        stats_fold(sbuf + j, sbuf + a.p + j, kk, 1.0 / (double)(kk + 1), (double)x[k]);
-                    }
-                }
-            }
-        }
-    }
-    if (writer) {
-#pragma unroll
-        for (int k = 0; k < NK; ++k)
-            if (r + 16 * k < a.p) a.state[chain * a.p + r + 16 * k] = x[k];
-        if (gl == 0) {
-            if (a.accepts) a.accepts[chain] += nacc;
-            if constexpr (KIND == KIND_RWMH || KIND == KIND_MALA) a.lp_state[chain] = lp;
-        }
-    }
-}
-
-// --------------------------------------------------------------------------------------------
 // the chain kernel
 template <typename T, int P, int G, int MODE, int R, int KIND>
 __global__ void __launch_bounds__(256) k_chain(ModelArgs<T, P> m, ChainArgs<T, P> a) {
@@ -800,20 +559,7 @@ __global__ void __launch_bounds__(256) k_chain(ModelArgs<T, P> m, ChainArgs<T, P
     const bool live = chain < a.first + a.count;
     if (!live) chain = a.first + a.count - 1;  // whole waves stay converged for the DPP reductions; stores are masked
     const bool writer = live && gl == 0;
-    // (lane per chain, float32, p = 16, HMC: the rows ONE at a time through the scalar unit -- a twisted row pair is 32 SGPRs, and beside
-    //  HMC's five constant vectors of 16 the kernel spilled SGPRs past its VGPR lanes into scratch)
-    constexpr bool kRowAtATime = KIND == KIND_HMC && P == 16 && G == 1 && MODE == MODE_GLOBAL && sizeof(T) == 4;
-    const auto rows = [&]() {
-        if constexpr (kRowAtATime) {
-            ScalarRows<T, P> r1;
-            r1.base = m.rows;
-            r1.i0 = 0;
-            r1.i1 = m.n;
-            return r1;
-        } else {
-            return make_rows<T, P, G, MODE, R>(m, gl, reinterpret_cast<T*>(smem_raw));
-        }
-    }();
+    const auto rows = make_rows<T, P, G, MODE, R>(m, gl, reinterpret_cast<T*>(smem_raw));
     const uint64_t gchain = (uint64_t)(a.chain_offset + chain);
 
     T x[P];
@@ -874,14 +620,13 @@ __global__ void __launch_bounds__(256) k_chain(ModelArgs<T, P> m, ChainArgs<T, P
                 } else if constexpr (KIND == KIND_MALA) {
                     // prop = advance(x) + sqrt(pre*dt) z ; advance(x) = x + 0.5*pre*dt*glp(x)
                     // a = lp' - ll + dprop(x,prop) - dprop(prop,x)           fit-np-mala.py:61-78
-                    {
-                        T advx[P];
-                        vfma_o<T, P>(a.a, g, x, advx);
-                        vfma_o<T, P>(a.b, z, advx, xp);
-                    }
+                    T advx[P], advp[P];
+                    vfma_o<T, P>(a.a, g, x, advx);
+                    vfma_o<T, P>(a.b, z, advx, xp);
                     eval_lpost<T, P, G, true, true>(rows, m.prior, xp, gp, llp, lprp);
+                    vfma_o<T, P>(a.a, gp, xp, advp);
                     // dprop(x, prop) - dprop(prop, x): (x - advance(prop))^2 - (prop - advance(x))^2, weighted 1/(pre dt)
-                    const T dq = mala_dq<T, P>(a.a, a.c, x, g, xp, gp);
+                    const T dq = vdiffsq<T, P>(a.c, x, advp, xp, advx);
                     logr = (llp + lprp) - lp - 0.5 * (double)dq;
                 } else {  // HMC
                     // p ~ N(0, dmm); leapfrog l steps; a = alpi(prop) - alpi(x)     fit-np-hmc.py:65-87
