@@ -454,6 +454,28 @@ __device__ __forceinline__ double fast_rcp(double x) {
     e = __builtin_fma(-x, r, 1.0);
     return __builtin_fma(r, e, r);
 }
+// exp(x) for x in [-745, 709] WITHOUT the range guards of the library function (its result select -- a compare and two v_cndmask per
+// call -- and nothing else is what separates the two: the same reduction x = n ln 2 + r, |r| <= ln 2 / 2, the same degree-11 minimax
+// polynomial, v_ldexp).  Below -745 the scaling underflows to 0 by itself as long as n fits an int and r stays a reduced argument: callers
+// clamp at -750 where the argument is unbounded (row_term).  19 instructions, < 1 ulp.
+__device__ __forceinline__ double exp_noguard(double x) {
+    const double n = __builtin_rint(x * 1.4426950408889634);
+    double r = __builtin_fma(n, -6.93147180559945286227e-01, x);
+    r = __builtin_fma(n, -2.31904681384629955842e-17, r);
+    double p = __builtin_bit_cast(double, 0x3e5ade156a5dcb37ull);
+    p = __builtin_fma(p, r, __builtin_bit_cast(double, 0x3e928af3fca7ab0cull));
+    p = __builtin_fma(p, r, __builtin_bit_cast(double, 0x3ec71dee623fde64ull));
+    p = __builtin_fma(p, r, __builtin_bit_cast(double, 0x3efa01997c89e6b0ull));
+    p = __builtin_fma(p, r, __builtin_bit_cast(double, 0x3f2a01a014761f6eull));
+    p = __builtin_fma(p, r, __builtin_bit_cast(double, 0x3f56c16c1852b7b0ull));
+    p = __builtin_fma(p, r, __builtin_bit_cast(double, 0x3f81111111122322ull));
+    p = __builtin_fma(p, r, __builtin_bit_cast(double, 0x3fa55555555502a1ull));
+    p = __builtin_fma(p, r, __builtin_bit_cast(double, 0x3fc5555555555511ull));
+    p = __builtin_fma(p, r, __builtin_bit_cast(double, 0x3fe000000000000bull));
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return __builtin_amdgcn_ldexp(p, (int)n);
+}
 // log(1 + e) for e in [0, 1]
 __device__ __forceinline__ float log1p_unit(float e) { return __builtin_amdgcn_logf(1.0f + e) * 0.693147180559945309f; }
 // float64: the fdlibm log kernel (e_log.c: log(1 + f) = f - (f^2/2 - s (f^2/2 + R(s^2))), s = f / (2 + f), |f| < 0.4143) on 1 + e split
@@ -699,7 +721,10 @@ template <> struct ExpScale<double> {
 
 // one signed row: accumulate sigma(-t) * xs into g[], and (VALUE) log sigma(t) into v.
 // `bs` is beta * ExpScale<T>::k.
-template <typename T, int P, bool VALUE, bool GRAD>
+// FASTW (float64, gradient only): the weight as rcp(1 + exp(t)) -- HMC's INTERIOR evaluations, whose gradients never meet a
+// value + gradient evaluation of the same point (chunk boundaries fall between iterations): the sign-symmetric form below costs a
+// compare, two selects and a multiply more per row.
+template <typename T, int P, bool VALUE, bool GRAD, bool FASTW = false>
 __device__ __forceinline__ void row_term(const T (&xs)[P], const T (&bs)[P], T (&g)[P], T& v) {
     T ts;
     if constexpr (sizeof(T) == 4 && P % 2 == 0 && P >= 4) {
@@ -722,7 +747,19 @@ __device__ __forceinline__ void row_term(const T (&xs)[P], const T (&bs)[P], T (
         // exp(-|t|), a clamped reciprocal and the library log1p per row: 220 instructions per row with value and gradient, 114 now).
         // The gradient-only form uses the SAME weights (3 instructions more than rcp(1 + exp(t)) there): a chunked MALA run starts
         // each launch with a gradient-only evaluation of a state whose gradient the previous launch took from a value + gradient one.
-        const T e = exp(-__builtin_fabs(ts));
+        if constexpr (FASTW && GRAD && !VALUE) {
+            // (clamped: exp stays finite -- 1 + e <= 1e304, no guard in the reciprocal -- and the reduction stays a reduction)
+            const T s1 = T(1) + exp_noguard(__builtin_fmin(__builtin_fmax(ts, T(-750)), T(700)));
+            T r = __builtin_amdgcn_rcp(s1);
+            T err = __builtin_fma(-s1, r, T(1));
+            r = __builtin_fma(r, err, r);
+            err = __builtin_fma(-s1, r, T(1));
+            r = __builtin_fma(r, err, r);
+#pragma unroll
+            for (int j = 0; j < P; ++j) g[j] = fma_t(r, xs[j], g[j]);
+            return;
+        }
+        const T e = exp_noguard(__builtin_fmax(-__builtin_fabs(ts), T(-750)));
         if constexpr (GRAD) {
             const T s1 = T(1) + e;
             T r = __builtin_amdgcn_rcp(s1);
@@ -1009,7 +1046,10 @@ template <typename T, int P, int G> struct StridedRows {  // LDS or global: same
         // round trip per row, which nothing else in the wave covers
         // (256-byte rows -- float64 at padded p = 32 --: one at a time; two are 128 registers, beside the position and gradient
         //  32-vectors the whole file)
-        constexpr int UB = sizeof(T) * P <= 64 ? 4 : (sizeof(T) * P <= 128 ? 2 : 1);
+#ifndef LR_ROWS_AHEAD64
+#define LR_ROWS_AHEAD64 4
+#endif
+        constexpr int UB = sizeof(T) * P <= 64 ? (sizeof(T) == 8 ? LR_ROWS_AHEAD64 : 4) : (sizeof(T) * P <= 128 ? 2 : 1);
         const int64_t n = hi;
         int64_t i = lo + gl;
         for (; i + (UB - 1) * G < n; i += UB * G) {
@@ -1220,7 +1260,7 @@ __device__ __forceinline__ void eval_lpost(const Rows& rows, const Prior<T, P>& 
         }
     } else if constexpr (G == 1 && sizeof(T) == 4 && is_scalar_rows<Rows>::value) {
         if (rows.i1 - rows.i0 <= kSeqRows) {
-            rows.for_each([&](const T(&xs)[P]) { row_term<T, P, VALUE, GRAD>(xs, bs, g, v); });
+            rows.for_each([&](const T(&xs)[P]) { row_term<T, P, VALUE, GRAD, PRESCALED>(xs, bs, g, v); });
         } else {  // as above, for the row-at-a-time scalar form (P = 32)
             double gd[P], vd = 0.0;
 #pragma unroll
@@ -1230,7 +1270,7 @@ __device__ __forceinline__ void eval_lpost(const Rows& rows, const Prior<T, P>& 
                 sub.i0 = ib;
                 sub.i1 = ib + kSeqRows < rows.i1 ? ib + kSeqRows : rows.i1;
                 T vb = T(0);
-                sub.for_each([&](const T(&xs)[P]) { row_term<T, P, VALUE, GRAD>(xs, bs, g, vb); });
+                sub.for_each([&](const T(&xs)[P]) { row_term<T, P, VALUE, GRAD, PRESCALED>(xs, bs, g, vb); });
 #pragma unroll
                 for (int j = 0; j < P; ++j) {
                     gd[j] += (double)g[j];
@@ -1244,7 +1284,7 @@ __device__ __forceinline__ void eval_lpost(const Rows& rows, const Prior<T, P>& 
         }
     } else if constexpr (sizeof(T) == 4 && is_strided_rows<Rows>::value) {
         if (rows.n <= (int64_t)kSeqRows * G) {
-            rows.for_each([&](const T(&xs)[P]) { row_term<T, P, VALUE, GRAD>(xs, bs, g, v); });
+            rows.for_each([&](const T(&xs)[P]) { row_term<T, P, VALUE, GRAD, PRESCALED>(xs, bs, g, v); });
         } else {  // LDS / global rows with few lanes per chain (lds G = 1 reaches n = 4096 at p = 4): as above
             double gd[P], vd = 0.0;
 #pragma unroll
@@ -1252,7 +1292,7 @@ __device__ __forceinline__ void eval_lpost(const Rows& rows, const Prior<T, P>& 
             for (int64_t ib = 0; ib < rows.n; ib += (int64_t)kSeqRows * G) {
                 const int64_t ie = ib + (int64_t)kSeqRows * G < rows.n ? ib + (int64_t)kSeqRows * G : rows.n;
                 T vb = T(0);
-                rows.for_each_in(ib, ie, [&](const T(&xs)[P]) { row_term<T, P, VALUE, GRAD>(xs, bs, g, vb); });
+                rows.for_each_in(ib, ie, [&](const T(&xs)[P]) { row_term<T, P, VALUE, GRAD, PRESCALED>(xs, bs, g, vb); });
 #pragma unroll
                 for (int j = 0; j < P; ++j) {
                     gd[j] += (double)g[j];
@@ -1265,7 +1305,7 @@ __device__ __forceinline__ void eval_lpost(const Rows& rows, const Prior<T, P>& 
             if constexpr (VALUE) vwide = vd;
         }
     } else {
-        rows.for_each([&](const T(&xs)[P]) { row_term<T, P, VALUE, GRAD>(xs, bs, g, v); });
+        rows.for_each([&](const T(&xs)[P]) { row_term<T, P, VALUE, GRAD, PRESCALED>(xs, bs, g, v); });
     }
     if constexpr (GRAD) {
         if constexpr (sizeof(T) == 4) {
