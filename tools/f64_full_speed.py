@@ -13,11 +13,11 @@ X, y, _ = la.synthetic_logreg(200, 8, seed=20240001)
 m = la.LogReg(X, y, np.array([10.0] + [1.0] * 7), dtype="float64")
 q0 = bench.headline_init(0, 4096)
 k = la.hmcKernel(m.lpost, m.glp, eps=0.1, l=50, dmm=np.ones(8))
-for C in (4096, 8192):
-    cs = la.ChainSet(k, np.tile(q0, (C // 4096, 1)), seed=42, stream=stream, precision="full")
+for C, mode, g in ((4096, "auto", 0), (4096, "lds", 16), (4096, "lds", 8), (4096, "reg", 32), (8192, "auto", 0), (8192, "lds", 16), (16384, "auto", 0)):
+    cs = la.ChainSet(k, np.tile(q0, (C // 4096, 1)), seed=42, stream=stream, precision="full", mode=mode, group=g)
     ms = bench._timed_chainset(la, timer, cs, 10, 20, repeats=3)
     its = C * 200 / (ms * 1e-3)
-    print(f"HMC all-float64 {C} chains: {its:.4g} it/s, {its * 50 * bench.flops_per_grad_eval(200, 8) / 1e12 / 78.6:.3f} of the fp64 vector peak, plan {cs.plan()}, accept {cs.get_accepts().sum() / (C * 620):.4f}", flush=True)
+    print(f"HMC all-float64 {C} chains {mode}/{g}: {its:.4g} it/s, {its * 50 * bench.flops_per_grad_eval(200, 8) / 1e12 / 78.6:.3f} of the fp64 vector peak, plan {cs.plan()}, accept {cs.get_accepts().sum() / (C * 620):.4f}", flush=True)
 km = la.malaKernel(m.lpost, m.glp, dt=1e-3, pre=np.ones(8))
 cs = la.ChainSet(km, np.tile(q0, (2, 1)), seed=42, stream=stream)
 ms = bench._timed_chainset(la, timer, cs, 2, 500, repeats=3)
