@@ -285,6 +285,27 @@ LR_API int lr_event_record(int device, void* event, void* stream);
 /* synchronises on `stop`, then returns the time between the two events in milliseconds */
 LR_API int lr_event_elapsed_ms(int device, void* start, void* stop, float* ms);
 
+/*
+ * The multi-GPU exchange of the path at the C level (SURVEY.md section 8(b) `lr_gather`): one process per GPU, chains sharded in
+ * contiguous blocks (lr_run_opts.chain_offset / plan_chains / plan_first), ONE exchange -- the gather of the thinned samples to a root
+ * rank, or the sum of the statistics rows (lr_stats_reduce) over the ranks.  A thin wrapper over RCCL (point-to-point send / receive
+ * group and all-reduce over xGMI), loaded at first use (dlopen of librccl.so.1: the library has no link-time dependency on it), so
+ * that a host language needs no other collective runtime; the Python face uses torch.distributed (the same RCCL) and does not call
+ * these.  The reference has no counterpart (single process).
+ *   lr_comm_unique_id   one rank makes the LR_COMM_ID_BYTES identifier and hands it to the others by any means (a file, a socket)
+ *   lr_comm_create      every rank, with the same identifier: collective; binds the communicator to `device`
+ *   lr_gather           every rank sends `bytes` bytes at `send` (device memory); rank `root` receives world blocks, in rank order, at
+ *                       `recv` (device memory, world * bytes; ignored elsewhere).  Enqueued on `stream`.
+ *   lr_allreduce_sum_f64  in place over `count` doubles of device memory (the [LR_STATS_ROWS][p] sums + a chain count)
+ */
+typedef struct lr_comm lr_comm;
+#define LR_COMM_ID_BYTES 128
+LR_API int lr_comm_unique_id(void* id);
+LR_API int lr_comm_create(const void* id, int32_t rank, int32_t world, int device, lr_comm** out);
+LR_API int lr_comm_destroy(lr_comm* comm);
+LR_API int lr_gather(lr_comm* comm, const void* send, void* recv, uint64_t bytes, int32_t root, void* stream);
+LR_API int lr_allreduce_sum_f64(lr_comm* comm, double* buf, uint64_t count, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

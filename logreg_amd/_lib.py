@@ -73,6 +73,12 @@ SYMBOLS = {
     "lr_event_destroy": (C.c_int, [C.c_int, _vp]),
     "lr_event_record": (C.c_int, [C.c_int, _vp, _vp]),
     "lr_event_elapsed_ms": (C.c_int, [C.c_int, _vp, _vp, C.POINTER(C.c_float)]),
+    # the C-level exchange (RCCL, loaded at first use); the Python face itself goes through torch.distributed
+    "lr_comm_unique_id": (C.c_int, [_vp]),
+    "lr_comm_create": (C.c_int, [_vp, _i32, _i32, C.c_int, C.POINTER(_vp)]),
+    "lr_comm_destroy": (C.c_int, [_vp]),
+    "lr_gather": (C.c_int, [_vp, _vp, _vp, _u64, _i32, _vp]),
+    "lr_allreduce_sum_f64": (C.c_int, [_vp, _vp, _u64, _vp]),
 }
 
 _lib = None

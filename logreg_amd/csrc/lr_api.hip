@@ -634,4 +634,108 @@ int lr_event_elapsed_ms(int device, void* start, void* stop, float* ms) {
     return LR_OK;
 }
 
+// ---- the C-level exchange: RCCL, resolved at first use (no link-time dependency; see include/logreg_hip.h)
+}  // extern "C"
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+struct lr_comm {
+    ncclComm_t comm;
+    int rank, world, device;
+};
+namespace {
+struct Rccl {
+    void* h = nullptr;
+    decltype(&ncclGetUniqueId) get_unique_id = nullptr;
+    decltype(&ncclCommInitRank) comm_init_rank = nullptr;
+    decltype(&ncclCommDestroy) comm_destroy = nullptr;
+    decltype(&ncclGroupStart) group_start = nullptr;
+    decltype(&ncclGroupEnd) group_end = nullptr;
+    decltype(&ncclSend) send = nullptr;
+    decltype(&ncclRecv) recv = nullptr;
+    decltype(&ncclAllReduce) all_reduce = nullptr;
+    decltype(&ncclGetErrorString) error_string = nullptr;
+};
+Rccl g_rccl;
+int rccl_load() {
+    if (g_rccl.h) return LR_OK;
+    void* h = nullptr;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (h) break;
+    }
+    if (!h) return fail(LR_ERR_UNSUPPORTED, "RCCL (librccl.so.1) could not be loaded: %s", dlerror());
+    Rccl r;
+    r.h = h;
+#define LR_SYM(field, name)                                                     \
+    r.field = reinterpret_cast<decltype(r.field)>(dlsym(h, name));              \
+    if (!r.field) return fail(LR_ERR_UNSUPPORTED, "RCCL symbol %s not found", name);
+    LR_SYM(get_unique_id, "ncclGetUniqueId")
+    LR_SYM(comm_init_rank, "ncclCommInitRank")
+    LR_SYM(comm_destroy, "ncclCommDestroy")
+    LR_SYM(group_start, "ncclGroupStart")
+    LR_SYM(group_end, "ncclGroupEnd")
+    LR_SYM(send, "ncclSend")
+    LR_SYM(recv, "ncclRecv")
+    LR_SYM(all_reduce, "ncclAllReduce")
+    LR_SYM(error_string, "ncclGetErrorString")
+#undef LR_SYM
+    g_rccl = r;
+    return LR_OK;
+}
+#define LR_NCCL(call)                                                                                       \
+    do {                                                                                                    \
+        const ncclResult_t r_ = (call);                                                                     \
+        if (r_ != ncclSuccess) return fail(LR_ERR_HIP, "%s failed: %s", #call, g_rccl.error_string(r_));    \
+    } while (0)
+}  // namespace
+extern "C" {
+
+int lr_comm_unique_id(void* id) {
+    static_assert(LR_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "identifier size");
+    if (!id) return fail(LR_ERR_INVALID, "id is NULL");
+    if (int rc = rccl_load()) return rc;
+    ncclUniqueId u;
+    LR_NCCL(g_rccl.get_unique_id(&u));
+    std::memcpy(id, u.internal, LR_COMM_ID_BYTES);
+    return LR_OK;
+}
+int lr_comm_create(const void* id, int32_t rank, int32_t world, int device, lr_comm** out) {
+    if (!id || !out) return fail(LR_ERR_INVALID, "id / out is NULL");
+    if (world < 1 || rank < 0 || rank >= world) return fail(LR_ERR_INVALID, "rank %d of world %d", rank, world);
+    if (int rc = rccl_load()) return rc;
+    LR_HIP(hipSetDevice(device));
+    ncclUniqueId u;
+    std::memcpy(u.internal, id, LR_COMM_ID_BYTES);
+    ncclComm_t c;
+    LR_NCCL(g_rccl.comm_init_rank(&c, world, u, rank));
+    *out = new lr_comm{c, rank, world, device};
+    return LR_OK;
+}
+int lr_comm_destroy(lr_comm* comm) {
+    if (!comm) return LR_OK;
+    if (g_rccl.h) (void)g_rccl.comm_destroy(comm->comm);
+    delete comm;
+    return LR_OK;
+}
+int lr_gather(lr_comm* comm, const void* send, void* recv, uint64_t bytes, int32_t root, void* stream) {
+    if (!comm || !send) return fail(LR_ERR_INVALID, "comm / send is NULL");
+    if (root < 0 || root >= comm->world) return fail(LR_ERR_INVALID, "root %d of world %d", root, comm->world);
+    if (comm->rank == root && !recv) return fail(LR_ERR_INVALID, "recv is NULL on the root rank");
+    LR_HIP(hipSetDevice(comm->device));
+    // every rank sends its block to the root, the root receives world blocks in rank order: ONE group (xGMI point-to-point)
+    LR_NCCL(g_rccl.group_start());
+    LR_NCCL(g_rccl.send(send, bytes, ncclUint8, root, comm->comm, (hipStream_t)stream));
+    if (comm->rank == root)
+        for (int r = 0; r < comm->world; ++r)
+            LR_NCCL(g_rccl.recv(static_cast<unsigned char*>(recv) + (uint64_t)r * bytes, bytes, ncclUint8, r, comm->comm, (hipStream_t)stream));
+    LR_NCCL(g_rccl.group_end());
+    return LR_OK;
+}
+int lr_allreduce_sum_f64(lr_comm* comm, double* buf, uint64_t count, void* stream) {
+    if (!comm || !buf) return fail(LR_ERR_INVALID, "comm / buf is NULL");
+    LR_HIP(hipSetDevice(comm->device));
+    LR_NCCL(g_rccl.all_reduce(buf, buf, count, ncclDouble, ncclSum, comm->comm, (hipStream_t)stream));
+    return LR_OK;
+}
+
 }  // extern "C"

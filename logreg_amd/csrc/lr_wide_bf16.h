@@ -1091,13 +1091,13 @@ __global__ void __launch_bounds__(512) k_wide_traj2_bf16(TallArgs<float, P> a) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 const u32x4 w0 = {spk[0], spk[1], spk[2], spk[3]}, w1 = {spk[4], spk[5], spk[6], spk[7]};
+                // both tiles' gradient MFMAs of an operand back to back, then block b's operand takes its place: the transposed reads are
+                // spread over the 2 NG slots, and all but the last have returned when the next trip asks (it waits for them before its DMA
+                // request may overwrite their slot)
 #pragma unroll
                 for (int mb = 0; mb < NG; ++mb) {
                     grad_mfma(0, mb, w0);
                     __builtin_amdgcn_sched_barrier(0);
-                }
-#pragma unroll
-                for (int mb = 0; mb < NG; ++mb) {  // the last use of xt[mb]: block b's operand takes its place
                     grad_mfma(1, mb, w1);
                     xt[mb][0] = lds_read_tr16(base + G::tile1(0, mb >> 1) + tr_off[mb & 1]);
                     xt[mb][1] = lds_read_tr16(base + G::tile1(1, mb >> 1) + tr_off[mb & 1]);

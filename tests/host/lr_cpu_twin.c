@@ -400,3 +400,37 @@ LR_API int lr_event_elapsed_ms(int device, void *start, void *stop, float *ms) {
     if (ms) *ms = (float)(*(double *)stop - *(double *)start);
     return LR_OK;
 }
+
+/* the C-level exchange on the test double: a world of ONE rank (the gather and the sum are copies / no-ops); more ranks need RCCL */
+struct lr_comm { int rank, world; };
+LR_API int lr_comm_unique_id(void *id) {
+    if (!id) return fail(LR_ERR_INVALID, "NULL id");
+    memset(id, 0x5a, LR_COMM_ID_BYTES);
+    return LR_OK;
+}
+LR_API int lr_comm_create(const void *id, int32_t rank, int32_t world, int device, lr_comm **out) {
+    (void)device;
+    if (!id || !out) return fail(LR_ERR_INVALID, "NULL id / out");
+    if (world != 1 || rank != 0) return fail(LR_ERR_UNSUPPORTED, "the CPU test double has no collective library: world 1 only (got rank %d of %d)", rank, world);
+    *out = (lr_comm *)malloc(sizeof(lr_comm));
+    (*out)->rank = 0;
+    (*out)->world = 1;
+    return LR_OK;
+}
+LR_API int lr_comm_destroy(lr_comm *comm) {
+    free(comm);
+    return LR_OK;
+}
+LR_API int lr_gather(lr_comm *comm, const void *send, void *recv, uint64_t bytes, int32_t root, void *stream) {
+    (void)stream;
+    if (!comm || !send || !recv) return fail(LR_ERR_INVALID, "NULL comm / send / recv");
+    if (root != 0) return fail(LR_ERR_INVALID, "root %d of world 1", root);
+    memmove(recv, send, bytes);
+    return LR_OK;
+}
+LR_API int lr_allreduce_sum_f64(lr_comm *comm, double *buf, uint64_t count, void *stream) {
+    (void)count;
+    (void)stream;
+    if (!comm || !buf) return fail(LR_ERR_INVALID, "NULL comm / buf");
+    return LR_OK;
+}

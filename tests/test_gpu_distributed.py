@@ -113,3 +113,40 @@ def test_bench_with_two_ranks_sharing_the_gpu_over_gloo():
     assert d["config"]["kernel_variant"] == {"mode": "reg", "group": 16, "rows_per_lane": 13}
     rows = {row["config"]: row for row in d["extra"]["configs"]}
     assert rows[3]["n_gpus"] == 2 and rows[5]["n_gpus"] == 2 and rows[3]["scaled_down"] == 8
+
+
+def test_c_level_exchange_over_rccl_at_one_rank():
+    """include/logreg_hip.h lr_comm_* / lr_gather / lr_allreduce_sum_f64 on the real library: RCCL loaded at first use (the library has no
+    link-time dependency on it), a communicator of one rank on the box's GPU, the gather of a device block to the root and the in-place
+    float64 sum -- in a child process, so that the ROCm RCCL this entry loads does not meet the copy torch carries in another test's
+    process.  (More ranks need more GPUs: the multi-GPU bench is the driver's.)"""
+    code = r"""
+import ctypes as C, numpy as np, sys
+sys.path.insert(0, %r)
+import logreg_amd as la
+from logreg_amd import _lib
+L = _lib.load()
+ident = (C.c_ubyte * 128)()
+_lib.check(L.lr_comm_unique_id(ident))
+assert any(ident)
+comm = C.c_void_p()
+_lib.check(L.lr_comm_create(ident, 0, 1, 0, C.byref(comm)))
+src = la.DeviceArray(0, (4, 96, 8), np.float32)
+dst = la.DeviceArray(0, (1, 4, 96, 8), np.float32)
+host = np.random.default_rng(1).standard_normal((4, 96, 8)).astype(np.float32)
+_lib.check(L.lr_memcpy_h2d(0, src.ptr, host.ctypes.data, host.nbytes, None))
+st = C.c_void_p(); _lib.check(L.lr_stream_create(0, C.byref(st)))
+_lib.check(L.lr_gather(comm, src.ptr, dst.ptr, host.nbytes, 0, st))
+sums = la.DeviceArray(0, (57,), np.float64)
+hs = np.linspace(1, 2, 57)
+_lib.check(L.lr_memcpy_h2d(0, sums.ptr, hs.ctypes.data, hs.nbytes, None))
+_lib.check(L.lr_allreduce_sum_f64(comm, sums.ptr, 57, st))
+_lib.check(L.lr_stream_sync(0, st))
+assert np.array_equal(dst.to_host()[0], host), "gather"
+assert np.array_equal(sums.to_host(), hs), "allreduce at world 1"
+assert L.lr_gather(comm, src.ptr, dst.ptr, host.nbytes, 3, st) < 0
+_lib.check(L.lr_comm_destroy(comm))
+print("exchange ok")
+""" % REPO
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0 and "exchange ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]

@@ -400,3 +400,26 @@ def test_the_scripts_own_rprop_is_recognised_and_fused(la, models, map_beta):
     before = np.random.get_state()[1].copy()
     assert not isinstance(la.mhKernel(m.lpost, lambda beta: beta + 0.02 * np.random.normal(size=p)), K.FusedKernel)
     assert np.array_equal(np.random.get_state()[1], before)
+
+
+def test_c_level_exchange_on_the_test_double(la):
+    """include/logreg_hip.h lr_comm_* / lr_gather / lr_allreduce_sum_f64 through the binding on the CPU test double: a world of one rank
+    (identifier, communicator, the gather as a copy, the sum in place); more ranks are refused there -- they need RCCL (GPU suite)."""
+    import ctypes as C
+    from logreg_amd import _lib
+    L = _lib.load()
+    ident = (C.c_ubyte * 128)()
+    _lib.check(L.lr_comm_unique_id(ident))
+    comm = C.c_void_p()
+    _lib.check(L.lr_comm_create(ident, 0, 1, 0, C.byref(comm)))
+    src = np.arange(24, dtype=np.float32)
+    dst = np.zeros(24, dtype=np.float32)
+    _lib.check(L.lr_gather(comm, src.ctypes.data, dst.ctypes.data, src.nbytes, 0, None))
+    assert np.array_equal(dst, src)
+    sums = np.linspace(0, 1, 57)
+    keep = sums.copy()
+    _lib.check(L.lr_allreduce_sum_f64(comm, sums.ctypes.data, sums.size, None))
+    assert np.array_equal(sums, keep)
+    assert L.lr_gather(comm, src.ctypes.data, dst.ctypes.data, src.nbytes, 1, None) < 0
+    _lib.check(L.lr_comm_destroy(comm))
+    assert L.lr_comm_create(ident, 1, 2, 0, C.byref(comm)) < 0 and b"world 1 only" in L.lr_last_error()
