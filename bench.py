@@ -274,6 +274,14 @@ def extra_configs(la, L, check, dev, stream):
                                        "algorithmic flops counted once (SURVEY 8(d)); 17.4 GFLOP per evaluation; the interior steps run as ONE "
                                        "launch per trajectory (k_wide_traj2_bf16: 32 chains per workgroup, one workgroup per CU); the MFMAs issued "
                                        "are 1.5x the algorithmic ones (beta in two bf16 pieces): MFMA-busy 52-57 % (profiles/r5_cfg5_whole*.txt)"}
+        if label == "5_whole":
+            # the same workload under precision="bf16" (the caller's explicit request: beta in ONE bf16 piece on the trajectory kernel --
+            # a third of the MFMAs fewer; the kernel is power-bound, so the time follows the work) with the acceptance it costs
+            cb = la.ChainSet(k, q0, seed=5, stream=stream, precision="bf16")
+            msb = _timed_chainset(la, timer, cb, iters, 1)
+            row["precision_bf16"] = {"us_per_evaluation_all_chains": msb * 1e-3 / evals * 1e6, "accept_rate": float(cb.get_accepts().sum() / (C * (3 * iters + 1))),
+                                     "frac_bf16_peak": C * fg / (msb * 1e-3 / evals) / 1e12 / PEAK_BF16_TFLOPS,
+                                     "note": "not the default: acceptance drops by ~0.02 (0.756 -> 0.737); still an exact sampler"}
         res.append(row)
     return res
 

@@ -288,7 +288,11 @@ int do_stepwise_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs
     const int64_t traj_tiles = (Cp + 15) / 16;
     // Two chain tiles per workgroup (k_wide_traj2_bf16, round 5; the same trajectories bit for bit) from the chain count at which
     // the one-tile kernel needs a second round of workgroups: measured rule below.  LOGREG_DEBUG_OPTS wide_traj=2 / 1 force either.
-    a.traj_tiles = m->dbg.wide_traj == 2 ? 2 : (m->dbg.wide_traj == 1 ? 1 : (traj_tiles > (int64_t)kTraj2FromTilesPerCu * m->cus ? 2 : 1));
+    // LR_PREC_BF16 (the caller's explicit request for the cheapest interior force): beta in ONE bf16 piece, on the two-tile kernel at any
+    // tile count the trajectory path takes -- a third of the MFMAs fewer for ~0.02 of acceptance (lr_wide_bf16.h)
+    const bool one_piece = o->precision == LR_PREC_BF16 && m->dbg.wide_traj != 1 && traj_tiles > (int64_t)kTraj2FromTilesPerCu * m->cus;  // (where the two-tile kernel runs anyway; 4096 chains: 16.6 against 16.9 us on the one-tile kernel -- nothing to buy)
+    a.beta_pieces = one_piece ? 1 : 2;
+    a.traj_tiles = (m->dbg.wide_traj == 2 || one_piece) ? 2 : (m->dbg.wide_traj == 1 ? 1 : (traj_tiles > (int64_t)kTraj2FromTilesPerCu * m->cus ? 2 : 1));
     const bool traj = P > 32 && bf16_interior && m->d_xblk1 != nullptr && t->launch_tall_traj != nullptr && rs.l > 1 &&
                       m->dbg.wide_traj != 0 &&
                       (m->dbg.wide_traj >= 1 || traj_tiles >= m->cus ||

@@ -91,6 +91,7 @@ template <typename T, int P> struct TallArgs {
     int64_t slice_len_i;    //   and rows per slice (a multiple of 32 * rowsplit_waves: whole 32-row blocks per wave)
     int rowsplit_waves;     //   4 or 8 waves per workgroup (wide); 16: the 16-wave tall kernel k_tall_partial_mx16 is in use
     int traj_tiles;         // wide models, trajectory kernel: chain tiles (16 chains) per workgroup -- 1: k_wide_traj_bf16, 2: k_wide_traj2_bf16
+    int beta_pieces;        // ... and the bf16 pieces of beta in its eta MFMAs: 2, or 1 (LR_PREC_BF16 on the two-tile kernel)
     int p, l;
     T step;
     T a[P], b[P], c[P];

@@ -886,7 +886,10 @@ __global__ void __launch_bounds__(512) k_wide_traj_bf16(TallArgs<float, P> a) {
 //  * Reduction over the waves through the wave's OWN last ring slot, one tile (16 chains x P floats = one slot) at a time: 4
 //    barriers per step instead of 16, 16-byte accesses only; thread (chain oc, chunk oq) owns coordinates 4 oq .. 4 oq + 3.
 // LDS: 8 rings x 16 KB + the new positions (16 KB) = 144 KB.
-template <int P>
+// NB = pieces of beta in the eta MFMAs: 2 (hi + lo: the default policy) or 1 (LR_PREC_BF16, the caller's explicit request: a third of the
+// MFMAs fewer -- the kernel is POWER-bound, 1300 W at 2.04 GHz, so the time follows the work: 24.2 -> 20.5 us per evaluation at config 5
+// whole -- for 0.019 of acceptance, 0.756 -> 0.737; still an exact sampler: a deterministic force, exact end points).
+template <int P, int NB = 2>
 __global__ void __launch_bounds__(512) k_wide_traj2_bf16(TallArgs<float, P> a) {
     using G = WideBf16Geom<P>;
     constexpr int NW = 8, NT2 = 2, BLK_BYTES = G::BUF1 * 2, NBUF = P >= 128 ? 2 : 4, RING_BYTES = NBUF * BLK_BYTES;
@@ -988,13 +991,13 @@ __global__ void __launch_bounds__(512) k_wide_traj2_bf16(TallArgs<float, P> a) {
     LR_TRAJ_PHASES_BEGIN  // development builds: shader cycles per phase of a step (lr_stamps.h)
     for (int s = 0; s < nsteps; ++s) {
         // beta = hi + lo (two round-to-nearest bf16 pieces) of the lane's coordinates 32 m + 8 kg + i, times log2(e), per tile: ready in qop
-        u32x4 bq[NT2][G::M32][2];
+        u32x4 bq[NT2][G::M32][NB];
 #pragma unroll
         for (int t = 0; t < NT2; ++t)
 #pragma unroll
             for (int m = 0; m < G::M32; ++m)
 #pragma unroll
-                for (int h = 0; h < 2; ++h) bq[t][m][h] = *reinterpret_cast<const u32x4*>(&qop[t][m][kg][h][c ^ ((4 * m + kg) & 15)][0]);
+                for (int h = 0; h < NB; ++h) bq[t][m][h] = *reinterpret_cast<const u32x4*>(&qop[t][m][kg][h][c ^ ((4 * m + kg) & 15)][0]);
         f32x4 gacc[NT2][G::MBP];
 #pragma unroll
         for (int t = 0; t < NT2; ++t)
@@ -1018,9 +1021,11 @@ __global__ void __launch_bounds__(512) k_wide_traj2_bf16(TallArgs<float, P> a) {
         };
         // One MFMA "slot" = the MFMA and the vector / LDS instructions that issue in its shadow; a scheduling barrier closes every slot, so
         // the emitted order is the source order (the group-barrier form left the sigmoid in one run in front of the MFMAs).
-        constexpr int NE = 4 * G::M32, NG = G::MBP;  // eta / gradient MFMAs per tile
+        constexpr int SPC = 2 * NB, NE = SPC * G::M32, NG = G::MBP;  // MFMA slots per 32-coordinate chunk; eta / gradient MFMAs per tile
         auto eta_mfma = [&](const u32x4 (&xa)[2][G::M32], int i, f32x4 (&en)[NT2][2]) {  // slot i of the 2 NE: tile i / NE, then (m, h, T)
-            const int t = i / NE, r = i % NE, m = r / 4, h = (r >> 1) & 1, T = r & 1;
+            // (the two row tiles T alternate, a tile's accumulator every second slot; one accumulator's MFMAs in consecutive slots, or the
+            //  sigmoid behind every second slot only: 24.3 - 24.4 us against 24.4 -- the kernel is power-bound, not issue-order-bound)
+            const int t = i / NE, r = i % NE, m = r / SPC, h = (r >> 1) % NB, T = r & 1;
             if (LR_TRAJ_EXP(2) && h) return;
             if (m == 0 && h == 0) en[t][T] = f32x4{0, 0, 0, 0};
             en[t][T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(xa[T][m]), as_bf16x8(bq[t][m][h]), en[t][T], 0, 0, 0);
@@ -1062,8 +1067,8 @@ __global__ void __launch_bounds__(512) k_wide_traj2_bf16(TallArgs<float, P> a) {
                 xa[1][m] = *reinterpret_cast<const u32x4*>(base + G::tile1(1, m) + eta_off);
             };
             auto xa_ahead = [&](int i) {  // in the shadow of eta slot i: the chunk two ahead in the (tile, chunk) order
-                if (i % 4 != 0) return;
-                const int seq = i / 4 + 2;  // chunk sequence number over both tiles
+                if (i % SPC != 0) return;
+                const int seq = i / SPC + 2;  // chunk sequence number over both tiles
                 if (seq < 2 * G::M32) read_xa(seq % G::M32);
             };
             read_xa(0);
@@ -1079,7 +1084,7 @@ __global__ void __launch_bounds__(512) k_wide_traj2_bf16(TallArgs<float, P> a) {
                 }
                 read_xt(base);
             } else {
-                constexpr int Q = 2 * NE / 4, VPS = 16 / Q;  // slots per sigmoid stage, values per slot (P = 128: 8 and 2, P = 64: 4 and 4)
+                constexpr int Q = 2 * NE / 4, VPS = 16 / Q;  // slots per sigmoid stage, values per slot (P = 128, two pieces: 8 and 2)
                 static_assert(2 * NE % 4 == 0 && Q * VPS == 16, "sixteen sigmoid values over a quarter of the eta slots per stage");
 #pragma unroll
                 for (int i = 0; i < 2 * NE; ++i) {

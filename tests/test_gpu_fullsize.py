@@ -186,7 +186,7 @@ def test_config5_whole_8192_chains_on_one_gpu(la, monkeypatch):
     k = la.hmcKernel(m.lpost, m.glp, **kw)
     # (b) + (c)
     res = {}
-    for prec in ("auto", "full"):
+    for prec in ("auto", "full", "bf16"):  # ("bf16": the explicit request -- beta in ONE bf16 piece on the trajectory kernel)
         cs = la.ChainSet(k, q0, seed=2025, precision=prec)
         first = cs.advance(1, 1).to_host()
         if prec == "auto":
@@ -198,11 +198,12 @@ def test_config5_whole_8192_chains_on_one_gpu(la, monkeypatch):
         zm, zs = _z(la, samples, fix)
         print(f"cfg5 whole precision={prec}: accept {acc:.4f} (oracle {fix['accept']:.4f}), max|z| mean {np.max(np.abs(zm)):.2f} sd "
               f"{np.max(np.abs(zs)):.2f}, rms z mean {np.sqrt(np.mean(zm ** 2)):.2f} sd {np.sqrt(np.mean(zs ** 2)):.2f}")
-        assert abs(acc - fix["accept"]) < 4 * fix["accept_se"] + (0.01 if prec == "full" else 0.03)
+        assert abs(acc - fix["accept"]) < 4 * fix["accept_se"] + {"full": 0.01, "auto": 0.03, "bf16": 0.05}[prec]
         assert np.max(np.abs(zm)) < 4.2 and np.max(np.abs(zs)) < 4.2, prec
         assert 0.5 < np.sqrt(np.mean(zm ** 2)) < 1.3 and 0.5 < np.sqrt(np.mean(zs ** 2)) < 1.3, prec
         res[prec] = acc
     assert res["auto"] > res["full"] - 0.03
+    assert res["full"] - 0.05 < res["bf16"] < res["auto"] + 0.005  # measured: 0.758 / 0.756 / 0.737
 
 
 def test_config1_rwmh_single_chain_thin_1000(la, pima, oracle_model, map_beta):

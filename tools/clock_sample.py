@@ -63,4 +63,7 @@ for cfg in (4, 5):
     qc = np.array(fix["map"]) + np.array(fix["laplace_sd"]) * np.random.default_rng(1).standard_normal((1024, fix["p"]))
     run(f"config {cfg} (stepwise, bf16 interior)", la.ChainSet(kc, qc, seed=3), 4, 1)
     run(f"config {cfg}, precision full", la.ChainSet(kc, qc, seed=3, precision="full"), 2, 1)
+    if cfg == 5:  # config 5 as a whole: 8192 chains (two-tile trajectory kernel)
+        q8 = np.array(fix["map"]) + np.array(fix["laplace_sd"]) * np.random.default_rng(1).standard_normal((8192, fix["p"]))
+        run("config 5 whole, 8192 chains (k_wide_traj2_bf16)", la.ChainSet(kc, q8, seed=3), 4, 1, seconds=4.0)
 stop.set()
