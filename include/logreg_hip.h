@@ -162,7 +162,9 @@ LR_API int lr_model_info(const lr_model* m, int64_t* n, int32_t* p, int32_t* dty
  *   tall_mx16=0       tall models: 4-wave interior kernel with separate update launches instead of the fused 16-wave form
  *   wide_traj=0|1|2   wide models: forbid / force the one-launch trajectory kernel with 1 / 2 chain tiles per workgroup (default: by chain count)
  *   wide_waves=4|8    wide models: waves (x 16 chains) per workgroup of the exact-split / chain-split kernels (default: by chain count)
- * Writes "" to buf for a model on the defaults (what a benchmark must run with), else the four settings.  No reference counterpart. */
+ *   wide_f16=0|1|2    wide float32 models, trajectory kernels: 0 = bf16 rows x two bf16 pieces of beta where the default policy would run
+ *                     the one-piece half-precision (f16) interior, 2 = f16 under LR_PREC_BF16 too (default 1: under LR_PREC_AUTO only)
+ * Writes "" to buf for a model on the defaults (what a benchmark must run with), else all the settings.  No reference counterpart. */
 LR_API int lr_model_debug_opts(const lr_model* m, char* buf, int len);
 
 /*

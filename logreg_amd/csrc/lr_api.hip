@@ -179,7 +179,7 @@ int lr_model_create(const double* X, const double* y, int64_t n, int32_t p, cons
         if (!parse_debug_opts(std::getenv("LOGREG_DEBUG_OPTS"), &m->dbg, bad, sizeof bad)) {
             delete m;
             return fail(LR_ERR_INVALID, "LOGREG_DEBUG_OPTS: unknown or out-of-range item '%s' (keys: residency_cap=0|1, tall_mx16=0|1, "
-                                        "wide_traj=0|1|2, wide_waves=4|8)", bad);
+                                        "wide_traj=0|1|2, wide_waves=4|8, wide_f16=0|1|2)", bad);
         }
     }
     m->device = device;
@@ -312,6 +312,14 @@ int lr_model_create(const double* X, const double* y, int64_t n, int32_t p, cons
             lr_model_destroy(m);
             return fail(LR_ERR_NOMEM, "allocating the single-piece bf16 block images (%zu bytes) failed", img1.size() * 2);
         }
+        if (dtype == LR_F32) {  // the trajectory kernels' half-precision image, where the rows fit its range (lr_wide_bf16.h)
+            const bool fits = m->P == 64 ? lr::wide_f16_prepare_rne<64>(hrows, n, img1.data()) : lr::wide_f16_prepare_rne<128>(hrows, n, img1.data());
+            if (fits && (hipMalloc(&m->d_xblk1h, img1.size() * 2) != hipSuccess ||
+                         hipMemcpy(m->d_xblk1h, img1.data(), img1.size() * 2, hipMemcpyHostToDevice) != hipSuccess)) {
+                lr_model_destroy(m);
+                return fail(LR_ERR_NOMEM, "allocating the single-piece f16 block images (%zu bytes) failed", img1.size() * 2);
+            }
+        }
     }
     *out = m;
     return LR_OK;
@@ -326,6 +334,7 @@ void lr_model_destroy(lr_model* m) {
         if (e.p) (void)hipFree(e.p);
     if (m->d_xblk) (void)hipFree(m->d_xblk);
     if (m->d_xblk1) (void)hipFree(m->d_xblk1);
+    if (m->d_xblk1h) (void)hipFree(m->d_xblk1h);
     if (m->d_xmx) (void)hipFree(m->d_xmx);
     if (m->d_xmf) (void)hipFree(m->d_xmf);
     if (m->d_xms) (void)hipFree(m->d_xms);
@@ -341,7 +350,7 @@ int lr_model_debug_opts(const lr_model* m, char* buf, int len) {
     if (!m || !buf || len <= 0) return fail(LR_ERR_INVALID, "NULL argument / empty buffer");
     const DebugOpts& d = m->dbg;
     if (d.is_default()) snprintf(buf, (size_t)len, "%s", "");
-    else snprintf(buf, (size_t)len, "residency_cap=%d,tall_mx16=%d,wide_traj=%d,wide_waves=%d", d.residency_cap, d.tall_mx16, d.wide_traj, d.wide_waves);
+    else snprintf(buf, (size_t)len, "residency_cap=%d,tall_mx16=%d,wide_traj=%d,wide_waves=%d,wide_f16=%d", d.residency_cap, d.tall_mx16, d.wide_traj, d.wide_waves, d.wide_f16);
     return LR_OK;
 }
 

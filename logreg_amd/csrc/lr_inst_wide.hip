@@ -48,9 +48,16 @@ int launch_tall_partial(hipStream_t st, int want_value, int /*want_grad*/, const
 
 int launch_tall_traj(hipStream_t st, const void* tall_args) {
     const auto& a = *static_cast<const TallArgs<float, P>*>(tall_args);
-    if (a.traj_tiles == 2 && a.beta_pieces == 1) hipLaunchKernelGGL((k_wide_traj2_bf16<P, 1>), dim3((unsigned)((a.C + 31) / 32)), dim3(512), 0, st, a);
-    else if (a.traj_tiles == 2) hipLaunchKernelGGL((k_wide_traj2_bf16<P, 2>), dim3((unsigned)((a.C + 31) / 32)), dim3(512), 0, st, a);
-    else hipLaunchKernelGGL((k_wide_traj_bf16<P>), dim3((unsigned)((a.C + 15) / 16)), dim3(512), 0, st, a);
+    const dim3 g2((unsigned)((a.C + 31) / 32)), g1((unsigned)((a.C + 15) / 16)), block(512);
+    if (a.traj_tiles == 2) {
+        if (a.traj_fmt == 2) hipLaunchKernelGGL((k_wide_traj2_bf16<P, 2>), g2, block, 0, st, a);
+        else if (a.traj_fmt == 1) hipLaunchKernelGGL((k_wide_traj2_bf16<P, 1>), g2, block, 0, st, a);
+        else hipLaunchKernelGGL((k_wide_traj2_bf16<P, 0>), g2, block, 0, st, a);
+    } else if (a.traj_fmt == 2) {
+        hipLaunchKernelGGL((k_wide_traj_bf16<P, true>), g1, block, 0, st, a);
+    } else {
+        hipLaunchKernelGGL((k_wide_traj_bf16<P, false>), g1, block, 0, st, a);
+    }
     return check(hipGetLastError());
 }
 #define LR_WIDE_TRAJ_HOOK &launch_tall_traj

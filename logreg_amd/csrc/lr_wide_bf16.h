@@ -88,6 +88,20 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_rne(float a, float b) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2w{a, b}, bf16x2));
 }
+// ... and the IEEE half-precision (f16: 11 significant bits, 2^-14 .. 65504) forms of the trajectory kernels' one-piece interior:
+// v_cvt_pk_f16_f32 (round to nearest even), v_mfma_f32_16x16x32_f16 -- the same rate and operand layout as the bf16 instruction
+typedef _Float16 f16x2w __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8w __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ uint32_t pack_f16(float a, float b) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2w{a, b}, f16x2w));
+}
+// (a position times log2 e beyond the f16 range saturates instead of becoming an infinity: the force stays finite and deterministic)
+__device__ __forceinline__ float clamp_f16(float x) { return __builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f); }
+template <bool F16> __device__ __forceinline__ uint32_t pack16(float a, float b) { return F16 ? pack_f16(a, b) : pack_rne(a, b); }
+template <bool F16> __device__ __forceinline__ f32x4 mfma16(const u32x4& x, const u32x4& y, const f32x4& acc) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8w, x), __builtin_bit_cast(f16x8w, y), acc, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(x), as_bf16x8(y), acc, 0, 0, 0);
+}
 
 // NW waves per workgroup (4 or 8): every wave owns 16 chains, all share the staged 32-row block.
 // 8 waves halve the staging traffic per chain (191 vs 140 TF at 8192 chains); 4 waves give more
@@ -719,9 +733,12 @@ __global__ void __launch_bounds__((64 * NW)) __attribute__((amdgpu_waves_per_eu(
 // are on their way before the reduction starts.  One workgroup streams the whole single-piece image every step
 // (n p 2 bytes from L2: 1 MB for config 5, >= 6.8 us at 64 B/clk/CU), so a step costs the same from 16 to
 // 16 x CUs chains.  Results do not depend on the chain count, the tile position or any slice plan.
-template <int P>
+// F16: the one-piece half-precision interior (rows and beta in one f16 piece each, the sigmoid weights in f16; a.xblk1h) instead of
+// bf16 rows x two bf16 pieces of beta -- see k_wide_traj2_bf16.
+template <int P, bool F16 = false>
 __global__ void __launch_bounds__(512) k_wide_traj_bf16(TallArgs<float, P> a) {
     using G = WideBf16Geom<P>;
+    const uint16_t* const image = F16 ? a.xblk1h : a.xblk1;
     constexpr int NW = 8, BLK_BYTES = G::BUF1 * 2, NBUF = P >= 128 ? 2 : 4, RING_BYTES = NBUF * BLK_BYTES, RW = 36;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[NW * RING_BYTES];
     __shared__ __attribute__((aligned(16))) float red[NW][16][RW];
@@ -739,7 +756,7 @@ __global__ void __launch_bounds__(512) k_wide_traj_bf16(TallArgs<float, P> a) {
 
     auto issue = [&](int b) {  // block b of this wave -> ring slot b % NBUF; one M0 set-up per block (see k_wide_partial_bf16r)
         static_assert(BLK_BYTES == 8192 || BLK_BYTES == 4096, "pieces addressed around the middle of the block");
-        const unsigned char* src = reinterpret_cast<const unsigned char*>(a.xblk1 + (wb0 + b) * (int64_t)G::BUF1) + lane * 16 + BLK_BYTES / 2;
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(image + (wb0 + b) * (int64_t)G::BUF1) + lane * 16 + BLK_BYTES / 2;
         const uint32_t dst = ring_lds + (uint32_t)((b & (NBUF - 1)) * BLK_BYTES) + BLK_BYTES / 2;
         uint32_t keep;
         if constexpr (BLK_BYTES == 8192)
@@ -786,7 +803,7 @@ __global__ void __launch_bounds__(512) k_wide_traj_bf16(TallArgs<float, P> a) {
     const int nsteps = a.l - 1;
     for (int s = 0; s < nsteps; ++s) {
         // beta = hi + lo (two round-to-nearest bf16 pieces) of the lane's coordinates 32 m + 8 kg + i, times log2(e)
-        u32x4 bq[G::M32][2];
+        u32x4 bq[G::M32][F16 ? 1 : 2];
 #pragma unroll
         for (int m = 0; m < G::M32; ++m) {
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(&qnew[c][32 * m + 8 * kg]);
@@ -796,15 +813,19 @@ __global__ void __launch_bounds__(512) k_wide_traj_bf16(TallArgs<float, P> a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float x0 = x[2 * i] * ExpScale<float>::k, x1 = x[2 * i + 1] * ExpScale<float>::k;
-                hi[i] = pack_rne(x0, x1);
-                const float h0 = __builtin_bit_cast(float, hi[i] << 16), h1 = __builtin_bit_cast(float, hi[i] & 0xFFFF0000u);
-                lo[i] = pack_rne(x0 - h0, x1 - h1);
+                if constexpr (F16) {
+                    hi[i] = pack_f16(clamp_f16(x0), clamp_f16(x1));
+                } else {
+                    hi[i] = pack_rne(x0, x1);
+                    const float h0 = __builtin_bit_cast(float, hi[i] << 16), h1 = __builtin_bit_cast(float, hi[i] & 0xFFFF0000u);
+                    lo[i] = pack_rne(x0 - h0, x1 - h1);
+                }
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int j = (kg & 1) ? (i ^ 2) : i;  // odd kg: halves swapped, as the eta read delivers them
                 bq[m][0][i] = hi[j];
-                bq[m][1][i] = lo[j];
+                if constexpr (!F16) bq[m][1][i] = lo[j];
             }
         }
         f32x4 gacc[G::MBP];
@@ -822,14 +843,14 @@ __global__ void __launch_bounds__(512) k_wide_traj_bf16(TallArgs<float, P> a) {
 #pragma unroll
                 for (int m = 0; m < G::M32; ++m) {
                     const u32x4 xa = *reinterpret_cast<const u32x4*>(base + G::tile1(T, m) + eta_off);
-                    e0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(xa), as_bf16x8(bq[m][0]), e0, 0, 0, 0);
-                    e0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(xa), as_bf16x8(bq[m][1]), e0, 0, 0, 0);
+                    e0 = mfma16<F16>(xa, bq[m][0], e0);
+                    if constexpr (!F16) e0 = mfma16<F16>(xa, bq[m][1], e0);
                 }
                 float w[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) w[r] = fast_rcp(1.0f + __builtin_amdgcn_exp2f(e0[r]));
-                wq[2 * T] = pack_rne(w[0], w[1]);
-                wq[2 * T + 1] = pack_rne(w[2], w[3]);
+                wq[2 * T] = pack16<F16>(w[0], w[1]);
+                wq[2 * T + 1] = pack16<F16>(w[2], w[3]);
             }
             const u32x4 wv = {wq[0], wq[1], wq[2], wq[3]};
 #pragma unroll
@@ -837,7 +858,7 @@ __global__ void __launch_bounds__(512) k_wide_traj_bf16(TallArgs<float, P> a) {
                 const u32x2 t0 = lds_read_tr16(base + G::tile1(0, mb >> 1) + tr_off[mb & 1]);
                 const u32x2 t1 = lds_read_tr16(base + G::tile1(1, mb >> 1) + tr_off[mb & 1]);
                 const u32x4 xg = {t0[0], t0[1], t1[0], t1[1]};
-                gacc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(xg), as_bf16x8(wv), gacc[mb], 0, 0, 0);
+                gacc[mb] = mfma16<F16>(xg, wv, gacc[mb]);
             }
         }
         // every ring slot has been read: the next step's first blocks travel while the step is finished
@@ -889,9 +910,12 @@ __global__ void __launch_bounds__(512) k_wide_traj_bf16(TallArgs<float, P> a) {
 // NB = pieces of beta in the eta MFMAs: 2 (hi + lo: the default policy) or 1 (LR_PREC_BF16, the caller's explicit request: a third of the
 // MFMAs fewer -- the kernel is POWER-bound, 1300 W at 2.04 GHz, so the time follows the work: 24.2 -> 20.5 us per evaluation at config 5
 // whole -- for 0.019 of acceptance, 0.756 -> 0.737; still an exact sampler: a deterministic force, exact end points).
-template <int P, int NB = 2>
+template <int P, int FMT = 0>
 __global__ void __launch_bounds__(512) k_wide_traj2_bf16(TallArgs<float, P> a) {
     using G = WideBf16Geom<P>;
+    constexpr int NB = FMT == 0 ? 2 : 1;
+    constexpr bool F16 = FMT == 2;
+    const uint16_t* const image = F16 ? a.xblk1h : a.xblk1;
     constexpr int NW = 8, NT2 = 2, BLK_BYTES = G::BUF1 * 2, NBUF = P >= 128 ? 2 : 4, RING_BYTES = NBUF * BLK_BYTES;
     constexpr int NQ = P / 4;             // 16-byte chunks per chain
     static_assert(16 * P * 4 == BLK_BYTES, "a tile's gradients fill exactly one ring slot");
@@ -915,7 +939,7 @@ __global__ void __launch_bounds__(512) k_wide_traj2_bf16(TallArgs<float, P> a) {
 
     auto issue = [&](int b) {  // block b of this wave -> ring slot b % NBUF; one M0 set-up per block (see k_wide_partial_bf16r)
         static_assert(BLK_BYTES == 8192 || BLK_BYTES == 4096, "pieces addressed around the middle of the block");
-        const unsigned char* src = reinterpret_cast<const unsigned char*>(a.xblk1 + (wb0 + b) * (int64_t)G::BUF1) + lane * 16 + BLK_BYTES / 2;
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(image + (wb0 + b) * (int64_t)G::BUF1) + lane * 16 + BLK_BYTES / 2;
         const uint32_t dst = ring_lds + (uint32_t)((b & (NBUF - 1)) * BLK_BYTES) + BLK_BYTES / 2;
         uint32_t keep;
         if constexpr (BLK_BYTES == 8192)
@@ -957,13 +981,17 @@ __global__ void __launch_bounds__(512) k_wide_traj2_bf16(TallArgs<float, P> a) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const float x0 = q[2 * i] * ExpScale<float>::k, x1 = q[2 * i + 1] * ExpScale<float>::k;
-            hi[i] = pack_rne(x0, x1);
-            const float h0 = __builtin_bit_cast(float, hi[i] << 16), h1 = __builtin_bit_cast(float, hi[i] & 0xFFFF0000u);
-            lo[i] = pack_rne(x0 - h0, x1 - h1);
+            if constexpr (F16) {
+                hi[i] = pack_f16(clamp_f16(x0), clamp_f16(x1));
+            } else {
+                hi[i] = pack_rne(x0, x1);
+                const float h0 = __builtin_bit_cast(float, hi[i] << 16), h1 = __builtin_bit_cast(float, hi[i] & 0xFFFF0000u);
+                lo[i] = pack_rne(x0 - h0, x1 - h1);
+            }
         }
         const int cs = occ ^ ((4 * m + okg) & 15);
         *reinterpret_cast<u32x2*>(&qop[t][m][okg][0][cs][ip]) = u32x2{hi[0], hi[1]};
-        *reinterpret_cast<u32x2*>(&qop[t][m][okg][1][cs][ip]) = u32x2{lo[0], lo[1]};
+        if constexpr (NB == 2) *reinterpret_cast<u32x2*>(&qop[t][m][okg][1][cs][ip]) = u32x2{lo[0], lo[1]};
     };
 #pragma unroll
     for (int t = 0; t < NT2; ++t) {
@@ -1028,12 +1056,12 @@ __global__ void __launch_bounds__(512) k_wide_traj2_bf16(TallArgs<float, P> a) {
             const int t = i / NE, r = i % NE, m = r / SPC, h = (r >> 1) % NB, T = r & 1;
             if (LR_TRAJ_EXP(2) && h) return;
             if (m == 0 && h == 0) en[t][T] = f32x4{0, 0, 0, 0};
-            en[t][T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(xa[T][m]), as_bf16x8(bq[t][m][h]), en[t][T], 0, 0, 0);
+            en[t][T] = mfma16<F16>(xa[T][m], bq[t][m][h], en[t][T]);
         };
         auto grad_mfma = [&](int t, int mb, const u32x4& wv) {
             if (LR_TRAJ_EXP(1) && mb) return;
             const u32x4 xg = {xt[mb][0][0], xt[mb][0][1], xt[mb][1][0], xt[mb][1][1]};
-            gacc[t][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(xg), as_bf16x8(wv), gacc[t][mb], 0, 0, 0);
+            gacc[t][mb] = mfma16<F16>(xg, wv, gacc[t][mb]);
         };
         // the sigmoid of both tiles of the pending block as four stages over 16 values (v = 8 t + 4 T + r), two values per slot
         float sx[16];
@@ -1043,7 +1071,7 @@ __global__ void __launch_bounds__(512) k_wide_traj2_bf16(TallArgs<float, P> a) {
             if (stage == 0) sx[v] = LR_TRAJ_EXP(0) ? e[t][T][r] : __builtin_amdgcn_exp2f(e[t][T][r]);
             else if (stage == 1) sx[v] = LR_TRAJ_EXP(0) ? sx[v] : 1.0f + sx[v];
             else if (stage == 2) sx[v] = LR_TRAJ_EXP(0) ? sx[v] : fast_rcp(sx[v]);
-            else if ((v & 1) == 0) spk[v >> 1] = pack_rne(sx[v], sx[v + 1]);
+            else if ((v & 1) == 0) spk[v >> 1] = pack16<F16>(sx[v], sx[v + 1]);
         };
         auto trip = [&](int b, auto first_tag) {
             constexpr bool FIRST = decltype(first_tag)::value;
@@ -1254,6 +1282,52 @@ template <int P> inline void wide_bf16_prepare_rne(const float* rows, int64_t n,
             }
         }
     }
+}
+
+
+// ... and its half-precision twin (the trajectory kernels' f16 interior): IEEE binary16 round-to-nearest-even of the signed rows in
+// the same layout.  Returns false -- no image, the bf16 pieces stay in use -- unless every |x| <= 2^15 and every non-zero column
+// reaches 2^-10 somewhere (below 2^-14 an f16 loses bits one by one; a column that small as a whole would be carried worse than in bf16).
+inline uint16_t f16_bits_rne(float x) {  // finite |x| <= 2^15
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    const uint32_t sign = (u >> 16) & 0x8000u;
+    u &= 0x7FFFFFFFu;
+    if (u < 0x33000001u) return (uint16_t)sign;  // <= 2^-25: rounds to zero (ties to even)
+    if (u < 0x38800000u) {                       // subnormal result: shift the 24-bit significand into place, round to nearest even
+        const int shift = 126 - (int)(u >> 23);  // 14 .. 24
+        const uint32_t sig = (u & 0x7FFFFFu) | 0x800000u;
+        const uint32_t q = sig >> shift, rem = sig & ((1u << shift) - 1u), half = 1u << (shift - 1);
+        return (uint16_t)(sign | (q + ((rem > half || (rem == half && (q & 1u))) ? 1u : 0u)));
+    }
+    const uint32_t r = u + 0xFFFu + ((u >> 13) & 1u);  // normal: round the 13 dropped bits, a carry moves into the exponent
+    return (uint16_t)(sign | ((r - 0x38000000u) >> 13));
+}
+template <int P> inline bool wide_f16_prepare_rne(const float* rows, int64_t n, uint16_t* out) {
+    using G = WideBf16Geom<P>;
+    for (int cc = 0; cc < P; ++cc) {
+        float cmax = 0.0f;
+        for (int64_t r = 0; r < n; ++r) {
+            const float ax = rows[r * P + cc] < 0 ? -rows[r * P + cc] : rows[r * P + cc];
+            cmax = ax > cmax ? ax : cmax;
+        }
+        if (cmax > 32768.0f || (cmax != 0.0f && cmax < 0x1p-10f)) return false;
+    }
+    const int64_t nblk = (n + 31) / 32;
+    for (int64_t b = 0; b < nblk; ++b) {
+        uint16_t* base = out + b * (int64_t)G::BUF1;
+        for (int e = 0; e < G::BUF1; ++e) base[e] = 0;
+        for (int srow = 0; srow < 32; ++srow) {
+            const int64_t r = 32 * b + srow;
+            if (r >= n) continue;
+            const int T = srow >> 4, rr = srow & 15;
+            for (int cc = 0; cc < P; ++cc) {
+                const int m = cc >> 5, w5 = cc & 31;
+                base[G::tile1(T, m) + G::elem(w5 >> 3, rr, w5 & 7)] = f16_bits_rne(rows[r * P + cc]);
+            }
+        }
+    }
+    return true;
 }
 
 }  // namespace lr

@@ -13,8 +13,43 @@
 #include "lr_tall.h"
 
 #include "lr_plan.h"
+#include "lr_wide_bf16.h"
 
-int main() {
+#include <cstring>
+#include <vector>
+
+// "f16": float32 bit patterns (hex, one per line) -> the f16 bit pattern lr_model_create writes into the half-precision image;
+// "f16fit <n>": n x 64 float32 bit patterns -> "1 <sum of the image's 16-bit words>" or "0" (the range rule of wide_f16_prepare_rne)
+static int f16_modes(const char* mode) {
+    unsigned u;
+    if (!std::strcmp(mode, "f16")) {
+        while (std::scanf("%x", &u) == 1) {
+            float x;
+            std::memcpy(&x, &u, 4);
+            std::printf("%04x\n", (unsigned)lr::f16_bits_rne(x));
+        }
+        return 0;
+    }
+    long long n = 0;
+    if (std::scanf("%lld", &n) != 1 || n <= 0) return 2;
+    std::vector<float> rows((size_t)n * 64);
+    for (auto& x : rows) {
+        if (std::scanf("%x", &u) != 1) return 2;
+        std::memcpy(&x, &u, 4);
+    }
+    std::vector<uint16_t> img((size_t)((n + 31) / 32) * lr::WideBf16Geom<64>::BUF1);
+    if (!lr::wide_f16_prepare_rne<64>(rows.data(), n, img.data())) {
+        std::printf("0\n");
+        return 0;
+    }
+    unsigned long long sum = 0;
+    for (uint16_t w : img) sum += w;
+    std::printf("1 %llu\n", sum);
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    if (argc > 1) return f16_modes(argv[1]);
     int dtype, p, kind, prec, group, mode, cus;
     long long n, chains;
     while (std::scanf("%d %d %lld %lld %d %d %d %d %d", &dtype, &p, &n, &chains, &kind, &prec, &group, &mode, &cus) == 9) {

@@ -387,7 +387,7 @@ def test_wide_models_run_on_the_matrix_cores(la, p, n, C, engine, monkeypatch):
     ps = np.full(p, 1.5)
     orc = OracleModel(X, y, ps)
     m = la.LogReg(X, y, ps)
-    assert m.plan(C)["mode"] == "stepwise" and m.debug_opts() == ("" if engine == "bf16x3" else "residency_cap=1,tall_mx16=1,wide_traj=-1,wide_waves=8")
+    assert m.plan(C)["mode"] == "stepwise" and m.debug_opts() == ("" if engine == "bf16x3" else "residency_cap=1,tall_mx16=1,wide_traj=-1,wide_waves=8,wide_f16=1")
     rng = np.random.default_rng(p)
     b = 0.1 * rng.standard_normal((C, p))
     r = m.eval(b)
@@ -1162,6 +1162,54 @@ def test_wide_many_chains_use_the_chain_split_interior_kernel(la, engine, monkey
         for sub in (80, 70):
             part = la.mcmc(b[:sub], k, thin=1, iters=2, verb=False, seed=4, mode="stepwise", group=4)
             assert np.array_equal(part, pinned[:, :sub])
+
+
+def test_half_precision_interior_of_the_trajectory_kernels(la, monkeypatch):
+    """Default policy on the trajectory kernels of wide float32 models: rows and beta in ONE f16 piece each (11 significant bits; a
+    third of the MFMAs of bf16 rows x two bf16 pieces of beta fewer, lr_wide_bf16.h).  (a) Its trajectories are CLOSER to the exact ones
+    than the bf16 form's; (b) a design with a column beyond the f16 range gets no f16 image and runs the bf16 pieces -- bit-identical
+    with wide_f16=0; (c) a position beyond the f16 range saturates: finite, reproducible results."""
+    n, p, C = 500, 64, 1024  # (a small design: the trajectory kernel by the engine's own rule)
+    X, y, _ = la.synthetic_logreg(n, p, seed=31, beta_sd=0.1)
+    ps = np.full(p, 1.5)
+    b = 0.1 * np.random.default_rng(6).standard_normal((C, p))
+    kw = dict(thin=1, iters=2, verb=False, seed=8, return_info=True)
+
+    def run(Xd, opt, start=b, dmm=np.ones(p), **more):
+        if opt:
+            monkeypatch.setenv("LOGREG_DEBUG_OPTS", opt)
+        else:
+            monkeypatch.delenv("LOGREG_DEBUG_OPTS", raising=False)
+        m = la.LogReg(Xd, y, ps)
+        k = la.hmcKernel(m.lpost, m.glp, eps=0.02, l=8, dmm=dmm)
+        return la.mcmc(start, k, **kw, **more)
+    full, fi = run(X, "", precision="full")
+    half, hi = run(X, "")
+    bf2, bi = run(X, "wide_f16=0")
+    same = (fi["accepts"] == hi["accepts"]) & (fi["accepts"] == bi["accepts"])
+    assert same.mean() > 0.9
+    eh, eb = np.abs(half - full)[:, same].max(), np.abs(bf2 - full)[:, same].max()
+    print(f"trajectory error against the exact interior: f16 {eh:.2e}, bf16 x 2 {eb:.2e}")
+    assert 0 < eh < 0.5 * eb and eb < 2e-2
+    assert np.array_equal(half, run(X, "", chunk=1)[0])
+    # (b) out of range: too large (> 2^15) / a whole column too small (< 2^-10)
+    for col_scale in (1e5, 1e-5):
+        Xs = X.copy()
+        Xs[:, 3] *= col_scale
+        start = b.copy()
+        start[:, 3] /= col_scale
+        dmm = np.ones(p)
+        dmm[3] = col_scale ** 2
+        o1, i1 = run(Xs, "", start, dmm)
+        o2, i2 = run(Xs, "wide_f16=0", start, dmm)
+        assert np.isfinite(o1).all() and np.array_equal(o1, o2) and np.array_equal(i1["accepts"], i2["accepts"])
+        assert 0 < i1["accepts"].sum()
+    # (c) saturation of beta * log2(e) at +-65504
+    far = b.copy()
+    far[:8, 5] = 1e5
+    o1, i1 = run(X, "", far)
+    assert np.isfinite(o1).all() and np.isfinite(i1["ll"]).all()
+    assert np.array_equal(o1, run(X, "", far)[0]) and np.array_equal(o1[:, 8:], half[:, 8:])
 
 
 @pytest.mark.parametrize("n,p", [(900, 128), (3000, 8), (1500, 20)])

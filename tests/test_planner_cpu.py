@@ -48,6 +48,7 @@ def harness(tmp_path_factory):
                 plan["tail"] = {"from": int(f[7]), "mode": MODES[int(f[10])], "group": int(f[8]), "rows_per_lane": int(f[9])}
             res.append(plan)
         return res
+    ask.exe = exe
     return ask
 
 
@@ -131,3 +132,32 @@ def test_interior_step_slicing_on_the_cpu(harness):
         rs, ln, wv = pl["interior"]
         if rs:
             assert rs * ln >= rq[2] and (rs - 1) * ln < rq[2] and ln % 32 == 0 and wv in (4, 8, 16), (rq, pl)
+
+
+def test_half_precision_image_rounding_and_range_rule(harness):
+    """The f16 one-piece image of the trajectory kernels (lr_wide_bf16.h wide_f16_prepare_rne): its float32 -> binary16 conversion is
+    numpy's round-to-nearest-even bit for bit (normals, subnormals, ties, the zero threshold), and the image is refused unless every
+    |x| <= 2^15 and every non-zero column reaches 2^-10."""
+    import numpy as np
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.standard_normal(4000) * np.exp2(rng.integers(-28, 15, 4000)), [0.0, -0.0, 2.0**-24, 2.0**-25, 2.0**-25 * 1.0000001, 3 * 2.0**-25,
+                        2.0**-14, 2.0**-14 * (1 - 2.0**-12), 32768.0, -32768.0, 1 + 2.0**-11, 1 + 3 * 2.0**-11, 1 + 2.0**-11 + 2.0**-20, 65504.0 / 2]]).astype(np.float32)
+    x = x[np.abs(x) <= 32768]
+    r = subprocess.run([harness.exe, "f16"], input="".join("%08x\n" % u for u in x.view(np.uint32)), capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = np.array([int(t, 16) for t in r.stdout.split()], dtype=np.uint16)
+    assert np.array_equal(got, x.astype(np.float16).view(np.uint16))
+
+    def fit(rows):
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        rr = subprocess.run([harness.exe, "f16fit"], input="%d\n" % len(rows) + "".join("%08x\n" % u for u in rows.view(np.uint32).ravel()), capture_output=True, text=True, env=env)
+        assert rr.returncode == 0, rr.stderr[-2000:]
+        return rr.stdout.split()
+    rows = rng.standard_normal((70, 64)).astype(np.float32)
+    rows[:, 60:] = 0  # padding columns are all zero: allowed
+    ok = fit(rows)
+    assert ok[0] == "1" and int(ok[1]) == int(rows.astype(np.float16).view(np.uint16).astype(np.uint64).sum())  # every element placed exactly once, the rest zero
+    big = rows.copy(); big[3, 7] = 40000.0
+    tiny = rows.copy(); tiny[:, 9] *= 1e-5
+    assert fit(big) == ["0"] and fit(tiny) == ["0"]
