@@ -113,7 +113,8 @@ typedef struct lr_run_opts {
  *                      and beta in two bf16 pieces each, w = sigma(-eta) in one), planned from about 4 chains per CU
  *                      (p > 8) / 16 per CU (p <= 8) upward, i.e. 1024 - 4096 chains on MI355X;
  *                    tall models on the stepwise engine (the same scheme with the rows streamed: lr_tall_mx.h);
- *                    wide models, 32 < p <= 128 (rows in one bf16 piece, beta in two: lr_wide_bf16.h);
+ *                    wide models, 32 < p <= 128: rows, beta and w in ONE half-precision (f16) piece each where every |x| <= 2^15 and every
+ *                      column reaches 2^-10 (config 5: the exact interior's acceptance rate), else rows in one bf16 piece, beta in two (lr_wide_bf16.h);
  *                  ... and for a float64 model with p <= 16 and rows within the register variants (LR_MODE_MIXED): float32 interior gradients -- the
  *                    trajectory's position and momentum, both end-point evaluations, the half kicks, the kinetic energies and
  *                    the Metropolis test stay float64; only the force applied inside the trajectory is computed from the
@@ -125,8 +126,9 @@ typedef struct lr_run_opts {
  *                  A default HMC run is therefore NOT step-for-step comparable with a float64 reference run (the
  *                  posterior is the same; acceptance rates measured within 0.001 - 0.01 of the exact-gradient run);
  *   LR_PREC_FULL   every evaluation in the model's dtype (comparable with the float64 oracle step by step)
- *   LR_PREC_BF16   request the reduced-precision interior kernels (ignored where none exists); on the wide models' trajectory kernel
- *                  additionally beta in ONE bf16 piece (config 5 whole: 24.2 -> 20.5 us per evaluation, acceptance 0.756 -> 0.737)
+ *   LR_PREC_BF16   request the reduced-precision interior kernels (ignored where none exists); on the wide models' two-tile trajectory
+ *                  kernel rows and beta in ONE bf16 piece each (config 5 whole: 20.0 us per evaluation against the default's 20.9,
+ *                  acceptance 0.738 against 0.758)
  * RWMH, MALA and UL ignore the field (every evaluation of theirs enters an accept ratio or is the sample itself).
  */
 enum { LR_PREC_AUTO = 0, LR_PREC_FULL = 1, LR_PREC_BF16 = 2 };
@@ -162,8 +164,8 @@ LR_API int lr_model_info(const lr_model* m, int64_t* n, int32_t* p, int32_t* dty
  *   tall_mx16=0       tall models: 4-wave interior kernel with separate update launches instead of the fused 16-wave form
  *   wide_traj=0|1|2   wide models: forbid / force the one-launch trajectory kernel with 1 / 2 chain tiles per workgroup (default: by chain count)
  *   wide_waves=4|8    wide models: waves (x 16 chains) per workgroup of the exact-split / chain-split kernels (default: by chain count)
- *   wide_f16=0|1|2    wide float32 models, trajectory kernels: 0 = bf16 rows x two bf16 pieces of beta where the default policy would run
- *                     the one-piece half-precision (f16) interior, 2 = f16 under LR_PREC_BF16 too (default 1: under LR_PREC_AUTO only)
+ *   wide_f16=0|1|2    wide models, reduced-precision interior steps: 0 = bf16 rows x two bf16 pieces of beta even where the rows fit the
+ *                     one-piece half-precision (f16) format (the default, 1), 2 = f16 also where LR_PREC_BF16 would take bf16 x one piece
  * Writes "" to buf for a model on the defaults (what a benchmark must run with), else all the settings.  No reference counterpart. */
 LR_API int lr_model_debug_opts(const lr_model* m, char* buf, int len);
 

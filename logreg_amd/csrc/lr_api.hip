@@ -312,7 +312,7 @@ int lr_model_create(const double* X, const double* y, int64_t n, int32_t p, cons
             lr_model_destroy(m);
             return fail(LR_ERR_NOMEM, "allocating the single-piece bf16 block images (%zu bytes) failed", img1.size() * 2);
         }
-        if (dtype == LR_F32) {  // the trajectory kernels' half-precision image, where the rows fit its range (lr_wide_bf16.h)
+        {  // the interior kernels' half-precision image, where the rows fit its range (lr_wide_bf16.h)
             const bool fits = m->P == 64 ? lr::wide_f16_prepare_rne<64>(hrows, n, img1.data()) : lr::wide_f16_prepare_rne<128>(hrows, n, img1.data());
             if (fits && (hipMalloc(&m->d_xblk1h, img1.size() * 2) != hipSuccess ||
                          hipMemcpy(m->d_xblk1h, img1.data(), img1.size() * 2, hipMemcpyHostToDevice) != hipSuccess)) {

@@ -292,8 +292,11 @@ int do_stepwise_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs
     // LR_PREC_BF16 (the caller's explicit request for the cheapest interior force): beta in ONE bf16 piece, on the two-tile kernel at any
     // tile count the trajectory path takes -- a third of the MFMAs fewer for ~0.02 of acceptance (lr_wide_bf16.h)
     const bool one_piece = o->precision == LR_PREC_BF16 && m->dbg.wide_traj != 1 && traj_tiles > (int64_t)kTraj2FromTilesPerCu * m->cus;  // (where the two-tile kernel runs anyway; 4096 chains: 16.6 against 16.9 us on the one-tile kernel -- nothing to buy)
-    const bool half_ok = m->d_xblk1h != nullptr && m->dbg.wide_f16 != 0 && std::is_same<T, float>::value;
-    a.traj_fmt = m->dbg.wide_f16 == 2 && half_ok ? 2 : one_piece ? 1 : (half_ok && o->precision == LR_PREC_AUTO ? 2 : 0);
+    const bool half_ok = m->d_xblk1h != nullptr && m->dbg.wide_f16 != 0;
+    // Operand format of every reduced-precision interior kernel of a wide model: rows and beta in ONE f16 piece each where the rows fit f16
+    // (11 significant bits against bf16's 8: closer to the exact force than bf16 rows x two bf16 pieces of beta, with a third of the MFMAs
+    // fewer -- config 5 whole: 23.9 -> 20.9 us per evaluation, acceptance 0.756 -> 0.758 = the exact interior's), else the bf16 pieces.
+    a.traj_fmt = m->dbg.wide_f16 == 2 && half_ok ? 2 : one_piece ? 1 : (half_ok ? 2 : 0);
     a.traj_tiles = (m->dbg.wide_traj == 2 || one_piece) ? 2 : (m->dbg.wide_traj == 1 ? 1 : (traj_tiles > (int64_t)kTraj2FromTilesPerCu * m->cus ? 2 : 1));
     const bool traj = P > 32 && bf16_interior && m->d_xblk1 != nullptr && t->launch_tall_traj != nullptr && rs.l > 1 &&
                       m->dbg.wide_traj != 0 &&

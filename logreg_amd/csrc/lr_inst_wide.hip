@@ -25,14 +25,22 @@ int launch_tall_partial(hipStream_t st, int want_value, int /*want_grad*/, const
     const dim3 grid((unsigned)((a.C + 63) / 64), (unsigned)a.RS), block(256);
     const dim3 gridb((unsigned)((a.C + 127) / 128), (unsigned)a.RS), blockb(512);
     if (a.interior && !want_value && a.xblk1) {  // reduced-precision interior leapfrog step
+        const bool h = a.traj_fmt == 2;  // rows and beta in one f16 piece each (lr_engine.h)
         if (a.RS_i > 0) {  // few chains: one chain tile per workgroup, rows split over its waves
             const dim3 gridr((unsigned)((a.C + 15) / 16), (unsigned)a.RS_i);
-            if (a.rowsplit_waves == 8) hipLaunchKernelGGL((k_wide_partial_bf16r<P, 8>), gridr, dim3(512), 0, st, a);
-            else hipLaunchKernelGGL((k_wide_partial_bf16r<P, 4>), gridr, block, 0, st, a);
+            if (a.rowsplit_waves == 8) {
+                if (h) hipLaunchKernelGGL((k_wide_partial_bf16r<P, 8, float, true>), gridr, dim3(512), 0, st, a);
+                else hipLaunchKernelGGL((k_wide_partial_bf16r<P, 8, float, false>), gridr, dim3(512), 0, st, a);
+            } else {
+                if (h) hipLaunchKernelGGL((k_wide_partial_bf16r<P, 4, float, true>), gridr, block, 0, st, a);
+                else hipLaunchKernelGGL((k_wide_partial_bf16r<P, 4, float, false>), gridr, block, 0, st, a);
+            }
         } else if (a.wide_bf16 == 2) {
-            hipLaunchKernelGGL((k_wide_partial_bf16i<P, 8>), gridb, blockb, 0, st, a);
+            if (h) hipLaunchKernelGGL((k_wide_partial_bf16i<P, 8, float, true>), gridb, blockb, 0, st, a);
+            else hipLaunchKernelGGL((k_wide_partial_bf16i<P, 8, float, false>), gridb, blockb, 0, st, a);
         } else {
-            hipLaunchKernelGGL((k_wide_partial_bf16i<P, 4>), grid, block, 0, st, a);
+            if (h) hipLaunchKernelGGL((k_wide_partial_bf16i<P, 4, float, true>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((k_wide_partial_bf16i<P, 4, float, false>), grid, block, 0, st, a);
         }
         return check(hipGetLastError());
     }
@@ -66,10 +74,15 @@ int launch_tall_partial(hipStream_t st, int want_value, int /*want_grad*/, const
     const auto& a = *static_cast<const TallArgs<double, P>*>(tall_args);
     const dim3 grid((unsigned)((a.C + 63) / 64), (unsigned)a.RS), block(256);
     if (a.interior && !want_value && a.xblk1) {  // interior leapfrog step of the default precision policy: the bf16 pipe
-        if (a.RS_i > 0)  // few chains: the row-split kernel (one chain tile per workgroup), its update a launch of its own
-            hipLaunchKernelGGL((k_wide_partial_bf16r<P, 8, double>), dim3((unsigned)((a.C + 15) / 16), (unsigned)a.RS_i), dim3(512), 0, st, a);
-        else
-            hipLaunchKernelGGL((k_wide_partial_bf16i<P, 4, double>), grid, block, 0, st, a);
+        const bool h = a.traj_fmt == 2;  // rows and beta in one f16 piece each (lr_engine.h)
+        const dim3 gridr((unsigned)((a.C + 15) / 16), (unsigned)a.RS_i);
+        if (a.RS_i > 0) {  // few chains: the row-split kernel (one chain tile per workgroup), its update a launch of its own
+            if (h) hipLaunchKernelGGL((k_wide_partial_bf16r<P, 8, double, true>), gridr, dim3(512), 0, st, a);
+            else hipLaunchKernelGGL((k_wide_partial_bf16r<P, 8, double, false>), gridr, dim3(512), 0, st, a);
+        } else {
+            if (h) hipLaunchKernelGGL((k_wide_partial_bf16i<P, 4, double, true>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((k_wide_partial_bf16i<P, 4, double, false>), grid, block, 0, st, a);
+        }
         return check(hipGetLastError());
     }
     if (want_value) hipLaunchKernelGGL((k_wide_partial_f64<P, true>), grid, block, 0, st, a);

@@ -66,8 +66,8 @@ struct DebugOpts {
                             //    instead of the 16-wave kernel that finishes the previous step in its prologue (lr_tall_mx.h)
     int wide_traj = -1;     // wide models: 1 / 2 force the one-launch trajectory kernel with 1 / 2 chain tiles per workgroup, 0 forbids it (-1: by chain count; lr_engine.h)
     int wide_waves = 0;     // wide models: 4 | 8 waves (64 | 128 chains) per workgroup of the exact and chain-split kernels (0: by chain count)
-    int wide_f16 = 1;       // wide float32 models, trajectory kernels: 0 keeps the bf16 two-piece interior where the default policy would use the
-                            //    one-piece f16 interior, 2 uses f16 under every reduced-precision policy (1: LR_PREC_AUTO only; lr_engine.h)
+    int wide_f16 = 1;       // wide models: 0 keeps the bf16 two-piece interior where the rows fit the one-piece f16 format, 2 uses f16 also
+                            //    where LR_PREC_BF16 would take bf16 x one piece (lr_engine.h)
     bool is_default() const { return residency_cap == 1 && tall_mx16 == 1 && wide_traj == -1 && wide_waves == 0 && wide_f16 == 1; }
 };
 // returns false (and names the culprit) on an unknown key or a value outside its range
@@ -125,7 +125,7 @@ struct lr_model {
     const lr::InstTable* table = nullptr;
     void* d_xblk = nullptr;  // wide float32 models: per-32-row-block bf16-piece images of the rows (lr_wide_bf16.h)
     void* d_xblk1 = nullptr;  // wide models: single-piece round-to-nearest images (interior leapfrog steps)
-    void* d_xblk1h = nullptr; // wide float32 models whose rows fit the f16 range: the same in half precision (trajectory kernels)
+    void* d_xblk1h = nullptr; // wide models whose rows fit the f16 range: the same in half precision (the default interior format)
     void* d_xmx = nullptr;    // float32, P = 8: two-piece bf16 tile images for interior leapfrog steps (lr_tall_mx.h)
     void* d_xmf = nullptr;    // float32, P = 8 / 16, data beyond the register variants of the matrix-core chain kernel:
                               // fp32 MFMA operand images for the end-point evaluations (lr_mfma.h)

@@ -76,7 +76,7 @@ template <typename T, int P> struct TallArgs {
     int wide_bf16;  // wide models: 0 = fp32 MFMA partial kernel, 1 = exact-split bf16 MFMA partial kernel
     const uint16_t* xblk;  // wide bf16: per-32-row-block LDS images of the split rows (lr_wide_bf16.h)
     const uint16_t* xblk1;  // wide bf16: single-piece (round-to-nearest) images for interior leapfrog steps
-    const uint16_t* xblk1h; // ... and their half-precision (f16) twin for the trajectory kernels; null when the rows do not fit f16
+    const uint16_t* xblk1h; // ... and their half-precision (f16) twin; null when the rows do not fit f16
     const uint16_t* xmx;    // narrow models (P = 8, float32): two-piece bf16 tile images (lr_tall_mx.h), else null
     int interior;  // this launch is an interior HMC gradient evaluation that may run in reduced precision
     int part_f32;  // float64 models: part_g holds FLOAT32 partials [RS][C][P] (written by a reduced-precision interior kernel)
@@ -92,8 +92,8 @@ template <typename T, int P> struct TallArgs {
     int64_t slice_len_i;    //   and rows per slice (a multiple of 32 * rowsplit_waves: whole 32-row blocks per wave)
     int rowsplit_waves;     //   4 or 8 waves per workgroup (wide); 16: the 16-wave tall kernel k_tall_partial_mx16 is in use
     int traj_tiles;         // wide models, trajectory kernel: chain tiles (16 chains) per workgroup -- 1: k_wide_traj_bf16, 2: k_wide_traj2_bf16
-    int traj_fmt;           // ... and its operand format: 0 = bf16 rows x two bf16 pieces of beta, 1 = x one piece (LR_PREC_BF16 on the
-                            //     two-tile kernel), 2 = f16 rows x one f16 piece of beta (xblk1h)
+    int traj_fmt;           // wide models, operand format of the interior kernels: 0 = bf16 rows x two bf16 pieces of beta, 1 = x one piece
+                            //     (LR_PREC_BF16, on the two-tile trajectory kernel only), 2 = f16 rows x one f16 piece of beta (xblk1h)
     int p, l;
     T step;
     T a[P], b[P], c[P];

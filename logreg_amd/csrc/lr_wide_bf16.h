@@ -102,6 +102,28 @@ template <bool F16> __device__ __forceinline__ f32x4 mfma16(const u32x4& x, cons
     if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8w, x), __builtin_bit_cast(f16x8w, y), acc, 0, 0, 0);
     else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(x), as_bf16x8(y), acc, 0, 0, 0);
 }
+// The lane's eight coordinates 32 m + 8 kg + i of its chain's position, times log2(e), as the B operands of the eta MFMAs: two
+// round-to-nearest bf16 pieces (hi, lo) -- or ONE f16 piece (F16: NB = 1).  Odd kg: halves swapped, as the eta read of the rows delivers them.
+template <bool F16> __device__ __forceinline__ void beta_operands(const float (&x)[8], int kg, u32x4 (&out)[F16 ? 1 : 2]) {
+    uint32_t hi[4], lo[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float x0 = x[2 * i] * ExpScale<float>::k, x1 = x[2 * i + 1] * ExpScale<float>::k;
+        if constexpr (F16) {
+            hi[i] = pack_f16(clamp_f16(x0), clamp_f16(x1));
+        } else {
+            hi[i] = pack_rne(x0, x1);
+            const float h0 = __builtin_bit_cast(float, hi[i] << 16), h1 = __builtin_bit_cast(float, hi[i] & 0xFFFF0000u);
+            lo[i] = pack_rne(x0 - h0, x1 - h1);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int j = (kg & 1) ? (i ^ 2) : i;
+        out[0][i] = hi[j];
+        if constexpr (!F16) out[1][i] = lo[j];
+    }
+}
 
 // NW waves per workgroup (4 or 8): every wave owns 16 chains, all share the staged 32-row block.
 // 8 waves halve the staging traffic per chain (191 vs 140 TF at 8192 chains); 4 waves give more
@@ -278,9 +300,11 @@ __global__ void __launch_bounds__((64 * NW)) k_wide_partial_bf16(TallArgs<float,
 // with the per-block barrier the loop paid the global-load latency of every block: 11.3 us per launch).
 // S = double: the same kernel on a FLOAT64 model (the default precision policy there: lr_wide_f64.h runs the end points) -- the
 // position is read as float64 and rounded, the slice partials stay float32 (TallArgs::part_f32) for k_tall_update<double> to sum.
-template <int P, int NW, typename S = float>
+template <int P, int NW, typename S = float, bool F16 = false>
 __global__ void __launch_bounds__((64 * NW)) k_wide_partial_bf16i(TallArgs<S, P> a) {
     using G = WideBf16Geom<P>;
+    constexpr int NB = F16 ? 1 : 2;  // (F16: the one-piece half-precision interior, as in the trajectory kernels)
+    const uint16_t* const image = F16 ? a.xblk1h : a.xblk1;
     constexpr int NT = 64 * NW, CPB = 16 * NW;
     constexpr int kPassBytes = 32768, BLK_BYTES = G::BUF1 * 2;
     constexpr int SB = kPassBytes / BLK_BYTES;  // blocks per pass
@@ -304,7 +328,7 @@ __global__ void __launch_bounds__((64 * NW)) k_wide_partial_bf16i(TallArgs<S, P>
     auto issue = [&](int64_t g) {  // pass g -> buffer g & 1; 1 KB per wave-instruction, chunks dealt round-robin to the waves
         const int64_t b0 = g * SB;
         const int nb = (int)(nblk - b0 < SB ? nblk - b0 : SB);
-        const char* src = reinterpret_cast<const char*>(a.xblk1 + (blk0 + b0) * (int64_t)G::BUF1);
+        const char* src = reinterpret_cast<const char*>(image + (blk0 + b0) * (int64_t)G::BUF1);
         char* dst = reinterpret_cast<char*>(smem) + (g & 1) * kPassBytes;
         const int nchunk = nb * (BLK_BYTES / 1024);
         for (int ch = wave; ch < nchunk; ch += NW)
@@ -313,7 +337,7 @@ __global__ void __launch_bounds__((64 * NW)) k_wide_partial_bf16i(TallArgs<S, P>
     if (npass > 0) issue(0);  // in flight under the beta split below
 
     // beta = hi + lo (two round-to-nearest bf16 pieces) of the lane's coordinates 32 m + 8 kg + i, times log2(e)
-    u32x4 bq[G::M32][2];
+    u32x4 bq[G::M32][NB];
 #pragma unroll
     for (int m = 0; m < G::M32; ++m) {
         float x[8];
@@ -326,20 +350,7 @@ __global__ void __launch_bounds__((64 * NW)) k_wide_partial_bf16i(TallArgs<S, P>
 #pragma unroll
             for (int i = 0; i < 8; ++i) x[i] = (float)a.q1[chain * P + 32 * m + 8 * kg + i];
         }
-        uint32_t hi[4], lo[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float x0 = x[2 * i] * ExpScale<float>::k, x1 = x[2 * i + 1] * ExpScale<float>::k;
-            hi[i] = pack_rne(x0, x1);
-            const float h0 = __builtin_bit_cast(float, hi[i] << 16), h1 = __builtin_bit_cast(float, hi[i] & 0xFFFF0000u);
-            lo[i] = pack_rne(x0 - h0, x1 - h1);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int j = (kg & 1) ? (i ^ 2) : i;  // odd kg: halves swapped, as the eta read delivers them
-            bq[m][0][i] = hi[j];
-            bq[m][1][i] = lo[j];
-        }
+        beta_operands<F16>(x, kg, bq[m]);
     }
     const int eta_off = G::elem(kg, c, 0) & ~7;
     const int ri = (lane & 15) >> 2, ci = lane & 3;
@@ -368,14 +379,14 @@ __global__ void __launch_bounds__((64 * NW)) k_wide_partial_bf16i(TallArgs<S, P>
 #pragma unroll
                 for (int m = 0; m < G::M32; ++m) {
                     const u32x4 xa = *reinterpret_cast<const u32x4*>(base + G::tile1(T, m) + eta_off);
-                    e0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(xa), as_bf16x8(bq[m][0]), e0, 0, 0, 0);
-                    e1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(xa), as_bf16x8(bq[m][1]), e1, 0, 0, 0);
+                    e0 = mfma16<F16>(xa, bq[m][0], e0);
+                    if constexpr (!F16) e1 = mfma16<F16>(xa, bq[m][1], e1);
                 }
                 float w[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) w[r] = fast_rcp(1.0f + __builtin_amdgcn_exp2f(e0[r] + e1[r]));
-                wq[2 * T] = pack_rne(w[0], w[1]);  // K-slot 8 kg + 4 T + r <-> row 4 kg + r of tile T
-                wq[2 * T + 1] = pack_rne(w[2], w[3]);
+                for (int r = 0; r < 4; ++r) w[r] = fast_rcp(1.0f + __builtin_amdgcn_exp2f(F16 ? e0[r] : e0[r] + e1[r]));
+                wq[2 * T] = pack16<F16>(w[0], w[1]);  // K-slot 8 kg + 4 T + r <-> row 4 kg + r of tile T
+                wq[2 * T + 1] = pack16<F16>(w[2], w[3]);
             }
             const u32x4 wv = {wq[0], wq[1], wq[2], wq[3]};
             // ---- grad += Xs^T . W
@@ -384,7 +395,7 @@ __global__ void __launch_bounds__((64 * NW)) k_wide_partial_bf16i(TallArgs<S, P>
                 const u32x2 t0 = lds_read_tr16(base + G::tile1(0, mb >> 1) + tr_off[mb & 1]);
                 const u32x2 t1 = lds_read_tr16(base + G::tile1(1, mb >> 1) + tr_off[mb & 1]);
                 const u32x4 xg = {t0[0], t0[1], t1[0], t1[1]};
-                gacc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(xg), as_bf16x8(wv), gacc[mb], 0, 0, 0);
+                gacc[mb] = mfma16<F16>(xg, wv, gacc[mb]);
             }
         }
     }
@@ -431,10 +442,12 @@ template <int BYTES> __device__ __forceinline__ void wait_vm_blocks(int younger)
 
 // S = double: a FLOAT64 model's interior steps -- position, momentum and the fused update (kick, drift) are float64, the position
 // enters the GEMM rounded to two bf16 pieces, the slice partials are float32 as for float32 models (TallArgs::part_f32).
-template <int P, int NW, typename S = float>
+template <int P, int NW, typename S = float, bool F16 = false>
 __global__ void __launch_bounds__((64 * NW)) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4))) k_wide_partial_bf16r(TallArgs<S, P> a) {
     constexpr bool kFusable = sizeof(S) == 4;
     using G = WideBf16Geom<P>;
+    constexpr int NB = F16 ? 1 : 2;  // (F16: the one-piece half-precision interior, as in the trajectory kernels)
+    const uint16_t* const image = F16 ? a.xblk1h : a.xblk1;
     // NW = 4: one wave per SIMD, ring of 4 block images per wave; NW = 8: two waves per SIMD (each hides the other's
     // LDS -> MFMA latency, which is what a block costs at one wave per SIMD), ring of 2
     constexpr int BLK_BYTES = G::BUF1 * 2, NBUF = NW == 4 ? 4 : 2, RING_BYTES = NBUF * BLK_BYTES;
@@ -466,7 +479,7 @@ __global__ void __launch_bounds__((64 * NW)) __attribute__((amdgpu_waves_per_eu(
         // block's 1 KB pieces are the offsets -4096 ... +3072 around its middle.  (A set-up per piece -- 4 scalar instructions
         // each -- made the 8 pieces of a block cost ~230 cycles of the wave's issue: 1.2 of the loop's 4.6 us at config 5.)
         static_assert(BLK_BYTES == 8192 || BLK_BYTES == 4096, "pieces addressed around the middle of the block");
-        const unsigned char* src = reinterpret_cast<const unsigned char*>(a.xblk1 + (blk0 + b) * (int64_t)G::BUF1) + lane * 16 + BLK_BYTES / 2;
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(image + (blk0 + b) * (int64_t)G::BUF1) + lane * 16 + BLK_BYTES / 2;
         const uint32_t dst = ring_lds + (uint32_t)((b & (NBUF - 1)) * BLK_BYTES) + BLK_BYTES / 2;
         uint32_t keep;
         if constexpr (BLK_BYTES == 8192)
@@ -598,7 +611,7 @@ __global__ void __launch_bounds__((64 * NW)) __attribute__((amdgpu_waves_per_eu(
     }
     LR_STAMP(a, 2);
     // beta = hi + lo (two round-to-nearest bf16 pieces) of the lane's coordinates 32 m + 8 kg + i, times log2(e)
-    u32x4 bq[G::M32][2];
+    u32x4 bq[G::M32][NB];
 #pragma unroll
     for (int m = 0; m < G::M32; ++m) {
         const int64_t at = chain * P + 32 * m + 8 * kg;
@@ -623,20 +636,7 @@ __global__ void __launch_bounds__((64 * NW)) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] = (float)a.q1[at + e];
         }
-        uint32_t hi[4], lo[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float x0 = x[2 * i] * ExpScale<float>::k, x1 = x[2 * i + 1] * ExpScale<float>::k;
-            hi[i] = pack_rne(x0, x1);
-            const float h0 = __builtin_bit_cast(float, hi[i] << 16), h1 = __builtin_bit_cast(float, hi[i] & 0xFFFF0000u);
-            lo[i] = pack_rne(x0 - h0, x1 - h1);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int j = (kg & 1) ? (i ^ 2) : i;  // odd kg: halves swapped, as the eta read delivers them
-            bq[m][0][i] = hi[j];
-            bq[m][1][i] = lo[j];
-        }
+        beta_operands<F16>(x, kg, bq[m]);
     }
     const int eta_off = G::elem(kg, c, 0) & ~7;
     const int ri = (lane & 15) >> 2, ci = lane & 3;
@@ -675,20 +675,20 @@ __global__ void __launch_bounds__((64 * NW)) __attribute__((amdgpu_waves_per_eu(
             f32x4 e0 = {0, 0, 0, 0}, e1 = {0, 0, 0, 0};
 #pragma unroll
             for (int m = 0; m < G::M32; ++m) {
-                e0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(xa[T][m]), as_bf16x8(bq[m][0]), e0, 0, 0, 0);
-                e1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(xa[T][m]), as_bf16x8(bq[m][1]), e1, 0, 0, 0);
+                e0 = mfma16<F16>(xa[T][m], bq[m][0], e0);
+                if constexpr (!F16) e1 = mfma16<F16>(xa[T][m], bq[m][1], e1);
             }
             float w[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) w[r] = fast_rcp(1.0f + __builtin_amdgcn_exp2f(e0[r] + e1[r]));
-            wq[2 * T] = pack_rne(w[0], w[1]);
-            wq[2 * T + 1] = pack_rne(w[2], w[3]);
+            for (int r = 0; r < 4; ++r) w[r] = fast_rcp(1.0f + __builtin_amdgcn_exp2f(F16 ? e0[r] : e0[r] + e1[r]));
+            wq[2 * T] = pack16<F16>(w[0], w[1]);
+            wq[2 * T + 1] = pack16<F16>(w[2], w[3]);
         }
         const u32x4 wv = {wq[0], wq[1], wq[2], wq[3]};
 #pragma unroll
         for (int mb = 0; mb < G::MBP; ++mb) {
             const u32x4 xg = {xt[mb][0][0], xt[mb][0][1], xt[mb][1][0], xt[mb][1][1]};
-            gacc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(xg), as_bf16x8(wv), gacc[mb], 0, 0, 0);
+            gacc[mb] = mfma16<F16>(xg, wv, gacc[mb]);
         }
     }
     LR_STAMP_CLK(a, 9);
@@ -809,24 +809,7 @@ __global__ void __launch_bounds__(512) k_wide_traj_bf16(TallArgs<float, P> a) {
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(&qnew[c][32 * m + 8 * kg]);
             const f32x4 v1 = *reinterpret_cast<const f32x4*>(&qnew[c][32 * m + 8 * kg + 4]);
             const float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-            uint32_t hi[4], lo[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float x0 = x[2 * i] * ExpScale<float>::k, x1 = x[2 * i + 1] * ExpScale<float>::k;
-                if constexpr (F16) {
-                    hi[i] = pack_f16(clamp_f16(x0), clamp_f16(x1));
-                } else {
-                    hi[i] = pack_rne(x0, x1);
-                    const float h0 = __builtin_bit_cast(float, hi[i] << 16), h1 = __builtin_bit_cast(float, hi[i] & 0xFFFF0000u);
-                    lo[i] = pack_rne(x0 - h0, x1 - h1);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int j = (kg & 1) ? (i ^ 2) : i;  // odd kg: halves swapped, as the eta read delivers them
-                bq[m][0][i] = hi[j];
-                if constexpr (!F16) bq[m][1][i] = lo[j];
-            }
+            beta_operands<F16>(x, kg, bq[m]);
         }
         f32x4 gacc[G::MBP];
 #pragma unroll

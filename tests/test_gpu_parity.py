@@ -1175,12 +1175,12 @@ def test_half_precision_interior_of_the_trajectory_kernels(la, monkeypatch):
     b = 0.1 * np.random.default_rng(6).standard_normal((C, p))
     kw = dict(thin=1, iters=2, verb=False, seed=8, return_info=True)
 
-    def run(Xd, opt, start=b, dmm=np.ones(p), **more):
+    def run(Xd, opt, start=b, dmm=np.ones(p), pscale=ps, **more):
         if opt:
             monkeypatch.setenv("LOGREG_DEBUG_OPTS", opt)
         else:
             monkeypatch.delenv("LOGREG_DEBUG_OPTS", raising=False)
-        m = la.LogReg(Xd, y, ps)
+        m = la.LogReg(Xd, y, pscale)
         k = la.hmcKernel(m.lpost, m.glp, eps=0.02, l=8, dmm=dmm)
         return la.mcmc(start, k, **kw, **more)
     full, fi = run(X, "", precision="full")
@@ -1200,8 +1200,10 @@ def test_half_precision_interior_of_the_trajectory_kernels(la, monkeypatch):
         start[:, 3] /= col_scale
         dmm = np.ones(p)
         dmm[3] = col_scale ** 2
-        o1, i1 = run(Xs, "", start, dmm)
-        o2, i2 = run(Xs, "wide_f16=0", start, dmm)
+        pss = ps.copy()
+        pss[3] /= col_scale  # (the same sampler in rescaled units)
+        o1, i1 = run(Xs, "", start, dmm, pss)
+        o2, i2 = run(Xs, "wide_f16=0", start, dmm, pss)
         assert np.isfinite(o1).all() and np.array_equal(o1, o2) and np.array_equal(i1["accepts"], i2["accepts"])
         assert 0 < i1["accepts"].sum()
     # (c) saturation of beta * log2(e) at +-65504
