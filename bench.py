@@ -49,6 +49,9 @@ PREWARM_S = 0.15  # seconds of untimed load before the warm-up steps (GPU clock 
 SEED = 42
 PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector == FP32-input MFMA peak
 PEAK_BF16_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
+MFMA16_PIPE = "16-bit MFMA (v_mfma_f32_16x16x32_f16 where the design fits f16 -- these synthetic designs do --, else _bf16), fp32 accumulate"
+INTERIOR_NOTE = ("auto (the L-1 interior gradients on the matrix pipe from rows, beta and sigmoid weights in one f16 piece each -- bf16 rows x two "
+                 "bf16 pieces of beta for a design outside the f16 range; end points exact)")
 HBM_PEAK_GBS = 8000.0
 # the reference's own script timed in BASELINE.md section 2 (Python/fit-np-hmc.py, Pima n=200 p=8, eps=1e-3 L=50)
 REFERENCE_CPU = {"it_per_s": 1368.0, "grad_evals_per_s": 6.98e4, "min_ess_per_s": 24.8, "cores": 1,
@@ -246,7 +249,7 @@ def extra_configs(la, L, check, dev, stream):
         row = {"config": label, "workload": f"HMC L={fix['l']} eps={fix['eps']} unit mass, synthetic n={n} p={p}, {C} chains"
                + (" (one GPU's shard of 8192)" if label == 5 else " (BASELINE.json configs[4] as a whole on ONE GPU)" if label == "5_whole" else ""),
                "kernel_variant": cs.plan(),
-               "interior_precision": "auto (bf16 matrix pipe for the L-1 interior gradients; end points exact)",
+               "interior_precision": INTERIOR_NOTE,
                "chain_iterations_per_s": C * iters / (ms * 1e-3), "grad_evals_per_s": C * evals / (ms * 1e-3),
                "accept_rate": acc, "us_per_evaluation_all_chains": per_eval_s * 1e6,
                "timing": "HIP events around 4 HMC iterations = 200 log-posterior-gradient evaluations of all chains (every "
@@ -266,22 +269,22 @@ def extra_configs(la, L, check, dev, stream):
                                        "the fp32 formulation needs), but the interior multiply-adds run on the matrix pipe, so the "
                                        "operative bound is the transcendental unit; 1024 chains share every X pass: HBM is idle"}
         else:
-            row["roofline"] = {"bound": "mfma", "pipe": "bf16 MFMA (v_mfma_f32_16x16x32_bf16), fp32 accumulate",
+            row["roofline"] = {"bound": "mfma", "pipe": MFMA16_PIPE,
                                "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
                                "frac_of_fp32_peak": ach / PEAK_FP32_TFLOPS, "flops_per_grad_eval": fg,
                                "note": "algorithmic flops counted once (SURVEY 8(d)); at 1024 chains an evaluation is 2.15 GFLOP = "
                                        "0.9 us of the bf16 pipe: launch, prologue and epilogue dominate (DESIGN.md section 5)" if C == 1024 else
                                        "algorithmic flops counted once (SURVEY 8(d)); 17.4 GFLOP per evaluation; the interior steps run as ONE "
-                                       "launch per trajectory (k_wide_traj2_bf16: 32 chains per workgroup, one workgroup per CU); the MFMAs issued "
-                                       "are 1.5x the algorithmic ones (beta in two bf16 pieces): MFMA-busy 52-57 % (profiles/r5_cfg5_whole*.txt)"}
+                                       "launch per trajectory (k_wide_traj2_bf16: 32 chains per workgroup, one workgroup per CU); rows and beta in "
+                                       "one f16 piece each: the MFMAs issued are the algorithmic ones; power-bound at 1300 W / 2.04 GHz (profiles/r5_cfg5_whole*.txt)"}
         if label == "5_whole":
-            # the same workload under precision="bf16" (the caller's explicit request: beta in ONE bf16 piece on the trajectory kernel --
-            # a third of the MFMAs fewer; the kernel is power-bound, so the time follows the work) with the acceptance it costs
+            # the same workload under precision="bf16" (the caller's explicit request: bf16 rows x beta in ONE bf16 piece on the trajectory
+            # kernel -- the same MFMA count as the default's f16 pieces, 8 significant bits instead of 11) with the acceptance it costs
             cb = la.ChainSet(k, q0, seed=5, stream=stream, precision="bf16")
             msb = _timed_chainset(la, timer, cb, iters, 1)
             row["precision_bf16"] = {"us_per_evaluation_all_chains": msb * 1e-3 / evals * 1e6, "accept_rate": float(cb.get_accepts().sum() / (C * (3 * iters + 1))),
                                      "frac_bf16_peak": C * fg / (msb * 1e-3 / evals) / 1e12 / PEAK_BF16_TFLOPS,
-                                     "note": "not the default: acceptance drops by ~0.02 (0.756 -> 0.737); still an exact sampler"}
+                                     "note": "not the default: acceptance drops by ~0.02 (0.758 -> 0.738); still an exact sampler"}
         res.append(row)
     return res
 
@@ -643,13 +646,13 @@ def dist_configs(la, L, check, dev, stream, ex, rank, world, scale=1):
                      "workload": f"HMC L={fix['l']} eps={fix['eps']} unit mass, synthetic n={n} p={p}, {C5} chains per GPU = {world * C5} "
                                  f"chains (BASELINE.json configs[4]: 8192 over 8 GPUs), {iters} iterations, every sample kept",
                      "kernel_variant": cs.plan(), "chains_total": world * C5,
-                     "interior_precision": "auto (bf16 matrix pipe for the L-1 interior gradients; end points exact)",
+                     "interior_precision": INTERIOR_NOTE,
                      "chain_iterations_per_s": world * C5 * iters / wall, "grad_evals_per_s": world * C5 * evals / wall,
                      "accept_rate": acc / (world * C5 * iters), "wall_ms": wall * 1e3, "gather_ms": xs * 1e3,
                      "gathered_bytes_per_rank": iters * C5 * p * 4, "kernel_ms_min": kmin, "kernel_ms_max": kmax,
                      "us_per_evaluation_all_chains_of_a_gpu": wall / evals * 1e6,
                      "blocks_ok": all(tuple(b.shape) == (iters, C5, p) for b in bufs),
-                     "roofline": {"bound": "mfma", "pipe": "bf16 MFMA (v_mfma_f32_16x16x32_bf16), fp32 accumulate",
+                     "roofline": {"bound": "mfma", "pipe": MFMA16_PIPE,
                                   "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s per GPU", "frac": ach / PEAK_BF16_TFLOPS,
                                   "flops_per_grad_eval": fg, "note": "whole-job flops / wall (max over ranks, gather included) / GPUs"}})
     out5.free()
