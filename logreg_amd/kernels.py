@@ -483,7 +483,7 @@ def mcmc(init, kernel, thin=10, iters=10000, verb=True, *, seed=None, chunk=None
     `np.random.seed(s)` before the call makes a run reproducible, like the reference.
 
     `precision="auto"` (the DEFAULT) lets HMC's l - 1 gradient evaluations strictly inside a trajectory run in reduced precision where such
-    a kernel exists -- on a float64 model too (float64 state, end points and Metropolis test; float32 / bf16 force inside the
+    a kernel exists -- on a float64 model too (float64 state, end points and Metropolis test; float32 / 16-bit force inside the
     trajectory, at any chain count): such a run is NOT step-for-step comparable with the reference; `precision="full"` is (every
     evaluation in the model's dtype).  INTEGRATION.md section 3b has the numbers.
 
@@ -491,12 +491,12 @@ def mcmc(init, kernel, thin=10, iters=10000, verb=True, *, seed=None, chunk=None
     running statistics and the call returns a dict (mean, sd, rhat, ess, mcse, accept_rate, ...): what the
     reference computes from the full matrix afterwards (fit-np-hmc.py:113-117, analyse.R:17-19).
 
-    `precision` (HMC): "auto" (DEFAULT) lets the L - 1 interior leapfrog gradients of a trajectory run on the bf16 matrix
-    pipe where such a kernel exists (the end-point value + gradient and the Metropolis test stay in the model's dtype, so
+    `precision` (HMC): "auto" (DEFAULT) lets the L - 1 interior leapfrog gradients of a trajectory run on the matrix
+    pipe from 16-bit operands (bf16 pieces; IEEE half precision for wide models whose design fits it) where such a kernel exists (the end-point value + gradient and the Metropolis test stay in the model's dtype, so
     the sampler stays exact; the acceptance rate is the only thing that can move); "full" keeps every evaluation in the
     model's dtype (step-for-step comparable with the float64 reference); see include/logreg_hip.h LR_PREC_*.  float64 models
     follow the same policy with more kept exact: position, momentum, end points, kinetic energies and the Metropolis test are
-    float64, only the force inside the trajectory comes from float32 / bf16 operands (4 - 6 x the all-float64 rate).
+    float64, only the force inside the trajectory comes from float32 / 16-bit operands (4 - 6 x the all-float64 rate).
     `plan_chains`, `plan_first`: chain count to plan the kernel variant for and the global id of that run's first chain (a shard of
     a larger run passes the whole run's: its chains then run on the variants they have in the whole run, bit for bit).
     """
