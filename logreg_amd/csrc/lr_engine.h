@@ -188,6 +188,7 @@ int setup_tall(lr_model* m, const Plan& pl, hipStream_t st, int64_t C, int64_t C
     a.nacc = (uint32_t*)carve(align((size_t)C * 4));
     a.part_g = (T*)carve(pg);
     a.RS_i = RS_i;
+    a.traj_tiles = 1, a.traj_fmt = 0;  // (set per run by do_stepwise_t)
     a.slice_len_i = slice_len_i;
     a.rowsplit_waves = rs_waves;
     a.part_v = (double*)carve(align((size_t)RS * C * sizeof(double)));

@@ -460,6 +460,9 @@ __global__ void __launch_bounds__((64 * NW)) __attribute__((amdgpu_waves_per_eu(
     const int64_t chain0 = (int64_t)blockIdx.x * 16;
     int64_t chain = chain0 + c;
     if (chain >= a.C) chain = a.C - 1;
+    // (grid (tile, slice): the slice workgroups of a tile share an XCD, so the partials they exchange from launch to launch stay in its L2.
+    //  Dealing the SLICES to the XCDs instead -- each L2 then streams one slice of the image, not all -- was measured in round 5 and lost:
+    //  config 5 at 1024 chains 8.6 -> 10.9 us per evaluation, FETCH_SIZE 5.66 -> 7.12 MB per launch; profiles/r5_cfg5_1024.txt)
     const int rs = blockIdx.y;
     const int64_t s0 = (int64_t)rs * a.slice_len_i, s1 = s0 + a.slice_len_i < a.n ? s0 + a.slice_len_i : a.n;
     const int nblk_slice = s1 > s0 ? (int)((s1 - s0 + 31) / 32) : 0;
