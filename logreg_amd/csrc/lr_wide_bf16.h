@@ -1,4 +1,7 @@
-// lr_wide_bf16.h -- wide-model partial kernel on the bf16 matrix pipe with fp32-EXACT inputs.
+// lr_wide_bf16.h -- wide models (32 < p <= 128) on the 16-bit matrix pipe: the partial kernel with fp32-EXACT inputs (trajectory end points,
+// every evaluation of RWMH / MALA / UL and of precision = full) described first, and the INTERIOR-step kernels of HMC's default policy
+// (chain-split, row-split, one-launch trajectory kernels) that share its operand layout with one-piece images -- rows, beta and sigmoid
+// weights in IEEE half precision where the design fits f16, else bf16 rows x two bf16 pieces of beta (beta_operands / mfma16 below).
 //
 // v_mfma_f32_16x16x32_bf16 runs at 16x the fp32-MFMA rate on a pipe of its own.  To keep fp32
 // numerics every fp32 operand is split by truncation into three bf16 pieces, x = h + m + l (8 + 8 + 8
