@@ -138,6 +138,8 @@ __device__ __forceinline__ void mx_pairs(uint32_t eta_lds, uint32_t tr_lds, cons
 #pragma unroll
         for (int T = 0; T < 2; ++T) {
             const mx_f32x4& et = e[2 * pr + T];
+            // (the "1 +" as two packed adds: as four v_add_f32 -- packed f32 VALU being an anti-lever beside MFMAs elsewhere -- config 4 measured
+            //  25.9 -> 26.4 us per evaluation at 1024 chains, 84.5 -> 87.7 at 4096: round 5)
             const mx_f32x2 d0 = mx_f32x2{__builtin_amdgcn_exp2f(et[0]), __builtin_amdgcn_exp2f(et[1])} + mx_f32x2{1.0f, 1.0f};
             const mx_f32x2 d1 = mx_f32x2{__builtin_amdgcn_exp2f(et[2]), __builtin_amdgcn_exp2f(et[3])} + mx_f32x2{1.0f, 1.0f};
             wq[2 * T] = mx_pack_rne(fast_rcp(d0.x), fast_rcp(d0.y));
