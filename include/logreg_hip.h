@@ -168,6 +168,12 @@ LR_API int lr_model_info(const lr_model* m, int64_t* n, int32_t* p, int32_t* dty
  *                     one-piece half-precision (f16) format (the default, 1), 2 = f16 also where LR_PREC_BF16 would take bf16 x one piece
  * Writes "" to buf for a model on the defaults (what a benchmark must run with), else all the settings.  No reference counterpart. */
 LR_API int lr_model_debug_opts(const lr_model* m, char* buf, int len);
+/* Operand format of the reduced-precision interior leapfrog steps (LR_PREC_AUTO / LR_PREC_BF16) this model's HMC runs take where such a
+ * matrix-pipe kernel is planned: LR_INTERIOR_NONE (none exists for the shape: p < 5), LR_INTERIOR_BF16 (bf16 operand pieces),
+ * LR_INTERIOR_F16 (wide models whose design fits IEEE half precision: every |x| <= 2^15, no column below 2^-10 throughout).
+ * No reference counterpart (the reference has one arithmetic). */
+enum { LR_INTERIOR_NONE = 0, LR_INTERIOR_BF16 = 1, LR_INTERIOR_F16 = 2 };
+LR_API int lr_model_interior_format(const lr_model* m, int32_t* format);
 
 /*
  * ll(beta), lprior(beta), lpost(beta), glp(beta) for C parameter vectors at once.

@@ -51,6 +51,7 @@ SYMBOLS = {
     "lr_model_destroy": (None, [_vp]),
     "lr_model_info": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
     "lr_model_debug_opts": (C.c_int, [_vp, C.c_char_p, C.c_int]),
+    "lr_model_interior_format": (C.c_int, [_vp, C.POINTER(C.c_int32)]),
     "lr_eval": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _op]),
     "lr_run_rwmh": (C.c_int, [_vp, _vp, _vp, _vp, _op, _vp, _vp]),
     "lr_run_mala": (C.c_int, [_vp, _vp, _vp, C.c_double, _vp, _op, _vp, _vp]),

@@ -354,6 +354,13 @@ int lr_model_debug_opts(const lr_model* m, char* buf, int len) {
     return LR_OK;
 }
 
+int lr_model_interior_format(const lr_model* m, int32_t* format) {
+    if (!m || !format) return fail(LR_ERR_INVALID, "NULL argument");
+    if (m->P > 32) *format = (m->d_xblk1h && m->dbg.wide_f16 != 0) ? LR_INTERIOR_F16 : (m->d_xblk1 ? LR_INTERIOR_BF16 : LR_INTERIOR_NONE);
+    else *format = m->P >= 8 ? LR_INTERIOR_BF16 : LR_INTERIOR_NONE;  // (the matrix-core kernels of lr_mfma.h / lr_mfma_f64.h / lr_tall_mx.h)
+    return LR_OK;
+}
+
 int lr_model_info(const lr_model* m, int64_t* n, int32_t* p, int32_t* dtype, int32_t* device, int32_t* padded_p) {
     if (!m) return fail(LR_ERR_INVALID, "model is NULL");
     if (n) *n = m->n;

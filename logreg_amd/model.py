@@ -168,6 +168,13 @@ class LogReg:
         check(self._L.lr_model_debug_opts(self.handle, buf, 128))
         return buf.value.decode()
 
+    def interior_format(self) -> str:
+        """Operand format of HMC's reduced-precision interior steps under precision="auto" where such a kernel is planned for this
+        model: "none", "bf16" (bf16 operand pieces) or "f16" (wide models whose design fits IEEE half precision)."""
+        f = C.c_int32()
+        check(self._L.lr_model_interior_format(self.handle, C.byref(f)))
+        return ("none", "bf16", "f16")[f.value]
+
     def plan(self, chains: int, group: int = 0, mode: str = "auto") -> dict:
         """Kernel variant the library will launch for `chains` chains."""
         m, g, r = C.c_int32(), C.c_int32(), C.c_int32()

@@ -108,6 +108,11 @@ LR_API int lr_model_debug_opts(const lr_model *m, char *buf, int len) {
     buf[0] = 0; /* the double has no switches */
     return LR_OK;
 }
+LR_API int lr_model_interior_format(const lr_model *m, int32_t *format) {
+    if (!m || !format) return fail(LR_ERR_INVALID, "NULL argument");
+    *format = LR_INTERIOR_NONE; /* the double computes everything in float64 */
+    return LR_OK;
+}
 LR_API int lr_model_info(const lr_model *m, int64_t *n, int32_t *p, int32_t *dtype, int32_t *device, int32_t *padded_p) {
     if (!m) return fail(LR_ERR_INVALID, "model is NULL");
     if (n) *n = m->n;

@@ -1181,11 +1181,14 @@ def test_half_precision_interior_of_the_trajectory_kernels(la, monkeypatch):
         else:
             monkeypatch.delenv("LOGREG_DEBUG_OPTS", raising=False)
         m = la.LogReg(Xd, y, pscale)
+        formats.append(m.interior_format())
         k = la.hmcKernel(m.lpost, m.glp, eps=0.02, l=8, dmm=dmm)
         return la.mcmc(start, k, **kw, **more)
+    formats = []
     full, fi = run(X, "", precision="full")
     half, hi = run(X, "")
     bf2, bi = run(X, "wide_f16=0")
+    assert formats == ["f16", "f16", "bf16"]
     same = (fi["accepts"] == hi["accepts"]) & (fi["accepts"] == bi["accepts"])
     assert same.mean() > 0.9
     eh, eb = np.abs(half - full)[:, same].max(), np.abs(bf2 - full)[:, same].max()
@@ -1204,6 +1207,7 @@ def test_half_precision_interior_of_the_trajectory_kernels(la, monkeypatch):
         pss[3] /= col_scale  # (the same sampler in rescaled units)
         o1, i1 = run(Xs, "", start, dmm, pss)
         o2, i2 = run(Xs, "wide_f16=0", start, dmm, pss)
+        assert formats[-2:] == ["bf16", "bf16"]
         assert np.isfinite(o1).all() and np.array_equal(o1, o2) and np.array_equal(i1["accepts"], i2["accepts"])
         assert 0 < i1["accepts"].sum()
     # (c) saturation of beta * log2(e) at +-65504

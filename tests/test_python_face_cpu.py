@@ -49,6 +49,7 @@ def test_model_closures_through_the_python_face(models):  # F1
     assert isinstance(m.lpost(b), float) and m.glp(b).shape == (8,) and isinstance(m.ll(b), float)
     assert m.ll(b) == pytest.approx(-93.29888360251877, rel=1e-12)
     assert set(m.eval(b, ("ll", "glp"))) == {"ll", "glp"}
+    assert m.interior_format() == "none" and m.debug_opts() == ""  # (the test double computes everything in float64)
     with pytest.raises(ValueError):
         m.eval(np.zeros(7))
     # a float32 model hands float32 values back through the same face
