@@ -19,6 +19,22 @@ using T = double;
 #endif
 inline int check(hipError_t e) { return e == hipSuccess ? 0 : -2; }
 
+// the one-launch trajectory kernels (float32 and float64 models)
+int launch_tall_traj(hipStream_t st, const void* tall_args) {
+    const auto& a = *static_cast<const TallArgs<T, P>*>(tall_args);
+    const dim3 g2((unsigned)((a.C + 31) / 32)), g1((unsigned)((a.C + 15) / 16)), block(512);
+    if (a.traj_tiles == 2) {
+        if (a.traj_fmt == 2) hipLaunchKernelGGL((k_wide_traj2_bf16<P, 2, T>), g2, block, 0, st, a);
+        else if (a.traj_fmt == 1) hipLaunchKernelGGL((k_wide_traj2_bf16<P, 1, T>), g2, block, 0, st, a);
+        else hipLaunchKernelGGL((k_wide_traj2_bf16<P, 0, T>), g2, block, 0, st, a);
+    } else if (a.traj_fmt == 2) {
+        hipLaunchKernelGGL((k_wide_traj_bf16<P, true, T>), g1, block, 0, st, a);
+    } else {
+        hipLaunchKernelGGL((k_wide_traj_bf16<P, false, T>), g1, block, 0, st, a);
+    }
+    return check(hipGetLastError());
+}
+
 #if LR_DTYPE == 0
 int launch_tall_partial(hipStream_t st, int want_value, int /*want_grad*/, const void* tall_args) {
     const auto& a = *static_cast<const TallArgs<float, P>*>(tall_args);
@@ -54,21 +70,6 @@ int launch_tall_partial(hipStream_t st, int want_value, int /*want_grad*/, const
     return check(hipGetLastError());
 }
 
-int launch_tall_traj(hipStream_t st, const void* tall_args) {
-    const auto& a = *static_cast<const TallArgs<float, P>*>(tall_args);
-    const dim3 g2((unsigned)((a.C + 31) / 32)), g1((unsigned)((a.C + 15) / 16)), block(512);
-    if (a.traj_tiles == 2) {
-        if (a.traj_fmt == 2) hipLaunchKernelGGL((k_wide_traj2_bf16<P, 2>), g2, block, 0, st, a);
-        else if (a.traj_fmt == 1) hipLaunchKernelGGL((k_wide_traj2_bf16<P, 1>), g2, block, 0, st, a);
-        else hipLaunchKernelGGL((k_wide_traj2_bf16<P, 0>), g2, block, 0, st, a);
-    } else if (a.traj_fmt == 2) {
-        hipLaunchKernelGGL((k_wide_traj_bf16<P, true>), g1, block, 0, st, a);
-    } else {
-        hipLaunchKernelGGL((k_wide_traj_bf16<P, false>), g1, block, 0, st, a);
-    }
-    return check(hipGetLastError());
-}
-#define LR_WIDE_TRAJ_HOOK &launch_tall_traj
 #else
 int launch_tall_partial(hipStream_t st, int want_value, int /*want_grad*/, const void* tall_args) {
     const auto& a = *static_cast<const TallArgs<double, P>*>(tall_args);
@@ -89,7 +90,6 @@ int launch_tall_partial(hipStream_t st, int want_value, int /*want_grad*/, const
     else hipLaunchKernelGGL((k_wide_partial_f64<P, false>), grid, block, 0, st, a);
     return check(hipGetLastError());
 }
-#define LR_WIDE_TRAJ_HOOK nullptr
 #endif
 
 int launch_tall_update(hipStream_t st, int kind, int phase, int64_t iter, int64_t out_row, int begin_next,
@@ -106,7 +106,7 @@ int launch_tall_update(hipStream_t st, int kind, int phase, int64_t iter, int64_
     return check(hipGetLastError());
 }
 
-const InstTable kTable = {LR_DTYPE, P, 0, nullptr, nullptr, nullptr, &launch_tall_partial, &launch_tall_update, LR_WIDE_TRAJ_HOOK, nullptr, nullptr};
+const InstTable kTable = {LR_DTYPE, P, 0, nullptr, nullptr, nullptr, &launch_tall_partial, &launch_tall_update, &launch_tall_traj, nullptr, nullptr};
 
 }  // namespace
 }  // namespace lr

@@ -741,8 +741,10 @@ __global__ void __launch_bounds__((64 * NW)) __attribute__((amdgpu_waves_per_eu(
 // 16 x CUs chains.  Results do not depend on the chain count, the tile position or any slice plan.
 // F16: the one-piece half-precision interior (rows and beta in one f16 piece each, the sigmoid weights in f16; a.xblk1h) instead of
 // bf16 rows x two bf16 pieces of beta -- see k_wide_traj2_bf16.
-template <int P, bool F16 = false>
-__global__ void __launch_bounds__(512) k_wide_traj_bf16(TallArgs<float, P> a) {
+// S = double: a FLOAT64 model's trajectory -- position, momentum, kick and drift float64 (the thread's registers); the position enters the
+// GEMM rounded to float32, the gradient sums come out of it as the float64 wave-order sums of float32 wave partials, as for float32 models.
+template <int P, bool F16 = false, typename S = float>
+__global__ void __launch_bounds__(512) k_wide_traj_bf16(TallArgs<S, P> a) {
     using G = WideBf16Geom<P>;
     const uint16_t* const image = F16 ? a.xblk1h : a.xblk1;
     constexpr int NW = 8, BLK_BYTES = G::BUF1 * 2, NBUF = P >= 128 ? 2 : 4, RING_BYTES = NBUF * BLK_BYTES, RW = 36;
@@ -786,7 +788,7 @@ __global__ void __launch_bounds__(512) k_wide_traj_bf16(TallArgs<float, P> a) {
     int64_t ochain = chain0 + oc;
     const bool olive = ochain < a.C;
     if (!olive) ochain = a.C - 1;
-    float sq[G::M32], sp[G::M32], sb[G::M32], si[G::M32];
+    S sq[G::M32], sp[G::M32], sb[G::M32], si[G::M32];
 #pragma unroll
     for (int r = 0; r < G::M32; ++r) {
         const int j = 32 * r + oj;
@@ -796,7 +798,7 @@ __global__ void __launch_bounds__(512) k_wide_traj_bf16(TallArgs<float, P> a) {
         si[r] = a.cvec[P + j];
     }
 #pragma unroll
-    for (int r = 0; r < G::M32; ++r) qnew[oc][32 * r + oj] = sq[r];
+    for (int r = 0; r < G::M32; ++r) qnew[oc][32 * r + oj] = (float)sq[r];
     __builtin_amdgcn_s_waitcnt(0x0F70);  // nothing but the DMA ring counts on vmcnt from here on
 #pragma unroll
     for (int b = 0; b < NBUF - 1; ++b)
@@ -864,10 +866,10 @@ __global__ void __launch_bounds__(512) k_wide_traj_bf16(TallArgs<float, P> a) {
             double gs = 0.0;
 #pragma unroll
             for (int w = 0; w < NW; ++w) gs += (double)red[w][oc][oj];  // wave order
-            const float g1 = (float)gs - sq[r] * si[r];
+            const S g1 = (S)gs - sq[r] * si[r];
             sp[r] = fma_t(a.step, g1, sp[r]);
             sq[r] = fma_t(sb[r], sp[r], sq[r]);
-            qnew[oc][32 * r + oj] = sq[r];
+            qnew[oc][32 * r + oj] = (float)sq[r];
             __syncthreads();
         }
     }
@@ -899,11 +901,14 @@ __global__ void __launch_bounds__(512) k_wide_traj_bf16(TallArgs<float, P> a) {
 // NB = pieces of beta in the eta MFMAs: 2 (hi + lo: the default policy) or 1 (LR_PREC_BF16, the caller's explicit request: a third of the
 // MFMAs fewer -- the kernel is POWER-bound, 1300 W at 2.04 GHz, so the time follows the work: 24.2 -> 20.5 us per evaluation at config 5
 // whole -- for 0.019 of acceptance, 0.756 -> 0.737; still an exact sampler: a deterministic force, exact end points).
-template <int P, int FMT = 0>
-__global__ void __launch_bounds__(512) k_wide_traj2_bf16(TallArgs<float, P> a) {
+// S = double (a FLOAT64 model): the owner thread's position and momentum are float64 and BOTH wait in global memory between the
+// reductions (a.q1, a.pm: 32 bytes each per thread and tile; the LDS has no room for float64 momenta); kick and drift in float64.
+template <int P, int FMT = 0, typename S = float>
+__global__ void __launch_bounds__(512) k_wide_traj2_bf16(TallArgs<S, P> a) {
     using G = WideBf16Geom<P>;
     constexpr int NB = FMT == 0 ? 2 : 1;
-    constexpr bool F16 = FMT == 2;
+    constexpr bool F16 = FMT == 2, F64 = sizeof(S) == 8;
+    typedef double f64x2t __attribute__((ext_vector_type(2)));
     const uint16_t* const image = F16 ? a.xblk1h : a.xblk1;
     constexpr int NW = 8, NT2 = 2, BLK_BYTES = G::BUF1 * 2, NBUF = P >= 128 ? 2 : 4, RING_BYTES = NBUF * BLK_BYTES;
     constexpr int NQ = P / 4;             // 16-byte chunks per chain
@@ -962,7 +967,7 @@ __global__ void __launch_bounds__(512) k_wide_traj2_bf16(TallArgs<float, P> a) {
     };
     // Between the reductions the thread's momenta wait in LDS (pmom) and its positions in a.q1 itself -- the row loop needs every
     // register, and the LDS is full: 8 + 8 floats per thread.
-    __shared__ __attribute__((aligned(16))) f32x4 pmom[NT2][512];
+    __shared__ __attribute__((aligned(16))) f32x4 pmom[NT2][F64 ? 1 : 512];
     // the two bf16 pieces of k * position for the thread's four coordinates -> qop
     auto put_ops = [&](int t, const f32x4& q) {
         const int m = oq >> 3, okg = (oq >> 1) & 3, ip = ((oq & 1) << 1) ^ ((okg & 1) << 1);  // pair slot after the odd-kg half swap
@@ -986,9 +991,14 @@ __global__ void __launch_bounds__(512) k_wide_traj2_bf16(TallArgs<float, P> a) {
     for (int t = 0; t < NT2; ++t) {
         bool live;
         const int64_t at = state_at(t, live);
-        const f32x4 q0 = *reinterpret_cast<const f32x4*>(a.q1 + at);
-        pmom[t][tid] = *reinterpret_cast<const f32x4*>(a.pm + at);
-        if (owner) put_ops(t, q0);
+        if constexpr (!F64) {
+            const f32x4 q0 = *reinterpret_cast<const f32x4*>(a.q1 + at);
+            pmom[t][tid] = *reinterpret_cast<const f32x4*>(a.pm + at);
+            if (owner) put_ops(t, q0);
+        } else {
+            const f64x2t lo = *reinterpret_cast<const f64x2t*>(a.q1 + at), hi = *reinterpret_cast<const f64x2t*>(a.q1 + at + 2);
+            if (owner) put_ops(t, f32x4{(float)lo[0], (float)lo[1], (float)hi[0], (float)hi[1]});
+        }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);  // nothing but the DMA ring counts on vmcnt from here on
 #pragma unroll
@@ -1151,14 +1161,29 @@ __global__ void __launch_bounds__(512) k_wide_traj2_bf16(TallArgs<float, P> a) {
         // are inline asm: the compiler's own wait insertion knows nothing of the DMA requests queued behind them and would wait for
         // vmcnt(0) -- the whole prefetch -- at their first use; the counted wait below is tied to the four registers instead.
         f32x4 sb, si, qg[NT2];
+        f32x4 raw[F64 ? 12 : 1];  // float64 models: drift factors (0, 1), prior precisions (2, 3), positions (4 + 2 t ..), momenta (8 + 2 t ..) as 16-byte halves
         bool qlive[NT2];
         int64_t qat[NT2];
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sb) : "v"(a.cvec + 4 * oq) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(si) : "v"(a.cvec + P + 4 * oq) : "memory");
+        if constexpr (!F64) {
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sb) : "v"(a.cvec + 4 * oq) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(si) : "v"(a.cvec + P + 4 * oq) : "memory");
+        } else {
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(raw[0]) : "v"(a.cvec + 4 * oq) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(raw[1]) : "v"(a.cvec + 4 * oq) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(raw[2]) : "v"(a.cvec + P + 4 * oq) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(raw[3]) : "v"(a.cvec + P + 4 * oq) : "memory");
+        }
 #pragma unroll
         for (int t = 0; t < NT2; ++t) {
             qat[t] = state_at(t, qlive[t]);
-            asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(qg[t]) : "v"(a.q1 + qat[t]) : "memory");
+            if constexpr (!F64) {
+                asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(qg[t]) : "v"(a.q1 + qat[t]) : "memory");
+            } else {
+                asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(raw[4 + 2 * t]) : "v"(a.q1 + qat[t]) : "memory");
+                asm volatile("global_load_dwordx4 %0, %1, off offset:16 nt" : "=v"(raw[5 + 2 * t]) : "v"(a.q1 + qat[t]) : "memory");
+                asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(raw[8 + 2 * t]) : "v"(a.pm + qat[t]) : "memory");
+                asm volatile("global_load_dwordx4 %0, %1, off offset:16 nt" : "=v"(raw[9 + 2 * t]) : "v"(a.pm + qat[t]) : "memory");
+            }
         }
         int dma_pending = 0;
         if (!LR_TRAJ_EXP(3) && s + 1 < nsteps) {
@@ -1180,29 +1205,68 @@ __global__ void __launch_bounds__(512) k_wide_traj2_bf16(TallArgs<float, P> a) {
                 static_assert(NT2 == 2, "registers named in the waits");
                 constexpr int per = BLK_BYTES / 1024;
 #define LR_WAIT_VM4(N) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(sb), "+v"(si), "+v"(qg[0]), "+v"(qg[1]) : "n"(N) : "memory")
-                if (dma_pending >= 3) LR_WAIT_VM4(3 * per);
-                else if (dma_pending == 2) LR_WAIT_VM4(2 * per);
-                else if (dma_pending == 1) LR_WAIT_VM4(per);
-                else LR_WAIT_VM4(0);
+#define LR_WAIT_VM12(N)                                                                                                                         \
+    asm volatile("s_waitcnt vmcnt(%12)"                                                                                                         \
+                 : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]), "+v"(raw[5]), "+v"(raw[6]), "+v"(raw[7]), "+v"(raw[8]), \
+                   "+v"(raw[9]), "+v"(raw[10]), "+v"(raw[11])                                                                                   \
+                 : "n"(N)                                                                                                                       \
+                 : "memory")
+                if constexpr (!F64) {
+                    if (dma_pending >= 3) LR_WAIT_VM4(3 * per);
+                    else if (dma_pending == 2) LR_WAIT_VM4(2 * per);
+                    else if (dma_pending == 1) LR_WAIT_VM4(per);
+                    else LR_WAIT_VM4(0);
+                } else {
+                    if (dma_pending >= 3) LR_WAIT_VM12(3 * per);
+                    else if (dma_pending == 2) LR_WAIT_VM12(2 * per);
+                    else if (dma_pending == 1) LR_WAIT_VM12(per);
+                    else LR_WAIT_VM12(0);
+                }
 #undef LR_WAIT_VM4
+#undef LR_WAIT_VM12
             }
             if (owner) {
                 f32x4 pw[NW];
 #pragma unroll
                 for (int w = 0; w < NW; ++w) pw[w] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(smem + w * RING_BYTES + (NBUF - 1) * BLK_BYTES) + xr_off);
-                f32x4 qn = qg[t], pn = pmom[t][tid];
+                if constexpr (!F64) {
+                    f32x4 qn = qg[t], pn = pmom[t][tid];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    double gs = 0.0;
+                    for (int i = 0; i < 4; ++i) {
+                        double gs = 0.0;
 #pragma unroll
-                    for (int w = 0; w < NW; ++w) gs += (double)pw[w][i];  // wave order
-                    const float g1 = (float)gs - qn[i] * si[i];
-                    pn[i] = fma_t(a.step, g1, pn[i]);
-                    qn[i] = fma_t(sb[i], pn[i], qn[i]);
+                        for (int w = 0; w < NW; ++w) gs += (double)pw[w][i];  // wave order
+                        const float g1 = (float)gs - qn[i] * si[i];
+                        pn[i] = fma_t(a.step, g1, pn[i]);
+                        qn[i] = fma_t(sb[i], pn[i], qn[i]);
+                    }
+                    put_ops(t, qn);
+                    pmom[t][tid] = pn;
+                    if (qlive[t]) *reinterpret_cast<f32x4*>(a.q1 + qat[t]) = qn;
+                } else {
+                    S qn[4], pn[4];
+                    f32x4 qf;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const S vb = __builtin_bit_cast(f64x2t, raw[i >> 1])[i & 1], vi = __builtin_bit_cast(f64x2t, raw[2 + (i >> 1)])[i & 1];
+                        qn[i] = __builtin_bit_cast(f64x2t, raw[4 + 2 * t + (i >> 1)])[i & 1];
+                        pn[i] = __builtin_bit_cast(f64x2t, raw[8 + 2 * t + (i >> 1)])[i & 1];
+                        double gs = 0.0;
+#pragma unroll
+                        for (int w = 0; w < NW; ++w) gs += (double)pw[w][i];  // wave order
+                        const S g1 = (S)gs - qn[i] * vi;
+                        pn[i] = fma_t(a.step, g1, pn[i]);
+                        qn[i] = fma_t(vb, pn[i], qn[i]);
+                        qf[i] = (float)qn[i];
+                    }
+                    put_ops(t, qf);
+                    if (qlive[t]) {
+                        *reinterpret_cast<f64x2t*>(a.q1 + qat[t]) = f64x2t{(double)qn[0], (double)qn[1]};
+                        *reinterpret_cast<f64x2t*>(a.q1 + qat[t] + 2) = f64x2t{(double)qn[2], (double)qn[3]};
+                        *reinterpret_cast<f64x2t*>(a.pm + qat[t]) = f64x2t{(double)pn[0], (double)pn[1]};
+                        *reinterpret_cast<f64x2t*>(a.pm + qat[t] + 2) = f64x2t{(double)pn[2], (double)pn[3]};
+                    }
                 }
-                put_ops(t, qn);
-                pmom[t][tid] = pn;
-                if (qlive[t]) *reinterpret_cast<f32x4*>(a.q1 + qat[t]) = qn;
             }
             __syncthreads();  // the exchange slots have been read (next tile / the next step's DMA may overwrite them); qop is complete
         }
@@ -1213,7 +1277,11 @@ __global__ void __launch_bounds__(512) k_wide_traj2_bf16(TallArgs<float, P> a) {
     for (int t = 0; t < NT2; ++t) {
         bool live;
         const int64_t at = state_at(t, live);
-        if (live) *reinterpret_cast<f32x4*>(a.pm + at) = pmom[t][tid];  // (the position is in a.q1 already)
+        if constexpr (!F64) {
+            if (live) *reinterpret_cast<f32x4*>(a.pm + at) = pmom[t][tid];  // (the position is in a.q1 already)
+        } else {
+            (void)at;  // (float64 models: position and momentum are in a.q1 / a.pm already)
+        }
     }
 }
 

@@ -186,12 +186,13 @@ def test_config5_whole_8192_chains_on_one_gpu(la, monkeypatch):
     res = {}
     # "auto": the f16 interior; "auto/bf16x2": the default policy where the rows do not fit f16; "bf16": the explicit request -- beta in
     # ONE bf16 piece on the trajectory kernel
-    for prec in ("auto", "full", "bf16", "auto/bf16x2"):
+    # "auto/float64": a float64 MODEL under the default policy (float64 state on the trajectory kernel, end points on the f64 matrix pipe)
+    for prec in ("auto", "full", "bf16", "auto/bf16x2", "auto/float64"):
         if prec == "auto/bf16x2":
             monkeypatch.setenv("LOGREG_DEBUG_OPTS", "wide_f16=0")
         else:
             monkeypatch.delenv("LOGREG_DEBUG_OPTS", raising=False)
-        m = la.LogReg(X, y, ps)
+        m = la.LogReg(X, y, ps, dtype="float64" if prec == "auto/float64" else "float32")
         assert m.debug_opts() == ("" if prec != "auto/bf16x2" else "residency_cap=1,tall_mx16=1,wide_traj=-1,wide_waves=0,wide_f16=0")
         k = la.hmcKernel(m.lpost, m.glp, **kw)
         policy = prec.split("/")[0]
@@ -206,12 +207,12 @@ def test_config5_whole_8192_chains_on_one_gpu(la, monkeypatch):
         zm, zs = _z(la, samples, fix)
         print(f"cfg5 whole precision={prec}: accept {acc:.4f} (oracle {fix['accept']:.4f}), max|z| mean {np.max(np.abs(zm)):.2f} sd "
               f"{np.max(np.abs(zs)):.2f}, rms z mean {np.sqrt(np.mean(zm ** 2)):.2f} sd {np.sqrt(np.mean(zs ** 2)):.2f}")
-        assert abs(acc - fix["accept"]) < 4 * fix["accept_se"] + {"full": 0.01, "auto": 0.01, "auto/bf16x2": 0.03, "bf16": 0.05}[prec]
+        assert abs(acc - fix["accept"]) < 4 * fix["accept_se"] + {"full": 0.01, "auto": 0.01, "auto/float64": 0.01, "auto/bf16x2": 0.03, "bf16": 0.05}[prec]
         assert np.max(np.abs(zm)) < 4.2 and np.max(np.abs(zs)) < 4.2, prec
         assert 0.5 < np.sqrt(np.mean(zm ** 2)) < 1.3 and 0.5 < np.sqrt(np.mean(zs ** 2)) < 1.3, prec
         res[prec] = acc
     # measured: full 0.758 | f16 0.758 | bf16 x two pieces 0.756 | bf16 x one piece 0.737
-    assert abs(res["auto"] - res["full"]) < 0.005 and res["auto/bf16x2"] > res["full"] - 0.03
+    assert abs(res["auto"] - res["full"]) < 0.005 and abs(res["auto/float64"] - res["full"]) < 0.005 and res["auto/bf16x2"] > res["full"] - 0.03
     assert res["full"] - 0.05 < res["bf16"] < res["auto/bf16x2"] + 0.005
 
 

@@ -1400,6 +1400,50 @@ def test_tall_sixteen_wave_interior_kernel_with_the_update_folded_in(la, n, p, L
     assert np.max(np.abs(old[:, same] - out[:, same])) < 1e-3 / np.sqrt(n)
 
 
+@pytest.mark.parametrize("p,n", [(64, 500), (128, 900)])
+def test_float64_wide_models_on_the_trajectory_kernels(la, p, n, monkeypatch):
+    """Round 5: the one-launch trajectory kernels carry a FLOAT64 model's state too (k_wide_traj_bf16 / k_wide_traj2_bf16 with S = double:
+    position, momentum, kick and drift float64 -- in the two-tile kernel both wait in global memory between the reductions --, the
+    16-bit force inside the trajectory, end points on the f64 matrix pipe).  (a) One tile per workgroup and two compute the same
+    trajectories bit for bit, ragged chain counts included; (b) against the launch-per-step interior kernels (wide_traj=0: another
+    summation order) the same decisions and states to 1e-4; (c) against the float64 oracle at the reduced-precision tolerance, exact
+    mode at 1e-9; (d) reruns, chunks and shards bit-identical."""
+    from oracle.oracle import OracleModel
+    X, y, _ = la.synthetic_logreg(n, p, seed=905 + p, beta_sd=0.1)
+    ps = np.full(p, 1.5)
+    C = 600  # (38 tiles, the last one ragged)
+    b = 0.1 * np.random.default_rng(p + 1).standard_normal((C, p))
+    eps, L = 0.02, 9
+    kw = dict(thin=1, iters=2, verb=False, seed=12, return_info=True)
+    outs = {}
+    for opt in ("wide_traj=1", "wide_traj=2", "wide_traj=0"):
+        monkeypatch.setenv("LOGREG_DEBUG_OPTS", opt)
+        m = la.LogReg(X, y, ps, dtype="float64")
+        assert opt in m.debug_opts() and m.interior_format() == "f16"
+        k = la.hmcKernel(m.lpost, m.glp, eps=eps, l=L, dmm=np.ones(p))
+        outs[opt] = la.mcmc(b, k, **kw)
+        if opt == "wide_traj=2":
+            assert outs[opt][0].dtype == np.float64
+            assert np.array_equal(outs[opt][0], la.mcmc(b, k, chunk=1, **kw)[0])
+            sub = la.mcmc(b[100:170], k, chain_offset=100, plan_chains=C, **kw)[0]
+            assert np.array_equal(sub, outs[opt][0][:, 100:170])
+            full = la.mcmc(b, k, precision="full", **kw)
+    (o1, i1), (o2, i2), (o0, i0) = outs["wide_traj=1"], outs["wide_traj=2"], outs["wide_traj=0"]
+    assert np.array_equal(o1, o2) and np.array_equal(i1["accepts"], i2["accepts"])
+    same = i0["accepts"] == i2["accepts"]
+    assert same.mean() > 0.98 and np.max(np.abs(o0[:, same] - o2[:, same])) < 1e-4
+    assert 0 < i2["accepts"].sum() < 2 * C
+    orc = OracleModel(X, y, ps)
+    ref = orc.run("hmc", b[:64], step=eps, l=L, scale=np.ones(p), thin=1, iters=2, seed=12, threads=0)
+    ok = ref["margin"] > 1e-8
+    assert np.array_equal(full[1]["accepts"][:64][ok], ref["accepts"][ok].astype(np.uint32))
+    assert np.max(np.abs(full[0][:, :64][:, ok] - ref["out"][:, ok])) < 1e-9
+    clear = ref["margin"] > 0.05
+    assert clear.mean() > 0.7 and np.array_equal(i2["accepts"][:64][clear], ref["accepts"][clear].astype(np.uint32))
+    assert np.max(np.abs(o2[:, :64][:, clear] - ref["out"][:, clear])) < 5e-3
+    assert np.max(np.abs(o2 - full[0])) > 1e-9  # (the 16-bit force did run)
+
+
 @pytest.mark.parametrize("p,n,C", [(128, 1000, 70), (100, 513, 64), (40, 300, 130)])
 def test_float64_wide_models_run_on_the_f64_matrix_pipe(la, p, n, C):
     """LogReg(dtype="float64") at 32 < p <= 128 -- the arithmetic the reference computes in (fit-np-hmc.py:17-19) at config 5's

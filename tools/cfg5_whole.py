@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """BASELINE config 5 AS A WHOLE on one GPU: HMC L=50 on synthetic n=4096, p=128, 8192 chains (the fixture's design and step size).
-    python3 tools/cfg5_whole.py [chains ...] [--iters K] [--prec auto|full|bf16] [--cfg 5|4]      (--cfg 4: BASELINE config 4's design, n = 100 000, p = 8)
+    python3 tools/cfg5_whole.py [chains ...] [--iters K] [--prec auto|full|bf16] [--cfg 5|4] [--dtype float32|float64]      (--cfg 4: BASELINE config 4's design, n = 100 000, p = 8)
 Prints one JSON line per chain count: us per log-posterior-gradient evaluation of all chains (HIP events on the launch stream, interior
 steps + end points + every launch boundary included), algorithmic TFLOP/s, acceptance, the plan."""
 import ctypes as Ct, json, os, sys
@@ -16,7 +16,8 @@ cfg = int(sys.argv[sys.argv.index("--cfg") + 1]) if "--cfg" in sys.argv else 5
 fix = json.load(open(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", f"fullsize_cfg{cfg}.json")))
 n, p = fix["n"], fix["p"]
 X, y, _ = la.synthetic_logreg(n, p, seed=fix["data_seed"], beta_sd=fix["beta_sd"])
-m = la.LogReg(X, y, np.array(fix["pscale"]))
+dtype = sys.argv[sys.argv.index("--dtype") + 1] if "--dtype" in sys.argv else "float32"
+m = la.LogReg(X, y, np.array(fix["pscale"]), dtype=dtype)
 k = la.hmcKernel(m.lpost, m.glp, eps=fix["eps"], l=fix["l"], dmm=np.array(fix["dmm"]))
 L = _lib.load()
 stream = Ct.c_void_p()
@@ -29,6 +30,6 @@ for C in [int(a) for a in args] or [8192]:
     cs = la.ChainSet(k, q0, seed=5, stream=stream, precision=prec)
     ms = bench._timed_chainset(la, timer, cs, iters, 1)
     per_eval = ms * 1e-3 / (iters * fix["l"])
-    print(json.dumps({"chains": C, "precision": prec, "us_per_evaluation_all_chains": per_eval * 1e6, "algorithmic_TFLOPs": C * fg / per_eval / 1e12,
+    print(json.dumps({"chains": C, "dtype": dtype, "precision": prec, "us_per_evaluation_all_chains": per_eval * 1e6, "algorithmic_TFLOPs": C * fg / per_eval / 1e12,
                       "frac_bf16_peak": C * fg / per_eval / 2.5e15, "accept_rate": float(cs.get_accepts().sum() / (C * (3 * iters + 1))),
                       "chain_iterations_per_s": C * iters / (ms * 1e-3), "plan": cs.plan(), "debug_opts": m.debug_opts()}), flush=True)
