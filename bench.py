@@ -392,10 +392,20 @@ def f64_wide_run(la, L, check, dev, stream):
         res[prec] = {"kernel_variant": cs.plan(), "chain_iterations_per_s": C * iters / (ms * 1e-3), "us_per_evaluation_all_chains": ms * 1e3 / evals,
                      "accept_rate": float(cs.get_accepts().sum() / (C * (2 * iters + 1)))}
     tf = C * flops_per_grad_eval(n, p) / (res["full"]["us_per_evaluation_all_chains"] * 1e-6) / 1e12
+    # ... and config 5 as a whole (8192 chains) under the default policy: float64 state on the two-tile trajectory kernel
+    Cw = 8192
+    qw = np.array(fix["map"]) + np.array(fix["laplace_sd"]) * np.random.Generator(np.random.Philox(4005)).standard_normal((Cw, p))
+    cw = la.ChainSet(k, qw, seed=5, stream=stream)
+    msw = _timed_chainset(la, timer, cw, iters, 1, repeats=2, warm=1)
+    res["auto"]["whole_8192_chains"] = {"kernel_variant": cw.plan(), "us_per_evaluation_all_chains": msw * 1e3 / evals,
+                                        "chain_iterations_per_s": Cw * iters / (msw * 1e-3),
+                                        "accept_rate": float(cw.get_accepts().sum() / (Cw * (3 * iters + 1))),
+                                        "note": "interior steps: k_wide_traj2_bf16<.., double> (float64 position / momentum / kick / drift, 16-bit force); "
+                                                "end points on the f64 matrix pipe (about a third of the time)"}
     return {"dtype": "f64", "workload": f"HMC L={fix['l']} eps={fix['eps']}, synthetic n={n} p={p}, {C} chains, float64 model", **res["full"],
             "algorithmic_TFLOPs": tf, "peak": PEAK_FP64_TFLOPS, "frac_of_fp64_matrix_peak": tf / PEAK_FP64_TFLOPS,
-            "default_policy": {**res["auto"], "note": "precision='auto': interior gradients on the bf16 pipe (the float32 engine's row-split kernel on a float64 state: position, "
-                               "momentum and the fused update float64), end points on the f64 pipe"},
+            "default_policy": {**res["auto"], "note": "precision='auto': interior gradients on the 16-bit matrix pipe (the float32 engine's row-split kernel on a float64 state: "
+                               "position, momentum and the fused update float64), end points on the f64 pipe"},
             "note": "top level = precision='full': every evaluation on v_mfma_f64_16x16x4_f64; not part of `value`"}
 
 
