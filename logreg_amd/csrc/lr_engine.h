@@ -7,7 +7,7 @@
 namespace {
 
 template <typename T, int P> lr::ModelArgs<T, P> model_args(const lr_model* m) {
-    lr::ModelArgs<T, P> a;
+    lr::ModelArgs<T, P> a{};
     a.rows = static_cast<const T*>(m->d_rows);
     a.rows_tw = static_cast<const float*>(m->d_rows_tw);
     a.rows_mf = static_cast<const float*>(m->d_xmf);
@@ -51,7 +51,7 @@ template <typename T, int P>
 int do_chain_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs, const lr_run_opts* o, void* state,
                double* lp_state, void* out, uint32_t* accepts) {
     auto ma = model_args<T, P>(m);
-    lr::ChainArgs<T, P> ca;
+    lr::ChainArgs<T, P> ca{};
     ca.state = static_cast<T*>(state);
     ca.lp_state = lp_state;
     ca.out = static_cast<T*>(out);
@@ -134,6 +134,10 @@ template <typename T, int P>
 int setup_tall(lr_model* m, const Plan& pl, hipStream_t st, int64_t C, int64_t Cp, lr::TallArgs<T, P>* pa) {
     // C: chains of this call (sizes the workspace and the grids);  Cp: chains the slicing decisions are made for
     lr::TallArgs<T, P>& a = *pa;
+    // every field starts from zero: the flags a run sets only on some paths (part_f32, fuse_mid, interior) were left to whatever the
+    // caller's stack held -- found in round 5 when a float64 run on the trajectory kernels, which never touches part_f32, now and then
+    // had its end-point update read float64 partials as float32
+    a = lr::TallArgs<T, P>{};
     const int RS = pl.G;
     auto align = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t vec = align((size_t)C * P * sizeof(T)), dbl = align((size_t)C * sizeof(double));
