@@ -1434,7 +1434,7 @@ def test_float64_wide_models_on_the_trajectory_kernels(la, p, n, monkeypatch):
     assert np.array_equal(o1, o2) and np.array_equal(i1["accepts"], i2["accepts"])
     same = i0["accepts"] == i2["accepts"]
     assert same.mean() > 0.98 and np.max(np.abs(o0[:, same] - o2[:, same])) < 5e-4  # (measured 1.1e-4 at p = 128)
-    assert 0 < i2["accepts"].sum() < 2 * C
+    assert 0 < i2["accepts"].sum() <= 2 * C
     orc = OracleModel(X, y, ps)
     ref = orc.run("hmc", b[:64], step=eps, l=L, scale=np.ones(p), thin=1, iters=2, seed=12, threads=0)
     ok = ref["margin"] > 1e-8
