@@ -1154,42 +1154,39 @@ __global__ void __launch_bounds__(512) k_wide_traj2_bf16(TallArgs<S, P> a) {
 #pragma unroll
             for (int mb = 0; mb < NG; ++mb) grad_mfma(1, mb, w1);
         }
-        // every ring slot has been read: the next step's first blocks travel while the step is finished
-        // (the step's constants -- drift factors, prior precisions of the thread's coordinates -- are fetched again every step, AHEAD of
-        //  the DMA requests so that a counted vmcnt wait reaches them: held in registers across the row loop they spilled to scratch)
-        // ... and so are the thread's positions, which it stored itself a step ago (L1-bypassing loads: the stores went to L2).  The loads
-        // are inline asm: the compiler's own wait insertion knows nothing of the DMA requests queued behind them and would wait for
-        // vmcnt(0) -- the whole prefetch -- at their first use; the counted wait below is tied to the four registers instead.
-        f32x4 sb, si, qg[NT2];
-        f32x4 raw[F64 ? 12 : 1];  // float64 models: drift factors (0, 1), prior precisions (2, 3), positions (4 + 2 t ..), momenta (8 + 2 t ..) as 16-byte halves
+        // Every ring slot has been read.  The step is finished from the thread's share of the state, which waits in global memory between
+        // the reductions (positions in a.q1; float64 models: momenta in a.pm as well) together with the step's constants (drift factors,
+        // prior precisions of the thread's coordinates: held in registers across the row loop all of it spilled to scratch).  Plain loads,
+        // complete -- an explicit vmcnt(0): nothing else is in flight here -- BEFORE the next step's first blocks are requested, so that
+        // vmcnt counts nothing but the DMA ring from then on.  (Round 5 first fetched them with inline-asm loads in front of the DMA
+        // requests and a hand-counted s_waitcnt tied to the registers; the compiler, for whom an asm load's result is there when the
+        // statement ends, placed register copies between load and wait: a rare wrong trajectory when a load was slow.)
+        f32x4 sb, si, qg[NT2];          // float32 models
+        f64x2t vbd[2], vid[2], qd[NT2][2], pd[NT2][2];  // float64 models: drift factors, prior precisions, positions, momenta as pairs
         bool qlive[NT2];
         int64_t qat[NT2];
         if constexpr (!F64) {
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sb) : "v"(a.cvec + 4 * oq) : "memory");
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(si) : "v"(a.cvec + P + 4 * oq) : "memory");
+            sb = *reinterpret_cast<const f32x4*>(a.cvec + 4 * oq);
+            si = *reinterpret_cast<const f32x4*>(a.cvec + P + 4 * oq);
         } else {
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(raw[0]) : "v"(a.cvec + 4 * oq) : "memory");
-            asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(raw[1]) : "v"(a.cvec + 4 * oq) : "memory");
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(raw[2]) : "v"(a.cvec + P + 4 * oq) : "memory");
-            asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(raw[3]) : "v"(a.cvec + P + 4 * oq) : "memory");
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                vbd[h] = *reinterpret_cast<const f64x2t*>(a.cvec + 4 * oq + 2 * h);
+                vid[h] = *reinterpret_cast<const f64x2t*>(a.cvec + P + 4 * oq + 2 * h);
+            }
         }
 #pragma unroll
         for (int t = 0; t < NT2; ++t) {
             qat[t] = state_at(t, qlive[t]);
             if constexpr (!F64) {
-                asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(qg[t]) : "v"(a.q1 + qat[t]) : "memory");
+                qg[t] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.q1 + qat[t]));
             } else {
-                asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(raw[4 + 2 * t]) : "v"(a.q1 + qat[t]) : "memory");
-                asm volatile("global_load_dwordx4 %0, %1, off offset:16 nt" : "=v"(raw[5 + 2 * t]) : "v"(a.q1 + qat[t]) : "memory");
-                asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(raw[8 + 2 * t]) : "v"(a.pm + qat[t]) : "memory");
-                asm volatile("global_load_dwordx4 %0, %1, off offset:16 nt" : "=v"(raw[9 + 2 * t]) : "v"(a.pm + qat[t]) : "memory");
-            }
-        }
-        int dma_pending = 0;
-        if (!LR_TRAJ_EXP(3) && s + 1 < nsteps) {
 #pragma unroll
-            for (int b = 0; b < NBUF - 1; ++b)
-                if (b < wnb) issue(b), ++dma_pending;
+                for (int h = 0; h < 2; ++h) {
+                    qd[t][h] = __builtin_nontemporal_load(reinterpret_cast<const f64x2t*>(a.q1 + qat[t] + 2 * h));
+                    pd[t][h] = __builtin_nontemporal_load(reinterpret_cast<const f64x2t*>(a.pm + qat[t] + 2 * h));
+                }
+            }
         }
         LR_TRAJ_PHASE(4);
         // the waves' gradients meet in every wave's own exchange slot, a tile at a time; wave-order fp64 sums, then the step's kick and drift
@@ -1200,31 +1197,15 @@ __global__ void __launch_bounds__(512) k_wide_traj2_bf16(TallArgs<S, P> a) {
                 const int q = 8 * (mb >> 1) + 2 * kg + (mb & 1);  // chunk of coordinates 32 (mb >> 1) + 8 kg + 4 (mb & 1) ..
                 *reinterpret_cast<f32x4*>(xslot + xw_row + ((q ^ xw_sw) << 2)) = gacc[t][mb];
             }
-            __syncthreads();
-            if (t == 0) {  // constants and positions have arrived (the DMA requests behind them may still be in flight)
-                static_assert(NT2 == 2, "registers named in the waits");
-                constexpr int per = BLK_BYTES / 1024;
-#define LR_WAIT_VM4(N) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(sb), "+v"(si), "+v"(qg[0]), "+v"(qg[1]) : "n"(N) : "memory")
-#define LR_WAIT_VM12(N)                                                                                                                         \
-    asm volatile("s_waitcnt vmcnt(%12)"                                                                                                         \
-                 : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]), "+v"(raw[5]), "+v"(raw[6]), "+v"(raw[7]), "+v"(raw[8]), \
-                   "+v"(raw[9]), "+v"(raw[10]), "+v"(raw[11])                                                                                   \
-                 : "n"(N)                                                                                                                       \
-                 : "memory")
-                if constexpr (!F64) {
-                    if (dma_pending >= 3) LR_WAIT_VM4(3 * per);
-                    else if (dma_pending == 2) LR_WAIT_VM4(2 * per);
-                    else if (dma_pending == 1) LR_WAIT_VM4(per);
-                    else LR_WAIT_VM4(0);
-                } else {
-                    if (dma_pending >= 3) LR_WAIT_VM12(3 * per);
-                    else if (dma_pending == 2) LR_WAIT_VM12(2 * per);
-                    else if (dma_pending == 1) LR_WAIT_VM12(per);
-                    else LR_WAIT_VM12(0);
+            if (t == 0) {  // (the loads travelled under the writes above) ... now the next step's first blocks may go
+                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+                if (!LR_TRAJ_EXP(3) && s + 1 < nsteps) {
+#pragma unroll
+                    for (int b = 0; b < NBUF - 1; ++b)
+                        if (b < wnb) issue(b);
                 }
-#undef LR_WAIT_VM4
-#undef LR_WAIT_VM12
             }
+            __syncthreads();
             if (owner) {
                 f32x4 pw[NW];
 #pragma unroll
@@ -1248,15 +1229,14 @@ __global__ void __launch_bounds__(512) k_wide_traj2_bf16(TallArgs<S, P> a) {
                     f32x4 qf;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const S vb = __builtin_bit_cast(f64x2t, raw[i >> 1])[i & 1], vi = __builtin_bit_cast(f64x2t, raw[2 + (i >> 1)])[i & 1];
-                        qn[i] = __builtin_bit_cast(f64x2t, raw[4 + 2 * t + (i >> 1)])[i & 1];
-                        pn[i] = __builtin_bit_cast(f64x2t, raw[8 + 2 * t + (i >> 1)])[i & 1];
+                        qn[i] = qd[t][i >> 1][i & 1];
+                        pn[i] = pd[t][i >> 1][i & 1];
                         double gs = 0.0;
 #pragma unroll
                         for (int w = 0; w < NW; ++w) gs += (double)pw[w][i];  // wave order
-                        const S g1 = (S)gs - qn[i] * vi;
+                        const S g1 = (S)gs - qn[i] * vid[i >> 1][i & 1];
                         pn[i] = fma_t(a.step, g1, pn[i]);
-                        qn[i] = fma_t(vb, pn[i], qn[i]);
+                        qn[i] = fma_t((S)vbd[i >> 1][i & 1], pn[i], qn[i]);
                         qf[i] = (float)qn[i];
                     }
                     put_ops(t, qf);
