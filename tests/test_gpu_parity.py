@@ -1446,6 +1446,29 @@ def test_float64_wide_models_on_the_trajectory_kernels(la, p, n, monkeypatch):
     assert np.max(np.abs(o2 - full[0])) > 1e-9  # (the 16-bit force did run)
 
 
+def test_trajectory_kernel_first_run_on_a_fresh_model_is_the_same_run(la, monkeypatch):
+    """Regression (round 5): the two-tile trajectory kernel first fetched the thread's state with inline-asm loads and a hand-counted
+    s_waitcnt; the compiler placed register copies between load and wait, and about one run in 200 on a FRESH model (cold TLBs: slow
+    loads) computed wrong trajectories for the four chains of a wave (tools/traj_stress.py).  120 fresh float64 models (the form that
+    showed it) and 60 float32 ones: every run and its chunked repeat bit-identical with the first."""
+    monkeypatch.setenv("LOGREG_DEBUG_OPTS", "wide_traj=2")
+    n, p = 500, 64
+    X, y, _ = la.synthetic_logreg(n, p, seed=905 + p, beta_sd=0.1)
+    b = 0.1 * np.random.default_rng(p + 1).standard_normal((600, p))
+    kw = dict(thin=1, iters=2, verb=False, seed=12)
+    for dtype, reps in (("float64", 120), ("float32", 60)):
+        first, bad = None, []
+        for rep in range(reps):
+            m = la.LogReg(X, y, np.full(p, 1.5), dtype=dtype)
+            k = la.hmcKernel(m.lpost, m.glp, eps=0.02, l=9, dmm=np.ones(p))
+            for out in (la.mcmc(b, k, **kw), la.mcmc(b, k, chunk=1, **kw)):
+                first = out if first is None else first
+                if not np.array_equal(out, first):
+                    d = np.abs(out - first)
+                    bad.append((rep, float(d.max()), np.flatnonzero(d.max(axis=(0, 2)) > 0)[:12].tolist()))
+        assert not bad, (dtype, bad[:5])
+
+
 @pytest.mark.parametrize("p,n,C", [(128, 1000, 70), (100, 513, 64), (40, 300, 130)])
 def test_float64_wide_models_run_on_the_f64_matrix_pipe(la, p, n, C):
     """LogReg(dtype="float64") at 32 < p <= 128 -- the arithmetic the reference computes in (fit-np-hmc.py:17-19) at config 5's
