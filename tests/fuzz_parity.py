@@ -26,9 +26,9 @@ for case in range(cases):
     if p > 32:
         n = min(n, 1000)
     C = int(rng.choice([1, 2, 15, 16, 17, 63, 64, 65, 130, 300]))
-    big = rng.random() < 0.12 and p <= 32  # many chains (two-part plans, matrix-core kernels at full occupancy): few rows, the oracle
-    if big:                                  # replays the first 64 chains and 64 behind the largest exactly-filled count
-        C = int(rng.choice([1031, 4097, 5120, 9000, 10240, 17000]))
+    big = rng.random() < float(os.environ.get("FUZZ_BIG", "0.12"))  # (FUZZ_BIG=0.6: a campaign on many-chain cases)  many chains (two-part plans, matrix-core kernels at full occupancy; wide models: the trajectory kernels with one
+    if big:                    # and two chain tiles per workgroup): few rows, the oracle replays the first 64 chains and 64 behind the largest
+        C = int(rng.choice([1031, 4097, 5120, 9000, 10240, 17000]))  # exactly-filled count
         n = min(n, 256)
     kind = str(rng.choice(["hmc", "mala", "rwmh", "ul"]))
     X, y, _ = la.synthetic_logreg(n, p, seed=1000 + case, beta_sd=0.3 / np.sqrt(p))
