@@ -1342,14 +1342,15 @@ inline uint16_t f16_bits_rne(float x) {  // finite |x| <= 2^15
 }
 template <int P> inline bool wide_f16_prepare_rne(const float* rows, int64_t n, uint16_t* out) {
     using G = WideBf16Geom<P>;
-    for (int cc = 0; cc < P; ++cc) {
-        float cmax = 0.0f;
-        for (int64_t r = 0; r < n; ++r) {
+    float cmax[P];
+    for (int cc = 0; cc < P; ++cc) cmax[cc] = 0.0f;
+    for (int64_t r = 0; r < n; ++r)
+        for (int cc = 0; cc < P; ++cc) {
             const float ax = rows[r * P + cc] < 0 ? -rows[r * P + cc] : rows[r * P + cc];
-            cmax = ax > cmax ? ax : cmax;
+            cmax[cc] = ax > cmax[cc] ? ax : cmax[cc];
         }
-        if (cmax > 32768.0f || (cmax != 0.0f && cmax < 0x1p-10f)) return false;
-    }
+    for (int cc = 0; cc < P; ++cc)
+        if (cmax[cc] > 32768.0f || (cmax[cc] != 0.0f && cmax[cc] < 0x1p-10f)) return false;
     const int64_t nblk = (n + 31) / 32;
     for (int64_t b = 0; b < nblk; ++b) {
         uint16_t* base = out + b * (int64_t)G::BUF1;
