@@ -283,17 +283,14 @@ int do_stepwise_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs
         LR_STAMPS_DISARM(a);
         a.interior = 0;
     };
-    // wide models: the whole interior of a trajectory in one launch (k_wide_traj_bf16): no slice partials, no update
-    // launches.  One workgroup streams the whole design per step, so it pays once every CU has a tile of its own and
-    // until the 64-chain workgroups of the chain-split kernel amortise the stream better (config 5 design, us per
-    // evaluation of all chains, trajectory kernel | launch per step: 1024 chains 15.7 | 11.5, 2048: 16.1 | 14.4,
-    // 4096: 22.2 | 25.0, 8192: 39.5 | 44.9, 16 384: 73.4 | 72.5).  LOGREG_DEBUG_OPTS wide_traj=1 forces it on, wide_traj=0 off.
-    // Round 5: with two chain tiles per workgroup (below) it wins at every chain count from one tile per CU up (us per evaluation,
-    // launch per step | two-tile trajectory kernel: 12 288 chains 79.6 | 49.6, 16 384: 67.5 | 51.4, 32 768: 120.6 | 101.6, 65 536: 235.9 | 202.7;
-    // profiles/r5_cfg5_whole.txt), so the upper bound on the chain count is gone.
+    // wide models: the whole interior of a trajectory in one launch (k_wide_traj2_bf16): no slice partials, no update launches.  One
+    // workgroup streams the whole design per step.  With two chain tiles per workgroup it wins at every chain count from one tile per CU
+    // up (us per evaluation, launch per step | trajectory kernel: 12 288 chains 79.6 | 49.6, 16 384: 67.5 | 51.4, 32 768: 120.6 | 101.6,
+    // 65 536: 235.9 | 202.7; profiles/r5_cfg5_whole.txt); below that, with one tile per workgroup, by the measured rule further down.
+    // LOGREG_DEBUG_OPTS wide_traj=1 / 2 force it with one / two tiles per workgroup, wide_traj=0 forbids it.
     const int64_t traj_tiles = (Cp + 15) / 16;
-    // Two chain tiles per workgroup (k_wide_traj2_bf16, round 5; the same trajectories bit for bit) from the chain count at which
-    // the one-tile kernel needs a second round of workgroups: measured rule below.  LOGREG_DEBUG_OPTS wide_traj=2 / 1 force either.
+    // Two chain tiles per workgroup (the same trajectories bit for bit) from the chain count at which one tile per workgroup needs a
+    // second round of workgroups.
     // LR_PREC_BF16 (the caller's explicit request for the cheapest interior force): beta in ONE bf16 piece, on the two-tile kernel at any
     // tile count the trajectory path takes -- a third of the MFMAs fewer for ~0.02 of acceptance (lr_wide_bf16.h)
     const bool one_piece = o->precision == LR_PREC_BF16 && m->dbg.wide_traj != 1 && traj_tiles > (int64_t)kTraj2FromTilesPerCu * m->cus;  // (where the two-tile kernel runs anyway; 4096 chains: 16.6 against 16.9 us on the one-tile kernel -- nothing to buy)
@@ -303,13 +300,17 @@ int do_stepwise_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs
     // fewer -- config 5 whole: 23.9 -> 20.9 us per evaluation, acceptance 0.756 -> 0.758 = the exact interior's), else the bf16 pieces.
     a.traj_fmt = m->dbg.wide_f16 == 2 && half_ok ? 2 : one_piece ? 1 : (half_ok ? 2 : 0);
     a.traj_tiles = (m->dbg.wide_traj == 2 || one_piece) ? 2 : (m->dbg.wide_traj == 1 ? 1 : (traj_tiles > (int64_t)kTraj2FromTilesPerCu * m->cus ? 2 : 1));
+    // Below one chain tile per CU the kernel runs with ONE tile per workgroup (k_wide_traj2_bf16<.., 1>; round 5: it replaced round 3's
+    // one-tile kernel -- the same trajectories bit for bit, 1.1 - 1.5 x faster).  Its step costs what streaming the image through one
+    // CU costs, whatever the chain count; the launch-per-step kernels split the rows over workgroups but pay the launch boundary and the
+    // partial hand-over, and degrade from half the chip's tiles up (us per evaluation, trajectory | launch per step, tools/traj_rule_check.py:
+    // p=128 n=2000 (500 KB) 1024 chains 5.6 | 7.3; n=3000 (750 KB) 7.3 | 8.0; n=4096 (1 MB) 9.2 | 8.8 at 1024 chains, 10.2 | 12.0 at 2048,
+    // 12.1 | 15.8 at 3072; p=64 n=3000 (375 KB) 5.3 | 5.6; n=5000 (625 KB) 7.8 | 6.5 at 1024 chains; n=8000 (1000 KB) 11.6 | 8.0).
+    const int64_t image_bytes = (int64_t)m->n * m->P * 2;
     const bool traj = P > 32 && bf16_interior && m->d_xblk1 != nullptr && t->launch_tall_traj != nullptr && rs.l > 1 &&
                       m->dbg.wide_traj != 0 &&
-                      (m->dbg.wide_traj >= 1 || traj_tiles >= m->cus ||
-                       // small designs (the one-piece image within 256 KB): the per-step stream is cheap, the launch per step is not
-                       // (us per evaluation, launch per step | trajectory kernel: n=500 p=64: 5.5 | 2.8 at 1024 chains; n=300 p=100:
-                       //  7.0 | 4.7; n=1000 p=128: 7.5 | 6.5; n=2000 p=50: 6.2 | 5.3; n=2000 p=128 (512 KB): 8.4 | 9.3)
-                       (traj_tiles < m->cus && (int64_t)m->n * m->P * 2 <= 256 * 1024));
+                      (m->dbg.wide_traj >= 1 || traj_tiles >= m->cus || (traj_tiles >= m->cus / 2 && image_bytes <= 1024 * 1024) ||
+                       image_bytes <= 512 * 1024 || (P == 128 && image_bytes <= 768 * 1024));
     const bool fuse = bf16_interior && a.RS_i > 0 &&
                       ((P > 32 && a.RS_i <= 4) ||                                            // kFuseSlices (lr_wide_bf16.h)
                        (P <= 32 && a.rowsplit_waves == 16 && a.RS_i <= 16 && m->d_xmx));   // kMx16FuseSlices (lr_tall_mx.h)

@@ -27,10 +27,9 @@ int launch_tall_traj(hipStream_t st, const void* tall_args) {
         if (a.traj_fmt == 2) hipLaunchKernelGGL((k_wide_traj2_bf16<P, 2, T>), g2, block, 0, st, a);
         else if (a.traj_fmt == 1) hipLaunchKernelGGL((k_wide_traj2_bf16<P, 1, T>), g2, block, 0, st, a);
         else hipLaunchKernelGGL((k_wide_traj2_bf16<P, 0, T>), g2, block, 0, st, a);
-    } else if (a.traj_fmt == 2) {
-        hipLaunchKernelGGL((k_wide_traj_bf16<P, true, T>), g1, block, 0, st, a);
     } else {
-        hipLaunchKernelGGL((k_wide_traj_bf16<P, false, T>), g1, block, 0, st, a);
+        if (a.traj_fmt == 2) hipLaunchKernelGGL((k_wide_traj2_bf16<P, 2, T, 1>), g1, block, 0, st, a);
+        else hipLaunchKernelGGL((k_wide_traj2_bf16<P, 0, T, 1>), g1, block, 0, st, a);
     }
     return check(hipGetLastError());
 }

@@ -91,7 +91,7 @@ template <typename T, int P> struct TallArgs {
     int RS_i;               // row-split interior kernel (k_wide_partial_bf16r): slices, 0 = not used for this run
     int64_t slice_len_i;    //   and rows per slice (a multiple of 32 * rowsplit_waves: whole 32-row blocks per wave)
     int rowsplit_waves;     //   4 or 8 waves per workgroup (wide); 16: the 16-wave tall kernel k_tall_partial_mx16 is in use
-    int traj_tiles;         // wide models, trajectory kernel: chain tiles (16 chains) per workgroup -- 1: k_wide_traj_bf16, 2: k_wide_traj2_bf16
+    int traj_tiles;         // wide models, trajectory kernel: chain tiles (16 chains) per workgroup of k_wide_traj2_bf16: 1 or 2
     int traj_fmt;           // wide models, operand format of the interior kernels: 0 = bf16 rows x two bf16 pieces of beta, 1 = x one piece
                             //     (LR_PREC_BF16, on the two-tile trajectory kernel only), 2 = f16 rows x one f16 piece of beta (xblk1h)
     int p, l;

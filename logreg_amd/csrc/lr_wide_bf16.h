@@ -725,192 +725,51 @@ __global__ void __launch_bounds__((64 * NW)) __attribute__((amdgpu_waves_per_eu(
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// TRAJECTORY kernel: all L - 1 interior leapfrog steps of one chain tile (16 chains) in ONE launch, no row slicing
-// across workgroups.  Why: inside a launch of the row-split kernel above (config 5, 10 us) a third of the time is the
-// fused prologue re-reading the tile's slice partials and state in each of its 4 slice workgroups (16 MB per step
-// chip-wide), a fifth the reduction + stores, and the 4-block row loop per wave never leaves its start-up transient;
-// swapping the partials between resident workgroups instead (tools/xchg_probe.hip) costs 3.2 us per step on one XCD,
-// 9.5 us across XCDs -- no cheaper than the launch boundary.  So here a tile's gradient never leaves its CU: the 8
-// waves of the workgroup split ALL the rows of the design (each streams its own 32-row block images L2 -> LDS through
-// a private 2-slot DMA ring, exactly the row loop above), the wave partials meet in LDS one 32-coordinate chunk at a
-// time (18 KB: the rings keep 128 KB of the 160), and thread (chain c, coordinate j) -- which owns q[c][j], p[c][j] in
-// registers for the whole trajectory -- finishes the step: g = sum over the waves in wave order - q ivar,
-// p += eps g, q += (eps / m) p, new q to LDS for the next step's beta operand.  The first blocks of the next step
-// are on their way before the reduction starts.  One workgroup streams the whole single-piece image every step
-// (n p 2 bytes from L2: 1 MB for config 5, >= 6.8 us at 64 B/clk/CU), so a step costs the same from 16 to
-// 16 x CUs chains.  Results do not depend on the chain count, the tile position or any slice plan.
-// F16: the one-piece half-precision interior (rows and beta in one f16 piece each, the sigmoid weights in f16; a.xblk1h) instead of
-// bf16 rows x two bf16 pieces of beta -- see k_wide_traj2_bf16.
-// S = double: a FLOAT64 model's trajectory -- position, momentum, kick and drift float64 (the thread's registers); the position enters the
-// GEMM rounded to float32, the gradient sums come out of it as the float64 wave-order sums of float32 wave partials, as for float32 models.
-template <int P, bool F16 = false, typename S = float>
-__global__ void __launch_bounds__(512) k_wide_traj_bf16(TallArgs<S, P> a) {
-    using G = WideBf16Geom<P>;
-    const uint16_t* const image = F16 ? a.xblk1h : a.xblk1;
-    constexpr int NW = 8, BLK_BYTES = G::BUF1 * 2, NBUF = P >= 128 ? 2 : 4, RING_BYTES = NBUF * BLK_BYTES, RW = 36;
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[NW * RING_BYTES];
-    __shared__ __attribute__((aligned(16))) float red[NW][16][RW];
-    __shared__ __attribute__((aligned(16))) float qnew[16][P];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c = lane & 15, kg = lane >> 4;
-    const int64_t chain0 = (int64_t)blockIdx.x * 16;
-    const int nblk = (int)((a.n + 31) / 32);
-    const int per_wave = (nblk + NW - 1) / NW;
-    const int wb0 = wave * per_wave;
-    const int wnb = nblk - wb0 < 0 ? 0 : (nblk - wb0 < per_wave ? nblk - wb0 : per_wave);
-    unsigned char* ring = smem + wave * RING_BYTES;
-    const uint32_t ring_lds = (uint32_t)(uintptr_t)ring;
-
-    auto issue = [&](int b) {  // block b of this wave -> ring slot b % NBUF; one M0 set-up per block (see k_wide_partial_bf16r)
-        static_assert(BLK_BYTES == 8192 || BLK_BYTES == 4096, "pieces addressed around the middle of the block");
-        const unsigned char* src = reinterpret_cast<const unsigned char*>(image + (wb0 + b) * (int64_t)G::BUF1) + lane * 16 + BLK_BYTES / 2;
-        const uint32_t dst = ring_lds + (uint32_t)((b & (NBUF - 1)) * BLK_BYTES) + BLK_BYTES / 2;
-        uint32_t keep;
-        if constexpr (BLK_BYTES == 8192)
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                         "global_load_lds_dwordx4 %1, off offset:-4096\n\tglobal_load_lds_dwordx4 %1, off offset:-3072\n\t"
-                         "global_load_lds_dwordx4 %1, off offset:-2048\n\tglobal_load_lds_dwordx4 %1, off offset:-1024\n\t"
-                         "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
-                         "global_load_lds_dwordx4 %1, off offset:2048\n\tglobal_load_lds_dwordx4 %1, off offset:3072\n\t"
-                         "s_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
-        else
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                         "global_load_lds_dwordx4 %1, off offset:-2048\n\tglobal_load_lds_dwordx4 %1, off offset:-1024\n\t"
-                         "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
-                         "s_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
-    };
-
-    // the thread's share of the state: chain oc, coordinates 32 r + oj
-    const int oc = tid >> 5, oj = tid & 31;
-    int64_t ochain = chain0 + oc;
-    const bool olive = ochain < a.C;
-    if (!olive) ochain = a.C - 1;
-    S sq[G::M32], sp[G::M32], sb[G::M32], si[G::M32];
-#pragma unroll
-    for (int r = 0; r < G::M32; ++r) {
-        const int j = 32 * r + oj;
-        sq[r] = a.q1[ochain * P + j];
-        sp[r] = a.pm[ochain * P + j];
-        sb[r] = a.cvec[j];
-        si[r] = a.cvec[P + j];
-    }
-#pragma unroll
-    for (int r = 0; r < G::M32; ++r) qnew[oc][32 * r + oj] = (float)sq[r];
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // nothing but the DMA ring counts on vmcnt from here on
-#pragma unroll
-    for (int b = 0; b < NBUF - 1; ++b)
-        if (b < wnb) issue(b);
-    __syncthreads();
-
-    const int eta_off = G::elem(kg, c, 0) & ~7;
-    const int ri = (lane & 15) >> 2, ci = lane & 3;
-    const int tr_off[2] = {G::elem(ci, 4 * kg + ri, 0), G::elem(ci, 4 * kg + ri, 4)};
-    const int nsteps = a.l - 1;
-    for (int s = 0; s < nsteps; ++s) {
-        // beta = hi + lo (two round-to-nearest bf16 pieces) of the lane's coordinates 32 m + 8 kg + i, times log2(e)
-        u32x4 bq[G::M32][F16 ? 1 : 2];
-#pragma unroll
-        for (int m = 0; m < G::M32; ++m) {
-            const f32x4 v0 = *reinterpret_cast<const f32x4*>(&qnew[c][32 * m + 8 * kg]);
-            const f32x4 v1 = *reinterpret_cast<const f32x4*>(&qnew[c][32 * m + 8 * kg + 4]);
-            const float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-            beta_operands<F16>(x, kg, bq[m]);
-        }
-        f32x4 gacc[G::MBP];
-#pragma unroll
-        for (int mb = 0; mb < G::MBP; ++mb) gacc[mb] = f32x4{0, 0, 0, 0};
-        for (int b = 0; b < wnb; ++b) {
-            if (b + NBUF - 1 < wnb) issue(b + NBUF - 1);
-            const int last = b + NBUF - 1 < wnb ? b + NBUF - 1 : wnb - 1;
-            wait_vm_blocks<BLK_BYTES>(last - b);
-            const uint16_t* base = reinterpret_cast<const uint16_t*>(ring + (b & (NBUF - 1)) * BLK_BYTES);
-            uint32_t wq[4];
-#pragma unroll
-            for (int T = 0; T < 2; ++T) {
-                f32x4 e0 = {0, 0, 0, 0};  // (hi and lo products into ONE accumulator: the order k_wide_traj2_bf16 uses)
-#pragma unroll
-                for (int m = 0; m < G::M32; ++m) {
-                    const u32x4 xa = *reinterpret_cast<const u32x4*>(base + G::tile1(T, m) + eta_off);
-                    e0 = mfma16<F16>(xa, bq[m][0], e0);
-                    if constexpr (!F16) e0 = mfma16<F16>(xa, bq[m][1], e0);
-                }
-                float w[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) w[r] = fast_rcp(1.0f + __builtin_amdgcn_exp2f(e0[r]));
-                wq[2 * T] = pack16<F16>(w[0], w[1]);
-                wq[2 * T + 1] = pack16<F16>(w[2], w[3]);
-            }
-            const u32x4 wv = {wq[0], wq[1], wq[2], wq[3]};
-#pragma unroll
-            for (int mb = 0; mb < G::MBP; ++mb) {
-                const u32x2 t0 = lds_read_tr16(base + G::tile1(0, mb >> 1) + tr_off[mb & 1]);
-                const u32x2 t1 = lds_read_tr16(base + G::tile1(1, mb >> 1) + tr_off[mb & 1]);
-                const u32x4 xg = {t0[0], t0[1], t1[0], t1[1]};
-                gacc[mb] = mfma16<F16>(xg, wv, gacc[mb]);
-            }
-        }
-        // every ring slot has been read: the next step's first blocks travel while the step is finished
-        if (s + 1 < nsteps) {
-#pragma unroll
-            for (int b = 0; b < NBUF - 1; ++b)
-                if (b < wnb) issue(b);
-        }
-#pragma unroll
-        for (int r = 0; r < G::M32; ++r) {
-            *reinterpret_cast<f32x4*>(&red[wave][c][8 * kg]) = gacc[2 * r];
-            *reinterpret_cast<f32x4*>(&red[wave][c][8 * kg + 4]) = gacc[2 * r + 1];
-            __syncthreads();
-            double gs = 0.0;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) gs += (double)red[w][oc][oj];  // wave order
-            const S g1 = (S)gs - sq[r] * si[r];
-            sp[r] = fma_t(a.step, g1, sp[r]);
-            sq[r] = fma_t(sb[r], sp[r], sq[r]);
-            qnew[oc][32 * r + oj] = (float)sq[r];
-            __syncthreads();
-        }
-    }
-    if (olive) {
-#pragma unroll
-        for (int r = 0; r < G::M32; ++r) {
-            a.q1[ochain * P + 32 * r + oj] = sq[r];
-            a.pm[ochain * P + 32 * r + oj] = sp[r];
-        }
-    }
-}
-
+// TRAJECTORY kernels: all L - 1 interior leapfrog steps of a workgroup's chain tiles in ONE launch, no row slicing across workgroups.
+// Why (round 3, config 5 at 1024 chains on the row-split kernel above, 10 us per step): a third of the time is the fused prologue
+// re-reading the tile's slice partials and state in each of its 4 slice workgroups, a fifth the reduction + stores, and the 4-block row
+// loop per wave never leaves its start-up transient; swapping the partials between resident workgroups instead (tools/xchg_probe.hip)
+// costs 3.2 us per step on one XCD, 9.5 us across XCDs -- no cheaper than the launch boundary.  So here a tile's gradient never leaves
+// its CU: the 8 waves of the workgroup split ALL the rows of the design (each streams its own 32-row block images L2 -> LDS through a
+// private DMA ring, exactly the row loop above), the wave partials meet in LDS, and the thread that owns (chain, four coordinates)
+// finishes the step: g = sum over the waves in wave order - q ivar, p += eps g, q += (eps / m) p, the new position's beta operand to
+// LDS for the next step.  The first blocks of the next step are on their way while the reduction runs.  One workgroup streams the
+// whole single-piece image every step (n p 2 bytes from L2: 1 MB for config 5, >= 6.8 us at 64 B/clk/CU), so a step costs the same from
+// 16 to 16 x CUs chains.  Results do not depend on the chain count, the tile position, the tiles per workgroup or any slice plan.
+// (Round 3's first form, k_wide_traj_bf16 -- one tile per workgroup, beta operands rebuilt by every lane, no software pipelining, 8
+//  barriers per step -- was replaced in round 5 by the kernel below with NT2 = 1: the same trajectories bit for bit, 1.1 - 1.5 x faster.)
 // ---------------------------------------------------------------------------------------------------------------
-// TRAJECTORY kernel, TWO chain tiles (32 chains) per workgroup (round 5): config 5 as a whole -- 8192 chains on one GPU -- is 512
-// chain tiles on 256 CUs.  With one tile per workgroup every CU streams the whole one-piece image twice per leapfrog step
+// k_wide_traj2_bf16 (round 5), written for TWO chain tiles (32 chains) per workgroup: config 5 as a whole -- 8192 chains on one GPU -- is
+// 512 chain tiles on 256 CUs.  With one tile per workgroup every CU streams the whole one-piece image twice per leapfrog step
 // (512 MB per step chip-wide from the L2s: 17 TB/s sustained at the 30 us per step measured, half the L2's aggregate peak; MFMA
 // busy 38 %, profiles/r5_cfg5_whole_baseline.txt).  Here every wave carries the beta operands and gradient accumulators of TWO
 // tiles and uses each block image it fetched -- and every LDS operand read of it -- for both: per chain, half the L2 -> LDS traffic,
 // half the LDS operand reads, the same MFMAs; 256 workgroups of 8 waves = one per CU at 8192 chains.  Row partition over the
-// waves, MFMA order per tile and the wave-order fp64 reduction are those of k_wide_traj_bf16: a chain's trajectory is bit-identical
-// under either kernel (tests/test_gpu_fullsize.py), so the choice between them is a matter of speed only.
-//  * Block body, software-pipelined by hand (sched_group_barrier): left to itself the scheduler issues the 32 eta MFMAs of both
+// waves, MFMA order per tile and the wave-order fp64 reduction do not depend on the tiles per workgroup: a chain's trajectory is
+// bit-identical with one tile or two (tests/test_gpu_fullsize.py), so the choice between them is a matter of speed only.
+//  * Block body, software-pipelined by hand (a scheduling barrier per MFMA slot): left to itself the scheduler issues the 32 eta MFMAs of both
 //    tiles, then ALL 75 vector instructions of the two sigmoids with the matrix pipe idle, then the 16 gradient MFMAs (measured:
 //    2200-2600 cycles per block and wave against 768 of MFMA).  Here tile 0's sigmoid issues between tile 1's eta MFMAs and tile 1's
 //    between tile 0's gradient MFMAs.
 //  * Reduction over the waves through the wave's OWN last ring slot, one tile (16 chains x P floats = one slot) at a time: 4
 //    barriers per step instead of 16, 16-byte accesses only; thread (chain oc, chunk oq) owns coordinates 4 oq .. 4 oq + 3.
-// LDS: 8 rings x 16 KB + the new positions (16 KB) = 144 KB.
+// LDS (p = 128, two tiles): 8 rings x 16 KB + beta operands 16 KB + momenta 16 KB = 160 KB.
 // NB = pieces of beta in the eta MFMAs: 2 (hi + lo: the default policy) or 1 (LR_PREC_BF16, the caller's explicit request: a third of the
 // MFMAs fewer -- the kernel is POWER-bound, 1300 W at 2.04 GHz, so the time follows the work: 24.2 -> 20.5 us per evaluation at config 5
 // whole -- for 0.019 of acceptance, 0.756 -> 0.737; still an exact sampler: a deterministic force, exact end points).
 // S = double (a FLOAT64 model): the owner thread's position and momentum are float64 and BOTH wait in global memory between the
 // reductions (a.q1, a.pm: 32 bytes each per thread and tile; the LDS has no room for float64 momenta); kick and drift in float64.
-template <int P, int FMT = 0, typename S = float>
+// NT2 = chain tiles per workgroup: 2, or 1 -- the same kernel below one tile per CU, where a second tile per workgroup would leave CUs idle
+// (config 5's design at 4096 chains: 15.3 -> 13.9 us per evaluation against round 3's one-tile kernel; small designs 1.2 - 1.5 x).
+template <int P, int FMT = 0, typename S = float, int NT2 = 2>
 __global__ void __launch_bounds__(512) k_wide_traj2_bf16(TallArgs<S, P> a) {
     using G = WideBf16Geom<P>;
     constexpr int NB = FMT == 0 ? 2 : 1;
     constexpr bool F16 = FMT == 2, F64 = sizeof(S) == 8;
     typedef double f64x2t __attribute__((ext_vector_type(2)));
     const uint16_t* const image = F16 ? a.xblk1h : a.xblk1;
-    constexpr int NW = 8, NT2 = 2, BLK_BYTES = G::BUF1 * 2, NBUF = P >= 128 ? 2 : 4, RING_BYTES = NBUF * BLK_BYTES;
+    static_assert(NT2 == 1 || NT2 == 2, "one or two chain tiles per workgroup");
+    constexpr int NW = 8, BLK_BYTES = G::BUF1 * 2, NBUF = P >= 128 ? 2 : 4, RING_BYTES = NBUF * BLK_BYTES;
     constexpr int NQ = P / 4;             // 16-byte chunks per chain
     static_assert(16 * P * 4 == BLK_BYTES, "a tile's gradients fill exactly one ring slot");
     static_assert(P == 128 || P == 64, "chunk ownership below");
@@ -1049,7 +908,7 @@ __global__ void __launch_bounds__(512) k_wide_traj2_bf16(TallArgs<S, P> a) {
         // One MFMA "slot" = the MFMA and the vector / LDS instructions that issue in its shadow; a scheduling barrier closes every slot, so
         // the emitted order is the source order (the group-barrier form left the sigmoid in one run in front of the MFMAs).
         constexpr int SPC = 2 * NB, NE = SPC * G::M32, NG = G::MBP;  // MFMA slots per 32-coordinate chunk; eta / gradient MFMAs per tile
-        auto eta_mfma = [&](const u32x4 (&xa)[2][G::M32], int i, f32x4 (&en)[NT2][2]) {  // slot i of the 2 NE: tile i / NE, then (m, h, T)
+        auto eta_mfma = [&](const u32x4 (&xa)[2][G::M32], int i, f32x4 (&en)[NT2][2]) {  // slot i of the NT2 NE: tile i / NE, then (m, h, T)
             // (the two row tiles T alternate, a tile's accumulator every second slot; one accumulator's MFMAs in consecutive slots, or the
             //  sigmoid behind every second slot only: 24.3 - 24.4 us against 24.4 -- the kernel is power-bound, not issue-order-bound)
             const int t = i / NE, r = i % NE, m = r / SPC, h = (r >> 1) % NB, T = r & 1;
@@ -1062,9 +921,10 @@ __global__ void __launch_bounds__(512) k_wide_traj2_bf16(TallArgs<S, P> a) {
             const u32x4 xg = {xt[mb][0][0], xt[mb][0][1], xt[mb][1][0], xt[mb][1][1]};
             gacc[t][mb] = mfma16<F16>(xg, wv, gacc[t][mb]);
         };
-        // the sigmoid of both tiles of the pending block as four stages over 16 values (v = 8 t + 4 T + r), two values per slot
-        float sx[16];
-        uint32_t spk[8];
+        // the sigmoid of the tiles of the pending block as four stages over NV = 8 NT2 values (v = 8 t + 4 T + r), spread over the eta slots
+        constexpr int NV = 8 * NT2;
+        float sx[NV];
+        uint32_t spk[NV / 2];
         auto sig_stage = [&](int stage, int v) {
             const int t = v >> 3, T = (v >> 2) & 1, r = v & 3;
             if (stage == 0) sx[v] = LR_TRAJ_EXP(0) ? e[t][T][r] : __builtin_amdgcn_exp2f(e[t][T][r]);
@@ -1095,8 +955,8 @@ __global__ void __launch_bounds__(512) k_wide_traj2_bf16(TallArgs<S, P> a) {
             };
             auto xa_ahead = [&](int i) {  // in the shadow of eta slot i: the chunk two ahead in the (tile, chunk) order
                 if (i % SPC != 0) return;
-                const int seq = i / SPC + 2;  // chunk sequence number over both tiles
-                if (seq < 2 * G::M32) read_xa(seq % G::M32);
+                const int seq = i / SPC + 2;  // chunk sequence number over the tiles
+                if (seq < NT2 * G::M32) read_xa(seq % G::M32);
             };
             read_xa(0);
             if (G::M32 > 1) read_xa(1);
@@ -1104,17 +964,17 @@ __global__ void __launch_bounds__(512) k_wide_traj2_bf16(TallArgs<S, P> a) {
             f32x4 en[NT2][2];
             if constexpr (FIRST) {
 #pragma unroll
-                for (int i = 0; i < 2 * NE; ++i) {
+                for (int i = 0; i < NT2 * NE; ++i) {
                     eta_mfma(xa, i, en);
                     xa_ahead(i);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 read_xt(base);
             } else {
-                constexpr int Q = 2 * NE / 4, VPS = 16 / Q;  // slots per sigmoid stage, values per slot (P = 128, two pieces: 8 and 2)
-                static_assert(2 * NE % 4 == 0 && Q * VPS == 16, "sixteen sigmoid values over a quarter of the eta slots per stage");
+                constexpr int Q = NT2 * NE / 4, VPS = NV / Q;  // slots per sigmoid stage, values per slot (P = 128, two tiles, two pieces: 8 and 2)
+                static_assert(NT2 * NE % 4 == 0 && Q * VPS == NV, "the sigmoid values over a quarter of the eta slots per stage");
 #pragma unroll
-                for (int i = 0; i < 2 * NE; ++i) {
+                for (int i = 0; i < NT2 * NE; ++i) {
                     eta_mfma(xa, i, en);
                     xa_ahead(i);
                     const int stage = i / Q, k = i % Q;        // values VPS k .. VPS k + VPS - 1 of this stage
@@ -1122,15 +982,17 @@ __global__ void __launch_bounds__(512) k_wide_traj2_bf16(TallArgs<S, P> a) {
                     for (int v = 0; v < VPS; ++v) sig_stage(stage, VPS * k + v);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                const u32x4 w0 = {spk[0], spk[1], spk[2], spk[3]}, w1 = {spk[4], spk[5], spk[6], spk[7]};
-                // both tiles' gradient MFMAs of an operand back to back, then block b's operand takes its place: the transposed reads are
-                // spread over the 2 NG slots, and all but the last have returned when the next trip asks (it waits for them before its DMA
+                const u32x4 w0 = {spk[0], spk[1], spk[2], spk[3]}, w1 = {spk[NV / 2 - 4], spk[NV / 2 - 3], spk[NV / 2 - 2], spk[NV / 2 - 1]};
+                // the tiles' gradient MFMAs of an operand back to back, then block b's operand takes its place: the transposed reads are
+                // spread over the NT2 NG slots, and all but the last have returned when the next trip asks (it waits for them before its DMA
                 // request may overwrite their slot)
 #pragma unroll
                 for (int mb = 0; mb < NG; ++mb) {
                     grad_mfma(0, mb, w0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    grad_mfma(1, mb, w1);
+                    if constexpr (NT2 == 2) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        grad_mfma(1, mb, w1);
+                    }
                     xt[mb][0] = lds_read_tr16(base + G::tile1(0, mb >> 1) + tr_off[mb & 1]);
                     xt[mb][1] = lds_read_tr16(base + G::tile1(1, mb >> 1) + tr_off[mb & 1]);
                     __builtin_amdgcn_sched_barrier(0);
@@ -1147,12 +1009,14 @@ __global__ void __launch_bounds__(512) k_wide_traj2_bf16(TallArgs<S, P> a) {
 #pragma unroll
             for (int stage = 0; stage < 4; ++stage)
 #pragma unroll
-                for (int v = 0; v < 16; ++v) sig_stage(stage, v);
-            const u32x4 w0 = {spk[0], spk[1], spk[2], spk[3]}, w1 = {spk[4], spk[5], spk[6], spk[7]};
+                for (int v = 0; v < NV; ++v) sig_stage(stage, v);
+            const u32x4 w0 = {spk[0], spk[1], spk[2], spk[3]}, w1 = {spk[NV / 2 - 4], spk[NV / 2 - 3], spk[NV / 2 - 2], spk[NV / 2 - 1]};
 #pragma unroll
             for (int mb = 0; mb < NG; ++mb) grad_mfma(0, mb, w0);
+            if constexpr (NT2 == 2) {
 #pragma unroll
-            for (int mb = 0; mb < NG; ++mb) grad_mfma(1, mb, w1);
+                for (int mb = 0; mb < NG; ++mb) grad_mfma(1, mb, w1);
+            }
         }
         // Every ring slot has been read.  The step is finished from the thread's share of the state, which waits in global memory between
         // the reductions (positions in a.q1; float64 models: momenta in a.pm as well) together with the step's constants (drift factors,

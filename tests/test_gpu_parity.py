@@ -1218,13 +1218,16 @@ def test_half_precision_interior_of_the_trajectory_kernels(la, monkeypatch):
     assert np.array_equal(o1, run(X, "", far)[0]) and np.array_equal(o1[:, 8:], half[:, 8:])
 
 
-@pytest.mark.parametrize("n,p", [(900, 128), (3000, 8), (1500, 20)])
+@pytest.mark.parametrize("n,p,opt", [(900, 128, ""), (900, 128, "wide_traj=0"), (2600, 128, "wide_traj=0"), (3000, 8, ""), (1500, 20, "")])
 @pytest.mark.parametrize("L", [1, 2, 3, 4])
-def test_short_trajectories_on_the_reduced_precision_interior_kernels(la, n, p, L):
+def test_short_trajectories_on_the_reduced_precision_interior_kernels(la, n, p, opt, L, monkeypatch):
     """L = 1 has no interior step, L = 2 one (no fused prologue), L = 3 one fused hand-over, L = 4 two (the state and
     partial buffers of the wide row-split kernel swap twice): every launch sequence of the stepwise HMC loop under the
-    default policy, against the oracle at the reduced-precision tolerance, and reproducible run to run."""
+    default policy, against the oracle at the reduced-precision tolerance, and reproducible run to run.  (Wide models this
+    small run the one-launch trajectory kernel by default; wide_traj=0 keeps the launch-per-step row-split kernel covered.)"""
     from oracle.oracle import OracleModel
+    if opt:
+        monkeypatch.setenv("LOGREG_DEBUG_OPTS", opt)
     X, y, _ = la.synthetic_logreg(n, p, seed=n + p, beta_sd=0.4 / np.sqrt(p))
     ps = np.full(p, 2.0)
     orc = OracleModel(X, y, ps)

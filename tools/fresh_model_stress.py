@@ -10,10 +10,11 @@ import numpy as np
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 # (name, LOGREG_DEBUG_OPTS, dtype, n, p, chains, L, expected plan mode)
 SCEN = [
-    ("wide row-split (k_wide_partial_bf16r), fused prologue", "", "float32", 2200, 128, 600, 6),
-    ("wide row-split, float64 state", "", "float64", 2200, 128, 600, 6),
+    ("wide row-split (k_wide_partial_bf16r), fused prologue", "wide_traj=0", "float32", 2200, 128, 600, 6),
+    ("wide row-split, float64 state", "wide_traj=0", "float64", 2200, 128, 600, 6),
     ("wide chain-split (k_wide_partial_bf16i)", "wide_traj=0", "float32", 700, 64, 4200, 5),
-    ("wide one-tile trajectory kernel", "wide_traj=1", "float32", 500, 64, 600, 9),
+    ("wide trajectory kernel, one tile per workgroup", "wide_traj=1", "float32", 500, 64, 600, 9),
+    ("wide trajectory kernel, one tile per workgroup, float64 state", "", "float64", 2200, 128, 600, 6),
     ("wide two-tile trajectory kernel, p = 128", "wide_traj=2", "float32", 900, 128, 600, 9),
     ("tall 16-wave interior kernel (k_tall_partial_mx16)", "", "float32", 30000, 8, 1024, 6),
     ("tall 4-wave interior kernel (k_tall_partial_mx)", "tall_mx16=0", "float32", 30000, 8, 1024, 6),
