@@ -309,7 +309,9 @@ int do_stepwise_t(lr_model* m, const Plan& pl, hipStream_t st, const RunSpec& rs
     const int64_t image_bytes = (int64_t)m->n * m->P * 2;
     const bool traj = P > 32 && bf16_interior && m->d_xblk1 != nullptr && t->launch_tall_traj != nullptr && rs.l > 1 &&
                       m->dbg.wide_traj != 0 &&
-                      (m->dbg.wide_traj >= 1 || traj_tiles >= m->cus || (traj_tiles >= m->cus / 2 && image_bytes <= 1024 * 1024) ||
+                      (m->dbg.wide_traj >= 1 || traj_tiles >= m->cus ||
+                       (traj_tiles >= m->cus / 2 && image_bytes <= (P == 128 ? 1024 : 768) * 1024) ||  // (p = 64, n = 8000 at 2048 chains: 12.6 | 11.5)
+                       (traj_tiles >= 3 * m->cus / 4 && image_bytes <= 1024 * 1024) ||
                        image_bytes <= 512 * 1024 || (P == 128 && image_bytes <= 768 * 1024));
     const bool fuse = bf16_interior && a.RS_i > 0 &&
                       ((P > 32 && a.RS_i <= 4) ||                                            // kFuseSlices (lr_wide_bf16.h)
