@@ -162,7 +162,7 @@ LR_API int lr_model_info(const lr_model* m, int64_t* n, int32_t* p, int32_t* dty
  * lr_model_create (an unknown key or value fails the creation); nothing else on the run path consults the environment:
  *   residency_cap=0   fused chain kernels launched without the LDS request that spreads a grid evenly over the CUs
  *   tall_mx16=0       tall models: 4-wave interior kernel with separate update launches instead of the fused 16-wave form
- *   wide_traj=0|1|2   wide models: forbid / force the one-launch trajectory kernel with 1 / 2 chain tiles per workgroup (default: by chain count)
+ *   wide_traj=0|1|2   wide models: forbid / force the one-launch trajectory kernel with 1 / 2 chain tiles per workgroup (default: by chain count and design size)
  *   wide_waves=4|8    wide models: waves (x 16 chains) per workgroup of the exact-split / chain-split kernels (default: by chain count)
  *   wide_f16=0|1|2    wide models, reduced-precision interior steps: 0 = bf16 rows x two bf16 pieces of beta even where the rows fit the
  *                     one-piece half-precision (f16) format (the default, 1), 2 = f16 also where LR_PREC_BF16 would take bf16 x one piece
