@@ -59,6 +59,7 @@ def test_model_closures_match_golden(models, pima, dtype):  # F1 through the C A
     beta = np.array(g["beta"])
     m = models[dtype]
     X, _ = pima
+    assert m.interior_format() == "bf16" and m.debug_opts() == ""  # (p = 8: the bf16 matrix-pipe interior kernels exist; p < 5: none)
     r = m.eval(beta)
     colsum = np.abs(X).sum(axis=0)
     for nm in ("ll", "lprior", "lpost"):
