@@ -234,7 +234,9 @@ def extra_configs(la, L, check, dev, stream):
                                      "log and the Philox/Box-Muller work, ~60 % of the instructions, are not)"}})
     # ---- configs 4 and 5: stepwise engines at full size, tuned step sizes from the committed fixtures
     # ("5_whole": config 5 AS A WHOLE -- all 8192 chains on this one GPU instead of one eighth of them: the matrix-pipe roofline point)
-    for cfg, C, label in ((4, 1024, 4), (5, 1024, 5), (5, 8192, "5_whole")):
+    # ("5_quarter" / "5_half": what one GPU does when config 5's 8192 chains are split over 4 / 2 GPUs -- with 5 and "5_whole" the four
+    #  shard sizes of a 1 / 2 / 4 / 8-GPU run of the configuration AS STATED, each measured on this one GPU)
+    for cfg, C, label in ((4, 1024, 4), (5, 1024, 5), (5, 2048, "5_quarter"), (5, 4096, "5_half"), (5, 8192, "5_whole")):
         fix = json.load(open(os.path.join(REPO, "tests", "golden", f"fullsize_cfg{cfg}.json")))
         n, p = fix["n"], fix["p"]
         X, y, _ = la.synthetic_logreg(n, p, seed=fix["data_seed"], beta_sd=fix["beta_sd"])
@@ -251,7 +253,8 @@ def extra_configs(la, L, check, dev, stream):
         ach = C * fg / per_eval_s / 1e12
         acc = float(cs.get_accepts().sum() / (C * (5 * iters + 1)))  # 1 warm-up iteration + (2 warm + 3 timed) launches
         row = {"config": label, "workload": f"HMC L={fix['l']} eps={fix['eps']} unit mass, synthetic n={n} p={p}, {C} chains"
-               + (" (one GPU's shard of 8192)" if label == 5 else " (BASELINE.json configs[4] as a whole on ONE GPU)" if label == "5_whole" else ""),
+               + ({5: " (one GPU's shard of 8192 over 8 GPUs)", "5_quarter": " (one GPU's shard of 8192 over 4 GPUs)", "5_half": " (one GPU's shard of 8192 over 2 GPUs)",
+                   "5_whole": " (BASELINE.json configs[4] as a whole on ONE GPU)"}.get(label, "")),
                "kernel_variant": cs.plan(),
                "interior_precision": INTERIOR_NOTE,
                "chain_iterations_per_s": C * iters / (ms * 1e-3), "grad_evals_per_s": C * evals / (ms * 1e-3),
@@ -278,6 +281,8 @@ def extra_configs(la, L, check, dev, stream):
                                "frac_of_fp32_peak": ach / PEAK_FP32_TFLOPS, "flops_per_grad_eval": fg,
                                "note": "algorithmic flops counted once (SURVEY 8(d)); at 1024 chains an evaluation is 2.15 GFLOP = "
                                        "0.9 us of the bf16 pipe: launch, prologue and epilogue dominate (DESIGN.md section 5)" if C == 1024 else
+                                       "algorithmic flops counted once (SURVEY 8(d)); the interior steps run as ONE launch per trajectory with one chain "
+                                       "tile per workgroup (k_wide_traj2_bf16<.., 1>): a step costs what streaming the 1 MB image through one CU costs" if C < 8192 else
                                        "algorithmic flops counted once (SURVEY 8(d)); 17.4 GFLOP per evaluation; the interior steps run as ONE "
                                        "launch per trajectory (k_wide_traj2_bf16: 32 chains per workgroup, one workgroup per CU); rows and beta in "
                                        "one f16 piece each: the MFMAs issued are the algorithmic ones; power-bound at 1300 W / 2.04 GHz (profiles/r5_cfg5_whole*.txt)"}
@@ -290,6 +295,16 @@ def extra_configs(la, L, check, dev, stream):
                                      "frac_bf16_peak": C * fg / (msb * 1e-3 / evals) / 1e12 / PEAK_BF16_TFLOPS,
                                      "note": "not the default: acceptance drops by ~0.02 (0.758 -> 0.738); still an exact sampler"}
         res.append(row)
+    # config 5 as stated (8192 chains) on 1 / 2 / 4 / 8 GPUs, PROJECTED from the four shard sizes measured above on this one GPU: chains are
+    # independent, so a run's time is its slowest GPU's -- the only cross-GPU step, the gather of the kept samples, is not in it
+    by = {r["config"]: r for r in res}
+    if all(k in by for k in (5, "5_quarter", "5_half", "5_whole")):
+        t1 = by["5_whole"]["us_per_evaluation_all_chains"]
+        res.append({"config": "5_strong_scaling_projection",
+                    "what": "config 5's 8192 chains over N GPUs: us per evaluation of a GPU's shard, measured on ONE GPU per shard size; NOT a multi-GPU measurement",
+                    "rows": [{"n_gpus": n, "chains_per_gpu": 8192 // n, "us_per_evaluation": by[k]["us_per_evaluation_all_chains"],
+                              "speedup_over_one_gpu": t1 / by[k]["us_per_evaluation_all_chains"]}
+                             for n, k in ((1, "5_whole"), (2, "5_half"), (4, "5_quarter"), (8, 5))]})
     return res
 
 
