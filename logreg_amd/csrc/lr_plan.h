@@ -550,6 +550,9 @@ InteriorPlan plan_interior(const lr_model* m, int64_t Cp) {
         // 16-wave workgroups (one per CU) need a quarter of the slices for the same waves per SIMD: few enough to fold
         // the update launch into the next launch's prologue (k_tall_partial_mx16).  Only with enough rows per slice to
         // keep the 4 row groups of a workgroup busy, and when the slice count fits the fused prologue.
+        // (round 5: TWO such workgroups per CU -- 32 slices, 8 waves per SIMD, the fused prologue summing 32 partials -- measured slower:
+        //  config 4's design 24.7 -> 27.4 us per evaluation at 1024 chains, 44.5 -> 47.4 at 2048; the vector ALU is 71 % busy at 4 waves per SIMD
+        //  already and the extra slices cost more than the occupancy buys)
         int64_t want16 = (m->cus + blocks - 1) / blocks;
         if (want16 < 1) want16 = 1;
         int64_t len16 = ((m->n + want16 - 1) / want16 + 31) / 32 * 32;
