@@ -55,3 +55,37 @@ def test_float64_default_policy_is_within_ten_percent_of_the_best_alternative(C,
     print(f"float64 C={C}: AUTO {pb.fmt(auto[1])} {auto[2]:.3e}, best {pb.fmt(best[1])} {best[2]:.3e}; " + " | ".join(f"{pb.fmt(pl)} {r:.2e}" for _, pl, r in res[1:]))
     assert auto[1]["mode"] == expect and len(res) >= 4
     assert auto[2] >= 0.9 * best[2], (pb.fmt(auto[1]), pb.fmt(best[1]))
+
+
+@pytest.mark.parametrize("n,p,C", [(2000, 128, 1024), (3000, 128, 512), (4096, 128, 2048), (4096, 128, 3072), (3000, 64, 2048), (8000, 64, 512)])
+def test_wide_interior_engine_is_within_ten_percent_of_the_best_alternative(n, p, C, monkeypatch):
+    """Wide models below one chain tile per CU: the engine's choice between the one-launch trajectory kernel (one chain tile per
+    workgroup) and the launch-per-step interior kernels (lr_engine.h: by chain count and image size, from tools/traj_rule_check.py's
+    measurements) against both forced alternatives -- us per evaluation of HMC L = 50 under the default policy, best of 3."""
+    import ctypes as Ct
+    import numpy as np
+    sys.path.insert(0, REPO)
+    import bench
+    import logreg_amd as la
+    from logreg_amd import _lib
+    L = _lib.load()
+    stream = Ct.c_void_p()
+    _lib.check(L.lr_stream_create(0, Ct.byref(stream)))
+    timer = bench.Timer(L, _lib.check, 0, stream)
+    X, y, _ = la.synthetic_logreg(n, p, seed=1, beta_sd=0.3 / np.sqrt(p))
+    q0 = (0.3 / np.sqrt(n)) * np.random.default_rng(3).standard_normal((C, p))
+
+    def timed(opt):
+        if opt:
+            monkeypatch.setenv("LOGREG_DEBUG_OPTS", opt)
+        else:
+            monkeypatch.delenv("LOGREG_DEBUG_OPTS", raising=False)
+        m = la.LogReg(X, y, np.full(p, 2.0))
+        k = la.hmcKernel(m.lpost, m.glp, eps=0.4 / np.sqrt(n), l=50, dmm=np.ones(p))
+        cs = la.ChainSet(k, q0, seed=5, stream=stream)
+        return bench._timed_chainset(la, timer, cs, 8, 1, warm=1) * 1e3 / (8 * 50)
+    t = {opt: timed(opt) for opt in ("", "wide_traj=1", "wide_traj=0")}
+    if t[""] > 1.1 * min(t.values()):  # a timing test: measure once more
+        t = {opt: timed(opt) for opt in ("", "wide_traj=1", "wide_traj=0")}
+    print(f"n={n} p={p} C={C}: default {t['']:.2f} us, trajectory {t['wide_traj=1']:.2f}, launch per step {t['wide_traj=0']:.2f}")
+    assert t[""] <= 1.1 * min(t.values()), t
