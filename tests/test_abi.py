@@ -82,3 +82,77 @@ def test_no_kernel_of_the_library_uses_scratch_memory():
     bad = [(r["unit"], r["name"], r["scratch"]) for r in rows if r["scratch"]]
     assert not bad, bad
     b.resource_gate(strict=True, verbose=False)
+
+
+def test_no_join_block_runs_instructions_ahead_of_its_exec_restore():
+    """The second build gate (logreg_amd/build.py exec_prologue_gate, logreg_amd/isa_gate.py) on the objects both libraries are linked
+    from: no block entered with EXEC = 0 (target of s_cbranch_execz / fall-through of s_cbranch_execnz) has an EXEC-dependent
+    instruction ahead of its `s_or_b64 exec, exec, ...`.  That placement -- a register-allocator copy in front of the restore -- is what
+    made round 4's float64 p = 32 MALA kernel wrong in every chain under -amdgpu-sched-strategy=max-ilp (profiles/r6_f64_p32_bisect.txt)."""
+    from logreg_amd import build as b, isa_gate
+    for alt in (False, True):
+        b.build(verbose=False, alt=alt)
+        objs = b.unit_objects(alt)
+        assert len(objs) == 13 and all(os.path.exists(o) for o in objs)
+        assert isa_gate.scan_paths(objs) == []
+        b.exec_prologue_gate(strict=True, verbose=False, alt=alt)
+
+
+def test_the_exec_restore_scan_recognises_the_round_4_pattern():
+    """isa_gate.scan_kernel on hand-written instruction lists: the miscompiled shape (copies between the SGPR spills at the head of a
+    join and its restore), the same block compiled correctly, the body of an `if` entered by s_cbranch_execnz (runs under the narrowed
+    mask by design), an `if` without a skip branch, and a loop exit."""
+    from logreg_amd.isa_gate import scan_kernel
+
+    def prog(*rows):
+        out, addr = [], 0x100
+        labels = {r[1:]: None for r in rows if r.startswith(":")}
+        for r in rows:  # first pass: addresses of the labels
+            if r.startswith(":"):
+                labels[r[1:]] = addr
+            else:
+                addr += 4
+        addr = 0x100
+        for r in rows:
+            if r.startswith(":"):
+                continue
+            text, tgt = r, None
+            if "->" in r:
+                text, lab = [x.strip() for x in r.split("->")]
+                tgt = labels[lab]
+            out.append((addr, text, tgt))
+            addr += 4
+        return out
+
+    bad = prog("v_cmp_gt_i64_e32 vcc, s[36:37], v[2:3]", "s_and_saveexec_b64 s[4:5], vcc", "s_cbranch_execz 12 -> join",
+               "v_fmac_f64_e32 v[30:31], v[132:133], v[136:137]",
+               ":join", "v_writelane_b32 v255, s92, 17", "v_accvgpr_write_b32 a8, v120", "v_mov_b64_e32 v[70:71], v[30:31]",
+               "v_writelane_b32 v255, s31, 21", "s_or_b64 exec, exec, s[4:5]", "v_add_f64 v[14:15], v[88:89], v[68:69]", "s_endpgm")
+    found = scan_kernel(bad)
+    assert len(found) == 1 and [t for _, t in found[0][2]] == ["v_accvgpr_write_b32 a8, v120", "v_mov_b64_e32 v[70:71], v[30:31]"]
+    good = prog("s_and_saveexec_b64 s[4:5], vcc", "s_cbranch_execz 12 -> join", "v_fmac_f64_e32 v[30:31], v[132:133], v[136:137]",
+                ":join", "v_writelane_b32 v255, s92, 17", "s_or_b64 exec, exec, s[4:5]", "v_mov_b64_e32 v[70:71], v[30:31]", "s_endpgm")
+    assert scan_kernel(good) == []
+    body = prog("s_and_saveexec_b64 s[48:49], s[10:11]", "s_cbranch_execnz 45 -> body", ":back", "s_or_b64 exec, exec, s[48:49]", "s_endpgm",
+                ":body", "v_mov_b32_e32 v225, v1", "global_store_dword v[4:5], v143, off", "s_branch 3 -> back")
+    assert scan_kernel(body) == []
+    no_skip = prog("s_and_saveexec_b64 s[2:3], vcc", "global_store_dword v[4:5], v143, off", "s_or_b64 exec, exec, s[2:3]", "s_endpgm")
+    assert scan_kernel(no_skip) == []
+    loop_exit = prog(":loop", "v_fmac_f64_e32 v[0:1], v[2:3], v[4:5]", "s_andn2_b64 exec, exec, s[54:55]", "s_cbranch_execnz 9 -> loop",
+                     "v_writelane_b32 v254, s10, 57", "v_mov_b64_e32 v[178:179], v[168:169]", "s_or_b64 exec, exec, s[54:55]", "s_endpgm")
+    found = scan_kernel(loop_exit)
+    assert len(found) == 1 and found[0][2][0][1] == "v_mov_b64_e32 v[178:179], v[168:169]"
+
+
+def test_second_build_exports_the_same_abi():
+    """logreg_amd/lib_alt/liblogreg_hip.so -- the same sources under the compiler's default scheduler, SLP on (tests/altlib.py,
+    tests/test_gpu_builds.py) -- exports every symbol of the header and carries its own build id."""
+    import ctypes as C
+    from logreg_amd import _lib, build
+    build.build(verbose=False, alt=True)
+    L = C.CDLL(build.ALT_LIB)
+    for name in _lib.SYMBOLS:
+        assert hasattr(L, name), name
+    L.lr_build_id.restype = C.c_char_p
+    assert L.lr_build_id().decode() == build.source_hash(alt=True) != build.source_hash()
+    assert set(build.TUNING) & set(build.COMMON) and not set(build.TUNING) & set(build.ALT_COMMON)

@@ -1,45 +1,15 @@
 #!/usr/bin/env python3
-"""First run on a FRESH model against every later one, for each kernel family with hand-managed synchronisation (LDS-DMA rings, counted
-waits, fused prologues): the probe that exposed the two-tile trajectory kernel's undone wait (tools/traj_stress.py), pointed at the rest.
-Per scenario: `reps` fresh models, a seeded HMC run and its chunked repeat on each; counts runs that differ from the very first.
+"""Fresh-model stress campaign (the scenarios and the probe live in tests/stress_fresh_models.py; the suite runs a slice of it):
     python3 tools/fresh_model_stress.py [reps]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+import logreg_amd as la
+from stress_fresh_models import SCEN, run_scenario
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-# (name, LOGREG_DEBUG_OPTS, dtype, n, p, chains, L, expected plan mode)
-SCEN = [
-    ("wide row-split (k_wide_partial_bf16r), fused prologue", "wide_traj=0", "float32", 2200, 128, 600, 6),
-    ("wide row-split, float64 state", "wide_traj=0", "float64", 2200, 128, 600, 6),
-    ("wide chain-split (k_wide_partial_bf16i)", "wide_traj=0", "float32", 700, 64, 4200, 5),
-    ("wide trajectory kernel, one tile per workgroup", "wide_traj=1", "float32", 500, 64, 600, 9),
-    ("wide trajectory kernel, one tile per workgroup, float64 state", "", "float64", 2200, 128, 600, 6),
-    ("wide two-tile trajectory kernel, p = 128", "wide_traj=2", "float32", 900, 128, 600, 9),
-    ("tall 16-wave interior kernel (k_tall_partial_mx16)", "", "float32", 30000, 8, 1024, 6),
-    ("tall 4-wave interior kernel (k_tall_partial_mx)", "tall_mx16=0", "float32", 30000, 8, 1024, 6),
-    ("tall, float64 state", "", "float64", 30000, 8, 1024, 6),
-    ("fused matrix-core chain kernel (k_chain_mfma), 4096 chains", "", "float32", 200, 8, 4096, 10),
-    ("fused matrix-core chain kernel, rows in LDS", "", "float32", 1500, 8, 4096, 6),
-    ("fused register kernel, exact (k_chain rs16)", "", "float32", 200, 8, 4096, 10),
-]
-for name, opt, dtype, n, p, C, L in SCEN:
-    if opt:
-        os.environ["LOGREG_DEBUG_OPTS"] = opt
-    else:
-        os.environ.pop("LOGREG_DEBUG_OPTS", None)
-    import logreg_amd as la
-    X, y, _ = la.synthetic_logreg(n, p, seed=77 + p + n, beta_sd=0.3 / np.sqrt(p))
-    b = (0.3 / np.sqrt(n)) * np.random.default_rng(n).standard_normal((C, p))
-    prec = "full" if "exact" in name else "auto"
-    kw = dict(thin=1, iters=2, verb=False, seed=3, precision=prec, return_info=True)
-    first, bad, plan = None, 0, None
-    for rep in range(reps):
-        m = la.LogReg(X, y, np.full(p, 2.0), dtype=dtype)
-        k = la.hmcKernel(m.lpost, m.glp, eps=0.5 / np.sqrt(n), l=L, dmm=np.ones(p))
-        for chunk in (None, 1):
-            out, info = la.mcmc(b, k, chunk=chunk, **kw)
-            plan = info["plan"]
-            first = out if first is None else first
-            bad += not np.array_equal(out, first)
-    print(f"{name}: {bad} of {2 * reps} runs differ from the first  [{dtype}, n={n}, p={p}, {C} chains, L={L}, {prec}, plan {plan}, opts '{opt}']", flush=True)
+for scen in SCEN:
+    bad, runs, plan = run_scenario(la, scen, reps)
+    name, opt, dtype, n, p, C, L = scen
+    print(f"{name}: {bad} of {runs} runs differ from the first  [{dtype}, n={n}, p={p}, {C} chains, L={L}, plan {plan}, opts '{opt}']", flush=True)
