@@ -707,6 +707,11 @@ __device__ __forceinline__ void group16_allgather_pairs(const f32x2& mine, f32x2
                    __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, my, 0x15C, 0xF, 0xF, true))};
 }
 
+// min(a, b) that keeps a NaN: v_minimum3_f32 (gfx950).  The clamps in front of an exponential use it -- fminf returns its OTHER operand
+// for a NaN, which turned the logit of a beta with a NaN (or an infinity against a zero x entry) into 100 and the row's value term into
+// 0, the best possible, where the reference (fit-np-hmc.py:23-24) gives NaN.  One instruction, as v_min_f32.
+__device__ __forceinline__ float min_keep_nan(float a, float b) { return __builtin_elementwise_minimum(a, b); }
+
 // exp(t) given ts = t * kScale<T> (float: the log2(e) factor is folded into beta once per
 // evaluation instead of once per row; double: kScale = 1)
 template <typename T> struct ExpScale;
@@ -748,7 +753,9 @@ __device__ __forceinline__ void row_term(const T (&xs)[P], const T (&bs)[P], T (
         // The gradient-only form uses the SAME weights (3 instructions more than rcp(1 + exp(t)) there): a chunked MALA run starts
         // each launch with a gradient-only evaluation of a state whose gradient the previous launch took from a value + gradient one.
         if constexpr (FASTW && GRAD && !VALUE) {
-            // (clamped: exp stays finite -- 1 + e <= 1e304, no guard in the reciprocal -- and the reduction stays a reduction)
+            // (clamped: exp stays finite -- 1 + e <= 1e304, no guard in the reciprocal -- and the reduction stays a reduction; fmax / fmin
+            // swallow a NaN: the weight of a non-finite t is sigma(750) here, and the end point of the trajectory, evaluated on the
+            // exact path below, is what rejects such a state)
             const T s1 = T(1) + exp_noguard(__builtin_fmin(__builtin_fmax(ts, T(-750)), T(700)));
             T r = __builtin_amdgcn_rcp(s1);
             T err = __builtin_fma(-s1, r, T(1));
@@ -759,7 +766,12 @@ __device__ __forceinline__ void row_term(const T (&xs)[P], const T (&bs)[P], T (
             for (int j = 0; j < P; ++j) g[j] = fma_t(r, xs[j], g[j]);
             return;
         }
-        const T e = exp_noguard(__builtin_fmax(-__builtin_fabs(ts), T(-750)));
+        // (the clamp is a select, not fmax: fmax returns its other operand for a NaN, which made e = 0, w = 1 and the value term 0 -- the
+        // BEST possible log-likelihood and a finite gradient at a beta with a NaN, or an infinity against a zero x entry, where the
+        // reference and the float32 path give NaN.  Two instructions per row on the value + gradient path only: HMC's interior force
+        // above keeps fmax / fmin -- a non-finite state is judged at the trajectory's end point, on this path)
+        const T na = -__builtin_fabs(ts);
+        const T e = exp_noguard(na < T(-750) ? T(-750) : na);
         if constexpr (GRAD) {
             const T s1 = T(1) + e;
             T r = __builtin_amdgcn_rcp(s1);
@@ -892,7 +904,7 @@ __device__ __forceinline__ void pair_term(const f32x2 (&q)[P], const f32x2 (&bb)
     }
     // (the per-row form clamps ts so that 2^ts stays finite; the product form needs no clamp: an overflowing factor makes the lane's
     //  product infinite, which the caller detects and answers with the per-row form -- one v_min per row saved on the fast path)
-    if constexpr (VALUE && !PROD) ts = f2{__builtin_fminf(ts.x, 100.0f), __builtin_fminf(ts.y, 100.0f)};
+    if constexpr (VALUE && !PROD) ts = f2{min_keep_nan(ts.x, 100.0f), min_keep_nan(ts.y, 100.0f)};
     const f2 d = f2{ExpScale<float>::exp_scaled(ts.x), ExpScale<float>::exp_scaled(ts.y)} + f2{1.0f, 1.0f};
     if constexpr (GRAD) {
         const f2 w = {fast_rcp(d.x), fast_rcp(d.y)};  // sigma(-t); exp overflow -> rcp(inf) = 0
@@ -937,7 +949,7 @@ __device__ __forceinline__ void row_pairs_eval(const RegRowPairs<P, R, G>& rows,
 #pragma unroll
         for (int j = 1; j < P / 2; ++j) acc = __builtin_elementwise_fma(rows.s[j], bb[j], acc);
         float ts = acc.x + acc.y;
-        if constexpr (VALUE && !PROD) ts = __builtin_fminf(ts, 100.0f);
+        if constexpr (VALUE && !PROD) ts = min_keep_nan(ts, 100.0f);
         const float d = 1.0f + ExpScale<float>::exp_scaled(ts);
         if constexpr (GRAD) {
             const float w = fast_rcp(d);
@@ -962,7 +974,7 @@ __device__ __forceinline__ void row_pairs_eval(const RegRowPairs<P, R, G>& rows,
             for (int k = 0; k < RegRowPairs<P, R, G>::RP; ++k) pair_term<P, true, false, false>(rows.q[k], bb, g0, h0, va);
             float vo = 0.0f;
             if constexpr (RegRowPairs<P, R, G>::ODD) {
-                const float tc = __builtin_fminf(ts_odd, 100.0f);
+                const float tc = min_keep_nan(ts_odd, 100.0f);
                 vo = tc - __builtin_amdgcn_logf(1.0f + ExpScale<float>::exp_scaled(tc));
             }
             const float safe = (va.x + va.y) + vo;

@@ -114,7 +114,7 @@ __device__ __forceinline__ void mf_eval_stream(const float* __restrict__ rows, c
                 float w[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float tr = VALUE ? __builtin_fminf(e[r], 100.0f) : e[r];  // (see MfmaRows::eval)
+                    const float tr = VALUE ? min_keep_nan(e[r], 100.0f) : e[r];  // (see MfmaRows::eval)
                     const float d = 1.0f + __builtin_amdgcn_exp2f(tr);
                     w[r] = fast_rcp(d);
                     if constexpr (VALUE) v += tr - __builtin_amdgcn_logf(d);
@@ -333,7 +333,7 @@ template <int P, int NTW, int S, bool END_MEM = false> struct MfmaRows {
                 // value: log2 sigma = t - log2(1 + 2^t) from the same 2^t the gradient needs (pair_term's form, lr_device.h:
                 // t clamped at 100 so that 2^t stays finite -- sigma(-t) < 2^-100 there; the cancellation at large t costs
                 // an absolute ulp(t) ~ 1e-6 per row); one v_log per value instead of exp2 + log + 7 VALU
-                const float tr = VALUE ? __builtin_fminf(e[r], 100.0f) : e[r];
+                const float tr = VALUE ? min_keep_nan(e[r], 100.0f) : e[r];
                 const float d = 1.0f + __builtin_amdgcn_exp2f(tr);
                 w[r] = fast_rcp(d);
                 if constexpr (VALUE) v += tr - __builtin_amdgcn_logf(d);

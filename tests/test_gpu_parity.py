@@ -1521,3 +1521,50 @@ def test_float64_wide_models_run_on_the_f64_matrix_pipe(la, p, n, C):
             assert np.array_equal(mixed, la.mcmc(b, k, thin=1, iters=2, verb=False, seed=6, chunk=1))
             sub = la.mcmc(b[lo:hi], k, thin=1, iters=2, verb=False, seed=6, chain_offset=lo, mode="stepwise", group=info["plan"]["group"])
             assert np.array_equal(sub, mixed[:, lo:hi])
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+@pytest.mark.parametrize("n,p", [(200, 8), (300, 24), (30000, 8), (500, 64), (600, 128), (37, 3), (1500, 16)])
+def test_a_non_finite_beta_gives_nan_as_the_reference_does(la, dtype, n, p):
+    """`ll`, `lpost` and `glp` of a beta holding a NaN -- or an infinity against a zero entry of x (inf * 0 in
+    `X.dot(b)`, fit-np-hmc.py:23-24, 44-47) -- are NaN in the reference.  The float64 row term clamped its exponential's argument with
+    fmax, the float32 value path with fminf: both return the OTHER operand for a NaN, so such a beta scored log-likelihood 0 -- the
+    maximum -- with a finite gradient.  Every engine the planner can be forced onto, both dtypes; the finite chains beside them unharmed."""
+    X, y, _ = la.synthetic_logreg(n, p, seed=4242 + p, beta_sd=0.2)
+    zc = min(2, p - 1)
+    X[: max(3, n // 10), zc] = 0.0  # exact zeros: an infinite coefficient there makes inf * 0
+    m = la.LogReg(X, y, np.full(p, 2.0), dtype=dtype)
+    b = 0.05 * np.random.default_rng(p).standard_normal((6, p))
+    b[1, min(1, p - 1)] = np.nan
+    b[2, zc] = np.inf
+    b[3, zc] = -np.inf
+    b[5, p - 1] = np.nan
+    bad, good = [1, 2, 3, 5], [0, 4]
+    Xs = (2.0 * y - 1.0)[:, None] * X
+    with np.errstate(all="ignore"):
+        t = Xs @ b[good].T
+        ll_ref = -np.log1p(np.exp(-t)).sum(0)
+    modes = [("auto", 0)]
+    if p <= 32:
+        for md in ("reg", "lds", "global", "mfma"):
+            for g in (1, 4, 8, 16, 64):
+                try:
+                    m.plan(6, g, md)
+                    modes.append((md, g))
+                except la.LogregHipError:
+                    pass
+    for md, g in modes:
+        r = m.eval(b, mode=md, group=g)
+        for name in ("ll", "lpost"):
+            assert np.isnan(r[name][bad]).all(), (md, g, name, r[name])
+            assert np.isfinite(r[name][good]).all(), (md, g, name, r[name])
+        assert np.isnan(r["glp"][bad]).all(), (md, g, r["glp"][bad])
+        assert np.isfinite(r["glp"][good]).all(), (md, g)
+        np.testing.assert_allclose(r["ll"][good], ll_ref, rtol=2e-5 if dtype == "float32" else 1e-11)
+    # the fused samplers reject such a state and leave the finite chains' results untouched
+    for kern in (la.hmcKernel(m.lpost, m.glp, eps=0.01, l=3, dmm=np.ones(p)), la.malaKernel(m.lpost, m.glp, dt=1e-4, pre=np.ones(p))):
+        out, info = la.mcmc(b, kern, thin=1, iters=2, verb=False, seed=5, return_info=True, precision="full")
+        ref = la.mcmc(b[good], kern, thin=1, iters=2, verb=False, seed=5, precision="full", mode=info["plan"]["mode"], group=info["plan"]["group"]) \
+            if info["plan"]["mode"] != "stepwise" else None
+        assert np.isfinite(out[:, good]).all()
+        assert (info["accepts"][[1, 5]] == 0).all(), info["accepts"]  # a NaN coordinate never becomes an accepted finite state
