@@ -456,8 +456,9 @@ class Exchange:
                 # one rank per GPU or nothing: device_count() does not initialise the GPU, every rank sees the same count and
                 # leaves before the rendezvous, so a node with fewer GPUs than ranks ends the job at once with a non-zero code
                 have = torch.cuda.device_count()
-                if have < world:
-                    print(f"bench.py: {world} ranks but only {have} GPU(s) visible on this node -- refusing to share GPUs "
+                local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))  # (a multi-node launch: ranks of THIS node only)
+                if have < local_world or local_rank >= have:
+                    print(f"bench.py: {local_world} ranks on this node but only {have} GPU(s) visible -- refusing to share GPUs "
                           f"between ranks (rank {rank})", file=sys.stderr, flush=True)
                     sys.exit(3)
                 torch.cuda.set_device(local_rank)
@@ -559,7 +560,8 @@ def self_check(ex, ident, kernel_ms, gathered, check_rank, rerun):
     """What makes an N > 1 line verifiable from the line alone (every rank calls this; rank 0 gets the dict):
       ranks_seen        all-reduce of ones: the ranks the collective library actually connected
       devices           every rank's GPU identity (lr_device_info: PCI bus id, uuid), `devices_distinct`
-      kernel_ms_min/max this rank's average launch duration (HIP events on its launch stream), min / max over the ranks
+      kernel_ms_min/max this rank's average launch duration (HIP events on its launch stream), min / max over the ranks;
+                        kernel_ms_per_rank: all of them (main() turns them into per-rank chain-iterations/s and HBM fractions)
       gather_bitexact   rank 0 re-runs, on its own GPU and outside the timed region, the first CHECK_CHAINS chains of
                         rank `check_rank`'s block -- same start, same global chain ids (chain_offset), planned for the
                         block's chain count (plan_chains), the same launches -- and compares the kept samples with what
@@ -568,10 +570,11 @@ def self_check(ex, ident, kernel_ms, gathered, check_rank, rerun):
     seen = ex.reduce(1, "sum")
     devices = ex.all_gather_str(ident)
     kmin, kmax = ex.reduce(kernel_ms, "min"), ex.reduce(kernel_ms, "max")
+    per_rank_ns = ex.all_gather_i64(round(kernel_ms * 1e6))  # every rank's own average launch duration (HIP events), in ns
     if ex.rank != 0:
         return None
     res = {"ranks_seen": seen, "devices": devices, "devices_distinct": len(set(devices)) == len(devices),
-           "kernel_ms_min": kmin, "kernel_ms_max": kmax}
+           "kernel_ms_min": kmin, "kernel_ms_max": kmax, "kernel_ms_per_rank": [v / 1e6 for v in per_rank_ns]}
     if gathered is not None and rerun is not None:
         got = gathered[check_rank].cpu().numpy()
         ref = rerun(check_rank)
@@ -924,6 +927,19 @@ def main(argv=None):
             line["development_build_flags"] = dev_flags
         if check_block is not None:
             line["multi_gpu"] = check_block
+            # north_star: "chains/sec and achieved-HBM-fraction reported at 1/2/4/8 GPUs" -- per rank, from the rank's own HIP-event time
+            per = []
+            for r, kms in enumerate(check_block.get("kernel_ms_per_rank", [])):
+                ks = max(kms, 1e-9) / 1e3
+                per.append({"rank": r, "kernel_ms": kms, "chain_iterations_per_s": C * THIN / ks, "grad_evals_per_s": C * THIN * LEAP / ks,
+                            "valu_frac": C * THIN * LEAP * fg / ks / 1e12 / PEAK_FP32_TFLOPS,
+                            "hbm_GBps_algorithmic": alg_bytes / ks / 1e9, "hbm_frac": alg_bytes / ks / (HBM_PEAK_GBS * 1e9)})
+            line["per_rank"] = per
+        # the weak-scaling row of the headline (fixed chains per GPU): what a 1 / 2 / 4 / 8 GPU series of these lines is a curve of
+        line["weak_scaling"] = {"chains_per_gpu": C, "n_gpus": world, "chains_total": world * C, "chain_iterations_per_s": value,
+                                "per_gpu": value / world, "kernel_only_per_gpu": C * THIN / kern_s, "gather_share": gather_s / wall if wall > 0 else 0.0,
+                                "note": "efficiency is the driver's to compute from its own N = 1, 2, 4, 8 runs; no 1 -> 8 GPU curve has been "
+                                        "measured on hardware by this repo"}
         # HBM traffic of the same launch from the committed rocprofv3 PMC passes (profiles/), if they
         # were taken for this kernel variant and shape
         for name in ("r5_traffic.json", "r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
@@ -954,17 +970,37 @@ def main(argv=None):
             # N > 1 (or the forced one-rank process group): BASELINE configs 3 and 5 as stated, across the ranks
             line["extra"] = {"configs": dist_rows}
         elif world == 1 and not a.no_extra:
+            f64 = f64_run(la, L, _lib.check, dev, stream, X, y, pscale, q0, a.steps)
+            # TOP LEVEL: the same workload in the reference's own arithmetic (Python/fit-np-hmc.py:17-19 computes in float64; `value`
+            # above is the float32 instantiation the contract prescribes) -- HIP-event timed, same chains, same launches
+            line["reference_arithmetic"] = {
+                "dtype": "f64", "value": f64["chain_iterations_per_s"], "unit": "chain-iterations/s", "ms_per_step": f64["ms_per_step"],
+                "frac": f64["frac_of_fp64_vector_peak"], "peak": PEAK_FP64_TFLOPS, "peak_unit": "TFLOP/s (fp64 vector)",
+                "kernel_variant": f64["kernel_variant"], "accept_rate": f64["accept_rate"],
+                "policy_auto_value": f64["default_policy"]["chain_iterations_per_s"], "policy_auto_kernel_variant": f64["default_policy"]["kernel_variant"],
+                "ratio_to_value": f64["chain_iterations_per_s"] / value,
+                "note": "precision='full': every log-posterior / gradient evaluation float64 (k_chain_f64x, lr_f64x.h); policy_auto_value: the "
+                        "float64 model's default policy (float64 state, end points and Metropolis test; float32 force inside the trajectory)"}
             line["extra"] = {"configs": extra_configs(la, L, _lib.check, dev, stream),
                              "default_policy": default_policy_runs(la, L, _lib.check, dev, stream, kern, init, a.steps),
-                             "f64": f64_run(la, L, _lib.check, dev, stream, X, y, pscale, q0, a.steps),
+                             "f64": f64,
                              "f64_wide": f64_wide_run(la, L, _lib.check, dev, stream)}
     # the process group is closed first: at N > 1 the other ranks leave, and rank 0 times the CPU oracle on an otherwise idle
-    # host (they would spin in a barrier otherwise) before it prints the ONE line
-    ex.close()
+    # host (they would spin in a barrier otherwise) before it prints the ONE line.  Whatever happens in the teardown or in the CPU
+    # legs, the measured line is printed: the failure is recorded in it.
+    try:
+        ex.close()
+    except Exception as e:  # noqa: BLE001 -- a hung / failed RCCL teardown must not lose the measurement
+        if rank == 0:
+            line["teardown_error"] = repr(e)[:300]
     if rank == 0:
-        if not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(X, y, pscale, init)
-        print(json.dumps(line), flush=True)
+        try:
+            if not a.no_cpu_baseline:
+                line["cpu_baseline"] = cpu_baseline(X, y, pscale, init)
+        except Exception as e:  # noqa: BLE001
+            line["cpu_baseline"] = {"error": repr(e)[:300]}
+        finally:
+            print(json.dumps(line), flush=True)
     return 0
 
 

@@ -1,6 +1,10 @@
 // lr_f64x.h -- HMC on a FLOAT64 model, padded p = 8, EVERY evaluation float64 (Python/fit-np-hmc.py:17-19, 44-47, 65-87 in the
-// reference's own arithmetic), 16 lanes per chain with the rows in LDS: the lane-group kernel k_chain<double, 8, 16, lds> with the chain
-// state DISTRIBUTED over the group and the group laid ACROSS the four DPP rows of the wave (round 6).
+// reference's own arithmetic): the lane-group kernel k_chain<double, 8, G, ..> with the chain state DISTRIBUTED over the group and the
+// group laid ACROSS the four DPP rows of the wave (round 6).  Measured (HMC L = 50, n = 200, chain-iterations/s,
+// replicated | this, tools/f64_full_check.py): 1024 chains (64 lanes, rows in registers) 2.40 -> 3.6e7; 2048 (32 lanes, registers) 4.03 ->
+// 5.0e7; 4096 (16 lanes, LDS) 4.67 -> 5.07e7 = 0.24 of the float64 vector peak; 8192 / 16 384 (8 lanes, LDS) 5.69 -> 5.9 / 6.2e7 = 0.28 / 0.29.
+// (32 lanes x 7 register rows would run two waves per SIMD at 4096 chains if the kernel fitted 256 registers: it needs 280 -- the
+// float64 Box-Muller beside 112 registers of rows -- and capped there it spills 17 to scratch, which the build refuses.)
 //
 // What was wrong with the replicated form (ISA of k_chain<double, 8, 16, 1, 0, HMC>, 952 instructions per evaluation and wave): v_add_f64
 // has no DPP form, so the butterfly all-reduce of the 8 gradient sums over a 16-lane DPP row is 8 x 4 x (2 v_mov_b32_dpp + 1 add) = 96
@@ -10,7 +14,8 @@
 // it (profiles/r6_mfma_f64_rate.txt) -- a matrix-pipe formulation of this kernel measured 4.4e7 it/s against this one's lane-group
 // predecessor at 4.7e7.
 //
-// Layout: lane l of a wave = (row r = l >> 4, chain c = (l >> 2) & 3, k = l & 3): a wave carries 4 chains, a chain's 16 lanes are
+// Layout (16 lanes per chain; the kernel is a template over G = 8 / 16 / 32 / 64 lanes per chain, LPR = G / 4 of them per DPP row):
+// lane l of a wave = (row r = l >> 4, chain c = (l >> 2) & 3, k = l & 3): a wave carries 4 chains, a chain's 16 lanes are
 // one QUAD in each of the four 16-lane DPP rows, lane (r, k) of a chain takes rows gl, gl + 16, ... of the design, gl = 4 r + k.
 //   * reduce-scatter of the 8 gradient sums: v_permlane32_swap of (v[j], v[j + 4]) + add  ->  4 sums, coordinates 0-3 in rows 0, 1 and
 //     4-7 in rows 2, 3;  v_permlane16_swap of (u[j], u[j + 2]) + add  ->  row r holds coordinates 2 r, 2 r + 1 summed over the four rows;
@@ -35,9 +40,9 @@ __device__ __forceinline__ double f64x_join(float lo, float hi) {
     return __builtin_bit_cast(double, ((uint64_t)__builtin_bit_cast(uint32_t, hi) << 32) | (uint64_t)__builtin_bit_cast(uint32_t, lo));
 }
 
-// 8 per-lane partial sums -> the totals over the chain's 16 lanes of the lane's OWN coordinate pair (2 r, 2 r + 1), identical in the
-// four lanes of its quad
-__device__ __forceinline__ void f64x_reduce_scatter(const double (&v)[8], double& t0, double& t1) {
+// 8 per-lane partial sums -> the totals over the chain's 4 LPR lanes of the lane's OWN coordinate pair (2 r, 2 r + 1), identical in the
+// LPR lanes the chain has in the DPP row
+template <int LPR> __device__ __forceinline__ void f64x_reduce_scatter(const double (&v)[8], double& t0, double& t1) {
     float a[8], b[8];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -56,10 +61,8 @@ __device__ __forceinline__ void f64x_reduce_scatter(const double (&v)[8], double
     swap_pairs<16, 4>(c, d);  // even rows: (own u[0..1], the odd row's u[0..1]);  odd rows: (the even row's u[2..3], own u[2..3])
     t0 = f64x_join(c[0], c[1]) + f64x_join(d[0], d[1]);
     t1 = f64x_join(c[2], c[3]) + f64x_join(d[2], d[3]);
-    t0 += dpp_mov<0xB1>(t0);  // quad_perm [1,0,3,2]
-    t1 += dpp_mov<0xB1>(t1);
-    t0 += dpp_mov<0x4E>(t0);  // quad_perm [2,3,0,1]
-    t1 += dpp_mov<0x4E>(t1);
+    t0 = group_sum<LPR>(t0);  // the in-row levels (symmetric DPP exchanges: bit-identical in the LPR lanes)
+    t1 = group_sum<LPR>(t1);
 }
 // the lane's coordinate pair -> all 8 coordinates of the chain in every one of its lanes
 __device__ __forceinline__ void f64x_all_gather(double x0, double x1, double (&all)[8]) {
@@ -84,25 +87,24 @@ __device__ __forceinline__ void f64x_all_gather(double x0, double x1, double (&a
         all[4 + j] = f64x_join(f[2 * j], f[2 * j + 1]);
     }
 }
-// sum over the chain's 16 lanes of a per-lane value; bit-identical in all 16
-__device__ __forceinline__ double f64x_sum16(double v) {
-    v += dpp_mov<0xB1>(v);
-    v += dpp_mov<0x4E>(v);
-    return swap32_sum(swap16_sum(v));
-}
+// sum over the chain's 4 LPR lanes of a per-lane value; bit-identical in all of them
+template <int LPR> __device__ __forceinline__ double f64x_sum_group(double v) { return swap32_sum(swap16_sum(group_sum<LPR>(v))); }
 // sum over the four DPP rows of a value that is identical inside the quad (a function of the row's coordinate pair)
 __device__ __forceinline__ double f64x_sum_rows(double v) { return swap32_sum(swap16_sum(v)); }
 
+// G lanes per chain (8, 16, 32 or 64: LPR = G / 4 of them in each DPP row); MODE / R: where the rows live, as k_chain's
+template <int G, int MODE, int R>
 __global__ void __launch_bounds__(256) k_chain_f64x(ModelArgs<double, 8> m, ChainArgs<double, 8> a) {
-    constexpr int P = 8;
+    constexpr int P = 8, LPR = G / 4, CPW = 64 / G;  // lanes of a chain per DPP row, chains per wave
+    static_assert(G == 8 || G == 16 || G == 32 || G == 64, "a chain spans the four DPP rows of a wave");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = lane >> 4, c = (lane >> 2) & 3, k = lane & 3, gl = 4 * r + k;
-    int64_t chain = a.first + ((int64_t)blockIdx.x * 4 + wave) * 4 + c;
+    const int r = lane >> 4, c = (lane & 15) / LPR, k = lane % LPR, gl = LPR * r + k;
+    int64_t chain = a.first + ((int64_t)blockIdx.x * 4 + wave) * CPW + c;
     const bool live = chain < a.first + a.count;
     if (!live) chain = a.first + a.count - 1;  // whole waves stay converged for the cross-lane exchanges; stores are masked
     const bool writer = live && k == 0;
-    const auto rows = make_rows<double, P, 16, MODE_LDS, 0>(m, gl, reinterpret_cast<double*>(smem_raw));
+    const auto rows = make_rows<double, P, G, MODE, R>(m, gl, reinterpret_cast<double*>(smem_raw));
     const uint64_t gchain = (uint64_t)(a.chain_offset + chain);
 
     auto own = [&](const double (&v)[P], int h) {  // coordinate 2 r + h
@@ -129,8 +131,8 @@ __global__ void __launch_bounds__(256) k_chain_f64x(ModelArgs<double, 8> m, Chai
         for (int j = 0; j < P; ++j) g8[j] = 0.0;
         rows.for_each([&](const double(&xs)[P]) { row_term<double, P, VALUE, true, FASTW>(xs, b8, g8, v); });
         double t0, t1;
-        f64x_reduce_scatter(g8, t0, t1);
-        if constexpr (VALUE) ll = f64x_sum16(v);
+        f64x_reduce_scatter<LPR>(g8, t0, t1);
+        if constexpr (VALUE) ll = f64x_sum_group<LPR>(v + rows.value_fixup());
         grad[0] = __builtin_fma(-q[0], inv_var[0], t0);
         grad[1] = __builtin_fma(-q[1], inv_var[1], t1);
     };

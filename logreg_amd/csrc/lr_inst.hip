@@ -8,7 +8,7 @@
 #endif
 #if LR_DTYPE == 1 && LR_P == 8
 #include "lr_mfma_f64.h"
-#include "lr_mm_f64.h"
+#include "lr_f64x.h"
 #endif
 #if LR_P >= 8
 #include "lr_tall_mx.h"
@@ -92,20 +92,11 @@ constexpr int P = LR_P;
 #define LR_MFMA64_VARIANTS(X)
 #endif
 
-// float64, padded p = 8: HMC with every evaluation on the float64 matrix pipe (k_chain_mm_f64, lr_mm_f64.h): X(waves per chain tile W,
-// row tiles per wave T), ascending T per W; n <= 16 W T
-#if LR_DTYPE == 1 && LR_P == 8
-#define LR_MM64_VARIANTS(X) X(4, 1) X(4, 2) X(4, 4) X(8, 1) X(8, 2) X(8, 4) X(16, 1)
-#else
-#define LR_MM64_VARIANTS(X)
-#endif
-
 #define LR_VARIANT_ROW(M_, G_, R_) {M_, G_, R_},
 #define LR_MIXED_ROW(G_, R_) {MODE_MIXED, G_, R_},
 #define LR_MFMA64_ROW(N_) {MODE_MFMA, 1, N_},
 #define LR_MFMA_ROW(S_, N_) {MODE_MFMA, S_, N_},
-const Variant kVariants[] = {LR_VARIANTS(LR_VARIANT_ROW) LR_MFMA_VARIANTS(LR_MFMA_ROW) LR_MIXED_VARIANTS(LR_MIXED_ROW) LR_MFMA64_VARIANTS(LR_MFMA64_ROW)
-                             LR_MM64_VARIANTS(LR_MFMA_ROW)};
+const Variant kVariants[] = {LR_VARIANTS(LR_VARIANT_ROW) LR_MFMA_VARIANTS(LR_MFMA_ROW) LR_MIXED_VARIANTS(LR_MIXED_ROW) LR_MFMA64_VARIANTS(LR_MFMA64_ROW)};
 
 inline int check(hipError_t e) { return e == hipSuccess ? 0 : -2; }
 
@@ -159,6 +150,11 @@ int launch_chain_v(const LaunchCfg* cfg, int64_t C, const ModelArgs<T, P>& m, co
     if constexpr (G == 16 && MODE == MODE_REG) {  // state distributed over the 16 lanes of a chain (lr_kernels.h)
         if (cfg->kind == KIND_RWMH) return launch_capped<&k_chain_rs16<R, KIND_RWMH>>(cfg, grid, block, 0, m, a);
         if (cfg->kind == KIND_MALA) return launch_capped<&k_chain_rs16<R, KIND_MALA>>(cfg, grid, block, 0, m, a);
+    }
+#endif
+#if LR_DTYPE == 1 && LR_P == 8
+    if constexpr (G >= 8 && MODE != MODE_GLOBAL) {  // HMC: the chain state distributed over the group, the group across the DPP rows (lr_f64x.h)
+        if (cfg->kind == KIND_HMC) return launch_capped<&k_chain_f64x<G, MODE, R>>(cfg, grid, block, cfg->lds_bytes, m, a);
     }
 #endif
     switch (cfg->kind) {
@@ -245,10 +241,6 @@ int launch_chain(const LaunchCfg* cfg, int64_t C, const void* model_args, const 
     if (cfg->mode == MODE_MFMA && cfg->G == 1 && cfg->R == N_ && cfg->kind == KIND_HMC)   \
         return launch_capped<&k_chain_mfma_f64<N_>>(cfg, dim3((unsigned)((C + 63) / 64)), dim3(256), cfg->lds_bytes, m, a);
     LR_MFMA64_VARIANTS(LR_DISPATCH_MFMA64)
-#define LR_DISPATCH_MM64(W_, T_)                                                               \
-    if (cfg->mode == MODE_MFMA && cfg->G == W_ && cfg->R == T_ && cfg->kind == KIND_HMC)   \
-        return launch_capped<&k_chain_mm_f64<T_, (W_ > 8 ? 16 : 8)>>(cfg, dim3((unsigned)((C + 15) / 16)), dim3(64 * W_), 0, m, a);
-    LR_MM64_VARIANTS(LR_DISPATCH_MM64)
     return -3;
 }
 

@@ -57,11 +57,6 @@ struct PlanConst {
     // float64 HMC under LR_PREC_AUTO, p <= 8, n <= 256: k_chain_mixed from this many chains per CU
     int mixed_chains_per_cu = 0;
     int f64_mfma_chains_per_cu = 33;  // float64 HMC under LR_PREC_AUTO: k_chain_mfma_f64 beyond two rounds of k_chain_mixed (plan_mfma_hmc)
-    // float64 HMC with EVERY evaluation in float64 (LR_PREC_FULL; or rows beyond k_chain_mixed's shapes), p <= 8: the float64 matrix-pipe
-    // kernel (k_chain_mm_f64, lr_mm_f64.h) from this many chains per CU, its waves per chain tile chosen so that the launch has at most
-    // f64_mm_waves_per_simd waves per SIMD (round 6, tools/f64_full_speed.py)
-    int f64_mm_chains_per_cu = 4;
-    int f64_mm_waves_per_simd = 4;
     int f64_lds16_chains_per_cu = 16;
     int f64_lds8_chains_per_cu = 32;
     int mfma_fp32_chains_per_cu = 16;
@@ -188,7 +183,6 @@ bool plan_mfma_hmc(const lr_model* m, int64_t C, Plan* out) {
     if (m->dtype != LR_F32 && m->P != 8) return false;
     for (const MfmaRule& r : kMfmaRules) {
         if (r.P != m->P || m->n <= r.n_lo || m->n > r.n_hi) continue;
-        if (m->dtype != LR_F32 && r.S != 1) continue;  // (float64 variants with S > 1 are k_chain_mm_f64's: every evaluation float64, not this policy's)
         // (float64: the alternative is the float32-interior kernel in rounds of 16 chains per CU -- beyond two rounds the one launch
         //  of k_chain_mfma_f64 wins: 9216 chains 1.30 ms in two parts | 0.96 ms; at 8192 0.943 | 0.96)
         const int cpc_lo = m->dtype != LR_F32 ? kPlanConst.f64_mfma_chains_per_cu : r.cpc_lo;
@@ -308,8 +302,7 @@ int pick_variant(const PlanReq& q) {
             // fp32 matrix-core variants; G = row-split ways S, R = tiles per wave.  Here only on request (mode = LR_MODE_MFMA); the
             // planner's own uses are plan_mfma_hmc and measured_overrides.
             if (q.for_eval || q.mode != LR_MODE_MFMA) continue;
-            if (m->dtype != LR_F32 && q.kind != LR_KIND_HMC) continue;  // (float64: k_chain_mfma_f64 / k_chain_mm_f64 are HMC kernels)
-            if (m->dtype != LR_F32 && q.group == 0 && v.G != 1) continue;  // (float64, no row-split request: k_chain_mfma_f64; k_chain_mm_f64 by group = 4 / 8 / 16)
+            if (m->dtype != LR_F32 && q.kind != LR_KIND_HMC) continue;  // (float64: k_chain_mfma_f64 is an HMC kernel)
             if (v.R < 0 ? m->d_xms == nullptr
                         : (v.R == 0 ? mfma_lds_bytes(m, v.G) > mfma_lds_budget(m, v.G) : (int64_t)16 * v.G * v.R < m->n)) continue;
             if (q.group != 0 && v.G != q.group) continue;
@@ -354,24 +347,6 @@ int pick_variant(const PlanReq& q) {
     return best;
 }
 
-// float64 HMC, every evaluation float64, on the float64 matrix pipe (k_chain_mm_f64): W waves per chain tile of 16 chains -- the most
-// that keeps the launch within f64_mm_waves_per_simd waves per SIMD -- and the fewest row tiles per wave that hold the rows
-bool plan_mm_f64(const lr_model* m, int64_t C, Plan* out) {
-    const lr::InstTable* t = m->table;
-    const int64_t ctiles = (C + 15) / 16, max_waves = (int64_t)kPlanConst.f64_mm_waves_per_simd * 4 * m->cus;
-    const int64_t ntiles = (m->n + 15) / 16;
-    for (int W : {16, 8, 4}) {
-        if (W != 4 && (ctiles * W > max_waves || W / 2 >= ntiles)) continue;  // (... and no more waves than halve the row tiles)
-        for (int i = 0; i < t->nvariants; ++i) {
-            const lr::Variant& v = t->variants[i];
-            if (v.mode != lr::MODE_MFMA || v.G != W || v.R <= 0 || (int64_t)16 * v.G * v.R < m->n) continue;
-            *out = Plan{v.mode, v.G, v.R, 0};
-            return true;
-        }
-    }
-    return false;
-}
-
 // (5) vector-ALU plans the measurements overrule (kPlanConst).  Returns true when *out is final (a matrix-core plan); else `best`
 // may have been moved to another variant of the table.
 bool measured_overrides(const PlanReq& q, int* best, Plan* out) {
@@ -391,8 +366,6 @@ bool measured_overrides(const PlanReq& q, int* best, Plan* out) {
         else if (m->P >= 16 && q.C >= (int64_t)kPlanConst.mfma_fp32_chains_per_cu * m->cus && mfma_variant_fits(m, 4, ST_REG, out))
             return true;
     }
-    if (m->dtype == LR_F64 && m->P == 8 && q.kind == LR_KIND_HMC && q.C >= (int64_t)kPlanConst.f64_mm_chains_per_cu * m->cus && plan_mm_f64(m, q.C, out))
-        return true;
     if (m->dtype == LR_F64 && m->P == 8 && b.mode == lr::MODE_REG) {
         if (q.C >= (int64_t)kPlanConst.f64_lds8_chains_per_cu * m->cus) move_to_lds(8);
         else if (q.C >= (int64_t)kPlanConst.f64_lds16_chains_per_cu * m->cus) move_to_lds(16);
@@ -519,7 +492,7 @@ int make_plan(const lr_model* m, int64_t C, int group, int mode, Plan* out, bool
                     m->dtype, m->p, m->P, (long long)m->n, group, mode);
     if (q.automatic() && measured_overrides(q, &best, out)) return LR_OK;
     const lr::Variant& v = m->table->variants[best];
-    *out = Plan{v.mode, v.G, v.R, v.mode == lr::MODE_MIXED ? mixed_lds_bytes(m) : v.mode == lr::MODE_LDS ? lds_rows_bytes(m) : (v.mode == lr::MODE_MFMA && m->dtype != LR_F32) ? (v.G == 1 ? row_bytes : 0) : (v.mode == lr::MODE_MFMA && v.R == 0 ? mfma_lds_bytes(m, v.G) : 0)};
+    *out = Plan{v.mode, v.G, v.R, v.mode == lr::MODE_MIXED ? mixed_lds_bytes(m) : v.mode == lr::MODE_LDS ? lds_rows_bytes(m) : (v.mode == lr::MODE_MFMA && m->dtype != LR_F32) ? row_bytes : (v.mode == lr::MODE_MFMA && v.R == 0 ? mfma_lds_bytes(m, v.G) : 0)};
     if (v.mode == lr::MODE_REG && q.automatic() && kind >= 0) plan_second_part(q, v, out);
     return LR_OK;
 }
@@ -537,8 +510,7 @@ int check_group_for(const lr_model* m, int group, int mode) {
         return LR_OK;
     }
     if (mode == LR_MODE_MFMA) {
-        if (group != 1 && group != 4 && group != 8 && !(group == 16 && m->dtype == LR_F64))
-            return fail(LR_ERR_INVALID, "matrix-core mode: group (row-split ways) must be 0, 1, 4 or 8 (float64 models: or 16) (got %d)", group);
+        if (group != 1 && group != 4 && group != 8) return fail(LR_ERR_INVALID, "matrix-core mode: group (row-split ways) must be 0, 1, 4 or 8 (got %d)", group);
         return LR_OK;
     }
     if (group > 64 || (group & (group - 1))) return fail(LR_ERR_INVALID, "group (lanes per chain) must be 0 or a power of two <= 64 (got %d)", group);

@@ -36,9 +36,14 @@ def llvm_tool(name: str) -> str:
 BRANCH = re.compile(r"^(s_cbranch_\w+|s_branch)\b")
 ENDS = re.compile(r"^(s_endpgm|s_setpc_b64|s_swappc_b64)\b")
 EXEC_RESTORE = re.compile(r"^s_or_b64 exec, exec, ")
-# any other write of EXEC ahead of the restore of a join block: the save / set / restore bracket of an SGPR spill to memory
-# (-amdgpu-spill-sgpr-to-vgpr=0 builds); it excuses nothing -- the instructions around it still run under the incoming edge's mask
-EXEC_WRITE = re.compile(r"^(s_\w+saveexec\w* |s_\w+ exec(_lo|_hi)?,|v_cmpx_)")
+# other writes of EXEC inside a join block, ahead of its restore:
+#  * `s_and_saveexec / s_andn2_saveexec / s_or_saveexec`: the block is the `else` of an if / else (or holds a nested `if` whose skip
+#    branch was removed): what FOLLOWS runs under the mask it sets, by design -- but what PRECEDES it at the head of the block is as
+#    misplaced as in front of a plain restore;
+#  * `s_mov_b64 exec, ..` and the like: the set / restore bracket of an SGPR spill to memory (-amdgpu-spill-sgpr-to-vgpr=0 builds);
+#    it excuses nothing -- the instructions around it still run under the incoming edge's mask.
+EXEC_SAVE = re.compile(r"^s_\w+saveexec\w* ")
+EXEC_WRITE = re.compile(r"^(s_\w+ exec(_lo|_hi)?,|v_cmpx_)")
 # instructions whose effect does not depend on EXEC: the scalar unit, and the two cross-lane moves the SGPR spills are made of
 LANE_AGNOSTIC = re.compile(r"^(s_\w+|v_readlane_b32|v_writelane_b32|v_readfirstlane_b32)\b")
 
@@ -104,6 +109,9 @@ def scan_kernel(ins):
             if EXEC_RESTORE.match(t):
                 ahead = []  # what lies between two restores runs under the inner join's mask by design (an `if` nested in an
                 break       # `if` whose skip branch was removed); the earlier restore has its own entry
+            if EXEC_SAVE.match(t):
+                ahead = []
+                continue
             if EXEC_WRITE.match(t):
                 continue
             if not LANE_AGNOSTIC.match(t):

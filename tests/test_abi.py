@@ -138,6 +138,13 @@ def test_the_exec_restore_scan_recognises_the_round_4_pattern():
     assert scan_kernel(body) == []
     no_skip = prog("s_and_saveexec_b64 s[2:3], vcc", "global_store_dword v[4:5], v143, off", "s_or_b64 exec, exec, s[2:3]", "s_endpgm")
     assert scan_kernel(no_skip) == []
+    if_else = prog("s_and_saveexec_b64 s[12:13], s[10:11]", "s_cbranch_execz 19 -> else_", "v_mul_lo_u32 v137, v141, s77",
+                   ":else_", "s_andn2_saveexec_b64 s[10:11], s[10:11]", "v_mul_lo_u32 v136, v138, s76", "s_or_b64 exec, exec, s[10:11]", "s_endpgm")
+    assert scan_kernel(if_else) == []  # (the `else` body runs under the flipped mask by design)
+    bad_else = prog("s_and_saveexec_b64 s[12:13], s[10:11]", "s_cbranch_execz 19 -> else_", "v_mul_lo_u32 v137, v141, s77",
+                    ":else_", "v_mov_b64_e32 v[70:71], v[30:31]", "s_andn2_saveexec_b64 s[10:11], s[10:11]", "v_mul_lo_u32 v136, v138, s76",
+                    "s_or_b64 exec, exec, s[10:11]", "s_endpgm")
+    assert len(scan_kernel(bad_else)) == 1 and scan_kernel(bad_else)[0][2][0][1] == "v_mov_b64_e32 v[70:71], v[30:31]"
     loop_exit = prog(":loop", "v_fmac_f64_e32 v[0:1], v[2:3], v[4:5]", "s_andn2_b64 exec, exec, s[54:55]", "s_cbranch_execnz 9 -> loop",
                      "v_writelane_b32 v254, s10, 57", "v_mov_b64_e32 v[178:179], v[168:169]", "s_or_b64 exec, exec, s[54:55]", "s_endpgm")
     found = scan_kernel(loop_exit)

@@ -230,6 +230,17 @@ def test_bench_multi_gpu_line_on_the_abi_test_double(world):
     assert mg["ranks_seen"] == world and len(mg["devices"]) == world and mg["devices_distinct"]
     assert 0 < mg["kernel_ms_min"] <= mg["kernel_ms_max"]
     assert mg["gather_bitexact"] is True and mg["gather_checked_rank"] == 1 and mg["gather_checked_chains"] == 64
+    # north_star: "chains/sec and achieved-HBM-fraction reported at 1/2/4/8 GPUs" -- one row per rank from the rank's own event time,
+    # and the weak-scaling row of the headline (fixed chains per GPU)
+    assert len(mg["kernel_ms_per_rank"]) == world and min(mg["kernel_ms_per_rank"]) == pytest.approx(mg["kernel_ms_min"], rel=1e-3)
+    per = d["per_rank"]
+    assert [r["rank"] for r in per] == list(range(world))
+    for r in per:
+        assert r["chain_iterations_per_s"] == pytest.approx(80 * 20 / (r["kernel_ms"] / 1e3), rel=1e-9)
+        assert r["grad_evals_per_s"] == pytest.approx(50 * r["chain_iterations_per_s"]) and 0 < r["hbm_frac"] < 1 and r["valu_frac"] > 0
+    ws = d["weak_scaling"]
+    assert ws["chains_per_gpu"] == 80 and ws["n_gpus"] == world and ws["chains_total"] == 80 * world
+    assert ws["chain_iterations_per_s"] == d["value"] and ws["per_gpu"] == pytest.approx(d["value"] / world) and 0 <= ws["gather_share"] < 1
     rows = {r["config"]: r for r in d["extra"]["configs"]}
     assert set(rows) == {3, 5} and all(r["n_gpus"] == world and r["scaled_down"] == 64 for r in rows.values())
     c3, c5 = rows[3], rows[5]

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""k_chain_mm_f64 (float64 HMC on the float64 matrix pipe, lr_mm_f64.h): step-for-step parity with the float64 oracle for every
-(waves per chain tile) variant, bit-exact chunk / shard reruns, and the headline workload's rate beside the lane-group kernel's."""
+"""HMC on a float64 model with every evaluation float64: step-for-step parity of the 16-lanes-per-chain kernel (k_chain_f64x, lr_f64x.h:
+state distributed over the group, group across the DPP rows) with the float64 oracle, bit-exact chunk / shard reruns, and the headline
+workload's rate on every lane-group width."""
 import ctypes as Ct, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, logreg_amd as la
@@ -19,19 +20,19 @@ for (n, p, C) in ((200, 8, 70), (37, 5, 16), (255, 7, 33), (500, 8, 130), (16, 6
     scale = rng.uniform(0.5, 2.0, p)
     k = la.hmcKernel(m.lpost, m.glp, eps=0.3 * sc, l=5, dmm=scale)
     ref = orc.run("hmc", q0, step=0.3 * sc, l=5, scale=scale, thin=2, iters=3, seed=11, threads=0)
-    for g in (4, 8, 16):
+    for md, g in (("lds", 16), ("lds", 8), ("lds", 64), ("reg", 32), ("reg", 64)):
         try:
-            out, info = la.mcmc(q0, k, thin=2, iters=3, verb=False, seed=11, mode="mfma", group=g, precision="full", return_info=True)
+            out, info = la.mcmc(q0, k, thin=2, iters=3, verb=False, seed=11, mode=md, group=g, precision="full", return_info=True)
         except la.LogregHipError as e:
-            print(f"n={n} p={p} C={C} W={g}: {str(e)[:90]}"); continue
+            print(f"n={n} p={p} C={C} {md}/{g}: {str(e)[:90]}"); continue
         ok = ref["margin"] > 1e-8
         err = np.max(np.abs(out[:, ok] - ref["out"][:, ok]))
         accd = int((info["accepts"][ok] != ref["accepts"][ok]).sum())
-        ch = la.mcmc(q0, k, thin=2, iters=3, verb=False, seed=11, mode="mfma", group=g, precision="full", chunk=1)
+        ch = la.mcmc(q0, k, thin=2, iters=3, verb=False, seed=11, mode=md, group=g, precision="full", chunk=1)
         h = C // 2
-        sh = np.concatenate([la.mcmc(q0[:h], k, thin=2, iters=3, verb=False, seed=11, mode="mfma", group=g, precision="full"),
-                             la.mcmc(q0[h:], k, thin=2, iters=3, verb=False, seed=11, mode="mfma", group=g, precision="full", chain_offset=h)], axis=1)
-        print(f"n={n} p={p} C={C} W={g} plan={info['plan']}: max|d state| vs oracle {err:.3g}, accept diffs {accd}, chunk bit-exact {np.array_equal(ch, out)}, "
+        sh = np.concatenate([la.mcmc(q0[:h], k, thin=2, iters=3, verb=False, seed=11, mode=md, group=g, precision="full"),
+                             la.mcmc(q0[h:], k, thin=2, iters=3, verb=False, seed=11, mode=md, group=g, precision="full", chain_offset=h)], axis=1)
+        print(f"n={n} p={p} C={C} {md}/{g} plan={info['plan']}: max|d state| vs oracle {err:.3g}, accept diffs {accd}, chunk bit-exact {np.array_equal(ch, out)}, "
               f"shards bit-exact {np.array_equal(sh, out)}, accept rate {info['accepts'].mean() / 6:.3f}", flush=True)
 
 L = _lib.load()
@@ -41,8 +42,8 @@ X, y, _ = la.synthetic_logreg(200, 8, seed=20240001)
 m = la.LogReg(X, y, np.array([10.0] + [1.0] * 7), dtype="float64")
 q0 = bench.headline_init(0, 4096)
 k = la.hmcKernel(m.lpost, m.glp, eps=0.1, l=50, dmm=np.ones(8))
-for C in (256, 1024, 2048, 4096, 8192, 16384):
-    for mode, g in (("auto", 0), ("lds", 16), ("lds", 8), ("lds", 64), ("mfma", 4), ("mfma", 8), ("mfma", 16)):
+for C in (1024, 2048, 4096, 8192, 16384):
+    for mode, g in (("auto", 0), ("lds", 16), ("lds", 8), ("reg", 32), ("reg", 64), ("lds", 64)):
         init = np.tile(q0, ((C + 4095) // 4096, 1))[:C]
         try:
             cs = la.ChainSet(k, init, seed=42, stream=stream, precision="full", mode=mode, group=g)
