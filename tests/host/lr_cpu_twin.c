@@ -406,36 +406,115 @@ LR_API int lr_event_elapsed_ms(int device, void *start, void *stop, float *ms) {
     return LR_OK;
 }
 
-/* the C-level exchange on the test double: a world of ONE rank (the gather and the sum are copies / no-ops); more ranks need RCCL */
-struct lr_comm { int rank, world; };
+/* The C-level exchange on the test double: ranks are PROCESSES of one host that meet in a POSIX shared-memory segment named after the
+ * communicator id (lr_comm_unique_id: random; the caller hands it to the other ranks, as it hands RCCL's id on the GPU -- a file, a
+ * launcher variable).  The semantics are the header's and RCCL's: lr_gather delivers every rank's `bytes` block to `recv` of the root,
+ * in rank order (recv is not touched elsewhere); lr_allreduce_sum_f64 leaves in every rank's buffer the sum over the ranks, added in
+ * rank order (so all ranks hold the same bits); both return when the data is there.  A sense-reversing barrier in the segment orders
+ * the phases.  tests/test_distributed_gloo.py runs two and three processes against torch.distributed (gloo) on the same blocks. */
+#include <fcntl.h>
+#include <sched.h>
+#include <stdatomic.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#define TWIN_MAX_WORLD 8
+#define TWIN_SLOT_BYTES ((size_t)8 << 20) /* staging per rank (sparse: /dev/shm pages exist once touched) */
+typedef struct twin_seg {
+    atomic_int arrived, generation, attached;
+    unsigned char pad[64 - 3 * sizeof(atomic_int)];
+    unsigned char slot[TWIN_MAX_WORLD][TWIN_SLOT_BYTES];
+} twin_seg;
+struct lr_comm { int rank, world; twin_seg *seg; char name[80]; };
+static void twin_barrier(lr_comm *c) {
+    if (c->world == 1) return;
+    const int gen = atomic_load(&c->seg->generation);
+    if (atomic_fetch_add(&c->seg->arrived, 1) + 1 == c->world) {
+        atomic_store(&c->seg->arrived, 0);
+        atomic_fetch_add(&c->seg->generation, 1);
+    } else {
+        while (atomic_load(&c->seg->generation) == gen) sched_yield();
+    }
+}
 LR_API int lr_comm_unique_id(void *id) {
     if (!id) return fail(LR_ERR_INVALID, "NULL id");
-    memset(id, 0x5a, LR_COMM_ID_BYTES);
+    memset(id, 0, LR_COMM_ID_BYTES);
+    struct timespec ts;
+    clock_gettime(CLOCK_REALTIME, &ts);
+    snprintf((char *)id, LR_COMM_ID_BYTES, "lrtwin-%d-%lld-%ld", (int)getpid(), (long long)ts.tv_sec, ts.tv_nsec);
     return LR_OK;
 }
 LR_API int lr_comm_create(const void *id, int32_t rank, int32_t world, int device, lr_comm **out) {
     (void)device;
     if (!id || !out) return fail(LR_ERR_INVALID, "NULL id / out");
-    if (world != 1 || rank != 0) return fail(LR_ERR_UNSUPPORTED, "the CPU test double has no collective library: world 1 only (got rank %d of %d)", rank, world);
-    *out = (lr_comm *)malloc(sizeof(lr_comm));
-    (*out)->rank = 0;
-    (*out)->world = 1;
+    if (world < 1 || world > TWIN_MAX_WORLD || rank < 0 || rank >= world) return fail(LR_ERR_INVALID, "rank %d of world %d (the test double takes up to %d ranks)", rank, world, TWIN_MAX_WORLD);
+    lr_comm *c = (lr_comm *)calloc(1, sizeof(lr_comm));
+    c->rank = rank;
+    c->world = world;
+    if (world > 1) {
+        char tag[LR_COMM_ID_BYTES + 1];
+        memcpy(tag, id, LR_COMM_ID_BYTES);
+        tag[LR_COMM_ID_BYTES] = 0;
+        for (char *q = tag; *q; ++q)
+            if (*q == '/') *q = '_';
+        snprintf(c->name, sizeof c->name, "/%.70s", tag[0] ? tag : "lrtwin-default");
+        const int fd = shm_open(c->name, O_CREAT | O_RDWR, 0600);
+        if (fd < 0 || ftruncate(fd, (off_t)sizeof(twin_seg)) != 0) {
+            if (fd >= 0) close(fd);
+            free(c);
+            return fail(LR_ERR_HIP, "shared-memory segment %s of the test double's exchange could not be made", c->name);
+        }
+        c->seg = (twin_seg *)mmap(NULL, sizeof(twin_seg), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (c->seg == MAP_FAILED) {
+            free(c);
+            return fail(LR_ERR_NOMEM, "mapping the exchange segment failed");
+        }
+        atomic_fetch_add(&c->seg->attached, 1);
+        while (atomic_load(&c->seg->attached) < world) sched_yield(); /* (a fresh segment is zero-filled: the counters start at 0) */
+        twin_barrier(c);
+    }
+    *out = c;
     return LR_OK;
 }
 LR_API int lr_comm_destroy(lr_comm *comm) {
+    if (!comm) return LR_OK;
+    if (comm->world > 1) {
+        twin_barrier(comm);
+        munmap(comm->seg, sizeof(twin_seg));
+        if (comm->rank == 0) shm_unlink(comm->name);
+    }
     free(comm);
     return LR_OK;
 }
 LR_API int lr_gather(lr_comm *comm, const void *send, void *recv, uint64_t bytes, int32_t root, void *stream) {
     (void)stream;
-    if (!comm || !send || !recv) return fail(LR_ERR_INVALID, "NULL comm / send / recv");
-    if (root != 0) return fail(LR_ERR_INVALID, "root %d of world 1", root);
-    memmove(recv, send, bytes);
+    if (!comm || !send) return fail(LR_ERR_INVALID, "comm / send is NULL");
+    if (root < 0 || root >= comm->world) return fail(LR_ERR_INVALID, "root %d of world %d", root, comm->world);
+    if (comm->rank == root && !recv) return fail(LR_ERR_INVALID, "recv is NULL on the root rank");
+    if (comm->world == 1) {
+        memmove(recv, send, bytes);
+        return LR_OK;
+    }
+    if (bytes > TWIN_SLOT_BYTES) return fail(LR_ERR_UNSUPPORTED, "the test double stages at most %zu bytes per rank", TWIN_SLOT_BYTES);
+    memcpy(comm->seg->slot[comm->rank], send, bytes);
+    twin_barrier(comm);
+    if (comm->rank == root)
+        for (int r = 0; r < comm->world; ++r) memcpy((unsigned char *)recv + (uint64_t)r * bytes, comm->seg->slot[r], bytes);
+    twin_barrier(comm); /* the slots are free again */
     return LR_OK;
 }
 LR_API int lr_allreduce_sum_f64(lr_comm *comm, double *buf, uint64_t count, void *stream) {
-    (void)count;
     (void)stream;
-    if (!comm || !buf) return fail(LR_ERR_INVALID, "NULL comm / buf");
+    if (!comm || !buf) return fail(LR_ERR_INVALID, "comm / buf is NULL");
+    if (comm->world == 1) return LR_OK;
+    if (count * 8 > TWIN_SLOT_BYTES) return fail(LR_ERR_UNSUPPORTED, "the test double stages at most %zu bytes per rank", TWIN_SLOT_BYTES);
+    memcpy(comm->seg->slot[comm->rank], buf, count * 8);
+    twin_barrier(comm);
+    for (uint64_t i = 0; i < count; ++i) {
+        double s = ((const double *)comm->seg->slot[0])[i];
+        for (int r = 1; r < comm->world; ++r) s += ((const double *)comm->seg->slot[r])[i];
+        buf[i] = s;
+    }
+    twin_barrier(comm);
     return LR_OK;
 }

@@ -178,3 +178,79 @@ def test_mcmc_sharded_driver_on_cpu(tmp_path, C):
         np.testing.assert_allclose(s["sd"], flat.std(0, ddof=1), rtol=1e-8)
         np.testing.assert_allclose(s["rhat"], split_rhat(ref["out"]), rtol=1e-8)
         assert float(s["accept_rate"]) == pytest.approx(ref["accepts"].sum() / (C * 16))
+
+
+def _c_exchange_worker(rank, world, port, tmp):
+    """One rank = one process: the C-level exchange of the ABI (lr_comm_* / lr_gather / lr_allreduce_sum_f64, here the CPU test double's
+    shared-memory implementation) next to torch.distributed (gloo) on the SAME blocks."""
+    import ctypes as C
+    import time
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    import torch
+    import torch.distributed as dist
+    import twin
+    L = twin.install()
+    from logreg_amd import _lib
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # the communicator id travels from rank 0 to the others as RCCL's does on the GPU: here a file
+    idf = os.path.join(tmp, "comm.id")
+    ident = (C.c_ubyte * 128)()
+    if rank == 0:
+        _lib.check(L.lr_comm_unique_id(ident))
+        with open(idf + ".tmp", "wb") as f:
+            f.write(bytes(ident))
+        os.replace(idf + ".tmp", idf)
+    else:
+        while not os.path.exists(idf):
+            time.sleep(0.01)
+        ident = (C.c_ubyte * 128).from_buffer_copy(open(idf, "rb").read())
+    comm = C.c_void_p()
+    _lib.check(L.lr_comm_create(ident, rank, world, 0, C.byref(comm)))
+    rng = np.random.default_rng(100 + rank)
+    ok = True
+    for root in range(world):  # the thinned samples of this rank's chain block: [iters][chains per rank][p] float32
+        block = rng.standard_normal((3, 40, 8)).astype(np.float32)
+        recv = np.full((world,) + block.shape, np.nan, dtype=np.float32)
+        _lib.check(L.lr_gather(comm, block.ctypes.data, recv.ctypes.data if rank == root else None, block.nbytes, root, None))
+        t = torch.from_numpy(block)
+        bufs = [torch.empty_like(t) for _ in range(world)] if rank == root else None
+        dist.gather(t, bufs, dst=root)
+        if rank == root:
+            ok &= all(np.array_equal(recv[r], bufs[r].numpy()) for r in range(world))  # every rank's block, in rank order, bit for bit
+    # the statistics all-reduce: 7 p + 1 doubles per rank (lr_stats_reduce's sums + the chain count)
+    sums = rng.standard_normal(57) * 10.0 ** rng.integers(-3, 6, 57)
+    mine = sums.copy()
+    _lib.check(L.lr_allreduce_sum_f64(comm, mine.ctypes.data, mine.size, None))
+    t = torch.from_numpy(sums.copy())
+    dist.all_reduce(t)
+    gathered = [torch.empty(57, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(gathered, torch.from_numpy(sums))
+    in_rank_order = gathered[0].numpy().copy()
+    for r in range(1, world):
+        in_rank_order += gathered[r].numpy()
+    ok &= np.array_equal(mine, in_rank_order)                   # the sum in rank order: the same bits on every rank
+    ok &= np.allclose(mine, t.numpy(), rtol=1e-14, atol=0)      # torch's all_reduce (its own order) to rounding
+    bad_root = L.lr_gather(comm, block.ctypes.data, None, block.nbytes, world, None)
+    ok &= bad_root < 0
+    _lib.check(L.lr_comm_destroy(comm))
+    res = torch.tensor([int(ok)])
+    dist.all_reduce(res, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        with open(os.path.join(tmp, "c_exchange_ok"), "w") as f:
+            f.write(str(int(res.item())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_c_level_exchange_between_processes_matches_torch_distributed(tmp_path, world):
+    """`lr_comm_create` at world > 1 over a file-passed id, `lr_gather` (every root) and `lr_allreduce_sum_f64` --
+    the exchange a plain-C client of the ABI makes on the GPU through RCCL -- run between PROCESSES on the CPU test double and compared
+    with torch.distributed's gather / all_reduce of the same blocks: the same block order, the root alone receives, sums in rank order."""
+    import torch.multiprocessing as mp
+    mp.spawn(_c_exchange_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert open(os.path.join(str(tmp_path), "c_exchange_ok")).read() == "1"

@@ -405,7 +405,7 @@ def test_the_scripts_own_rprop_is_recognised_and_fused(la, models, map_beta):
 
 def test_c_level_exchange_on_the_test_double(la):
     """include/logreg_hip.h lr_comm_* / lr_gather / lr_allreduce_sum_f64 through the binding on the CPU test double: a world of one rank
-    (identifier, communicator, the gather as a copy, the sum in place); more ranks are refused there -- they need RCCL (GPU suite)."""
+    (identifier, communicator, the gather as a copy, the sum in place).  Several ranks: tests/test_distributed_gloo.py (processes)."""
     import ctypes as C
     from logreg_amd import _lib
     L = _lib.load()
@@ -423,4 +423,4 @@ def test_c_level_exchange_on_the_test_double(la):
     assert np.array_equal(sums, keep)
     assert L.lr_gather(comm, src.ctypes.data, dst.ctypes.data, src.nbytes, 1, None) < 0
     _lib.check(L.lr_comm_destroy(comm))
-    assert L.lr_comm_create(ident, 1, 2, 0, C.byref(comm)) < 0 and b"world 1 only" in L.lr_last_error()
+    assert L.lr_comm_create(ident, 2, 2, 0, C.byref(comm)) < 0 and b"rank 2 of world 2" in L.lr_last_error()

@@ -12,7 +12,7 @@ import tempfile
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(REPO, "tests", "host", "lr_cpu_twin.c")
-CFLAGS = ["-O2", "-std=gnu99", "-fPIC", "-fopenmp", "-Wall", "-Wextra", "-fno-fast-math", "-ffp-contract=off"]
+CFLAGS = ["-O2", "-std=gnu11", "-fPIC", "-fopenmp", "-Wall", "-Wextra", "-fno-fast-math", "-ffp-contract=off"]
 _state = {"dir": None, "path": None, "saved": None}
 
 
@@ -21,7 +21,7 @@ def build() -> str:
     if _state["path"] is None:
         _state["dir"] = tempfile.TemporaryDirectory(prefix="lr_twin_")
         path = os.path.join(_state["dir"].name, "liblogreg_twin.so")
-        subprocess.run(["gcc", *CFLAGS, "-shared", SRC, "-o", path, "-lm"], check=True, capture_output=True)
+        subprocess.run(["gcc", *CFLAGS, "-shared", SRC, "-o", path, "-lm", "-lrt", "-lpthread"], check=True, capture_output=True)
         _state["path"] = path
     return _state["path"]
 
