@@ -22,6 +22,21 @@ import pytest
 
 from conftest import load_golden
 
+# p = 128: 128 posterior means + 128 posterior SDs are compared at once.  north_star's "within 3 Monte-Carlo SEs" is a statement
+# about ONE parameter: asked of each of 256 statistics separately it would fail a correct sampler in half of the runs
+# (1 - 0.9973^256 = 0.50).  The bound the wide-model tests assert is therefore NOT 3 SEs but its family-wise equivalent, max |z| < 4.2
+# (P(max of 256 |z| > 4.2) = 0.7 %, the same risk as 3 sigma on a handful of parameters) -- and, as the per-parameter statement in its
+# testable form, at most Z3_MAX_EXCEEDANCES of the 256 |z| beyond 3 (expected 0.7; P(> 4) = 0.1 %) with unit-scale z scores.
+Z_FAMILYWISE_256 = 4.2
+Z3_MAX_EXCEEDANCES = 4
+
+
+def _assert_wide_posterior(zm, zs, tag):
+    z = np.concatenate([np.ravel(zm), np.ravel(zs)])
+    assert np.max(np.abs(z)) < Z_FAMILYWISE_256, (tag, float(np.max(np.abs(z))))
+    assert int((np.abs(z) > 3.0).sum()) <= Z3_MAX_EXCEEDANCES, (tag, int((np.abs(z) > 3.0).sum()))
+    assert 0.5 < np.sqrt(np.mean(np.square(zm))) < 1.3 and 0.5 < np.sqrt(np.mean(np.square(zs))) < 1.3, tag
+
 pytestmark = pytest.mark.gpu
 
 PSCALE8 = np.array([10.0, 1, 1, 1, 1, 1, 1, 1])
@@ -144,19 +159,18 @@ def test_config4_tall_data_full_size(la):
     assert res["auto"][2] > res["full"][2] - 0.03
 
 
-def test_config5_wide_model_full_size(la):
+def test_config5_wide_model_full_size_within_the_family_wise_4p2_bound_not_3_se(la):
     """n = 4096, p = 128, 1024 chains: 16 slices x 8 blocks of 32 rows on the bf16 matrix pipe -- with every
     evaluation exact ("full": six bf16 piece products per fp32 product) and with the default policy ("auto":
     interior leapfrog gradients from one-piece rows and two-piece beta; end points exact)."""
     res = _fullsize(la, 5, expect_slices=16, margin=5e-3, state_tol_sd=5e-3, burn=50, keep=200, precisions=("full", "auto"))
     for prec, (zm, zs, acc) in res.items():
-        assert np.max(np.abs(zm)) < 4.2 and np.max(np.abs(zs)) < 4.2, prec
-        assert 0.5 < np.sqrt(np.mean(zm ** 2)) < 1.3 and 0.5 < np.sqrt(np.mean(zs ** 2)) < 1.3, prec
+        _assert_wide_posterior(zm, zs, prec)
     # the price of the cheaper interior force is acceptance rate, and it is small
     assert res["auto"][2] > res["full"][2] - 0.03
 
 
-def test_config5_whole_8192_chains_on_one_gpu(la, monkeypatch):
+def test_config5_whole_8192_chains_on_one_gpu_within_the_family_wise_4p2_bound(la, monkeypatch):
     """BASELINE config 5 AS A WHOLE on one GPU (8192 chains, n = 4096, p = 128): the interior of every trajectory runs on the two-tile
     trajectory kernel (k_wide_traj2_bf16, 32 chains per workgroup).  (a) It computes the SAME trajectories, bit for bit, as the one-tile
     kernel -- ragged chain counts included -- so which of the two runs is a matter of speed only; (b) a shard of the run launched on its
@@ -208,8 +222,7 @@ def test_config5_whole_8192_chains_on_one_gpu(la, monkeypatch):
         print(f"cfg5 whole precision={prec}: accept {acc:.4f} (oracle {fix['accept']:.4f}), max|z| mean {np.max(np.abs(zm)):.2f} sd "
               f"{np.max(np.abs(zs)):.2f}, rms z mean {np.sqrt(np.mean(zm ** 2)):.2f} sd {np.sqrt(np.mean(zs ** 2)):.2f}")
         assert abs(acc - fix["accept"]) < 4 * fix["accept_se"] + {"full": 0.01, "auto": 0.01, "auto/float64": 0.01, "auto/bf16x2": 0.03, "bf16": 0.05}[prec]
-        assert np.max(np.abs(zm)) < 4.2 and np.max(np.abs(zs)) < 4.2, prec
-        assert 0.5 < np.sqrt(np.mean(zm ** 2)) < 1.3 and 0.5 < np.sqrt(np.mean(zs ** 2)) < 1.3, prec
+        _assert_wide_posterior(zm, zs, prec)
         res[prec] = acc
     # measured: full 0.758 | f16 0.758 | bf16 x two pieces 0.756 | bf16 x one piece 0.737
     assert abs(res["auto"] - res["full"]) < 0.005 and abs(res["auto/float64"] - res["full"]) < 0.005 and res["auto/bf16x2"] > res["full"] - 0.03

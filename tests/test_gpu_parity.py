@@ -94,7 +94,8 @@ def test_value_by_lane_product_and_its_overflow_fallback(models, group):
 
 
 @pytest.mark.parametrize("mode,group", VARIANTS)
-def test_every_kernel_variant_evaluates_the_same_model(models, oracle_model, mode, group):
+def test_every_kernel_variant_evaluates_the_same_model(models, oracle_model, pima, mode, group):
+    X_PIMA = pima[0]
     rng = np.random.default_rng(3)
     beta = np.array(load_golden("map.json")["map"]) + 2 * POST_SD * rng.standard_normal((300, 8))
     ref_lp, ref_g = oracle_model.lpost(beta), oracle_model.glp(beta)
@@ -105,8 +106,12 @@ def test_every_kernel_variant_evaluates_the_same_model(models, oracle_model, mod
         assert m.plan(300, group, mode) ["group"] == group
         r = m.eval(beta, group=group, mode=mode)
         np.testing.assert_allclose(r["lpost"], ref_lp, rtol=2e-5 if dtype == "float32" else 1e-11)
-        tol = 5e-2 if dtype == "float32" else 1e-7
-        assert np.max(np.abs(r["glp"] - ref_g)) < tol
+        # per coordinate, against the column's absolute sum (the fp32 term-sum bound, as tests/test_gpu_fullsize.py states it): a flat
+        # 5e-2 -- what this test asked until round 6 -- is that bound for the glucose column (sum |x| = 24 000) and 500x too loose
+        # for the pedigree column (sum |x| = 92)
+        colsum = np.abs(X_PIMA).sum(axis=0)
+        tol = 4e-6 if dtype == "float32" else 1e-12
+        assert np.max(np.abs(r["glp"] - ref_g) / colsum) < tol, np.max(np.abs(r["glp"] - ref_g) / colsum)
 
 
 # ------------------------------------------------------------------------------------------------
