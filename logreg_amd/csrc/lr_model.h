@@ -166,7 +166,8 @@ struct ModelImages { bool tall_mx, mf_end, wide, wide1; };
 inline ModelImages model_images(int64_t n, int P, int dtype) {
     constexpr int64_t kMfmaStreamMaxRows = 8192;  // rows the matrix-core chain kernel still takes with its operands streamed from device memory
     ModelImages im{};
-    // (float64 models: from the rows rounded to float32; float64 at padded p = 32 always runs the stepwise engine: lr_plan.h)
+    // (float64 models: from the rows rounded to float32; float64 at padded p = 32 gets the image whatever the row bytes -- the stepwise engine
+    //  is what runs such a model once its rows no longer fit the LDS of k_chain_dist, and under a forced LR_MODE_STEPWISE: lr_plan.h)
     im.tall_mx = P >= 8 && P <= 32 && ((size_t)n * P * (dtype == LR_F32 ? 4 : 8) > 64 * 1024 || (dtype != LR_F32 && P == 32));
     // (p = 16 / 32: from half the register variants' rows -- at the largest tile counts HMC streams its end-point operands: lr_mfma.h END_MEM)
     im.mf_end = P >= 8 && P <= 32 && dtype == LR_F32 && n > (P == 32 ? 16 * 4 * 4 : (P == 8 ? 16 * 13 : 16 * 4 * 8)) && n <= kMfmaStreamMaxRows;
