@@ -1061,6 +1061,9 @@ template <typename T, int P, int G> struct StridedRows {  // LDS or global: same
 #ifndef LR_ROWS_AHEAD64
 #define LR_ROWS_AHEAD64 4
 #endif
+        // (float64, rows of 64 bytes, HMC n = 200 p = 8 at 4096 chains on k_chain_f64x, rows ahead 1 / 2 / 3 / 4 / 8: 3.9 / 4.6 / 4.9 / 5.1 / 4.6e7
+        //  it/s -- tools/gpu/r6_f64_rows_ahead.sh; two ping-pong buffers of two rows with the next pair's reads issued before the current
+        //  pair's use measured 4.0e7: the compiler waits for the whole batch either way)
         constexpr int UB = sizeof(T) * P <= 64 ? (sizeof(T) == 8 ? LR_ROWS_AHEAD64 : 4) : (sizeof(T) * P <= 128 ? 2 : 1);
         const int64_t n = hi;
         int64_t i = lo + gl;
