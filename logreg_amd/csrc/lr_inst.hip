@@ -43,8 +43,8 @@ constexpr int P = LR_P;
 #define LR_VARIANTS(X) X(MODE_REG, 64, 4) X(MODE_LDS, 8, 0) X(MODE_LDS, 64, 0) X(MODE_GLOBAL, 64, 0) X(MODE_GLOBAL, 1, 0)
 #elif LR_DTYPE == 1 && LR_P == 8
 // (rows in LDS on 32 lanes per chain: built and measured in round 5 -- 3.0e7 it/s at 4096 chains against 4.75e7 on 16 lanes -- not kept)
-// float64 at Pima's width: the rows in registers as well (7 rows x 8 doubles = 112 VGPRs at 32 lanes per chain; 16 lanes x 13 rows = 208 of the 256 addressable registers spills
-// the state), plain (unpacked) v_fma_f64 arithmetic -- the reference computes in float64, so its rate is reported (bench.py extra.f64)
+// float64 at Pima's width: the rows in registers as well (7 rows x 8 doubles = 112 VGPRs at 32 lanes per chain; 16 lanes x 13 rows = 208 of the 256 addressable registers:
+// tried again in round 6 on the distributed-state kernel, whose state is 2 coordinates per lane -- 14 spills to scratch, 77 with scheduling fences between the rows), plain (unpacked) v_fma_f64 arithmetic -- the reference computes in float64, so its rate is reported (bench.py extra.f64)
 #define LR_VARIANTS(X) X(MODE_REG, 64, 4) X(MODE_REG, 32, 7) X(MODE_LDS, 1, 0) X(MODE_LDS, 8, 0) X(MODE_LDS, 16, 0) X(MODE_LDS, 64, 0) X(MODE_GLOBAL, 64, 0) X(MODE_GLOBAL, 1, 0)
 #elif LR_DTYPE == 1 && LR_P == 32
 // float64 at 17 <= p <= 32: chains on the distributed-state kernel (k_chain_dist: 16 lanes own the coordinates), so lane groups of 16 and
