@@ -653,7 +653,28 @@ int lr_event_elapsed_ms(int device, void* start, void* stop, float* ms) {
 // ---- the C-level exchange: RCCL, resolved at first use (no link-time dependency; see include/logreg_hip.h)
 }  // extern "C"
 #include <dlfcn.h>
+// (RCCL's header only where the ROCm installation has it -- the library is resolved with dlopen at first use either way; without the
+//  header, the handful of declarations this file needs, with the ABI values of rccl.h)
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclUint8 = 1, ncclDouble = 8 } ncclDataType_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+ncclResult_t ncclGetUniqueId(ncclUniqueId*);
+ncclResult_t ncclCommInitRank(ncclComm_t*, int, ncclUniqueId, int);
+ncclResult_t ncclCommDestroy(ncclComm_t);
+ncclResult_t ncclGroupStart();
+ncclResult_t ncclGroupEnd();
+ncclResult_t ncclSend(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+ncclResult_t ncclRecv(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+ncclResult_t ncclAllReduce(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+const char* ncclGetErrorString(ncclResult_t);
+}
+#endif
 struct lr_comm {
     ncclComm_t comm;
     int rank, world, device;
