@@ -659,8 +659,9 @@ int lr_event_elapsed_ms(int device, void* start, void* stop, float* ms) {
 #include <rccl/rccl.h>
 #else
 extern "C" {
+#define NCCL_UNIQUE_ID_BYTES 128
 typedef struct ncclComm* ncclComm_t;
-typedef struct { char internal[128]; } ncclUniqueId;
+typedef struct { char internal[NCCL_UNIQUE_ID_BYTES]; } ncclUniqueId;
 typedef enum { ncclSuccess = 0 } ncclResult_t;
 typedef enum { ncclUint8 = 1, ncclDouble = 8 } ncclDataType_t;
 typedef enum { ncclSum = 0 } ncclRedOp_t;
