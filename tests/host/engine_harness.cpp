@@ -29,6 +29,8 @@ long hipstub_live_events();
 long hipstub_mallocs();
 void hipstub_fail_malloc_at(long nth);
 void hipstub_set_devices(int n);
+long hipstub_work_on_device(int d);
+long hipstub_wrong_device();
 }
 
 static int g_fail = 0;
@@ -326,6 +328,66 @@ static void scenario_failing_allocations() {
     }
 }
 
+// A rank of a multi-GPU job works on device LOCAL_RANK, not 0 (bench.py, logreg_amd.distributed): everything the library allocates,
+// creates and launches for a model on device 1 must happen with device 1 current -- a path that forgot its hipSetDevice would put a
+// workspace or a launch on device 0 and only an 8-GPU node would ever show it.
+static void scenario_second_device() {
+    hipstub_set_devices(2);
+    EXPECT(lr_device_count() == 2 && lr_device_cus(1) == 256, "two devices");
+    char info[256];
+    EXPECT(lr_device_info(1, info, sizeof info) == LR_OK && std::strstr(info, "pci=") != nullptr, "device info of device 1");
+    void* stream = nullptr;
+    const long zero0 = hipstub_work_on_device(0);
+    EXPECT(lr_stream_create(1, &stream) == LR_OK, "stream on device 1");
+    struct Shape { int64_t n; int p; int64_t C; };
+    for (const Shape& s : {Shape{200, 8, 5120}, Shape{20000, 8, 256}, Shape{600, 64, 300}, Shape{300, 24, 600}}) {
+        const Data d = make_data(s.n, s.p, 77);
+        for (int dtype : {LR_F32, LR_F64}) {
+            lr_model* m = nullptr;
+            EXPECT(lr_model_create(d.X.data(), d.y.data(), d.n, d.p, d.sd.data(), dtype, 1, &m) == LR_OK, "create on device 1");
+            if (!m) continue;
+            int64_t n; int32_t p, dt, dev, pp;
+            EXPECT(lr_model_info(m, &n, &p, &dt, &dev, &pp) == LR_OK && dev == 1, "the model reports device 1");
+            const size_t es = dtype == LR_F32 ? 4 : 8;
+            void *st = nullptr, *lp = nullptr, *out = nullptr, *acc = nullptr, *stats = nullptr;
+            EXPECT(lr_malloc(1, (size_t)s.C * d.p * es, &st) == LR_OK && lr_malloc(1, (size_t)s.C * 8, &lp) == LR_OK && lr_malloc(1, (size_t)s.C * d.p * es, &out) == LR_OK &&
+                   lr_malloc(1, (size_t)s.C * 4, &acc) == LR_OK && lr_malloc(1, (size_t)s.C * 2 * d.p * 8, &stats) == LR_OK, "buffers on device 1");
+            std::vector<double> vec(d.p, 1.0);
+            lr_run_opts o{};
+            o.n_chains = s.C; o.thin = 1; o.iters = 1; o.on_device = 1; o.stream = stream; o.mode = LR_MODE_AUTO;
+            o.stats = (double*)stats; o.stats_batch = 1; o.stats_slots = 1;
+            for (int prec : {LR_PREC_AUTO, LR_PREC_FULL}) {
+                o.precision = prec;
+                EXPECT(lr_run_hmc(m, st, 0.01, 3, vec.data(), &o, out, (uint32_t*)acc) == LR_OK, "hmc on device 1");
+                EXPECT(lr_run_mala(m, st, (double*)lp, 1e-3, vec.data(), &o, out, (uint32_t*)acc) == LR_OK, "mala on device 1");
+            }
+            std::vector<double> piv(d.p, 0.0), sums((size_t)LR_STATS_ROWS * d.p);
+            EXPECT(lr_stats_reduce(1, (double*)stats, s.C, d.p, 1, 1, piv.data(), sums.data(), stream) == LR_OK, "stats reduce on device 1");
+            std::vector<unsigned char> host((size_t)s.C * d.p * es);
+            EXPECT(lr_memcpy_d2h(1, host.data(), out, host.size(), stream) == LR_OK && lr_memset(1, acc, 0, (size_t)s.C * 4, stream) == LR_OK, "copies on device 1");
+            // (host-pointer convenience path: the library stages through its own device buffers)
+            std::vector<unsigned char> hs((size_t)64 * d.p * es, 0), ho((size_t)64 * d.p * es);
+            std::vector<uint32_t> ha(64, 0);
+            lr_run_opts h{};
+            h.n_chains = 64; h.thin = 1; h.iters = 1; h.mode = LR_MODE_AUTO;
+            EXPECT(lr_run_hmc(m, hs.data(), 0.01, 2, vec.data(), &h, ho.data(), ha.data()) == LR_OK, "host buffers, model on device 1");
+            if (d.p <= 32) {
+                std::vector<double> b(d.p, 0.0), g(d.p), hh((size_t)d.p * d.p);
+                double lpost;
+                EXPECT(lr_hessian(m, b.data(), &lpost, g.data(), hh.data(), stream) == LR_OK, "hessian on device 1");
+            }
+            EXPECT(lr_stream_sync(1, stream) == LR_OK, "sync");
+            for (void* q : {st, lp, out, acc, stats}) EXPECT(lr_free(1, q) == LR_OK, "free");
+            lr_model_destroy(m);
+        }
+    }
+    EXPECT(lr_stream_destroy(1, stream) == LR_OK, "stream destroy");
+    EXPECT(hipstub_work_on_device(0) == zero0, "%ld allocations / creations / launches happened with device 0 current while working on device 1",
+           hipstub_work_on_device(0) - zero0);
+    EXPECT(hipstub_work_on_device(1) > 200, "work counted on device 1: %ld", hipstub_work_on_device(1));
+    hipstub_set_devices(1);
+}
+
 static void thread_body(int id, int* fails) {
     const Data d = id == 0 ? make_data(200, 8, 21) : make_data(600, 64, 22);
     lr_model* m = nullptr;
@@ -363,7 +425,9 @@ int main(int argc, char** argv) {
         scenario_two_streams();
         scenario_errors();
         scenario_failing_allocations();
+        scenario_second_device();
     }
+    EXPECT(hipstub_wrong_device() == 0, "%ld uses of another device's stream / event", hipstub_wrong_device());
     EXPECT(hipstub_bad_waits() == g_deliberate_bad_waits, "%ld waits on events that were never recorded", hipstub_bad_waits() - g_deliberate_bad_waits);
     EXPECT(hipstub_bad_launches() == 0, "%ld launches with an invalid configuration or a dead stream", hipstub_bad_launches());
     EXPECT(hipstub_live_allocs() == 0, "%ld device buffers alive at exit", hipstub_live_allocs());

@@ -20,8 +20,8 @@
 
 namespace {
 
-struct Stream { int id; std::atomic<long> launches{0}; };
-struct Event { std::atomic<int> recorded{0}; Stream* on = nullptr; };
+struct Stream { int id; int device; std::atomic<long> launches{0}; };
+struct Event { int device; std::atomic<int> recorded{0}; Stream* on = nullptr; };
 
 std::mutex g_mu;
 std::set<void*> g_allocs;
@@ -30,6 +30,9 @@ std::set<Event*> g_events;
 std::map<const void*, std::string> g_kernels;  // host stub address -> kernel name
 std::map<std::string, long> g_launch_by_kernel;
 std::atomic<long> g_mallocs{0}, g_fail_at{-1}, g_launches{0}, g_null_launches{0}, g_bad_waits{0}, g_bad_launch{0}, g_next_stream{1};
+std::atomic<long> g_work_on_device[8];  // allocations, stream / event creations and launches by the device that was CURRENT when they were made
+std::atomic<long> g_wrong_device{0};    // work on a stream / an event / memory of ANOTHER device than the current one
+std::map<void*, int> g_alloc_device;
 int g_devices = 1;
 thread_local hipError_t t_last = hipSuccess;
 thread_local int t_device = 0;
@@ -71,6 +74,8 @@ long hipstub_live_allocs() { std::lock_guard<std::mutex> lk(g_mu); return (long)
 long hipstub_live_streams() { std::lock_guard<std::mutex> lk(g_mu); return (long)g_streams.size(); }
 long hipstub_live_events() { std::lock_guard<std::mutex> lk(g_mu); return (long)g_events.size(); }
 long hipstub_mallocs() { return g_mallocs.load(); }
+long hipstub_work_on_device(int d) { return d >= 0 && d < 8 ? g_work_on_device[d].load() : -1; }
+long hipstub_wrong_device() { return g_wrong_device.load(); }  // a launch / record / copy that touched another device's stream, event or memory
 void hipstub_fail_malloc_at(long nth) { g_fail_at = nth; }  // the nth hipMalloc FROM NOW (1 = the next) fails once; -1: never
 void hipstub_set_devices(int n) { g_devices = n; }
 }
@@ -102,6 +107,8 @@ extern "C" hipError_t hipLaunchKernel(const void* fn, dim3 grid, dim3 block, voi
         return fail(hipErrorInvalidConfiguration);
     }
     ++g_launches;
+    ++g_work_on_device[t_device & 7];
+    if (stream && reinterpret_cast<Stream*>(stream)->device != t_device) anomaly(g_wrong_device, "kernel launched on a stream of another device than the current one");
     if (stream) ++reinterpret_cast<Stream*>(stream)->launches; else ++g_null_launches;
     std::lock_guard<std::mutex> lk(g_mu);
     auto it = g_kernels.find(fn);
@@ -160,8 +167,10 @@ extern "C" hipError_t hipMalloc(void** p, size_t bytes) {
     *p = std::malloc(bytes ? bytes : 1);
     if (!*p) return fail(hipErrorOutOfMemory);
     std::memset(*p, 0, bytes);  // (device memory of a fresh allocation is not zero on a GPU; zero keeps the no-op kernels' "results" defined for UBSan)
+    ++g_work_on_device[t_device & 7];
     std::lock_guard<std::mutex> lk(g_mu);
     g_allocs.insert(*p);
+    g_alloc_device[*p] = t_device;
     return hipSuccess;
 }
 extern "C" hipError_t hipFree(void* p) {
@@ -169,6 +178,7 @@ extern "C" hipError_t hipFree(void* p) {
     {
         std::lock_guard<std::mutex> lk(g_mu);
         if (!g_allocs.erase(p)) return fail(hipErrorInvalidValue);  // not a device pointer, or freed twice
+        g_alloc_device.erase(p);
     }
     std::free(p);
     return hipSuccess;
@@ -176,6 +186,7 @@ extern "C" hipError_t hipFree(void* p) {
 extern "C" hipError_t hipMemcpy(void* dst, const void* src, size_t bytes, hipMemcpyKind) { if (bytes) std::memcpy(dst, src, bytes); return hipSuccess; }
 extern "C" hipError_t hipMemcpyAsync(void* dst, const void* src, size_t bytes, hipMemcpyKind, hipStream_t s) {
     if (!live_stream(s)) return fail(hipErrorInvalidHandle);
+    if (s && reinterpret_cast<Stream*>(s)->device != t_device) anomaly(g_wrong_device, "asynchronous copy on a stream of another device than the current one");
     if (bytes) std::memcpy(dst, src, bytes);
     return hipSuccess;
 }
@@ -189,6 +200,8 @@ extern "C" hipError_t hipMemsetAsync(void* dst, int v, size_t bytes, hipStream_t
 extern "C" hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) {
     auto* st = new Stream;
     st->id = (int)g_next_stream++;
+    st->device = t_device;
+    ++g_work_on_device[t_device & 7];
     std::lock_guard<std::mutex> lk(g_mu);
     g_streams.insert(st);
     *s = reinterpret_cast<hipStream_t>(st);
@@ -206,6 +219,8 @@ extern "C" hipError_t hipStreamDestroy(hipStream_t s) {
 extern "C" hipError_t hipStreamSynchronize(hipStream_t s) { return live_stream(s) ? hipSuccess : fail(hipErrorInvalidHandle); }
 extern "C" hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) {
     auto* ev = new Event;
+    ev->device = t_device;
+    ++g_work_on_device[t_device & 7];
     std::lock_guard<std::mutex> lk(g_mu);
     g_events.insert(ev);
     *e = reinterpret_cast<hipEvent_t>(ev);
@@ -224,6 +239,7 @@ extern "C" hipError_t hipEventDestroy(hipEvent_t e) {
 extern "C" hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) {
     if (!live_event(e) || !live_stream(s)) return fail(hipErrorInvalidHandle);
     auto* ev = reinterpret_cast<Event*>(e);
+    if (ev->device != t_device || (s && reinterpret_cast<Stream*>(s)->device != t_device)) anomaly(g_wrong_device, "event recorded across devices");
     ev->on = reinterpret_cast<Stream*>(s);
     ++ev->recorded;
     return hipSuccess;

@@ -6,8 +6,9 @@ separately, -fsanitize=thread) and linked, with the library's own instantiation 
 runtime calls the library makes, on the host heap, launches as validated no-ops.  tests/host/engine_harness.cpp then drives the C ABI:
 13 model shapes x 2 dtypes (every image kind) x all four kernel families x both precision policies, host and device buffers,
 statistics, planned shards, the Hessian, every forced (mode, group), two chain sets on two streams + a wide model on alternating
-streams, 40 error returns, and a failing device allocation at EVERY allocation of model creation and of a run (LR_ERR_NOMEM, nothing
-leaked, the model still usable).  A sanitizer report, a leak, a wait on an unrecorded event or a bad launch configuration fails the test.
+streams, 40 error returns, a failing device allocation at EVERY allocation of model creation and of a run (LR_ERR_NOMEM, nothing
+leaked, the model still usable), and a model, its stream, buffers and runs on device 1 of two (what a rank > 0 of the multi-GPU job does:
+not one allocation, creation or launch may happen with device 0 current, none may touch another device's stream or event).  A sanitizer report, a leak, a wait on an unrecorded event or a bad launch configuration fails the test.
 (First run, round 6: found that a failed hipMalloc left HIP's sticky error for the next launch check to trip over -- lr_model.h fail().)"""
 import os
 import subprocess
