@@ -163,3 +163,25 @@ def test_second_build_exports_the_same_abi():
     L.lr_build_id.restype = C.c_char_p
     assert L.lr_build_id().decode() == build.source_hash(alt=True) != build.source_hash()
     assert set(build.TUNING) & set(build.COMMON) and not set(build.TUNING) & set(build.ALT_COMMON)
+
+
+def test_isa_symbolic_execution_tool_on_a_small_reduction(tmp_path):
+    """tools/isa_symexec.py (the analyser that cleared the dataflow of round 4's wrong kernel, profiles/r6_f64_p32_bisect.txt) on a
+    hand-written butterfly: two float64 values each reduced over the wave's halves by a v_permlane32_swap pair -- both final sums depend
+    on exactly their own input pair and have the same shape; a third, whose high half was taken from another value's register, is the odd one."""
+    import subprocess
+    import sys
+    src = "\n".join([
+        "\tv_mov_b32_e32 v10, v0", "\tv_mov_b32_e32 v11, v1", "\ts_nop 1", "\tv_permlane32_swap_b32 v0, v10", "\tv_permlane32_swap_b32 v1, v11", "\ts_nop 0",
+        "\tv_add_f64 v[20:21], v[0:1], v[10:11]",
+        "\tv_mov_b32_e32 v12, v2", "\tv_mov_b32_e32 v13, v3", "\ts_nop 1", "\tv_permlane32_swap_b32 v2, v12", "\tv_permlane32_swap_b32 v3, v13", "\ts_nop 0",
+        "\tv_add_f64 v[22:23], v[2:3], v[12:13]",
+        "\tv_mov_b32_e32 v14, v4", "\tv_mov_b32_e32 v15, v3", "\ts_nop 1", "\tv_permlane32_swap_b32 v4, v14", "\tv_permlane32_swap_b32 v5, v15", "\ts_nop 0",
+        "\tv_add_f64 v[24:25], v[4:5], v[14:15]", ""])
+    f = tmp_path / "k.s"
+    f.write_text(src)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "isa_symexec.py"), str(f), "1", "22", "--sums"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rows = [ln for ln in r.stdout.splitlines() if "v_add_f64" in ln]
+    assert len(rows) == 3 and "leaves(2): v0 v1" in rows[0] and "leaves(2): v2 v3" in rows[1] and "ODD" not in rows[0] + rows[1]
+    assert "ODD SHAPE" in rows[2] or "leaves(3)" in rows[2], rows[2]
