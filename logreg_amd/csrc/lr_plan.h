@@ -58,6 +58,11 @@ struct PlanConst {
     int mixed_chains_per_cu = 0;
     int f64_mfma_chains_per_cu = 33;  // float64 HMC under LR_PREC_AUTO: k_chain_mfma_f64 beyond two rounds of k_chain_mixed (plan_mfma_hmc)
     int f64_lds16_chains_per_cu = 16;
+    // ... and HMC from 256 chains per CU (one wave per SIMD of lane-per-chain work): rows in LDS, ONE lane per chain -- no reduction, no
+    // gather at all (round 6, tools/f64_many_chains.py, every evaluation float64, lds 8 | lds 1, it/s: 32 768 chains 6.17 | 3.3e7, 65 536:
+    // 6.30 | 6.44, 131 072: 6.36 | 6.82, 262 144: 6.37 | 6.92e7 = 0.33 of the fp64 vector peak -- the most ANY engine reaches at ANY chain count:
+    // 43 instructions per (row, chain), 27 of them the sigmoid)
+    int f64_lds1_chains_per_cu = 256;
     int f64_lds8_chains_per_cu = 32;
     int mfma_fp32_chains_per_cu = 16;
     int lds8_chains_per_cu = 64;
@@ -366,7 +371,11 @@ bool measured_overrides(const PlanReq& q, int* best, Plan* out) {
         else if (m->P >= 16 && q.C >= (int64_t)kPlanConst.mfma_fp32_chains_per_cu * m->cus && mfma_variant_fits(m, 4, ST_REG, out))
             return true;
     }
-    if (m->dtype == LR_F64 && m->P == 8 && b.mode == lr::MODE_REG) {
+    // (... also where the scalar-row lane-per-chain variant would have been picked: 262 144 chains global 1 | lds 1: 6.43 | 6.92e7)
+    if (m->dtype == LR_F64 && m->P == 8 && q.kind == LR_KIND_HMC && q.C >= (int64_t)kPlanConst.f64_lds1_chains_per_cu * m->cus &&
+        (b.mode == lr::MODE_REG || (b.mode == lr::MODE_GLOBAL && b.G == 1)) && lds_rows_bytes(m) <= kLdsBudget) {
+        move_to_lds(1);
+    } else if (m->dtype == LR_F64 && m->P == 8 && b.mode == lr::MODE_REG) {
         if (q.C >= (int64_t)kPlanConst.f64_lds8_chains_per_cu * m->cus) move_to_lds(8);
         else if (q.C >= (int64_t)kPlanConst.f64_lds16_chains_per_cu * m->cus) move_to_lds(16);
     }

@@ -72,6 +72,8 @@ CASES = [
     (200, 8, 2048, "hmc", "full", {"dtype": "float64", "mode": "reg", "group": 32, "rows_per_lane": 7}),
     # ... from one wave per SIMD in LDS with 16 lanes per chain, from two with 8 (8 x 25 rows = 200 exactly; round 4)
     (200, 8, 4096, "hmc", "full", {"dtype": "float64", "mode": "lds", "group": 16}),
+    (200, 8, 16384, "hmc", "full", {"dtype": "float64", "mode": "lds", "group": 8}), (200, 8, 65536, "hmc", "full", {"dtype": "float64", "mode": "lds", "group": 1}),
+    (200, 8, 262144, "hmc", "full", {"dtype": "float64", "mode": "lds", "group": 1}), (200, 8, 65536, "mala", "full", {"dtype": "float64", "mode": "lds", "group": 8}),
     (200, 8, 8192, "mala", "auto", {"dtype": "float64", "mode": "lds", "group": 8}),
     (200, 12, 4096, "hmc", "full", {"dtype": "float64", "mode": "lds", "group": 8}), (200, 12, 2048, "mala", "auto", {"dtype": "float64", "mode": "lds", "group": 64}),
     (200, 3, 4096, "mala", "auto", {"dtype": "float64", "mode": "lds", "group": 8}),
