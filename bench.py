@@ -788,6 +788,7 @@ def main(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ess", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the configs 1/3/4/5 sub-results")
+    ap.add_argument("--host-boundary", action="store_true", help="also time the headline through mcmc(): host array in, host samples out (PCIe inclusive)")
     ap.add_argument("--dry-run", action="store_true", help="launch plumbing only (gloo, no GPU work)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend (gloo: the CPU tests)")
     ap.add_argument("--scale", type=int, default=1, help="divide the chain counts / run lengths of the multi-GPU configs 3 and 5 "
@@ -1000,7 +1001,10 @@ def main(argv=None):
                 "ratio_to_value": f64["chain_iterations_per_s"] / value,
                 "note": "precision='full': every log-posterior / gradient evaluation float64 (k_chain_f64x, lr_f64x.h); policy_auto_value: the "
                         "float64 model's default policy (float64 state, end points and Metropolis test; float32 force inside the trajectory)"}
-            line["host_boundary"] = host_boundary_run(la, kern, q0, a.steps)  # the PCIe-inclusive rate of the same workload
+            if a.host_boundary:  # the PCIe-inclusive rate of the same workload.  Opt-in: mcmc() runs its 200 kept samples as
+                # ONE launch of the headline kernel, which would drag that kernel's AVERAGE duration in a rocprofv3 trace of this command
+                # away from the per-step time the roofline is computed from
+                line["host_boundary"] = host_boundary_run(la, kern, q0, a.steps)
             line["extra"] = {"configs": extra_configs(la, L, _lib.check, dev, stream),
                              "default_policy": default_policy_runs(la, L, _lib.check, dev, stream, kern, init, a.steps),
                              "f64": f64,
