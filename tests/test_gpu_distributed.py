@@ -60,7 +60,7 @@ def test_bench_rccl_branch_runs_on_a_gpu_under_torchrun():
     gather of the thinned samples inside the timed region, the max / sum reductions -- launched exactly as the driver
     launches it for N > 1 (a fresh child under `python -m torch.distributed.run`), on the one GPU a test box has
     (LOGREG_BENCH_FORCE_DIST=1 keeps the process group at world size 1).  Checked against the plain single-process run
-    of the same command: same workload, same acceptance rate (same seed and chain ids), throughput of the same order (wall clock on a possibly shared host)."""
+    of the same command: same workload, the same acceptance rate to Monte-Carlo error (same seed and chain ids), throughput of the same order (wall clock on a possibly shared host)."""
     plain = _bench({})
     dist = _bench({"LOGREG_BENCH_FORCE_DIST": "1"}, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
                   "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), extra=True)
@@ -73,7 +73,9 @@ def test_bench_rccl_branch_runs_on_a_gpu_under_torchrun():
         # does guard the kernel -- the wall-clock comparisons below are sanity factors only
         assert d["roofline"]["kernel_ms"] < 0.45 and d["roofline"]["frac"] > 0.42, d["roofline"]
     assert dist["config"]["parallelism"] == "chains sharded x1" and dist["gather_ms"] > 0 and plain["gather_ms"] == 0
-    assert dist["accept_rate"] == plain["accept_rate"]
+    # (same seed and chain ids; the timed window starts after a TIME-bounded pre-warm, so the two runs may sit 20 launches apart in the
+    #  chains' history -- equal to the Monte-Carlo error of 3.3e6 proposals, not to the bit: round 6 saw 0.92223 against 0.92232)
+    assert abs(dist["accept_rate"] - plain["accept_rate"]) < 2e-3, (dist["accept_rate"], plain["accept_rate"])
     # 40 timed steps = 15 ms (round 5; with 5 steps = 2 ms the closing RCCL barrier alone, inside the timed region, decided the
     # comparison): the gather (5 MB device-to-device at N = 1) is inside the timed region of the distributed run
     # (wall clock with barriers on a possibly shared host: a sanity factor, not a performance claim -- measured 0.95 - 1.0 on a quiet box)
