@@ -757,11 +757,11 @@ __device__ __forceinline__ void row_term(const T (&xs)[P], const T (&bs)[P], T (
             // swallow a NaN: the weight of a non-finite t is sigma(750) here, and the end point of the trajectory, evaluated on the
             // exact path below, is what rejects such a state)
             const T s1 = T(1) + exp_noguard(__builtin_fmin(__builtin_fmax(ts, T(-750)), T(700)));
-            T r = __builtin_amdgcn_rcp(s1);
-            T err = __builtin_fma(-s1, r, T(1));
-            r = __builtin_fma(r, err, r);
-            err = __builtin_fma(-s1, r, T(1));
-            r = __builtin_fma(r, err, r);
+            // 1 / s1 in three fma: v_rcp_f64 is good to ~2^-23, and r0 (1 + e + e^2) with e = 1 - s1 r0 converges cubically (2^-69:
+            // below the final rounding) where two Newton steps take four
+            const T r0 = __builtin_amdgcn_rcp(s1);
+            const T err = __builtin_fma(-s1, r0, T(1));
+            const T r = __builtin_fma(r0, __builtin_fma(err, err, err), r0);
 #pragma unroll
             for (int j = 0; j < P; ++j) g[j] = fma_t(r, xs[j], g[j]);
             return;
